@@ -1,0 +1,224 @@
+/*
+ * pmesh_amd.h — C ABI of the MI355X-native particle-mesh hot path.
+ *
+ * This is the drop-in boundary for the PM cycle
+ *     decompose -> paint -> r2c -> apply-transfer -> c2r -> readout
+ * of MP-Gadget/pmesh.  Every entry point replaces one native interface of the
+ * reference (cited per function as file:line relative to the reference tree).
+ * The reference's native boundary is per particle (pmesh/_window_imp.h:76-86:
+ * pmesh_painter_paint(painter, pos[], weight, hsml) called from a Python-level
+ * loop, pmesh/_window.pyx:157-165); a GPU needs the whole particle batch, so
+ * the entry points here are the batched form of the same contract.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no torch / numpy types.
+ *  - all `void*` data pointers are DEVICE pointers (HBM) for the pmx_* library
+ *    (libpmesh_amd.so).  The test oracle (oracle/liboracle.so) exports the
+ *    same signatures with the prefix pmo_ and HOST pointers.
+ *  - strides are in BYTES (as numpy strides; pmesh/_window.pyx:152-154).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *    are asynchronous with respect to the host unless stated otherwise.
+ *  - every function returns a pmx_status; pmx_last_error() gives the message.
+ */
+#ifndef PMESH_AMD_H
+#define PMESH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_MAXDIM 3
+#define PMX_MAXRANKS 64      /* decomposition targets are kept as a 64-bit mask */
+#define PMX_MAXSUPPORT 32    /* same cap as the reference (_window_generics.h:23) */
+
+typedef enum pmx_status {
+    PMX_OK = 0,
+    PMX_EINVAL = 1,       /* bad argument */
+    PMX_EUNSUPPORTED = 2, /* valid in the reference but not built here (yet) */
+    PMX_EHIP = 3,         /* HIP runtime error */
+    PMX_EFFT = 4,         /* rocFFT error */
+    PMX_ENOMEM = 5
+} pmx_status;
+
+/* Window kinds on the path (pmesh/_window_imp.h:4-28; window.py:230-255).
+ * The table-driven kinds (lanczos/acg/db/sym) are outside the scope table. */
+typedef enum pmx_window_kind {
+    PMX_NEAREST = 0,   /* PMESH_PAINTER_NEAREST   */
+    PMX_LINEAR = 1,    /* PMESH_PAINTER_LINEAR    */
+    PMX_QUADRATIC = 2, /* PMESH_PAINTER_QUADRATIC */
+    PMX_CUBIC = 3,     /* PMESH_PAINTER_CUBIC     */
+    PMX_TUNED_NNB = 4, /* PMESH_PAINTER_TUNED_NNB */
+    PMX_TUNED_CIC = 5, /* PMESH_PAINTER_TUNED_CIC */
+    PMX_TUNED_TSC = 6, /* PMESH_PAINTER_TUNED_TSC */
+    PMX_TUNED_PCS = 7  /* PMESH_PAINTER_TUNED_PCS */
+} pmx_window_kind;
+
+/* The geometric part of `struct PMeshPainter` (pmesh/_window_imp.h:48-62):
+ * window, affine transform, periodicity and the canvas block it addresses. */
+typedef struct pmx_painter {
+    int32_t kind;          /* pmx_window_kind */
+    int32_t support;       /* <= 0: native support (window_info_init, _window_imp.c:24-47) */
+    int32_t ndim;          /* 1..3 */
+    int32_t canvas_elsize; /* 4 (float) or 8 (double) */
+    int32_t order[PMX_MAXDIM];   /* 0 = window, 1 = derivative along that axis */
+    int32_t _pad;
+    double scale[PMX_MAXDIM];     /* grid = pos * scale + translate (no FMA) */
+    double translate[PMX_MAXDIM];
+    int64_t period[PMX_MAXDIM];   /* Nmesh; 0 = non periodic */
+    int64_t size[PMX_MAXDIM];     /* extent of the local canvas block */
+    int64_t strides[PMX_MAXDIM];  /* canvas strides in bytes */
+} pmx_painter;
+
+/* A strided per-particle column set (numpy view semantics): element (i, c) is
+ * at data + i*stride0 + c*stride1 and is a float (elsize 4) or double (8).
+ * Mirrors the fused postype/masstype/hsmltype arguments of _window.pyx:6-16. */
+typedef struct pmx_vec {
+    void *data;      /* NULL = absent */
+    int32_t elsize;  /* 4 or 8 */
+    int32_t ncol;
+    int64_t stride0; /* bytes between particles (0 broadcasts one row) */
+    int64_t stride1; /* bytes between columns */
+} pmx_vec;
+
+const char *pmx_last_error(void);
+int pmx_version(void);
+/* number of visible HIP devices (0 if none); never throws */
+int pmx_device_count(void);
+
+/* ---- window metadata ---------------------------------------------------- */
+/* pmesh_painter_init + pmesh_window_info_init (_window_imp.c:24-47, 246-459):
+ * native support and effective integer support of (kind, support). */
+int pmx_window_info(int32_t kind, int32_t support, int32_t *nativesupport, int32_t *eff_support);
+/* pmesh_painter_get_fwindow (_window_imp.c:473-485) for n circular
+ * frequencies; HOST arrays (tiny, init-time). */
+int pmx_fwindow(int32_t kind, int32_t support, const double *w, int64_t n, double *out);
+
+/* ---- paint / readout ---------------------------------------------------- */
+/* Batched form of pmesh_painter_paint over the Cython loop _window.pyx:128-165:
+ *   for i < npart: canvas[cells of window at pos[i]] += mass[i] * W(...)
+ * mass == NULL or mass->data == NULL means every particle has `mass_scalar`
+ * (the 0-stride broadcast of window.py:6-16,146).  hsml NULL = 1.0.
+ * Cells outside the local block after periodic wrapping are dropped
+ * (_window_generics.h:144-167). Accumulates into the canvas (window.py:113). */
+int pmx_paint(const pmx_painter *p, void *canvas, const pmx_vec *pos, const pmx_vec *mass,
+              double mass_scalar, const pmx_vec *hsml, int64_t npart, void *stream);
+
+/* Batched form of pmesh_painter_readout (_window.pyx:167-205):
+ *   out[i] = sum over window cells canvas[cell] * W(...), in the reference's
+ * lexicographic cell order, stored as float or double per out->elsize. */
+int pmx_readout(const pmx_painter *p, const void *canvas, const pmx_vec *pos, const pmx_vec *hsml,
+                const pmx_vec *out, int64_t npart, void *stream);
+
+/* ---- tile-binned paint / readout (device-side acceleration structure) ---- */
+/* A bin plan orders the particles by mesh tile so that paint accumulates each
+ * tile in LDS and readout gathers from an LDS-staged tile.  Results equal
+ * pmx_paint / pmx_readout up to floating-point summation order. */
+typedef struct pmx_binplan pmx_binplan;
+int pmx_binplan_create(pmx_binplan **plan, const pmx_painter *p, int64_t max_particles);
+int pmx_binplan_destroy(pmx_binplan *plan);
+/* sort the particle batch by tile; keeps a device copy of the sorted
+ * positions (and masses) and the permutation */
+int pmx_binplan_build(pmx_binplan *plan, const pmx_painter *p, const pmx_vec *pos,
+                      const pmx_vec *mass, double mass_scalar, int64_t npart, void *stream);
+int pmx_paint_binned(pmx_binplan *plan, const pmx_painter *p, void *canvas, void *stream);
+int pmx_readout_binned(pmx_binplan *plan, const pmx_painter *p, const void *canvas,
+                       const pmx_vec *out, void *stream);
+
+/* ---- domain decomposition (pmesh/domain.py:561-652 + _domain.pyx:9-122) -- */
+typedef struct pmx_grid {
+    int32_t ndim;
+    int32_t periodic;
+    int32_t nranks;                 /* size of the communicator */
+    int32_t shape[PMX_MAXDIM];      /* domains per axis */
+    const double *edges[PMX_MAXDIM];/* shape[d]+1 doubles each */
+    const int32_t *assign;          /* DomainAssign[prod(shape)]        */
+    const int16_t *degenerate;      /* DomainDegenerate[prod(shape)]    */
+} pmx_grid;
+
+/* Pass 1 (domain.py:605-636, gridnd_fill mode 0): per particle the set of
+ * target ranks within +-smoothing of scale*pos, as a bit mask, and the number
+ * of particles per rank.  masks: npart uint64 (out); counts: nranks int64 (out). */
+int pmx_decompose_count(const pmx_grid *g, const pmx_vec *pos, const double *scale,
+                        const double *smoothing, int64_t npart, uint64_t *masks,
+                        int64_t *counts, void *stream);
+/* Pass 2 (gridnd_fill mode 1, _domain.pyx:45-51,120-121): rank-major, stable
+ * list of particle indices.  offsets: nranks int64 exclusive prefix of counts;
+ * indices: sum(counts) integers of index_elsize (4 or 8) bytes. */
+int pmx_decompose_fill(int32_t nranks, const uint64_t *masks, int64_t npart,
+                       const int64_t *offsets, void *indices, int32_t index_elsize,
+                       void *stream);
+
+/* Layout.exchange pack (domain.py:188 `data.take(indices)`): dst row j = src row indices[j]. */
+int pmx_take_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const void *indices,
+                  int32_t index_elsize, int64_t nrows, void *dst, void *stream);
+/* Layout.gather mode='sum' (domain.py:294-295, bincountv 26-48):
+ * out[i*ncol + c] = sum over j with indices[j] == i of values[j*ncol + c], for all
+ * i < nout (rows that receive nothing become 0, as numpy.bincount does). */
+int pmx_scatter_add(const void *values, int32_t elsize, int32_t ncol, const void *indices,
+                    int32_t index_elsize, int64_t nrows, void *out, int64_t nout, void *stream);
+
+/* ---- FFT (replaces pfft.Plan / plan.execute, pm.py:1429-1434, 689, 1017) -- */
+typedef enum pmx_fft_kind { PMX_FFT_R2C = 0, PMX_FFT_C2R = 1, PMX_FFT_C2C_FWD = 2, PMX_FFT_C2C_BWD = 3 } pmx_fft_kind;
+typedef struct pmx_fft pmx_fft;
+/* A batched strided transform of rank `ndim` over lengths n[] (C order, last
+ * axis fastest; for R2C/C2R the real lengths).  Strides/dists in ELEMENTS of
+ * the respective side (real elements on the real side, complex on the complex
+ * side).  `scale` multiplies the output (r2c carries 1/prod(Nmesh), pm.py:692). */
+int pmx_fft_create(pmx_fft **plan, int32_t kind, int32_t elsize, int32_t ndim, const int64_t *n,
+                   const int64_t *istride, int64_t idist, const int64_t *ostride, int64_t odist,
+                   int64_t batch, double scale, int32_t inplace);
+int pmx_fft_execute(pmx_fft *plan, void *in, void *out, void *stream);
+int pmx_fft_destroy(pmx_fft *plan);
+
+/* Local transposes either side of the slab all-to-all (PFFT's global transpose).
+ * pack:   src (n0, n1, n2) C order -> P contiguous blocks, block r = (n0, n1 range of r, n2)
+ * unpack: P blocks, block s = (n0 range of s, n1loc, n2) -> dst (n1loc, n0tot, n2) C order
+ * Elements are `elbytes` wide (8 = complex64, 16 = complex128). */
+int pmx_slab_pack(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
+                  const int64_t *n1_offsets /* host, P+1 */, int32_t nparts, int32_t elbytes,
+                  void *stream);
+int pmx_slab_unpack(const void *src, void *dst, const int64_t *n0_offsets /* host, P+1 */,
+                    int32_t nparts, int64_t n1loc, int64_t n2, int32_t elbytes, void *stream);
+/* inverse pair used by c2r */
+int pmx_slab_pack_t(const void *src, void *dst, const int64_t *n0_offsets, int32_t nparts,
+                    int64_t n1loc, int64_t n2, int32_t elbytes, void *stream);
+int pmx_slab_unpack_t(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
+                      const int64_t *n1_offsets, int32_t nparts, int32_t elbytes, void *stream);
+
+/* ---- apply-transfer (Field.apply, pm.py:617-648, with the transfer functions
+ * of examples/nbody.py:154-181 and pmesh/transfer.py fused) ---------------- */
+typedef struct pmx_transfer {
+    double amplitude;     /* real prefactor */
+    int32_t laplace_pow;  /* multiply by (k^2)^laplace_pow, k^2(0) := 1 (nbody.py:156-157); 0 = off */
+    int32_t grad_dir;     /* -1 = off; else multiply by i * D(k_dir) */
+    int32_t grad_kind;    /* 0: D = k (dx1_transfer nbody.py:154-160);
+                             1: D = (8 sin w - sin 2w)/(6 C), w = k C, C = L/N (force_transfer 162-171) */
+    int32_t deconv_pow;   /* divide by prod_d sinc(w_d/2)^deconv_pow (window.py:65-80); 0 = off */
+    double gauss_r;       /* multiply by exp(-0.5 k^2 r^2) (lowpass_transfer nbody.py:177-181); 0 = off */
+} pmx_transfer;
+
+/* out[m] = T(k(m)) * in[m] over a local complex block of logical shape
+ * shape[0..ndim) starting at global index start[], with byte strides; k_d =
+ * 2 pi / L_d * (i - N_d [i >= N_d/2]) (pm.py:1200-1226: Nyquist negative).
+ * in may equal out.  elsize = 4 (complex64) or 8 (complex128) per component. */
+int pmx_apply_transfer(const pmx_transfer *t, int32_t ndim, int32_t elsize, const void *in,
+                       const int64_t *in_strides, void *out, const int64_t *out_strides,
+                       const int64_t *shape, const int64_t *start, const int64_t *nmesh,
+                       const double *boxsize, void *stream);
+
+/* ---- synthetic inputs for bench.py ------------------------ */
+/* lattice + hashed jitter; writes pos (npart,3) for lattice ids [g0, g0+npart) */
+int pmx_synth_uniform(const pmx_vec *pos, int64_t nlat, double boxsize, uint64_t seed, int64_t g0,
+                      int64_t npart, void *stream);
+/* lattice + plane-wave Zel'dovich displacement; modes: nmodes x 8 doubles on the
+ * HOST (nx, ny, nz, dirx, diry, dirz, amplitude, phase) */
+int pmx_synth_clustered(const pmx_vec *pos, int64_t nlat, double boxsize, const double *modes,
+                        int32_t nmodes, double shift, int64_t g0, int64_t npart, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMESH_AMD_H */

@@ -1,0 +1,125 @@
+"""ctypes declarations of the C ABI in include/pmesh_amd.h.
+
+One table of prototypes, bound to a library under a symbol prefix: ``pmx_`` for
+the product library (device pointers) and, from tests only, ``pmo_`` for the
+CPU oracle (host pointers).  Nothing here computes anything.
+"""
+import ctypes as C
+
+PMX_MAXDIM = 3
+PMX_MAXRANKS = 64
+
+PMX_OK, PMX_EINVAL, PMX_EUNSUPPORTED, PMX_EHIP, PMX_EFFT, PMX_ENOMEM = range(6)
+STATUS_NAMES = {0: 'PMX_OK', 1: 'PMX_EINVAL', 2: 'PMX_EUNSUPPORTED', 3: 'PMX_EHIP',
+                4: 'PMX_EFFT', 5: 'PMX_ENOMEM'}
+
+# pmx_window_kind
+KINDS = {
+    'nearest': 0, 'linear': 1, 'quadratic': 2, 'cubic': 3,
+    'tunednnb': 4, 'tunedcic': 5, 'tunedtsc': 6, 'tunedpcs': 7,
+}
+
+PMX_FFT_R2C, PMX_FFT_C2R, PMX_FFT_C2C_FWD, PMX_FFT_C2C_BWD = range(4)
+
+
+class Painter(C.Structure):
+    _fields_ = [
+        ('kind', C.c_int32), ('support', C.c_int32), ('ndim', C.c_int32),
+        ('canvas_elsize', C.c_int32),
+        ('order', C.c_int32 * PMX_MAXDIM), ('_pad', C.c_int32),
+        ('scale', C.c_double * PMX_MAXDIM), ('translate', C.c_double * PMX_MAXDIM),
+        ('period', C.c_int64 * PMX_MAXDIM), ('size', C.c_int64 * PMX_MAXDIM),
+        ('strides', C.c_int64 * PMX_MAXDIM),
+    ]
+
+
+class Vec(C.Structure):
+    _fields_ = [
+        ('data', C.c_void_p), ('elsize', C.c_int32), ('ncol', C.c_int32),
+        ('stride0', C.c_int64), ('stride1', C.c_int64),
+    ]
+
+
+class Grid(C.Structure):
+    _fields_ = [
+        ('ndim', C.c_int32), ('periodic', C.c_int32), ('nranks', C.c_int32),
+        ('shape', C.c_int32 * PMX_MAXDIM),
+        ('edges', C.c_void_p * PMX_MAXDIM),
+        ('assign', C.c_void_p), ('degenerate', C.c_void_p),
+    ]
+
+
+class Transfer(C.Structure):
+    _fields_ = [
+        ('amplitude', C.c_double), ('laplace_pow', C.c_int32), ('grad_dir', C.c_int32),
+        ('grad_kind', C.c_int32), ('deconv_pow', C.c_int32), ('gauss_r', C.c_double),
+    ]
+
+
+_P = C.POINTER
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); names without the pmx_/pmo_ prefix
+PROTOTYPES = {
+    'window_info': (C.c_int, [_i32, _i32, _P(_i32), _P(_i32)]),
+    'fwindow': (C.c_int, [_i32, _i32, _P(_f64), _i64, _P(_f64)]),
+    'paint': (C.c_int, [_P(Painter), _vp, _P(Vec), _P(Vec), _f64, _P(Vec), _i64, _vp]),
+    'readout': (C.c_int, [_P(Painter), _vp, _P(Vec), _P(Vec), _P(Vec), _i64, _vp]),
+    'decompose_count': (C.c_int, [_P(Grid), _P(Vec), _P(_f64), _P(_f64), _i64, _vp, _vp, _vp]),
+    'decompose_fill': (C.c_int, [_i32, _vp, _i64, _vp, _vp, _i32, _vp]),
+    'take_rows': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i64, _vp, _vp]),
+    'scatter_add': (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i64, _vp, _i64, _vp]),
+    'apply_transfer': (C.c_int, [_P(Transfer), _i32, _i32, _vp, _P(_i64), _vp, _P(_i64),
+                                 _P(_i64), _P(_i64), _P(_i64), _P(_f64), _vp]),
+    'synth_uniform': (C.c_int, [_P(Vec), _i64, _f64, C.c_uint64, _i64, _i64, _vp]),
+    'synth_clustered': (C.c_int, [_P(Vec), _i64, _f64, _P(_f64), _i32, _f64, _i64, _i64, _vp]),
+}
+
+# entry points that only the device library has
+DEVICE_ONLY = {
+    'last_error': (C.c_char_p, []),
+    'version': (C.c_int, []),
+    'device_count': (C.c_int, []),
+    'binplan_create': (C.c_int, [_P(_vp), _P(Painter), _i64]),
+    'binplan_destroy': (C.c_int, [_vp]),
+    'binplan_build': (C.c_int, [_vp, _P(Painter), _P(Vec), _P(Vec), _f64, _i64, _vp]),
+    'paint_binned': (C.c_int, [_vp, _P(Painter), _vp, _vp]),
+    'readout_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _vp]),
+    'fft_create': (C.c_int, [_P(_vp), _i32, _i32, _i32, _P(_i64), _P(_i64), _i64, _P(_i64), _i64,
+                             _i64, _f64, _i32]),
+    'fft_execute': (C.c_int, [_vp, _vp, _vp, _vp]),
+    'fft_destroy': (C.c_int, [_vp]),
+    'slab_pack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
+    'slab_unpack': (C.c_int, [_vp, _vp, _P(_i64), _i32, _i64, _i64, _i32, _vp]),
+    'slab_pack_t': (C.c_int, [_vp, _vp, _P(_i64), _i32, _i64, _i64, _i32, _vp]),
+    'slab_unpack_t': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
+}
+
+
+def declare(lib, prefix, table):
+    """Attach restype/argtypes for every symbol of `table` found under `prefix`.
+    Returns the list of names that are missing from the library."""
+    missing = []
+    for name, (res, args) in table.items():
+        try:
+            fn = getattr(lib, prefix + name)
+        except AttributeError:
+            missing.append(prefix + name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    return missing
+
+
+def i64arr(seq, n=None):
+    seq = [int(x) for x in seq]
+    if n is not None:
+        seq = seq + [0] * (n - len(seq))
+    return (C.c_int64 * len(seq))(*seq)
+
+
+def f64arr(seq, n=None):
+    seq = [float(x) for x in seq]
+    if n is not None:
+        seq = seq + [0.0] * (n - len(seq))
+    return (C.c_double * len(seq))(*seq)

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import numpy
+    d = os.path.join(ROOT, 'tests', 'golden')
+    return {name: numpy.load(os.path.join(d, name + '.npz')) for name in ('window', 'decompose', 'cycle16')}
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """The CPU oracle (test infrastructure); built on demand."""
+    from oracle import oracle as O
+    O.lib('oracle')
+    return O
