@@ -1,0 +1,100 @@
+"""Moving caller arrays to the device and describing them to the C ABI.
+
+The reference is numpy-in / numpy-out.  Here particle and mesh data live in HBM
+as torch tensors (torch is only the allocator / handle); numpy arrays and lists
+are accepted for drop-in compatibility and staged through the device (the
+PCIe-inclusive path; results are copied back into the caller's array).
+"""
+import ctypes as C
+
+import numpy
+import torch
+
+from . import _abi
+
+_FLOATS = (torch.float32, torch.float64)
+
+
+def is_tensor(x):
+    return isinstance(x, torch.Tensor)
+
+
+def to_device(x, device, what='array', allow_int=False):
+    """-> (tensor on `device`, came_from_host).  Lists become float64."""
+    if is_tensor(x):
+        t = x
+        host = False
+    else:
+        a = numpy.asarray(x)
+        if a.dtype == object:
+            raise TypeError('%s: unsupported dtype object' % what)
+        if not a.flags.writeable:
+            a = a.copy()
+        if a.dtype.byteorder not in ('=', '|', '<'):
+            a = a.astype(a.dtype.newbyteorder('='))
+        # negative strides are not representable by from_numpy
+        if any(s < 0 for s in a.strides):
+            a = numpy.ascontiguousarray(a)
+        t = torch.from_numpy(a) if a.ndim else torch.tensor(a.item(), dtype=_torch_dtype(a.dtype))
+        host = True
+    if not allow_int and t.dtype not in _FLOATS:
+        # the reference's fused types are f4/f8 only (_window.pyx:6-16)
+        raise TypeError('%s must be float32 or float64, got %s '
+                        '(Function call with ambiguous argument types)' % (what, t.dtype))
+    if t.device != device:
+        t = t.to(device)
+    return t, host
+
+
+def _torch_dtype(dt):
+    return {'f4': torch.float32, 'f8': torch.float64, 'i4': torch.int32, 'i8': torch.int64,
+            'c8': torch.complex64, 'c16': torch.complex128, 'i2': torch.int16,
+            'u1': torch.uint8, 'b1': torch.bool}[numpy.dtype(dt).str[1:]]
+
+
+def torch_dtype(dt):
+    if isinstance(dt, torch.dtype):
+        return dt
+    return _torch_dtype(dt)
+
+
+def numpy_dtype(dt):
+    return {torch.float32: numpy.dtype('f4'), torch.float64: numpy.dtype('f8'),
+            torch.complex64: numpy.dtype('c8'), torch.complex128: numpy.dtype('c16'),
+            torch.int32: numpy.dtype('i4'), torch.int64: numpy.dtype('i8'),
+            torch.int16: numpy.dtype('i2')}[dt]
+
+
+def vec(t):
+    """pmx_vec describing a 1-d or 2-d float tensor (any strides)."""
+    v = _abi.Vec()
+    if t is None:
+        return v
+    es = t.element_size()
+    v.data = t.data_ptr()
+    v.elsize = es
+    if t.dim() == 0:
+        v.ncol = 1
+        v.stride0 = 0
+        v.stride1 = 0
+    elif t.dim() == 1:
+        v.ncol = 1
+        v.stride0 = t.stride(0) * es
+        v.stride1 = 0
+    else:
+        v.ncol = t.shape[1]
+        v.stride0 = t.stride(0) * es
+        v.stride1 = t.stride(1) * es
+    return v
+
+
+def vec_ref(v):
+    return C.byref(v) if v is not None else None
+
+
+def real_view(t):
+    """The float view of a canvas: complex canvases paint into their real part
+    (window.py:161-162 `real = real.real`)."""
+    if t.is_complex():
+        return torch.view_as_real(t)[..., 0]
+    return t

@@ -1,0 +1,124 @@
+"""Kernel backend: the one place where the host layer meets native code.
+
+The product backend is :class:`HipBackend`: it loads ``libpmesh_amd.so`` (the
+C ABI of include/pmesh_amd.h, hand-written HIP kernels for gfx950 + rocFFT) and
+runs on a real GPU.  There is NO CPU implementation in this package: if the
+library or the GPU is missing, :func:`get` raises — it never falls back.
+
+``use(backend)`` exists so that tests can drive the host logic (argument
+handling, layouts, the distributed FFT schedule, torch.distributed collectives
+over gloo) against the CPU oracle on machines without a GPU; the object they
+install lives in tests/, not here.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBNAME = 'libpmesh_amd.so'
+
+
+class PmxError(RuntimeError):
+    def __init__(self, what, code, msg=''):
+        self.code = code
+        RuntimeError.__init__(self, '%s failed: %s%s' % (
+            what, _abi.STATUS_NAMES.get(code, code), (' — ' + msg) if msg else ''))
+
+
+def library_path():
+    return os.path.join(_HERE, LIBNAME)
+
+
+def load_library(path=None):
+    """dlopen the C ABI and declare every prototype; raises if it is missing
+    or lacks a symbol that include/pmesh_amd.h declares."""
+    path = path or library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            '%s not found: build it with `make -C pmesh_amd/csrc` (hipcc, gfx950). '
+            'There is no CPU fallback.' % path)
+    lib = C.CDLL(path)
+    missing = _abi.declare(lib, 'pmx_', _abi.PROTOTYPES)
+    missing += _abi.declare(lib, 'pmx_', _abi.DEVICE_ONLY)
+    if missing:
+        raise ImportError('%s lacks symbols declared in include/pmesh_amd.h: %s' % (path, missing))
+    return lib
+
+
+class HipBackend(object):
+    """libpmesh_amd.so on cuda:<index> (ROCm)."""
+    name = 'hip'
+    prefix = 'pmx_'
+
+    def __init__(self, device_index=None):
+        self.lib = load_library()
+        if self.lib.pmx_device_count() < 1 or not torch.cuda.is_available():
+            raise RuntimeError('pmesh_amd needs an AMD GPU (gfx950): no HIP device is visible. '
+                               'There is no CPU fallback.')
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device = torch.device('cuda', device_index)
+
+    # -- plumbing ---------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, 'pmx_' + name)(*args)
+        if rc != 0:
+            raise PmxError('pmx_' + name, rc, self.lib.pmx_last_error().decode())
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # -- FFT plans --------------------------------------------------------
+    def fft_create(self, kind, elsize, n, istride, idist, ostride, odist, batch, scale, inplace):
+        plan = C.c_void_p()
+        nd = len(n)
+        self.call('fft_create', C.byref(plan), kind, elsize, nd, _abi.i64arr(n), _abi.i64arr(istride),
+                  idist, _abi.i64arr(ostride), odist, batch, float(scale), int(bool(inplace)))
+        return plan
+
+    def fft_execute(self, plan, tin, tout):
+        self.call('fft_execute', plan, tin.data_ptr(), tout.data_ptr(), self.stream())
+
+    def fft_destroy(self, plan):
+        self.call('fft_destroy', plan)
+
+    # -- slab transposes --------------------------------------------------
+    def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
+        name = 'slab_unpack_t' if inverse else 'slab_pack'
+        self.call(name, src.data_ptr(), dst.data_ptr(), n0, n1, n2, _abi.i64arr(n1_offsets),
+                  len(n1_offsets) - 1, elbytes, self.stream())
+
+    def slab_unpack(self, src, dst, n0_offsets, n1loc, n2, elbytes, inverse=False):
+        name = 'slab_pack_t' if inverse else 'slab_unpack'
+        self.call(name, src.data_ptr(), dst.data_ptr(), _abi.i64arr(n0_offsets),
+                  len(n0_offsets) - 1, n1loc, n2, elbytes, self.stream())
+
+
+_current = None
+
+
+def use(backend):
+    """Install a backend object (tests only; see module docstring)."""
+    global _current
+    _current = backend
+    return backend
+
+
+def get():
+    """The active backend; creates the HIP backend on first use and raises if
+    that is impossible."""
+    global _current
+    if _current is None:
+        _current = HipBackend()
+    return _current
+
+
+def reset():
+    global _current
+    _current = None

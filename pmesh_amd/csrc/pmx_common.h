@@ -1,0 +1,78 @@
+// pmx_common.h — shared host/device helpers of libpmesh_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/pmesh_amd.h"
+
+namespace pmx {
+
+void set_error(const char *fmt, ...);
+
+#define PMX_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            pmx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                 \
+                           hipGetErrorString(_e));                                       \
+            return PMX_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
+
+#define PMX_REQUIRE(cond, code, msg)                                                     \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            pmx::set_error("%s:%d: %s (%s)", __FILE__, __LINE__, msg, #cond);            \
+            return code;                                                                 \
+        }                                                                                \
+    } while (0)
+
+// Device-side copy of a pmx_vec (passed by value as a kernel argument).
+struct DVec {
+    const char *data;
+    int64_t stride0, stride1;
+    int32_t elsize;
+    __device__ __forceinline__ double get(int64_t i, int c) const
+    {
+        const char *p = data + i * stride0 + c * stride1;
+        return elsize == 8 ? *(const double *)p : (double)*(const float *)p;
+    }
+    __device__ __forceinline__ void set(int64_t i, int c, double v) const
+    {
+        char *p = const_cast<char *>(data) + i * stride0 + c * stride1;
+        if (elsize == 8) *(double *)p = v;
+        else *(float *)p = (float)v;
+    }
+};
+
+inline DVec dvec(const pmx_vec *v)
+{
+    DVec d;
+    if (v && v->data) {
+        d.data = (const char *)v->data;
+        d.stride0 = v->stride0;
+        d.stride1 = v->stride1;
+        d.elsize = v->elsize;
+    } else {
+        d.data = nullptr;
+        d.stride0 = d.stride1 = 0;
+        d.elsize = 8;
+    }
+    return d;
+}
+
+inline bool vec_ok(const pmx_vec *v) { return v && v->data && (v->elsize == 4 || v->elsize == 8); }
+
+// Grid sizing for HBM-bound streaming kernels: enough workgroups to fill
+// 256 CUs several times over, grid-stride for the rest.
+inline unsigned grid_for(int64_t n, int block, int64_t cap = 256 * 32)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace pmx

@@ -1,0 +1,540 @@
+// pmx_window.hip — paint / readout, direct form (one thread per particle).
+//
+// Replaces the reference's per-particle C kernels and the Python-level loop
+// around them: pmesh/_window.pyx:128-205 -> pmesh/_window_generics.h:4-142 ->
+// pmesh/_window_tuned_{nnb,cic,tsc,pcs}.h.  Arithmetic follows SURVEY.md
+// Appendix A: positions are widened to double, X = pos*scale + translate is a
+// separate multiply and add (this library is built with -ffp-contract=off),
+// the base index is (int)floor(X) [CIC/PCS] or (int)floor(X+0.5) [NNB/TSC],
+// weights use the UNWRAPPED indices and each sub-expression is written as in
+// the reference header so that weights are bit-identical; the window product
+// is ((V0*mass)*V1)*V2, left to right.
+//
+// This file is the order-independent baseline: it works for particles in any
+// order and canvases with any strides, scattering with hardware
+// global_atomic_add_f64/f32.  The LDS-tiled kernels for tile-sorted particles
+// are in pmx_binned.hip.
+//
+// Deliberate, documented deviations (the reference's behaviour there is
+// undefined): a particle whose grid coordinate is NaN or |X| >= 2^30 is
+// dropped (the reference spins in its wrap loop or overflows the int cast).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "pmx_common.h"
+
+namespace pmx {
+
+__host__ __device__ inline int native_support(int kind)
+{
+    switch (kind) {
+    case PMX_NEAREST: case PMX_TUNED_NNB: return 1;
+    case PMX_LINEAR: case PMX_TUNED_CIC: return 2;
+    case PMX_QUADRATIC: case PMX_TUNED_TSC: return 3;
+    case PMX_CUBIC: case PMX_TUNED_PCS: return 4;
+    }
+    return -1;
+}
+
+struct WInfo {
+    int support;
+    int left;
+    double vfactor, shift;
+};
+
+// pmesh_window_info_init (_window_imp.c:24-47)
+__host__ __device__ inline WInfo winfo_init(int nativesupport, double support)
+{
+    WInfo w;
+    if (support <= 0) {
+        w.support = nativesupport;
+        support = nativesupport;
+    } else {
+        w.support = (int)support;
+        w.support += (support != (double)w.support);
+    }
+    w.left = (w.support - 1) / 2;
+    w.shift = support / 2.0 - w.support / 2;
+    w.vfactor = nativesupport / (1. * support);
+    return w;
+}
+
+__device__ __forceinline__ int wrap1(int i, int64_t n)
+{
+    if (n <= 0) return i;
+    int m = (int)n;
+    int r = i % m;
+    return r < 0 ? r + m : r;
+}
+
+// ---- one axis of SETUP_KERNEL_* (tuned_nnb.h:1-27, tuned_cic.h:1-32,
+//      tuned_tsc.h:1-37, tuned_pcs.h:1-52) ---------------------------------
+template <int KIND> struct Tuned;
+
+template <> struct Tuned<PMX_TUNED_NNB> {
+    static constexpr int S = 1;
+    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
+    {
+        I[0] = (int)floor(X + 0.5);
+        V[0] = (order == 0) ? 1 : 0;
+    }
+};
+
+template <> struct Tuned<PMX_TUNED_CIC> {
+    static constexpr int S = 2;
+    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
+    {
+        I[0] = (int)floor(X);
+        I[1] = I[0] + 1;
+        if (order == 0) {
+            V[1] = X - I[0];
+            V[0] = 1. - V[1];
+        } else {
+            V[1] = scale;
+            V[0] = -scale;
+        }
+    }
+};
+
+template <> struct Tuned<PMX_TUNED_TSC> {
+    static constexpr int S = 3;
+    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
+    {
+        I[1] = (int)floor(X + 0.5);
+        I[0] = I[1] - 1;
+        I[2] = I[1] + 1;
+        if (order == 0) {
+            V[1] = 0.75 - (X - I[1]) * (X - I[1]);
+            V[0] = (1.5 - (X - I[0])) * (1.5 - (X - I[0])) * 0.5;
+            V[2] = (1.5 + (X - I[2])) * (1.5 + (X - I[2])) * 0.5;
+        } else {
+            V[1] = -2 * (X - I[1]) * scale;
+            V[0] = -(1.5 - (X - I[0])) * scale;
+            V[2] = (1.5 + (X - I[2])) * scale;
+        }
+    }
+};
+
+template <> struct Tuned<PMX_TUNED_PCS> {
+    static constexpr int S = 4;
+    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
+    {
+        I[1] = (int)floor(X);
+        I[0] = I[1] - 1;
+        I[2] = I[1] + 1;
+        I[3] = I[2] + 1;
+        if (order == 0) {
+            V[1] = 1.0 / 6.0 * (4 - 6 * (X - I[1]) * (X - I[1]) + 3 * (X - I[1]) * (X - I[1]) * (X - I[1]));
+            V[2] = 1.0 / 6.0 * (4 - 6 * (X - I[2]) * (X - I[2]) - 3 * (X - I[2]) * (X - I[2]) * (X - I[2]));
+            V[0] = 1.0 / 6.0 * (2 - (X - I[0])) * (2 - (X - I[0])) * (2 - (X - I[0]));
+            V[3] = 1.0 / 6.0 * (2 + (X - I[3])) * (2 + (X - I[3])) * (2 + (X - I[3]));
+        } else {
+            // quirk Q1: no scale factor in the tuned PCS derivative
+            V[1] = +1.0 / 6.0 * (-12 * (X - I[1]) + 9 * (X - I[1]) * (X - I[1]));
+            V[2] = -1.0 / 6.0 * (+12 * (X - I[2]) + 9 * (X - I[2]) * (X - I[2]));
+            V[0] = -1.0 / 2.0 * (2 - (X - I[0])) * (2 - (X - I[0]));
+            V[3] = +1.0 / 2.0 * (2 + (X - I[3])) * (2 + (X - I[3]));
+        }
+    }
+};
+
+template <typename T> __device__ __forceinline__ void canvas_add(char *canvas, int64_t off, double f)
+{
+    unsafeAtomicAdd((T *)(canvas + off), (T)f);
+}
+
+// _{nnb,cic,tsc,pcs}_tuned_{paint,readout}{1,2,3}.  `nd` is a compile-time
+// constant at the fast-path call sites (the loops unroll) and a run-time value
+// in the general kernel.
+template <int KIND, typename T, bool PAINT>
+__device__ __forceinline__ double tuned_particle(const pmx_painter &p, char *canvas,
+                                                 const double *x, double mass, int nd)
+{
+    constexpr int S = Tuned<KIND>::S;
+    int I[PMX_MAXDIM][S];
+    double V[PMX_MAXDIM][S];
+#pragma unroll
+    for (int d = 0; d < PMX_MAXDIM; d++) {
+        if (d >= nd) break;
+        double X = x[d] * p.scale[d] + p.translate[d];
+        if (!(fabs(X) < 1073741824.0)) return 0.0;  // NaN / out of int range: dropped
+        Tuned<KIND>::axis(X, p.order[d], p.scale[d], I[d], V[d]);
+        // consecutive indices: wrap the first, step the rest
+        int r = wrap1(I[d][0], p.period[d]);
+        I[d][0] = r;
+#pragma unroll
+        for (int a = 1; a < S; a++) {
+            r = r + 1;
+            if (p.period[d] > 0) {
+                while (r >= p.period[d]) r -= (int)p.period[d];
+            }
+            I[d][a] = r;
+        }
+    }
+    if (PAINT) {
+#pragma unroll
+        for (int a = 0; a < S; a++) V[0][a] *= mass;
+    }
+    const int Sb = nd > 1 ? S : 1, Sc = nd > 2 ? S : 1;
+    double value = 0;
+#pragma unroll
+    for (int a = 0; a < S; a++) {
+        bool in0 = !(I[0][a] < 0 || I[0][a] >= p.size[0]);
+        int64_t off0 = I[0][a] * p.strides[0];
+#pragma unroll
+        for (int b = 0; b < S; b++) {
+            if (b >= Sb) break;
+            double fb = V[0][a];
+            bool in1 = in0;
+            int64_t off1 = off0;
+            if (nd > 1) {
+                fb = fb * V[1][b];
+                in1 = in1 && !(I[1][b] < 0 || I[1][b] >= p.size[1]);
+                off1 += I[1][b] * p.strides[1];
+            }
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+                if (c >= Sc) break;
+                double f = fb;
+                bool in2 = in1;
+                int64_t off = off1;
+                if (nd > 2) {
+                    f = f * V[2][c];
+                    in2 = in2 && !(I[2][c] < 0 || I[2][c] >= p.size[2]);
+                    off += I[2][c] * p.strides[2];
+                }
+                if (PAINT) {
+                    if (in2) canvas_add<T>(canvas, off, f);
+                } else {
+                    // _REd3 returns 0 outside (generics.h:162-167)
+                    value += in2 ? (double)(*(const T *)(canvas + off)) * f : 0.0;
+                }
+            }
+        }
+    }
+    return value;
+}
+
+template <int KIND, int ND, typename T>
+__global__ void __launch_bounds__(256) paint_tuned_kernel(pmx_painter p, char *canvas, DVec pos,
+                                                          DVec mass, double mass_scalar, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double x[PMX_MAXDIM];
+#pragma unroll
+        for (int d = 0; d < ND; d++) x[d] = pos.get(i, d);
+        double m = mass.data ? mass.get(i, 0) : mass_scalar;
+        tuned_particle<KIND, T, true>(p, canvas, x, m, ND);
+    }
+}
+
+template <int KIND, int ND, typename T>
+__global__ void __launch_bounds__(256) readout_tuned_kernel(pmx_painter p, const char *canvas,
+                                                            DVec pos, DVec out, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double x[PMX_MAXDIM];
+#pragma unroll
+        for (int d = 0; d < ND; d++) x[d] = pos.get(i, d);
+        double v = tuned_particle<KIND, T, false>(p, const_cast<char *>(canvas), x, 0.0, ND);
+        out.set(i, 0, v);
+    }
+}
+
+// ---- analytic kernels of the generic path (_window_imp.c:108-236) ---------
+__device__ inline double k_eval(int kind, double x)
+{
+    switch (kind) {
+    case PMX_NEAREST: case PMX_TUNED_NNB:
+        return (x < 0.5 && x >= -0.5) ? 1.0 : 0.0;
+    case PMX_LINEAR: case PMX_TUNED_CIC:
+        x = fabs(x);
+        return (x < 1.0) ? 1.0 - x : 0.0;
+    case PMX_QUADRATIC: case PMX_TUNED_TSC:
+        x = fabs(x);
+        if (x <= 0.5) return 0.75 - x * x;
+        if (x < 1.5) { x = 1.5 - x; return (x * x) * 0.5; }
+        return 0;
+    default: {
+        x = fabs(x);
+        double xx = x * x;
+        if (x < 1.0) return 1.0 / 6.0 * (4 - 6 * xx + 3 * xx * x);
+        if (x < 2) return 1.0 / 6.0 * (2 - x) * (2 - x) * (2 - x);
+        return 0;
+    }
+    }
+}
+
+__device__ inline double d_eval(int kind, double x)
+{
+    double factor;
+    switch (kind) {
+    case PMX_NEAREST: case PMX_TUNED_NNB:
+        return 0;
+    case PMX_LINEAR: case PMX_TUNED_CIC:
+        if (x < 0) { factor = 1; x = -x; }
+        else if (x > 0) factor = -1;
+        else factor = 0;
+        return (x < 1.0) ? factor : 0.0;
+    case PMX_QUADRATIC: case PMX_TUNED_TSC:
+        if (x < 0) { x = -x; factor = -1; } else factor = +1;
+        if (x <= 0.5) return factor * (-2 * x);
+        if (x < 1.5) return factor * (-(1.5 - x));
+        return 0;
+    default: {
+        if (x < 0) { factor = -1; x = -x; } else factor = +1;
+        double xx = x * x;
+        if (x < 1.0) return factor * (1.0 / 6.0) * (-12 * x + 9 * xx);
+        if (x < 2.0) return factor * (-1.0 / 2.0) * (2 - x) * (2 - x);
+        return 0;
+    }
+    }
+}
+
+template <typename T, bool PAINT>
+__device__ double tuned_dispatch(const pmx_painter &p, char *canvas, const double *x, double m)
+{
+    switch (p.kind) {
+    case PMX_TUNED_NNB: return tuned_particle<PMX_TUNED_NNB, T, PAINT>(p, canvas, x, m, p.ndim);
+    case PMX_TUNED_CIC: return tuned_particle<PMX_TUNED_CIC, T, PAINT>(p, canvas, x, m, p.ndim);
+    case PMX_TUNED_TSC: return tuned_particle<PMX_TUNED_TSC, T, PAINT>(p, canvas, x, m, p.ndim);
+    default: return tuned_particle<PMX_TUNED_PCS, T, PAINT>(p, canvas, x, m, p.ndim);
+    }
+}
+
+// _generic_paint / _generic_readout (_window_generics.h:4-142) with _fill_k
+// (_window_imp.c:50-83): any kind, any integer support <= 32, per-particle
+// hsml; tuned kinds take their fast path per particle when the integer support
+// equals the native one (quirk Q6).  p.support holds the effective integer
+// support of the window object (pmesh_painter_init, _window_imp.c:456-458).
+template <typename T, bool PAINT>
+__global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canvas, DVec pos,
+                                                      DVec mass, double mass_scalar, DVec hsml,
+                                                      DVec out, int64_t n)
+{
+    const int nd = p.ndim;
+    const int ns = native_support(p.kind);
+    const bool tuned = p.kind >= PMX_TUNED_NNB;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double x[PMX_MAXDIM];
+        for (int d = 0; d < nd; d++) x[d] = pos.get(i, d);
+        double m = PAINT ? (mass.data ? mass.get(i, 0) : mass_scalar) : 0.0;
+        double h = hsml.data ? hsml.get(i, 0) : 1.0;
+        WInfo w = winfo_init(ns, p.support * h);
+        double value = 0;
+        if (tuned && w.support == ns) {
+            value = tuned_dispatch<T, PAINT>(p, canvas, x, m);
+        } else if (w.support <= PMX_MAXSUPPORT) {
+            int ipos[PMX_MAXDIM];
+            double k[PMX_MAXDIM][PMX_MAXSUPPORT];
+            bool finite = true;
+            for (int d = 0; d < nd; d++) {
+                double g = x[d] * p.scale[d] + p.translate[d];
+                if (!(fabs(g) < 1073741824.0)) { finite = false; break; }
+                ipos[d] = (int)(floor(g + w.shift) - w.left);
+                double dx = g - ipos[d];
+                for (int j = 0; j < w.support; j++) {
+                    double xx = (dx - j) * w.vfactor;
+                    if (p.order[d] == 0) k[d][j] = k_eval(p.kind, xx) * w.vfactor;
+                    else k[d][j] = d_eval(p.kind, xx) * p.scale[d] * w.vfactor * w.vfactor;
+                }
+            }
+            if (finite) {
+                int rel[PMX_MAXDIM] = {0, 0, 0};
+                const int s2 = w.support;
+                while (rel[0] != s2) {
+                    double kernel = 1.0;
+                    int64_t ind = 0;
+                    bool outside = false;
+                    for (int d = 0; d < nd; d++) {
+                        int r = rel[d];
+                        kernel *= k[d][r];
+                        int t = wrap1(ipos[d] + r, p.period[d]);
+                        if (t >= p.size[d] || t < 0) { outside = true; break; }
+                        ind += p.strides[d] * t;
+                    }
+                    if (!outside) {
+                        if (PAINT) canvas_add<T>(canvas, ind, m * kernel);
+                        else value += kernel * (double)(*(const T *)(canvas + ind));
+                    }
+                    rel[nd - 1]++;
+                    for (int d = nd - 1; d > 0; d--)
+                        if (rel[d] == s2) { rel[d - 1]++; rel[d] = 0; }
+                }
+            }
+        }
+        if (!PAINT) out.set(i, 0, value);
+    }
+}
+
+static int check_painter(const pmx_painter *p)
+{
+    PMX_REQUIRE(p != nullptr, PMX_EINVAL, "painter is NULL");
+    PMX_REQUIRE(p->ndim >= 1 && p->ndim <= PMX_MAXDIM, PMX_EUNSUPPORTED, "ndim must be 1..3");
+    PMX_REQUIRE(p->canvas_elsize == 4 || p->canvas_elsize == 8, PMX_EINVAL,
+                "canvas must be float or double (_window.pyx:135)");
+    PMX_REQUIRE(native_support(p->kind) > 0, PMX_EUNSUPPORTED, "window kind not built");
+    for (int d = 0; d < p->ndim; d++) {
+        PMX_REQUIRE(p->period[d] >= 0 && p->period[d] < (1 << 30), PMX_EINVAL, "bad period");
+        PMX_REQUIRE(p->size[d] >= 0 && p->size[d] < (1ll << 31), PMX_EINVAL, "bad size");
+    }
+    return PMX_OK;
+}
+
+template <int KIND, typename T>
+static void launch_paint_nd(const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
+                            int64_t n, hipStream_t st)
+{
+    dim3 block(256), grid(grid_for(n, 256));
+    switch (p.ndim) {
+    case 1: paint_tuned_kernel<KIND, 1, T><<<grid, block, 0, st>>>(p, (char *)canvas, pos, mass, ms, n); break;
+    case 2: paint_tuned_kernel<KIND, 2, T><<<grid, block, 0, st>>>(p, (char *)canvas, pos, mass, ms, n); break;
+    default: paint_tuned_kernel<KIND, 3, T><<<grid, block, 0, st>>>(p, (char *)canvas, pos, mass, ms, n); break;
+    }
+}
+
+template <int KIND, typename T>
+static void launch_readout_nd(const pmx_painter &p, const void *canvas, DVec pos, DVec out,
+                              int64_t n, hipStream_t st)
+{
+    dim3 block(256), grid(grid_for(n, 256));
+    switch (p.ndim) {
+    case 1: readout_tuned_kernel<KIND, 1, T><<<grid, block, 0, st>>>(p, (const char *)canvas, pos, out, n); break;
+    case 2: readout_tuned_kernel<KIND, 2, T><<<grid, block, 0, st>>>(p, (const char *)canvas, pos, out, n); break;
+    default: readout_tuned_kernel<KIND, 3, T><<<grid, block, 0, st>>>(p, (const char *)canvas, pos, out, n); break;
+    }
+}
+
+template <typename T>
+static void launch_paint_kind(const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
+                              int64_t n, hipStream_t st)
+{
+    switch (p.kind) {
+    case PMX_TUNED_NNB: launch_paint_nd<PMX_TUNED_NNB, T>(p, canvas, pos, mass, ms, n, st); break;
+    case PMX_TUNED_CIC: launch_paint_nd<PMX_TUNED_CIC, T>(p, canvas, pos, mass, ms, n, st); break;
+    case PMX_TUNED_TSC: launch_paint_nd<PMX_TUNED_TSC, T>(p, canvas, pos, mass, ms, n, st); break;
+    default: launch_paint_nd<PMX_TUNED_PCS, T>(p, canvas, pos, mass, ms, n, st); break;
+    }
+}
+
+template <typename T>
+static void launch_readout_kind(const pmx_painter &p, const void *canvas, DVec pos, DVec out,
+                                int64_t n, hipStream_t st)
+{
+    switch (p.kind) {
+    case PMX_TUNED_NNB: launch_readout_nd<PMX_TUNED_NNB, T>(p, canvas, pos, out, n, st); break;
+    case PMX_TUNED_CIC: launch_readout_nd<PMX_TUNED_CIC, T>(p, canvas, pos, out, n, st); break;
+    case PMX_TUNED_TSC: launch_readout_nd<PMX_TUNED_TSC, T>(p, canvas, pos, out, n, st); break;
+    default: launch_readout_nd<PMX_TUNED_PCS, T>(p, canvas, pos, out, n, st); break;
+    }
+}
+
+// true if every particle takes the tuned fast path
+static bool is_fast(const pmx_painter &p, const pmx_vec *hsml)
+{
+    if (p.kind < PMX_TUNED_NNB) return false;
+    if (hsml && hsml->data) return false;
+    WInfo w = winfo_init(native_support(p.kind), (double)p.support);
+    return w.support == native_support(p.kind);
+}
+
+}  // namespace pmx
+
+using namespace pmx;
+
+extern "C" int pmx_window_info(int32_t kind, int32_t support, int32_t *nativesupport,
+                               int32_t *eff_support)
+{
+    int ns = native_support(kind);
+    PMX_REQUIRE(ns > 0, PMX_EUNSUPPORTED, "window kind not built");
+    WInfo w = winfo_init(ns, (double)support);
+    if (nativesupport) *nativesupport = ns;
+    if (eff_support) *eff_support = w.support;
+    return PMX_OK;
+}
+
+static double sinc_unnormed(double x)
+{
+    // _window_imp.c:13-22
+    if (x < 1e-5 && x > -1e-5) {
+        double x2 = x * x;
+        return 1.0 - x2 / 6. + x2 * x2 / 120.;
+    }
+    return sin(x) / x;
+}
+
+extern "C" int pmx_fwindow(int32_t kind, int32_t support, const double *w, int64_t n, double *out)
+{
+    int ns = native_support(kind);
+    PMX_REQUIRE(ns > 0, PMX_EUNSUPPORTED, "window kind not built");
+    WInfo wi = winfo_init(ns, (double)support);
+    for (int64_t i = 0; i < n; i++) {
+        // pmesh_painter_get_fwindow (_window_imp.c:473-485): sinc^p at w / vfactor
+        double t = sinc_unnormed(0.5 * (w[i] / wi.vfactor));
+        double r = t;
+        for (int q = 1; q < ns; q++) r = r * t;
+        out[i] = r;
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_paint(const pmx_painter *p_, void *canvas, const pmx_vec *pos,
+                         const pmx_vec *mass, double mass_scalar, const pmx_vec *hsml,
+                         int64_t npart, void *stream)
+{
+    int rc = check_painter(p_);
+    if (rc) return rc;
+    if (npart == 0) return PMX_OK;  // empty pos: no-op
+    PMX_REQUIRE(canvas != nullptr, PMX_EINVAL, "canvas is NULL");
+    PMX_REQUIRE(vec_ok(pos) && pos->ncol >= p_->ndim, PMX_EINVAL, "pos must be (n, >=ndim) f4/f8");
+    PMX_REQUIRE(!mass || !mass->data || vec_ok(mass), PMX_EINVAL, "mass must be f4/f8");
+    PMX_REQUIRE(!hsml || !hsml->data || vec_ok(hsml), PMX_EINVAL, "hsml must be f4/f8");
+    pmx_painter p = *p_;
+    // effective integer support of the window object (_window_imp.c:456-458)
+    p.support = winfo_init(native_support(p.kind), (double)p.support).support;
+    hipStream_t st = (hipStream_t)stream;
+    DVec dpos = dvec(pos), dmass = dvec(mass), dh = dvec(hsml), none = dvec(nullptr);
+    if (is_fast(*p_, hsml)) {
+        if (p.canvas_elsize == 8) launch_paint_kind<double>(p, canvas, dpos, dmass, mass_scalar, npart, st);
+        else launch_paint_kind<float>(p, canvas, dpos, dmass, mass_scalar, npart, st);
+    } else {
+        dim3 block(256), grid(grid_for(npart, 256));
+        if (p.canvas_elsize == 8)
+            general_kernel<double, true><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart);
+        else
+            general_kernel<float, true><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart);
+    }
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_readout(const pmx_painter *p_, const void *canvas, const pmx_vec *pos,
+                           const pmx_vec *hsml, const pmx_vec *out, int64_t npart, void *stream)
+{
+    int rc = check_painter(p_);
+    if (rc) return rc;
+    if (npart == 0) return PMX_OK;
+    PMX_REQUIRE(canvas != nullptr, PMX_EINVAL, "canvas is NULL");
+    PMX_REQUIRE(vec_ok(pos) && pos->ncol >= p_->ndim, PMX_EINVAL, "pos must be (n, >=ndim) f4/f8");
+    PMX_REQUIRE(vec_ok(out), PMX_EINVAL, "out must be f4/f8");
+    PMX_REQUIRE(!hsml || !hsml->data || vec_ok(hsml), PMX_EINVAL, "hsml must be f4/f8");
+    pmx_painter p = *p_;
+    p.support = winfo_init(native_support(p.kind), (double)p.support).support;
+    hipStream_t st = (hipStream_t)stream;
+    DVec dpos = dvec(pos), dh = dvec(hsml), dout = dvec(out), none = dvec(nullptr);
+    if (is_fast(*p_, hsml)) {
+        if (p.canvas_elsize == 8) launch_readout_kind<double>(p, canvas, dpos, dout, npart, st);
+        else launch_readout_kind<float>(p, canvas, dpos, dout, npart, st);
+    } else {
+        dim3 block(256), grid(grid_for(npart, 256));
+        if (p.canvas_elsize == 8)
+            general_kernel<double, false><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart);
+        else
+            general_kernel<float, false><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart);
+    }
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}

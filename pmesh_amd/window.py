@@ -1,0 +1,313 @@
+"""Resampling windows: the host-side mirror of ``pmesh/window.py``.
+
+Same names, arguments and error behaviour as the reference module
+(pmesh/window.py:18-263): ``Affine``, ``ResampleWindow`` with ``paint`` /
+``readout`` / ``get_fwindow`` / ``get_compensation`` / ``resize``,
+``FindResampler`` and the ``windows`` registry.  The arithmetic is NOT here: it
+runs in the HIP kernels of csrc/pmx_window.hip (direct) and csrc/pmx_binned.hip
+(LDS-tiled) behind ``pmx_paint`` / ``pmx_readout`` (include/pmesh_amd.h), which
+replace the per-particle C API of pmesh/_window_imp.h:76-86 and the Cython loop
+of pmesh/_window.pyx:128-205.
+"""
+import ctypes as C
+
+import numpy
+import torch
+
+from . import _abi, backend
+from ._arrays import to_device, vec, vec_ref, real_view, is_tensor
+
+
+def _mkarr(var, shape, dtype):
+    # window.py:6-16
+    var = numpy.asarray(var, dtype=dtype)
+    if numpy.isscalar(shape):
+        shape = (int(shape),)
+    r = numpy.empty(shape, dtype)
+    r[...] = var
+    return r
+
+
+class Affine(object):
+    """ Defines an affine Transformation, used by ResampleWindow (window.py:18-55).
+
+        Parameters
+        ----------
+            translate : array_like, in integer mesh units.
+            period : array_like in integer mesh units.
+            scale : factor that multiples on position to obtain mesh units.
+    """
+    def __init__(self, ndim, scale=None, translate=None, period=None):
+        if scale is None:
+            scale = 1.0
+        if translate is None:
+            translate = 0
+        if period is None:
+            period = 0
+        self.scale = _mkarr(scale, ndim, 'f8')
+        self.period = _mkarr(period, ndim, 'intp')
+        self.translate = _mkarr(translate, ndim, 'f8')
+        self.ndim = ndim
+
+    def rescale(self, amount):
+        """ Returns a new Affine where the scale is multipled by amount. """
+        return Affine(self.ndim, self.scale * amount, self.translate, self.period)
+
+    def shift(self, amount):
+        """ Returns a new Affine where the translate is shifted by amount
+            (integer mesh units, as translate). """
+        return Affine(self.ndim, self.scale, self.translate + amount, self.period)
+
+
+# kinds of the reference registry that are table driven (lanczos/acg/db/sym,
+# _window_lanczos.h etc.): outside the hot-path scope table (SURVEY.md 2.1 #5b)
+_UNBUILT = ['lanczos2', 'lanczos3', 'lanczos4', 'lanczos5', 'lanczos6',
+            'acg2', 'acg3', 'acg4', 'acg5', 'acg6', 'db6', 'db12', 'db20', 'sym6', 'sym12', 'sym20']
+
+
+class ResampleWindow(object):
+    """A resampling window (window.py:57-221; _window.pyx:67-126).
+
+    Attributes ``kind``, ``support`` (effective integer support) and
+    ``nativesupport`` as in the reference.
+    """
+
+    def __init__(self, kind, support=-1):
+        self.kind = kind
+        if kind in _UNBUILT:
+            self._k = None
+            self.nativesupport = -1
+            self.support = support
+            return
+        if kind not in _abi.KINDS:
+            raise ValueError('unknown window kind %r' % (kind,))
+        self._k = _abi.KINDS[kind]
+        native = {0: 1, 4: 1, 1: 2, 5: 2, 2: 3, 6: 3, 3: 4, 7: 4}[self._k]
+        # pmesh_window_info_init (_window_imp.c:24-47): support <= 0 means native
+        self.nativesupport = native
+        self.support = native if support <= 0 else int(support)
+        self._support_arg = int(support)
+
+    def _require_built(self):
+        if self._k is None:
+            raise NotImplementedError(
+                "window kind %r is table driven (lanczos/acg/wavelet) and is outside the "
+                "GPU hot path built so far; use nnb/cic/tsc/pcs or nearest/linear/quadratic/cubic"
+                % (self.kind,))
+
+    def resize(self, support):
+        """ Change the support of the window, returning a new window. """
+        return ResampleWindow(self.kind, support)
+
+    def get_compensation(self):
+        """ Return a function that compensates the resampling window by deconvolving in
+            Fourier space; usable as an argument of ComplexField.apply with kind='circular'
+            (window.py:65-80). """
+        def function(w, v):
+            tf = 1.0
+            for wi in w:
+                tf = tf * self.get_fwindow(wi)
+            return v / tf
+        return function
+
+    def get_fwindow(self, w):
+        """ 1d fourier space window T(w) at circular frequencies w (window.py:82-104);
+            1 if the window has no analytic transform. Evaluated on the host: it feeds
+            init-time compensation tables, not the particle path. """
+        self._require_built()
+        dev = w.device if is_tensor(w) else None
+        wh = w.detach().cpu().numpy() if is_tensor(w) else w
+        w1d = numpy.ascontiguousarray(numpy.reshape(wh, -1).astype('float64'))
+        T = numpy.zeros_like(w1d)
+        be = backend.get()
+        be.call('fwindow', self._k, self.support,
+                w1d.ctypes.data_as(C.POINTER(C.c_double)), len(w1d),
+                T.ctypes.data_as(C.POINTER(C.c_double)))
+        T = T.reshape(numpy.shape(wh))
+        if dev is not None:
+            return torch.from_numpy(T).to(dev)
+        return T
+
+    # ------------------------------------------------------------------
+    def _painter(self, real, order, transform):
+        p = _abi.Painter()
+        p.kind = self._k
+        p.support = self.support
+        p.ndim = real.dim()
+        p.canvas_elsize = real.element_size()
+        es = real.element_size()
+        for d in range(real.dim()):
+            p.order[d] = int(order[d])
+            p.scale[d] = float(transform.scale[d])
+            p.translate[d] = float(transform.translate[d])
+            p.period[d] = int(transform.period[d])
+            p.size[d] = real.shape[d]
+            p.strides[d] = real.stride(d) * es
+        return p
+
+    @staticmethod
+    def _canvas(real, be):
+        """-> (device float view, writeback callable or None)"""
+        if is_tensor(real):
+            if real.device != be.device:
+                raise ValueError('canvas tensor is on %s, backend on %s' % (real.device, be.device))
+            view = real_view(real)
+            if view.dtype not in (torch.float32, torch.float64):
+                raise AssertionError("real.dtype.kind == 'f'")  # _window.pyx:135
+            return view, None
+        host = real  # numpy array: must be written back in place
+        if not isinstance(host, numpy.ndarray):
+            raise TypeError('canvas must be a numpy array or a torch tensor')
+        if numpy.iscomplexobj(host):
+            host = host.real
+        assert host.dtype.kind == 'f' and host.dtype.itemsize in (4, 8)
+        dev = torch.from_numpy(numpy.ascontiguousarray(host)).to(be.device)
+
+        def writeback():
+            host[...] = dev.cpu().numpy()
+        return dev, writeback
+
+    def _particles(self, pos, hsml, be):
+        pos, _ = to_device(pos, be.device, 'pos')
+        if pos.dim() != 2:
+            raise ValueError('pos must be 2 dimensional (npart, ndim)')
+        n = pos.shape[0]
+        hs = None
+        if hsml is not None:
+            hs, _ = to_device(hsml, be.device, 'hsml')
+            if hs.dim() > 1 or (hs.dim() == 1 and hs.shape[0] not in (1, n)):
+                raise ValueError('hsml must be a scalar or have one entry per particle')
+            if hs.dim() == 1 and hs.shape[0] == 1 and n != 1:
+                hs = hs[0]
+        return pos, hs, n
+
+    def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None):
+        """
+            paint to a field (window.py:106-163).
+
+            Parameters
+            ----------
+            real : array_like (numpy array or device tensor); original values are preserved.
+            pos : array_like (npart, ndim)
+            mass : array_like or None; None for 1
+            hsml: array_like or None; dimensionless scaling of the kernel
+            diffdir: int or None; direction for the differentiation kernel
+            transform: Affine; from position to grid units.
+        """
+        self._require_built()
+        be = backend.get()
+        canvas, writeback = self._canvas(real, be)
+        if transform is None:
+            transform = Affine(canvas.dim())
+        assert isinstance(transform, Affine)
+        order = numpy.zeros(canvas.dim(), dtype=int)
+        if diffdir is not None:
+            order[diffdir] = 1
+        pos, hs, n = self._particles(pos, hsml, be)
+        if pos.shape[1] < canvas.dim():
+            raise ValueError('pos has fewer columns than the canvas has dimensions')
+        mass_scalar = 1.0
+        mv = None
+        if mass is not None:
+            if numpy.isscalar(mass) or (hasattr(mass, 'ndim') and mass.ndim == 0):
+                mass_scalar = float(mass)
+            else:
+                m, _ = to_device(mass, be.device, 'mass')
+                if m.dim() != 1 or m.shape[0] not in (1, n):
+                    raise ValueError('mass must be a scalar or have one entry per particle')
+                if m.shape[0] == 1 and n != 1:
+                    mass_scalar = float(m[0])
+                else:
+                    mv = vec(m)
+        p = self._painter(canvas, order, transform)
+        pv = vec(pos)
+        hv = vec(hs) if hs is not None else None
+        be.call('paint', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv), mass_scalar,
+                vec_ref(hv), n, be.stream())
+        if writeback is not None:
+            writeback()
+
+    def readout(self, real, pos, hsml=None, out=None, diffdir=None, transform=None):
+        """
+            readout from a field (window.py:165-221).  Returns `out`; by default a new
+            float64 array with one value per particle, living where `pos` lives.
+        """
+        self._require_built()
+        be = backend.get()
+        if is_tensor(real):
+            canvas = real_view(real)
+        else:
+            host = numpy.asarray(real)
+            if numpy.iscomplexobj(host):
+                host = host.real
+            canvas = torch.from_numpy(numpy.ascontiguousarray(host)).to(be.device)
+        if canvas.dtype not in (torch.float32, torch.float64):
+            raise AssertionError("real.dtype.kind == 'f'")
+        if transform is None:
+            transform = Affine(canvas.dim())
+        assert isinstance(transform, Affine)
+        order = numpy.zeros(canvas.dim(), dtype=int)
+        if diffdir is not None:
+            order[diffdir] = 1
+        pos_in = pos
+        pos, hs, n = self._particles(pos, hsml, be)
+        host_out = None
+        if out is None:
+            dout = torch.zeros(n, dtype=torch.float64, device=be.device)
+            ret_host = not is_tensor(pos_in)
+        elif is_tensor(out):
+            dout = out
+            ret_host = False
+            if dout.device != be.device:
+                raise ValueError('out tensor is on the wrong device')
+        else:
+            host_out = out
+            if not isinstance(host_out, numpy.ndarray) or host_out.dtype.kind != 'f':
+                raise TypeError('out must be a float32/float64 numpy array or tensor')
+            dout = torch.empty(host_out.shape, dtype=torch.float32 if host_out.dtype.itemsize == 4
+                               else torch.float64, device=be.device)
+            ret_host = True
+        if dout.dim() != 1 or dout.shape[0] != n:
+            raise ValueError('out must have one entry per particle')
+        p = self._painter(canvas, order, transform)
+        pv = vec(pos)
+        hv = vec(hs) if hs is not None else None
+        ov = vec(dout)
+        be.call('readout', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(hv), C.byref(ov), n,
+                be.stream())
+        if host_out is not None:
+            host_out[...] = dout.cpu().numpy()
+            return host_out
+        if ret_host:
+            return dout.cpu().numpy()
+        return dout
+
+
+def FindResampler(window):
+    if isinstance(window, str) and window in windows:
+        window = windows[window]
+    if not isinstance(window, ResampleWindow):
+        raise TypeError("argument is not a ResampleWindow name or a ResampleWindow object")
+    return window
+
+
+windows = dict(
+    NEAREST=ResampleWindow(kind="nearest"),
+    LINEAR=ResampleWindow(kind="linear"),
+    NNB=ResampleWindow(kind="tunednnb"),
+    CIC=ResampleWindow(kind="tunedcic"),
+    TSC=ResampleWindow(kind="tunedtsc"),
+    PCS=ResampleWindow(kind="tunedpcs"),
+    QUADRATIC=ResampleWindow(kind="quadratic"),
+    CUBIC=ResampleWindow(kind="cubic"),
+)
+for _k in _UNBUILT:
+    windows[_k.upper()] = ResampleWindow(kind=_k)
+
+for m, p in list(windows.items()):
+    windows[m.lower()] = p
+    globals()[m] = p
+
+# compatible.
+methods = windows
+del m, p

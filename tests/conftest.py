@@ -25,3 +25,31 @@ def oracle():
     from oracle import oracle as O
     O.lib('oracle')
     return O
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(params=['double', pytest.param('hip', marks=pytest.mark.gpu)])
+def be(request):
+    """The kernel backend under test.
+
+    'hip'    (-m gpu)      : the product — libpmesh_amd.so on the GPU.
+    'double' (-m "not gpu"): the host layer driven against the CPU oracle
+                             (tests/oracle_backend.py), no GPU needed.
+    """
+    from pmesh_amd import backend
+    if request.param == 'hip':
+        backend.reset()
+        b = backend.get()      # raises if the library or the GPU is missing
+        assert b.name == 'hip'
+    else:
+        from tests import oracle_backend
+        b = oracle_backend.install()
+    yield b
+    backend.reset()

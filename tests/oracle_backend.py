@@ -1,0 +1,122 @@
+"""A test double for pmesh_amd.backend: the same C ABI served by the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY.  It lets the `-m "not gpu"` suite exercise the host
+layer of pmesh_amd (argument handling, Field/Layout logic, the distributed FFT
+schedule and the torch.distributed collectives over gloo) on machines without
+a GPU, against oracle/liboracle.so (prefix pmo_, host pointers) and numpy.fft.
+The product never installs it: pmesh_amd.backend.get() only ever builds the
+HIP backend.
+"""
+import ctypes as C
+
+import numpy
+import torch
+
+from pmesh_amd import _abi, backend
+from oracle import oracle as O
+
+
+class _Plan(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class OracleBackend(object):
+    name = 'oracle-double'
+    prefix = 'pmo_'
+
+    def __init__(self):
+        self.lib, _ = O.lib('oracle')
+        self.device = torch.device('cpu')
+
+    def stream(self):
+        return None
+
+    def synchronize(self):
+        pass
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, 'pmo_' + name)(*args)
+        if rc != 0:
+            raise backend.PmxError('pmo_' + name, rc)
+
+    # ---- FFT: numpy.fft with the plan's strided/batched geometry ---------
+    def fft_create(self, kind, elsize, n, istride, idist, ostride, odist, batch, scale, inplace):
+        return _Plan(kind=kind, elsize=elsize, n=tuple(int(x) for x in n),
+                     istride=tuple(int(x) for x in istride), idist=int(idist),
+                     ostride=tuple(int(x) for x in ostride), odist=int(odist), batch=int(batch),
+                     scale=float(scale), inplace=bool(inplace))
+
+    @staticmethod
+    def _view(t, is_complex, elsize, n, stride, dist, batch):
+        """numpy strided view (batch, *n) over the storage of tensor t, in elements
+        of the requested kind (real or complex)."""
+        rdt = numpy.dtype('f4' if elsize == 4 else 'f8')
+        cdt = numpy.dtype('c8' if elsize == 4 else 'c16')
+        dt = cdt if is_complex else rdt
+        base = t.detach().numpy()
+        if not base.flags.c_contiguous:
+            raise ValueError('FFT buffers must be contiguous storage')
+        flat = base.reshape(-1).view(dt)
+        shape = (batch,) + tuple(n)
+        strides = (dist * dt.itemsize,) + tuple(s * dt.itemsize for s in stride)
+        return numpy.lib.stride_tricks.as_strided(flat, shape=shape, strides=strides)
+
+    def fft_execute(self, plan, tin, tout):
+        n = plan.n
+        nd = len(n)
+        axes = tuple(range(1, nd + 1))
+        nc = n[:-1] + (n[-1] // 2 + 1,)
+        if plan.kind == _abi.PMX_FFT_R2C:
+            src = self._view(tin, False, plan.elsize, n, plan.istride, plan.idist, plan.batch)
+            res = numpy.fft.rfftn(numpy.array(src, dtype='f8'), axes=axes) * plan.scale
+            dst = self._view(tout, True, plan.elsize, nc, plan.ostride, plan.odist, plan.batch)
+            dst[...] = res
+        elif plan.kind == _abi.PMX_FFT_C2R:
+            src = self._view(tin, True, plan.elsize, nc, plan.istride, plan.idist, plan.batch)
+            res = numpy.fft.irfftn(numpy.array(src, dtype='c16'), s=n, axes=axes)
+            res *= numpy.prod(n, dtype='f8') * plan.scale  # unnormalised backward
+            dst = self._view(tout, False, plan.elsize, n, plan.ostride, plan.odist, plan.batch)
+            dst[...] = res
+        else:
+            src = self._view(tin, True, plan.elsize, n, plan.istride, plan.idist, plan.batch)
+            a = numpy.array(src, dtype='c16')
+            if plan.kind == _abi.PMX_FFT_C2C_FWD:
+                res = numpy.fft.fftn(a, axes=axes)
+            else:
+                res = numpy.fft.ifftn(a, axes=axes) * numpy.prod(n, dtype='f8')
+            dst = self._view(tout, True, plan.elsize, n, plan.ostride, plan.odist, plan.batch)
+            dst[...] = res * plan.scale
+
+    def fft_destroy(self, plan):
+        pass
+
+    # ---- slab transposes (numpy restatement of csrc/pmx_fft.hip kernels) ----
+    def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
+        cdt = 'c8' if elbytes == 8 else 'c16'
+        full = (dst if inverse else src).detach().numpy().reshape(-1).view(cdt)[:n0 * n1 * n2].reshape(n0, n1, n2)
+        blocks = (src if inverse else dst).detach().numpy().reshape(-1).view(cdt)
+        for r in range(len(n1_offsets) - 1):
+            a, b = int(n1_offsets[r]), int(n1_offsets[r + 1])
+            blk = blocks[a * n0 * n2:b * n0 * n2].reshape(n0, b - a, n2)
+            if inverse:
+                full[:, a:b, :] = blk
+            else:
+                blk[...] = full[:, a:b, :]
+
+    def slab_unpack(self, src, dst, n0_offsets, n1loc, n2, elbytes, inverse=False):
+        cdt = 'c8' if elbytes == 8 else 'c16'
+        n0tot = int(n0_offsets[-1])
+        full = (src if inverse else dst).detach().numpy().reshape(-1).view(cdt)[:n0tot * n1loc * n2].reshape(n1loc, n0tot, n2)
+        blocks = (dst if inverse else src).detach().numpy().reshape(-1).view(cdt)
+        for s in range(len(n0_offsets) - 1):
+            a, b = int(n0_offsets[s]), int(n0_offsets[s + 1])
+            blk = blocks[a * n1loc * n2:b * n1loc * n2].reshape(b - a, n1loc, n2)
+            if inverse:
+                blk[...] = full[:, a:b, :].transpose(1, 0, 2)
+            else:
+                full[:, a:b, :] = blk.transpose(1, 0, 2)
+
+
+def install():
+    return backend.use(OracleBackend())

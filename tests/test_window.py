@@ -1,0 +1,404 @@
+"""ResampleWindow.paint / readout through the public API of pmesh_amd.window.
+
+The test bodies restate the reference's own pmesh/tests/test_window.py (inline
+known answers, cited per block) and add the golden vectors generated from the
+compiled reference (tests/golden/window.npz).  Each test runs in two modes (see
+the `be` fixture in conftest.py):
+
+  -m gpu       : the HIP kernels of libpmesh_amd.so — the parity tests proper.
+                 Indexing is checked bit-exact (dyadic fixtures: every partial
+                 sum is exactly representable, so the result is independent of
+                 the atomics' order); values within the stated tolerance;
+                 readout is bit-exact in f8 (same summation order as the
+                 reference, no FMA contraction).
+  -m "not gpu" : the same host code against the CPU oracle (exact).
+"""
+import numpy
+import pytest
+from numpy.testing import assert_array_equal, assert_allclose, assert_almost_equal
+
+from pmesh_amd.window import ResampleWindow, Affine, FindResampler, windows
+from pmesh_amd.window import CIC, TSC, PCS, NNB, QUADRATIC, CUBIC, LINEAR, NEAREST
+
+TUNED = ['nnb', 'cic', 'tsc', 'pcs']
+GENERIC = ['nearest', 'linear', 'quadratic', 'cubic']
+
+# tolerances: |delta| <= tol * max(1, sum |contrib|)
+TOL_F8 = 1e-12
+TOL_F4 = 2e-6
+
+
+def check_paint(be, got, expected, scale=None):
+    if be.name != 'hip':
+        assert_array_equal(got, expected)
+        return
+    tol = TOL_F8 if expected.dtype.itemsize == 8 else TOL_F4
+    s = max(1.0, float(abs(expected).max())) if scale is None else scale
+    assert_allclose(got, expected, rtol=0, atol=tol * s)
+
+
+def check_readout(be, got, expected, dtype='f8'):
+    if be.name != 'hip' or dtype == 'f8':
+        assert_array_equal(got, expected)
+    else:
+        assert_allclose(got, expected, rtol=0, atol=TOL_F4 * max(1.0, float(abs(expected).max())))
+
+
+def _dd(tag):
+    return None if tag == 'n' else int(tag)
+
+
+# ---- the reference's inline known answers -----------------------------------
+
+def test_unweighted(be):          # test_window.py:11
+    real = numpy.zeros((4, 4))
+    CIC.paint(real, [[0., 0.], [1., 1.], [2., 2.], [3., 3.]])
+    assert_array_equal(real, numpy.eye(4))
+
+
+def test_weighted(be):            # test_window.py:27
+    real = numpy.zeros((4, 4))
+    CIC.paint(real, [[0., 0.], [1., 1.], [2., 2.], [3., 3.]], mass=[0., 1., 2., 3.])
+    assert_array_equal(real, numpy.diag([0., 1., 2., 3.]))
+
+
+def test_wide(be):                # test_window.py:43
+    wcic = ResampleWindow("linear", 4)
+    real = numpy.zeros((4))
+    wcic.paint(real, [[1.5]])
+    assert_almost_equal(real, [0.125, 0.375, 0.375, 0.125])
+    real = numpy.zeros((4))
+    wcic.paint(real, [[1.51]])
+    assert_almost_equal(real, [0.1225, 0.3725, 0.3775, 0.1275])
+    real = numpy.zeros((4))
+    wcic.paint(real, [[1.5]], diffdir=0)
+    assert_almost_equal(real, [-0.25, -0.25, 0.25, 0.25])
+
+
+def test_wrap(be):                # test_window.py:60
+    affine = Affine(ndim=2, period=2)
+    for pos in ([[-.5, -.5]], [[-.5, .5]], [[-.5, 1.5]]):
+        real = numpy.zeros((2, 2))
+        CIC.paint(real, pos, transform=affine)
+        assert_array_equal(real, [[0.25, 0.25], [0.25, 0.25]])
+
+
+def test_translate(be):           # test_window.py:89
+    real = numpy.zeros((2, 2))
+    CIC.paint(real, [[1., 0]], transform=Affine(ndim=2, translate=[-1, 0]))
+    assert_array_equal(real, [[1., 0.], [0., 0.]])
+
+
+def test_affine(be):              # test_window.py:100
+    affine = Affine(ndim=2)
+    real = numpy.zeros((4, 4))
+    CIC.paint(real, [[.5, .5]], transform=affine)
+    translate = numpy.zeros((4, 4))
+    CIC.paint(translate, [[0., 0.]], transform=affine.shift(0.5))
+    assert_array_equal(translate, real)
+
+
+def test_scale(be):               # test_window.py:118
+    real = numpy.zeros((2, 2))
+    CIC.paint(real, [[10., 0]], transform=Affine(ndim=2, translate=[-1, 0], scale=0.1))
+    assert_almost_equal(real, [[1., 0.], [0, 0.]])
+
+
+def test_scale_hsml(be):          # test_window.py:127
+    real = numpy.zeros(10)
+    CIC.paint(real, [[50., 0]], hsml=1., transform=Affine(ndim=1, translate=[0], scale=0.1))
+    assert_array_equal(real, [0., 0., 0., 0., 0., 1., 0., 0., 0., 0.])
+    real = numpy.zeros(10)
+    CIC.paint(real, [[5., 0]], hsml=None, transform=Affine(ndim=1, translate=[0], scale=1.))
+    assert_array_equal(real, [0., 0., 0., 0., 0., 1., 0., 0., 0., 0.])
+
+
+def test_strides(be):             # test_window.py:145
+    real = numpy.zeros((20, 20))[::10, ::10]
+    CIC.paint(real, [[1., 0]])
+    assert_array_equal(real, [[0, 0], [1, 0]])
+
+
+def test_anisotropic(be):         # test_window.py:155
+    real = numpy.zeros((2, 4))
+    CIC.paint(real, [[0., 0], [1., 0], [0., 1], [0., 2], [0., 3]])
+    assert_array_equal(real, [[1, 1, 1, 1], [1, 0, 0, 0]])
+
+
+def test_diff(be):                # test_window.py:169
+    real = numpy.zeros((2, 2))
+    CIC.paint(real, [[0.5, 0]], diffdir=0)
+    assert_array_equal(real, [[-1, 0], [1, 0]])
+    real = numpy.zeros((2, 2))
+    CIC.paint(real, [[0, 0.5]], diffdir=1)
+    assert_array_equal(real, [[-1, 1], [0, 0]])
+
+
+def test_nearest(be):             # test_window.py:188
+    real = numpy.zeros((4, 4))
+    NEAREST.paint(real, [[1.2, 1.2]])
+    e = numpy.zeros((4, 4))
+    e[1, 1] = 1
+    assert_allclose(real, e, atol=1e-5)
+    assert_array_equal(NEAREST.support, 1)
+
+
+def test_tsc(be):                 # test_window.py:222
+    real = numpy.zeros((4))
+    TSC.paint(real, [[1.5]])
+    assert_array_equal(real, [0, 0.5, 0.5, 0])
+    real = numpy.zeros((4))
+    TSC.paint(real, [[1.8]])
+    assert_almost_equal(real, [0., 0.245, 0.71, 0.045])
+    real = numpy.zeros((5))
+    TSC.paint(real, [[2.]])
+    assert_array_equal(real, [0, 0.125, 0.75, 0.125, 0])
+    real = numpy.zeros((5))
+    TSC.paint(real, [[0.]], transform=Affine(ndim=1, period=5))
+    assert_array_equal(real, [0.75, 0.125, 0, 0, 0.125])
+
+
+def test_cubic(be):               # test_window.py:253
+    real = numpy.zeros((6))
+    CUBIC.paint(real, [[2.5]])
+    assert_allclose(real, [0., 0.02083333, 0.47916667, 0.47916667, 0.02083333, 0.], rtol=1e-6)
+
+
+def test_cubic_hsml(be):          # test_window.py:264
+    real1 = numpy.zeros((10))
+    CUBIC.paint(real1, [[4.5]], hsml=2.0)
+    real2 = numpy.zeros((10))
+    CUBIC.resize(8).paint(real2, [[4.5]], hsml=1.0)
+    assert_array_equal(real1, real2)
+
+
+def test_cic_tuned(be):           # test_window.py:311
+    assert CIC.support == 2
+    assert LINEAR.support == 2
+    pos = [[1.1, 1.3, 2.5]]
+    real = numpy.zeros((4, 4, 4))
+    CIC.paint(real, pos)
+    real2 = numpy.zeros((4, 4, 4))
+    LINEAR.paint(real2, pos)
+    assert_array_equal(real, real2)
+    for d in range(3):
+        d1 = numpy.zeros((4, 4, 4))
+        d2 = numpy.zeros((4, 4, 4))
+        CIC.paint(d1, pos, diffdir=d)
+        LINEAR.paint(d2, pos, diffdir=d)
+        assert_array_equal(d1, d2)
+
+
+def test_tsc_tuned(be):           # test_window.py:332
+    affine = Affine(ndim=3, translate=[2, 1, 2], scale=[0.5, 2.0, 1.1], period=[8, 8, 8])
+    assert TSC.support == 3
+    assert QUADRATIC.support == 3
+    field = numpy.random.RandomState(1234).uniform(size=(8, 8, 8))
+    pos = [[1.1, 1.3, 2.9]]
+    for d in (None, 0, 1, 2):
+        d1 = numpy.zeros((8, 8, 8))
+        d2 = numpy.zeros((8, 8, 8))
+        TSC.paint(d1, pos, diffdir=d, transform=affine)
+        QUADRATIC.paint(d2, pos, diffdir=d, transform=affine)
+        assert_array_equal(d1, d2)
+        assert_array_equal(TSC.readout(field, pos, diffdir=d, transform=affine),
+                           QUADRATIC.readout(field, pos, diffdir=d, transform=affine))
+
+
+def test_compensation(be):        # test_window.py:362
+    assert_allclose(CIC.get_fwindow([0, 2 * numpy.pi]), [1, 0.0], atol=1e-9)
+
+
+# ---- API edge cases probed on the reference ----------------
+
+def test_api_edges(be):
+    real = numpy.ones((4, 4))
+    CIC.paint(real, [[1., 1.]])                      # accumulates (window.py:113)
+    assert real[1, 1] == 2 and real.sum() == 17
+    with pytest.raises(TypeError):                   # integer pos: fused types are f4/f8
+        CIC.paint(numpy.zeros((4, 4)), numpy.array([[1, 1]]))
+    with pytest.raises(TypeError):
+        CIC.paint(numpy.zeros((4, 4)), [[1., 1.]], mass=numpy.array([1]))
+    with pytest.raises(AssertionError):              # integer canvas (_window.pyx:135)
+        CIC.paint(numpy.zeros((4, 4), dtype='i4'), [[1., 1.]])
+    real = numpy.zeros((4, 4))
+    CIC.paint(real, numpy.zeros((0, 2)))             # empty pos: no-op
+    assert real.sum() == 0
+    real = numpy.zeros((4, 4))
+    CIC.paint(real, [[1., 1., 99.]])                 # extra columns ignored
+    assert real[1, 1] == 1
+    real = numpy.zeros(4)
+    CIC.paint(real, [[3.5]])                         # non periodic: outside dropped
+    assert_array_equal(real, [0, 0, 0, 0.5])
+    with pytest.raises(TypeError):
+        FindResampler('nosuchwindow')
+    assert FindResampler('cic') is CIC and FindResampler(TSC) is TSC
+    assert windows['PCS'] is PCS and PCS.support == 4 and NNB.support == 1
+    # mixed precisions: f4 pos, f8 mass, f4 canvas, f4 out
+    real = numpy.zeros((4, 4), dtype='f4')
+    CIC.paint(real, numpy.array([[1.5, 1.5]], dtype='f4'), mass=numpy.array([2.0]))
+    assert_array_equal(real[1:3, 1:3], numpy.full((2, 2), 0.5, dtype='f4'))
+    out = numpy.zeros(1, dtype='f4')
+    r = CIC.readout(real, numpy.array([[1.5, 1.5]], dtype='f4'), out=out)
+    assert r is out and out[0] == 0.5
+
+
+def test_nan_position_is_dropped(be):
+    if be.name != 'hip':
+        pytest.skip('defined for the HIP kernels only: the reference spins in its wrap loop on NaN')
+    real = numpy.zeros((4, 4))
+    CIC.paint(real, [[numpy.nan, 1.0], [1.0, 1.0]], transform=Affine(2, period=4))
+    assert real.sum() == 1.0
+    v = CIC.readout(numpy.ones((4, 4)), [[numpy.nan, 1.0], [1.0, 1.0]], transform=Affine(2, period=4))
+    assert v[1] == 1.0
+
+
+# ---- golden vectors from the compiled reference ----------------------------------
+
+@pytest.mark.parametrize('name', TUNED + GENERIC)
+def test_golden_A(be, golden, name):
+    g = golden['window']
+    W = windows[name]
+    aff = Affine(3, scale=g['A/scale'], translate=g['A/translate'], period=g['A/period'])
+    contrib = float(abs(g['A/mass']).sum())
+    for dt in ('f8', 'f4'):
+        for tag in ('n', '0', '1', '2'):
+            key = 'A/%s/%s/%s' % (name, dt, tag)
+            real = numpy.zeros(g[key + '/paint'].shape, dtype=dt)
+            W.paint(real, g['A/pos'], mass=g['A/mass'], diffdir=_dd(tag), transform=aff)
+            check_paint(be, real, g[key + '/paint'])
+            v = W.readout(g['A/field'].astype(dt), g['A/pos'], diffdir=_dd(tag), transform=aff)
+            check_readout(be, v, g[key + '/readout'])
+    assert contrib > 0
+
+
+@pytest.mark.parametrize('name', TUNED + GENERIC)
+def test_golden_B_f4(be, golden, name):
+    g = golden['window']
+    W = windows[name]
+    real = numpy.zeros(g['B/%s/paint' % name].shape, dtype='f4')
+    W.paint(real, g['B/pos'], mass=2.5)
+    check_paint(be, real, g['B/%s/paint' % name])
+    o = numpy.zeros(len(g['B/pos']), dtype='f4')
+    W.readout(g['B/field'], g['B/pos'], out=o)
+    assert_array_equal(o, g['B/%s/readout' % name])   # f8 sum, one rounding to f4
+
+
+@pytest.mark.parametrize('name', TUNED + GENERIC)
+def test_golden_C_lowdim(be, golden, name):
+    g = golden['window']
+    W = windows[name]
+    for tag in ('n', '0', '1'):
+        aff = Affine(2, scale=[1.0, 0.5], translate=[0.5, -1], period=[9, 7])
+        key = 'C/%s/2/%s' % (name, tag)
+        real = numpy.zeros((9, 7))
+        W.paint(real, g['C/pos2'], mass=g['C/mass'], diffdir=_dd(tag), transform=aff)
+        check_paint(be, real, g[key + '/paint'])
+        check_readout(be, W.readout(g['C/field2'], g['C/pos2'], diffdir=_dd(tag), transform=aff),
+                      g[key + '/readout'])
+    for tag in ('n', '0'):
+        aff = Affine(1, scale=[0.9], translate=[0.1], period=[11])
+        key = 'C/%s/1/%s' % (name, tag)
+        real = numpy.zeros((11,))
+        W.paint(real, g['C/pos1'], mass=g['C/mass'][:100], diffdir=_dd(tag), transform=aff)
+        check_paint(be, real, g[key + '/paint'])
+        check_readout(be, W.readout(g['C/field1'], g['C/pos1'], diffdir=_dd(tag), transform=aff),
+                      g[key + '/readout'])
+
+
+@pytest.mark.parametrize('name', TUNED + GENERIC)
+def test_golden_D_hsml_resize(be, golden, name):
+    g = golden['window']
+    W = windows[name]
+    aff = Affine(3, period=12)
+    real = numpy.zeros((12, 12, 12))
+    W.paint(real, g['D/pos'], hsml=g['D/hsml'], transform=aff)
+    check_paint(be, real, g['D/%s/paint' % name])
+    check_readout(be, W.readout(g['D/field'], g['D/pos'], hsml=g['D/hsml'], transform=aff),
+                  g['D/%s/readout' % name])
+    check_readout(be, W.readout(g['D/field'], g['D/pos'], hsml=g['D/hsml'], transform=aff, diffdir=1),
+                  g['D/%s/readout_g1' % name])
+    W6 = W.resize(6)
+    assert_array_equal([W6.support, W6.nativesupport], g['D/%s/resize6/support' % name])
+    real = numpy.zeros((12, 12, 12))
+    W6.paint(real, g['D/pos'], transform=aff)
+    check_paint(be, real, g['D/%s/resize6/paint' % name])
+    check_readout(be, W6.readout(g['D/field'], g['D/pos'], transform=aff),
+                  g['D/%s/resize6/readout' % name])
+
+
+@pytest.mark.parametrize('name', TUNED)
+def test_golden_E_dyadic_bit_exact(be, golden, name):
+    """Positions on a 1/16-cell lattice and small integer masses: every partial
+    sum is exactly representable, so paint must match the reference bit for bit
+    whatever order the GPU atomics arrive in => exact mesh indexing."""
+    g = golden['window']
+    W = windows[name]
+    for dt in ('f8', 'f4'):
+        aff = Affine(3, period=8)
+        real = numpy.zeros((8, 8, 8), dtype=dt)
+        W.paint(real, g['E/pos'], mass=g['E/mass'], transform=aff)
+        assert_array_equal(real, g['E/%s/%s/paint' % (name, dt)])
+        assert_array_equal(W.readout(g['E/field'].astype(dt), g['E/pos'], transform=aff),
+                           g['E/%s/%s/readout' % (name, dt)])
+
+
+@pytest.mark.parametrize('name', TUNED)
+def test_golden_F_cell_boundaries(be, golden, name):
+    """x = k L/N, +-1 ulp, negative, >= L, -0.0: floor(pos*scale+translate) must
+    round as the reference's separate multiply and add."""
+    g = golden['window']
+    W = windows[name]
+    N, L = int(g['F/N'][0]), float(g['F/L'][0])
+    aff = Affine(3, scale=1.0 * N / L, period=N)
+    real = numpy.zeros((N, N, N))
+    W.paint(real, g['F/pos'], transform=aff)
+    check_paint(be, real, g['F/%s/paint' % name])
+    # which cells are touched at all is an indexing statement: exact
+    assert_array_equal(real != 0, g['F/%s/paint' % name] != 0)
+    check_readout(be, W.readout(g['F/field'], g['F/pos'], transform=aff), g['F/%s/readout' % name])
+
+
+@pytest.mark.parametrize('name', TUNED)
+def test_golden_G_strided_and_complex_canvas(be, golden, name):
+    g = golden['window']
+    W = windows[name]
+    big = numpy.zeros((18, 12))
+    W.paint(big[::3, ::2], g['G/pos'], transform=Affine(2, period=[6, 6]))
+    check_paint(be, big, g['G/%s/big' % name])
+    cplx = numpy.zeros((6, 6), dtype='c16')
+    W.paint(cplx, g['G/pos'], transform=Affine(2, period=[6, 6]))
+    check_paint(be, cplx.real, g['G/%s/complex' % name].real)
+    assert (cplx.imag == 0).all()
+
+
+@pytest.mark.parametrize('name', TUNED + GENERIC)
+def test_golden_fwindow(be, golden, name):
+    g = golden['window']
+    W = windows[name]
+    assert_array_equal([W.support, W.nativesupport], g['W/%s/support' % name])
+    assert_allclose(W.get_fwindow(g['W/w']), g['W/%s/fwindow' % name], rtol=1e-15, atol=0)
+    assert_allclose(W.resize(6).get_fwindow(g['W/w']), g['W/%s/resize6/fwindow' % name], rtol=1e-15)
+
+
+def test_device_tensors_in_place(be):
+    """The product path: canvas, positions and output stay on the device."""
+    import torch
+    rs = numpy.random.RandomState(11)
+    pos = rs.uniform(0, 8, size=(500, 3))
+    mass = rs.uniform(0.5, 2, size=500)
+    expect = numpy.zeros((8, 8, 8))
+    CIC.paint(expect, pos, mass=mass, transform=Affine(3, period=8))
+    canvas = torch.zeros((8, 8, 8), dtype=torch.float64, device=be.device)
+    tpos = torch.from_numpy(pos).to(be.device)
+    tmass = torch.from_numpy(mass).to(be.device)
+    CIC.paint(canvas, tpos, mass=tmass, transform=Affine(3, period=8))
+    check_paint(be, canvas.cpu().numpy(), expect)
+    out = CIC.readout(canvas, tpos, transform=Affine(3, period=8))
+    assert isinstance(out, torch.Tensor) and out.device == canvas.device
+    ref = CIC.readout(canvas.cpu().numpy(), pos, transform=Affine(3, period=8))
+    assert_array_equal(out.cpu().numpy(), ref)
+    # transposed (non C-contiguous) device canvas
+    canvas_t = torch.zeros((8, 8, 8), dtype=torch.float64, device=be.device).permute(2, 0, 1)
+    CIC.paint(canvas_t, tpos, mass=tmass, transform=Affine(3, period=8))
+    check_paint(be, canvas_t.cpu().numpy(), expect)
