@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""PM-cycle benchmark: particles/s of paint -> r2c -> apply(transfer) -> c2r -> readout.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--mesh 512] [--window cic] [--dtype f8] [--data uniform|clustered]
+
+Contract (driver): with --gpus N > 1 it is launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank
+per GPU over RCCL.  W untimed warm-up cycles, then exactly K cycles timed between
+barrier + synchronize on both sides; the MAX over ranks is used; rank 0 prints ONE
+JSON line.  The workload is BASELINE.json's headline: 512^3 mesh, 512^3 uniform
+particles (lattice + hashed jitter), CIC, f64, generated in HBM —
+a "step" is one PM cycle over that particle set, inputs resident in HBM.
+
+For N > 1 the mesh is slab-decomposed, particles start on the rank that generated
+them (rank r: lattice ids [r, r+1) * N^3 / P) and every cycle includes the particle
+exchange (layout.exchange before paint and readout, layout.gather after readout) and
+the FFT's global transposes; `decompose` is done once, outside the timed region, and
+its time is reported separately (exchange reported included/excluded).
+
+Extra objects on the JSON line:
+  roofline     : dominant kernel's achieved algorithmic GB/s (HIP events on the launch
+                 stream, averaged over the timed cycles) against the 8 TB/s HBM peak.
+  cpu_baseline : the reference's own window kernels (oracle/_ref, compiled from the
+                 reference's _window_imp.c) + pocketfft on ONE host core, on a bounded
+                 sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(stage, e, pe, nu=1.0):
+    """compulsory HBM bytes per particle: e mesh element, pe position element"""
+    return {
+        'paint': 3 * pe + 2 * e / nu,          # positions + one read and one write per cell
+        'readout': 3 * pe + e + e / nu,        # positions + result + each cell once
+        'r2c': 2 * e / nu, 'c2r': 2 * e / nu,  # real in, half-complex out (single pass)
+        'apply': 2 * e / nu,                   # complex read + write
+        'zero': e / nu,
+    }[stage]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--mesh', type=int, default=512)
+    ap.add_argument('--particles', type=int, default=None, help='lattice size per side (default: mesh)')
+    ap.add_argument('--window', default='cic', choices=['nnb', 'cic', 'tsc', 'pcs'])
+    ap.add_argument('--dtype', default='f8', choices=['f4', 'f8'])
+    ap.add_argument('--data', default='uniform', choices=['uniform', 'clustered'])
+    ap.add_argument('--gradient', type=int, default=None, help='gradient readout direction')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-mesh', type=int, default=256)
+    ap.add_argument('--binned', type=int, default=-1, help='1/0 force the tile-binned kernels on/off')
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The reference path on the host: paint/readout by the reference's own compiled
+    window kernels (oracle/_ref; falls back to the oracle port), r2c/c2r by scipy's
+    pocketfft (PFFT/FFTW are not installable here), transfer by the oracle. One core."""
+    import numpy
+    from oracle import oracle as O
+    try:
+        import scipy.fft as sfft
+    except Exception:
+        sfft = None
+    which = 'ref' if O.have_ref() else 'oracle'
+    n = args.cpu_sample_mesh
+    L = 1000.0
+    kind = {'nnb': 'tunednnb', 'cic': 'tunedcic', 'tsc': 'tunedtsc', 'pcs': 'tunedpcs'}[args.window]
+    pos = O.synth_uniform(n, L, dtype=args.dtype)
+    W = O.Window(kind, which=which)
+    aff = O.Affine(3, scale=1.0 * n / L, period=n)
+    t0 = time.perf_counter()
+    real = numpy.zeros((n, n, n), dtype=args.dtype)
+    W.paint(real, pos, transform=aff)
+    t1 = time.perf_counter()
+    if sfft is not None:
+        ck = sfft.rfftn(real, workers=1) / float(n) ** 3
+    else:
+        ck = numpy.fft.rfftn(real) / float(n) ** 3
+    t2 = time.perf_counter()
+    ck = O.apply_transfer(O.make_transfer(laplace_pow=-1, grad_dir=0), ck.astype('c16' if args.dtype == 'f8' else 'c8'),
+                          (0, 0, 0), (n, n, n), (L, L, L))
+    t3 = time.perf_counter()
+    if sfft is not None:
+        back = sfft.irfftn(ck, s=(n, n, n), workers=1) * float(n) ** 3
+    else:
+        back = numpy.fft.irfftn(ck, s=(n, n, n), axes=(0, 1, 2)) * float(n) ** 3
+    back = numpy.ascontiguousarray(back, dtype=args.dtype)
+    t4 = time.perf_counter()
+    W.readout(back, pos, transform=aff, diffdir=args.gradient)
+    t5 = time.perf_counter()
+    total = t5 - t0
+    return {
+        'value': n ** 3 / total, 'unit': 'particles/s', 'cores': 1,
+        'kind': 'reference' if which == 'ref' else 'port',
+        'sample': '%d^3 mesh, %d^3 uniform particles, %s %s, one PM cycle on 1 core: paint+readout by '
+                  '%s, r2c/c2r by scipy pocketfft (workers=1) standing in for PFFT; %.1f s '
+                  '(paint %.2f r2c %.2f apply %.2f c2r %.2f readout %.2f)'
+                  % (n, n, args.window, args.dtype,
+                     "the reference's _window_imp.c (oracle/_ref)" if which == 'ref' else 'the oracle port',
+                     total, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4),
+    }
+
+
+def main():
+    args = parse()
+    import numpy
+    import torch
+    import ctypes as C
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`'
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')
+
+    from pmesh_amd import backend, _abi
+    from pmesh_amd._arrays import vec
+    from pmesh_amd.comm import default_comm
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+
+    be = backend.get()                     # raises if the HIP library / GPU is missing
+    comm = default_comm()
+    N = args.mesh
+    Np_side = args.particles or N
+    L = 1000.0
+    e = 8 if args.dtype == 'f8' else 4
+    tdt = torch.float64 if args.dtype == 'f8' else torch.float32
+    ntot = Np_side ** 3
+    g0 = rank * ntot // world
+    g1 = (rank + 1) * ntot // world
+    nloc = g1 - g0
+
+    # ---- synthetic particles, generated in HBM ---------------------------------
+    pos = torch.empty((nloc, 3), dtype=tdt, device=be.device)
+    pv = vec(pos)
+    if args.data == 'uniform':
+        be.call('synth_uniform', C.byref(pv), Np_side, L, 42, g0, nloc, be.stream())
+    else:
+        modes = zeldovich_modes(numpy, Np_side, L)
+        be.call('synth_clustered', C.byref(pv), Np_side, L,
+                modes.ctypes.data_as(C.POINTER(C.c_double)), len(modes), 0.0, g0, nloc, be.stream())
+
+    pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype=args.dtype, resampler=args.window,
+                      np=[world])
+    transfer = Transfer.dx1(0)             # T(k) = i k_x / k^2
+    rho = pm.create('real')
+
+    layout = None
+    t_decompose = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        layout = pm.decompose(pos)
+        torch.cuda.synchronize()
+        t_decompose = time.perf_counter() - t0
+
+    stages = ['zero', 'paint', 'r2c', 'apply', 'c2r', 'readout']
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
+          for _ in range(args.steps)]
+
+    def cycle(marks=None):
+        def mark(i):
+            if marks is not None:
+                marks[i].record()
+        mark(0)
+        rho.value.zero_()
+        mark(1)
+        pm.paint(pos, hold=True, layout=layout, out=rho)
+        mark(2)
+        rhok = rho.r2c(out=Ellipsis)
+        mark(3)
+        rhok.apply(transfer, out=Ellipsis)
+        mark(4)
+        back = rhok.c2r(out=Ellipsis)
+        mark(5)
+        f = back.readout(pos, gradient=args.gradient, layout=layout)
+        mark(6)
+        return f
+
+    for _ in range(args.warmup):
+        cycle()
+    comm.Barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        f = cycle(ev[k])
+    torch.cuda.synchronize()
+    comm.Barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = comm.allreduce(elapsed, op='max') if world > 1 else elapsed
+
+    stage_ms = {}
+    for i, s in enumerate(stages):
+        stage_ms[s] = sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
+
+    # sanity: mass conservation and a finite result (size-independent properties)
+    check = pm.paint(pos, layout=layout)
+    msum = check.csum()
+    assert abs(msum - ntot) <= 1e-9 * ntot if args.dtype == 'f8' else abs(msum - ntot) <= 1e-3 * ntot, msum
+    assert bool(torch.isfinite(f).all())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = ntot / (elapsed / args.steps)
+
+    if rank == 0:
+        nu = ntot / float(N) ** 3
+        pe = e
+        # the dominant kernel: the longest single-kernel stage on this rank
+        single = {'paint': stage_ms['paint'], 'readout': stage_ms['readout'], 'apply': stage_ms['apply']}
+        dom = max(single, key=single.get)
+        units = nloc
+        ach = algorithmic_bytes(dom, e, pe, nu) * units / (single[dom] * 1e-3) / 1e9
+        kname = {'paint': 'paint_tuned_kernel', 'readout': 'readout_tuned_kernel', 'apply': 'transfer_kernel'}[dom]
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = '%s/%d/%s/%s/%s' % (dom, N, args.window, args.dtype, args.data)
+                traffic = tj.get(key)
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'PM-cycle particles/s (paint+r2c+c2r+readout), 512^3 mesh',
+            'value': value, 'unit': 'particles/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64' if args.dtype == 'f8' else 'f32',
+            'data': 'synthetic',
+            'config': {'workload': '%d^3 mesh, %d^3 %s particles (lattice + %s), %s window, %s, '
+                                   'paint->r2c->apply(i kx/k^2)->c2r->readout%s'
+                                   % (N, Np_side, args.data,
+                                      'hashed jitter' if args.data == 'uniform' else "Zel'dovich plane waves",
+                                      args.window.upper(), 'fp64' if args.dtype == 'f8' else 'fp32',
+                                      '' if args.gradient is None else ' (gradient %d)' % args.gradient),
+                       'decomposition': 'single GPU' if world == 1 else 'slab np=[%d], particle exchange included' % world,
+                       'particles': ntot},
+            'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
+            'decompose_ms': round(1e3 * t_decompose, 3),
+            'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu) for s in
+                                        ('paint', 'r2c', 'apply', 'c2r', 'readout')) * units /
+                                    (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_particle': algorithmic_bytes(dom, e, pe, nu),
+                         'particles_per_launch': units, 'ms_per_launch': single[dom]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(args)
+            except Exception as ex:          # the baseline never takes the benchmark down
+                line['cpu_baseline'] = {'value': None, 'unit': 'particles/s', 'cores': 1,
+                                        'kind': 'port', 'sample': 'failed: %r' % (ex,)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def zeldovich_modes(numpy, nlat, boxsize, rms_cells=3.0, nmodes=16, seed=1234):
+    """SURVEY.md 8d plane-wave table (same as oracle.zeldovich_modes; restated here so the
+    timed path does not import the oracle)."""
+    rng = numpy.random.RandomState(seed)
+    n = rng.randint(-4, 5, size=(nmodes, 3)).astype('f8')
+    n[(n == 0).all(axis=1)] = [1, 0, 0]
+    norm = numpy.sqrt((n ** 2).sum(axis=1))
+    direc = n / norm[:, None]
+    amp = 1.0 / norm
+    phase = rng.uniform(0, 2 * numpy.pi, size=nmodes)
+    rms = numpy.sqrt(0.5 * (amp ** 2).sum())
+    amp *= rms_cells * (boxsize / nlat) / rms
+    modes = numpy.zeros((nmodes, 8), dtype='f8')
+    modes[:, 0:3] = n
+    modes[:, 3:6] = direc
+    modes[:, 6] = amp
+    modes[:, 7] = phase
+    return modes
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,135 @@
+"""Communicators for the PM cycle.
+
+The reference takes an mpi4py communicator everywhere (pmesh/pm.py:1311-1314,
+pmesh/domain.py:92-123).  Here the unit of parallelism is one process per GPU and
+the wire is RCCL over xGMI, reached through ``torch.distributed`` (backend
+"nccl" *is* RCCL on ROCm; "gloo" on CPU tensors is used by the host-logic
+tests).  Only the handful of operations the hot path needs are exposed, with
+mpi4py-like names so the calling code reads like the reference's:
+
+    rank, size, Barrier, bcast, allgather, allreduce           (python objects / scalars)
+    alltoall_counts(sendcounts) -> recvcounts                  (domain.py:113)
+    alltoallv(send, sendcounts, recv, recvcounts)              (domain.py:202, 278)
+    alltoall(send, recv)                                       (PFFT's global transpose)
+
+The reference brackets every exchange with two Barriers (domain.py:112-114, 199,
+205, 274, 281); they are pure overhead on a stream-ordered device and are not
+reproduced.
+"""
+import numpy
+import torch
+
+
+class SelfComm(object):
+    """The single-process communicator (size 1): every collective is the identity."""
+    rank = 0
+    size = 1
+
+    def Barrier(self):
+        pass
+
+    def bcast(self, obj, root=0):
+        return obj
+
+    def allgather(self, obj):
+        return [obj]
+
+    def allreduce(self, value, op='sum'):
+        return value
+
+    def alltoall_counts(self, sendcounts):
+        return numpy.array(sendcounts, copy=True)
+
+    def alltoallv(self, send, sendcounts, recv, recvcounts):
+        recv.copy_(send)
+
+    def alltoall(self, send, recv):
+        recv.copy_(send)
+
+    def split(self, color, key):
+        return self
+
+
+class TorchComm(object):
+    """torch.distributed process group (RCCL for device tensors, gloo for host)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def _device_for_objects(self):
+        backend = self._dist.get_backend(self.group)
+        return torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+
+    def Barrier(self):
+        self._dist.barrier(group=self.group)
+
+    def bcast(self, obj, root=0):
+        box = [obj]
+        src = root if self.group is None else self._dist.get_global_rank(self.group, root)
+        self._dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+    def allgather(self, obj):
+        out = [None] * self.size
+        self._dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def allreduce(self, value, op='sum'):
+        """Sum (or max/min) of a python/numpy scalar, small numpy array, or a tensor."""
+        ops = {'sum': self._dist.ReduceOp.SUM, 'max': self._dist.ReduceOp.MAX,
+               'min': self._dist.ReduceOp.MIN}
+        if isinstance(value, torch.Tensor):
+            t = value.clone()
+            self._dist.all_reduce(t, op=ops[op], group=self.group)
+            return t
+        a = numpy.asarray(value)
+        dev = self._device_for_objects()
+        if a.dtype.kind == 'c':
+            t = torch.view_as_real(torch.from_numpy(numpy.atleast_1d(a).astype('c16'))).to(dev)
+            self._dist.all_reduce(t, op=ops[op], group=self.group)
+            r = torch.view_as_complex(t.cpu()).numpy()
+        else:
+            t = torch.from_numpy(numpy.atleast_1d(a).copy()).to(dev)
+            self._dist.all_reduce(t, op=ops[op], group=self.group)
+            r = t.cpu().numpy()
+        if a.ndim == 0:
+            return r.reshape(()).item() if not isinstance(value, numpy.generic) else r.reshape(())[()]
+        return r
+
+    def alltoall_counts(self, sendcounts):
+        dev = self._device_for_objects()
+        s = torch.as_tensor(numpy.asarray(sendcounts, dtype='i8')).to(dev)
+        r = torch.empty_like(s)
+        self._dist.all_to_all_single(r, s, group=self.group)
+        return r.cpu().numpy()
+
+    def alltoallv(self, send, sendcounts, recv, recvcounts):
+        """rows of `send` (first axis) split by sendcounts -> rows of `recv`."""
+        self._dist.all_to_all_single(recv, send,
+                                     output_split_sizes=[int(c) for c in recvcounts],
+                                     input_split_sizes=[int(c) for c in sendcounts],
+                                     group=self.group)
+
+    def alltoall(self, send, recv, send_splits=None, recv_splits=None):
+        if send_splits is None:
+            self._dist.all_to_all_single(recv, send, group=self.group)
+        else:
+            self._dist.all_to_all_single(recv, send, output_split_sizes=list(recv_splits),
+                                         input_split_sizes=list(send_splits), group=self.group)
+
+
+def default_comm():
+    """WORLD if torch.distributed is initialised, else the single-process comm."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return TorchComm()
+    except Exception:
+        pass
+    return SelfComm()

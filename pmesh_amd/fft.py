@@ -1,0 +1,303 @@
+"""Mesh partition, buffers and FFT plans: what ``pfft-python`` provides to
+``pmesh/pm.py`` (pfft.ProcMesh / Partition / LocalBuffer / Plan; call sites
+pm.py:226, 1321, 1332-1349, 1393-1441, 689, 1017), rebuilt for one process per GPU.
+
+PFFT = serial FFTW per rank + MPI all-to-all transposes.  Here
+
+* one rank: a single in-device 3-D (or 1-/2-D) rocFFT R2C / C2R on the padded
+  in-place layout; the forward normalisation 1/prod(Nmesh) (pm.py:692) is the
+  plan's scale factor, so no extra pass over the mesh;
+* P ranks, slab decomposition (``np=[P]``): batched 2-D R2C over the local
+  planes -> pack kernel -> RCCL all-to-all over xGMI -> unpack kernel -> batched
+  1-D C2C along the formerly distributed axis.  The complex field comes out
+  "transposed" (axis 1 distributed, memory order (n1_local, N0, N2c)), which is
+  PFFT's TRANSPOSED_OUT and the reference's default ``ComplexField``.
+
+Partitions are block distributions with block = ceil(N / P) (FFTW-MPI / PFFT
+default): rank r owns [r*block, min((r+1)*block, N)).
+"""
+import numpy
+import torch
+
+from . import _abi, backend
+from ._arrays import torch_dtype
+
+
+def split_size_2d(s):
+    """pfft.split_size_2d: the most square factorisation a*d = s with a <= d."""
+    a = int(s ** 0.5) + 1
+    d = s
+    while a > 0:
+        if s % a == 0:
+            d = s // a
+            break
+        a = a - 1
+    return a, d
+
+
+def block_edges(n, p):
+    blk = -(-n // p)
+    e = [min(r * blk, n) for r in range(p + 1)]
+    return numpy.array(e, dtype='intp')
+
+
+class ProcMesh(object):
+    """pfft.ProcMesh(np, comm): this rank's coordinates on the process mesh."""
+    def __init__(self, np, comm):
+        self.np = [int(x) for x in np]
+        self.comm = comm
+        size = 1
+        for x in self.np:
+            size *= x
+        if size != comm.size:
+            raise ValueError('process mesh %s does not match the communicator size %d' % (self.np, comm.size))
+        self.this = numpy.unravel_index(comm.rank, self.np) if len(self.np) else ()
+        self.rank = comm.rank
+
+
+class Partition(object):
+    """The local blocks of the real ("i") and complex ("o") meshes
+    (pfft.Partition; attributes used by pm.py:237-242, 1185-1187, 1209-1211, 1450-1453)."""
+
+    def __init__(self, Nmesh, procmesh, transposed, is_c2c=False):
+        self.Nmesh = numpy.array(Nmesh, dtype='intp')
+        self.ndim = len(self.Nmesh)
+        self.procmesh = procmesh
+        self.transposed = transposed
+        nd = self.ndim
+        np_ = procmesh.np
+        P = procmesh.comm.size
+        if is_c2c:
+            raise NotImplementedError('complex-to-complex meshes (dtype c8/c16) are outside the '
+                                      'PM-cycle scope built so far')
+        if len(np_) > 1 and P > 1 and min(np_) > 1:
+            raise NotImplementedError('pencil decompositions (np=%s) are not built yet; use np=[%d]'
+                                      % (np_, P))
+        if nd == 1 and P > 1:
+            raise ValueError("Running 1d transforms on multiple ranks is not supported")
+        self.nproc = P
+        r = procmesh.comm.rank
+        Nc = self.Nmesh.copy()
+        Nc[-1] = Nc[-1] // 2 + 1
+        self.cshape_o = Nc
+        # real space: axis 0 distributed
+        self.i_edges = [block_edges(self.Nmesh[0], P)] + \
+                       [numpy.array([0, n], dtype='intp') for n in self.Nmesh[1:]]
+        self.local_i_start = numpy.array([self.i_edges[0][r]] + [0] * (nd - 1), dtype='intp')
+        self.local_i_shape = numpy.array([self.i_edges[0][r + 1] - self.i_edges[0][r]] +
+                                         list(self.Nmesh[1:]), dtype='intp')
+        # complex space: transposed -> axis 1 distributed; untransposed -> axis 0
+        if P == 1:
+            oax = None
+        elif transposed:
+            oax = 1
+        else:
+            oax = 0
+        self.o_axis = oax
+        self.o_edges = [numpy.array([0, n], dtype='intp') for n in Nc]
+        if oax is not None:
+            self.o_edges[oax] = block_edges(Nc[oax], P)
+        self.local_o_start = numpy.array([e[r] if d == oax else 0 for d, e in enumerate(self.o_edges)],
+                                         dtype='intp')
+        self.local_o_shape = numpy.array([(e[r + 1] - e[r]) if d == oax else e[-1]
+                                          for d, e in enumerate(self.o_edges)], dtype='intp')
+        # memory layout, in elements
+        # real: padded in place: last axis has 2*(N/2+1) reals
+        padded = list(self.local_i_shape)
+        padded[-1] = 2 * int(Nc[-1])
+        self.i_strides = _c_strides(padded)
+        self.i_alloc = int(numpy.prod(padded, dtype='i8'))
+        if oax == 1:
+            # memory order (n1_local, N0, N2c[, ...]) : swap the two leading axes
+            mshape = [int(self.local_o_shape[1]), int(self.local_o_shape[0])] + \
+                     [int(x) for x in self.local_o_shape[2:]]
+            ms = _c_strides(mshape)
+            self.o_strides = [ms[1], ms[0]] + ms[2:]
+        else:
+            self.o_strides = _c_strides([int(x) for x in self.local_o_shape])
+        self.o_alloc = int(numpy.prod(self.local_o_shape, dtype='i8'))
+        # one buffer serves both views (in-place transforms)
+        self.alloc_reals = max(self.i_alloc, 2 * self.o_alloc, 2)
+        if P > 1:
+            # the slab transpose needs the full local plane set on both sides
+            n0loc = int(self.local_i_shape[0])
+            mid = n0loc * int(numpy.prod(Nc[1:], dtype='i8'))
+            self.alloc_reals = max(self.alloc_reals, 2 * mid)
+
+
+def _c_strides(shape):
+    s = [1] * len(shape)
+    for d in range(len(shape) - 2, -1, -1):
+        s[d] = s[d + 1] * int(shape[d + 1])
+    return s
+
+
+class LocalBuffer(object):
+    """pfft.LocalBuffer(partition, base=None): device storage with a real
+    ("input") and a complex ("output") view (pm.py:226, 236, 240).  `a in b` tests
+    aliasing as the reference does (pm.py:677)."""
+
+    def __init__(self, partition, dtype, base=None):
+        self.partition = partition
+        self.rdtype = torch_dtype(dtype)
+        if base is None:
+            be = backend.get()
+            self.storage = torch.zeros(partition.alloc_reals, dtype=self.rdtype, device=be.device)
+        else:
+            self.storage = base.storage if isinstance(base, LocalBuffer) else base
+            if self.storage.numel() < partition.alloc_reals:
+                raise ValueError('base buffer is too small for this partition')
+
+    def __contains__(self, other):
+        return isinstance(other, LocalBuffer) and other.storage.data_ptr() == self.storage.data_ptr()
+
+    def view_input(self):
+        p = self.partition
+        return torch.as_strided(self.storage, [int(x) for x in p.local_i_shape], p.i_strides)
+
+    def view_output(self):
+        p = self.partition
+        c = torch.view_as_complex(self.storage.view(-1, 2))
+        return torch.as_strided(c, [int(x) for x in p.local_o_shape], p.o_strides)
+
+    def view_raw(self):
+        return self.storage
+
+
+class Plan(object):
+    """pfft.Plan(...).execute(bufin, bufout) for one direction."""
+
+    def __init__(self, partition, forward, dtype, inplace):
+        self.partition = partition
+        self.forward = forward
+        self.inplace = inplace
+        self.elsize = numpy.dtype(dtype).itemsize
+        self._plans = {}
+        self._work = None
+
+    # lazily created native plans (rocFFT kernels are built on first use)
+    def _native(self, key, maker):
+        if key not in self._plans:
+            self._plans[key] = maker()
+        return self._plans[key]
+
+    def execute(self, bufin, bufout):
+        p = self.partition
+        if p.nproc == 1:
+            self._execute_local(bufin, bufout)
+        else:
+            self._execute_slab(bufin, bufout)
+
+    def _execute_local(self, bufin, bufout):
+        be = backend.get()
+        p = self.partition
+        n = [int(x) for x in p.Nmesh]
+        norm = 1.0 / float(numpy.prod(p.Nmesh, dtype='f8'))
+        inplace = bufin.storage.data_ptr() == bufout.storage.data_ptr()
+
+        def make():
+            if self.forward:
+                return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, n, p.i_strides, p.i_alloc,
+                                     p.o_strides, p.o_alloc, 1, norm, inplace)
+            return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, n, p.o_strides, p.o_alloc,
+                                 p.i_strides, p.i_alloc, 1, 1.0, inplace)
+        plan = self._native(('local', inplace), make)
+        be.fft_execute(plan, bufin.storage, bufout.storage)
+
+    def _execute_slab(self, bufin, bufout):
+        """Slab-decomposed 3-D (or 2-D) transform with one global transpose."""
+        be = backend.get()
+        p = self.partition
+        comm = p.procmesh.comm
+        if not p.transposed:
+            raise NotImplementedError('untransposed complex fields on more than one rank are not '
+                                      'built yet (they need a second global transpose)')
+        nd = p.ndim
+        P = p.nproc
+        N0 = int(p.Nmesh[0])
+        n0loc = int(p.local_i_shape[0])
+        N1c = int(p.cshape_o[1])                 # complex extent of axis 1 (N1, or N1/2+1 in 2-D)
+        n1loc = int(p.local_o_shape[1])
+        rest = [int(x) for x in p.cshape_o[2:]]  # trailing complex extents
+        n2 = 1
+        for x in rest:
+            n2 *= x
+        e0 = [int(x) for x in p.i_edges[0]]
+        e1 = [int(x) for x in p.o_edges[1]]
+        elb = 2 * self.elsize
+        cdt = torch.complex64 if self.elsize == 4 else torch.complex128
+        norm = 1.0 / float(numpy.prod(p.Nmesh, dtype='f8'))
+        rdt = bufin.storage.dtype
+        need = max(2 * n0loc * N1c * n2, 2 * n1loc * N0 * n2, 2)
+        if self._work is None or self._work[0].numel() < need or self._work[0].dtype != rdt:
+            self._work = [torch.empty(need, dtype=rdt, device=bufin.storage.device) for _ in range(3)]
+        W0, W1, W2 = self._work
+        send_splits = [2 * n0loc * (e1[r + 1] - e1[r]) * n2 for r in range(P)]
+        recv_splits = [2 * (e0[s + 1] - e0[s]) * n1loc * n2 for s in range(P)]
+        inner_real = [int(x) for x in p.Nmesh[1:]]           # transform lengths of the local stage
+        inner_strides_r = p.i_strides[1:]
+        plane_r = p.i_strides[0]
+        inner_c = [int(x) for x in p.cshape_o[1:]]
+        inner_strides_c = _c_strides(inner_c)
+        plane_c = N1c * n2
+        nsend, nrecv = sum(send_splits), sum(recv_splits)
+
+        if self.forward:
+            # 1. local (nd-1)-D R2C over the n0loc planes: real (padded) -> W0 (n0loc, N1c, n2)
+            def make1():
+                return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, inner_real, inner_strides_r,
+                                     plane_r, inner_strides_c, plane_c, n0loc, norm, False)
+            if n0loc:
+                be.fft_execute(self._native('stage1', make1), bufin.storage, W0)
+            # 2. pack by destination rank, 3. all-to-all, 4. unpack into (n1loc, N0, n2)
+            be.slab_pack(W0, W1, n0loc, N1c, n2, e1, elb)
+            comm.alltoall(W1[:nsend], W2[:nrecv], send_splits, recv_splits)
+            out = bufout.storage
+            be.slab_unpack(W2, out, e0, n1loc, n2, elb)
+            # 5. 1-D C2C along N0 (stride n2), batched over the n2 trailing modes, per local row
+            def make2():
+                return be.fft_create(_abi.PMX_FFT_C2C_FWD, self.elsize, [N0], [n2], 1, [n2], 1, n2,
+                                     1.0, True)
+            if n1loc:
+                plan2 = self._native('stage2', make2)
+                for j in range(n1loc):
+                    row = out[2 * j * N0 * n2:]
+                    be.fft_execute(plan2, row, row)
+        else:
+            # the backward pass works on a copy so that c2r preserves its input
+            ncplx = 2 * n1loc * N0 * n2
+            W0[:ncplx].copy_(bufin.storage[:ncplx])
+
+            def make2():
+                return be.fft_create(_abi.PMX_FFT_C2C_BWD, self.elsize, [N0], [n2], 1, [n2], 1, n2,
+                                     1.0, True)
+            if n1loc:
+                plan2 = self._native('stage2', make2)
+                for j in range(n1loc):
+                    row = W0[2 * j * N0 * n2:]
+                    be.fft_execute(plan2, row, row)
+            # (n1loc, N0, n2) -> blocks by source rank; all-to-all back; blocks -> (n0loc, N1c, n2)
+            be.slab_unpack(W0, W1, e0, n1loc, n2, elb, inverse=True)
+            comm.alltoall(W1[:nrecv], W2[:nsend], recv_splits, send_splits)
+            be.slab_pack(W2, W0, n0loc, N1c, n2, e1, elb, inverse=True)
+
+            def make1():
+                return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, inner_real, inner_strides_c,
+                                     plane_c, inner_strides_r, plane_r, n0loc, 1.0, False)
+            if n0loc:
+                be.fft_execute(self._native('stage1', make1), W0, bufout.storage)
+
+    def destroy(self):
+        try:
+            be = backend.get()
+        except Exception:
+            return
+        for plan in self._plans.values():
+            try:
+                be.fft_destroy(plan)
+            except Exception:
+                pass
+        self._plans = {}
+
+    def __del__(self):
+        self.destroy()

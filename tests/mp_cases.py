@@ -1,0 +1,201 @@
+"""Multi-rank cases, run as `python -m torch.distributed.run --nproc-per-node P tests/mp_cases.py`
+(launched by tests/test_multirank.py).  One process per rank; on a CPU box the
+backend is the oracle double + gloo, on a GPU box (PMESH_MP_BACKEND=hip) the HIP
+library + RCCL.  Every assert runs on every rank; a failure exits non-zero.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy
+import torch
+import torch.distributed as dist
+from numpy.testing import assert_array_equal, assert_allclose, assert_almost_equal
+
+
+def setup():
+    use_hip = os.environ.get('PMESH_MP_BACKEND', 'double') == 'hip'
+    if use_hip:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        dist.init_process_group('nccl')
+        from pmesh_amd import backend
+        be = backend.get()
+    else:
+        dist.init_process_group('gloo')
+        from tests import oracle_backend
+        be = oracle_backend.install()
+    from pmesh_amd.comm import TorchComm
+    return be, TorchComm()
+
+
+def gather_field(comm, field, full_shape):
+    """assemble the global array from the local blocks (test_pm.py:257-259)"""
+    full = numpy.zeros(full_shape, dtype=field.dtype)
+    full[field.slices] = numpy.asarray(field)
+    parts = comm.allgather(full)
+    return sum(parts)
+
+
+def case_exchange(be, comm):
+    """pmesh/tests/test_domain.py:64-90, 243-266 known answers (first two ranks)"""
+    from pmesh_amd import domain
+    if comm.size != 2:
+        return
+    dcop = domain.GridND([[0, 1, 2], [0, 2]], comm=comm, periodic=True)
+    if comm.rank == 0:
+        pos = numpy.array(list(numpy.ndindex((2, 2))), dtype='f8')
+        mass = numpy.array([0., 1, 2, 3])
+    else:
+        pos = numpy.empty((0, 2), dtype='f8')
+        mass = numpy.array([], dtype='f8')
+    layout = dcop.decompose(pos, smoothing=0)
+    assert_array_equal(layout.get_exchange_cost(), [2, 0])
+    npos = comm.allgather(layout.exchange(pos))
+    assert_array_equal(npos[0], [[0, 0], [0, 1]])
+    assert_array_equal(npos[1], [[1, 0], [1, 1]])
+    nmass = layout.exchange(mass)
+    mass2 = layout.gather(nmass)
+    nmass = comm.allgather(nmass)
+    assert_array_equal(nmass[0], [0, 1])
+    assert_array_equal(nmass[1], [2, 3])
+    assert_array_equal(mass2, mass)
+    # smoothing 1: every particle is repeated once (test_domain.py:243-266)
+    layout = dcop.decompose(pos, smoothing=1)
+    npos = layout.exchange(pos)
+    ones = numpy.ones(len(npos))
+    assert_array_equal(layout.gather(ones, mode='sum'), 2 * numpy.ones(len(pos)))
+    assert_array_equal(layout.gather(ones, mode='any'), numpy.ones(len(pos)))
+    assert_array_equal(layout.gather(ones, mode=numpy.fmax), numpy.ones(len(pos)))
+    assert_array_equal(layout.gather(npos, mode='local'), pos)
+    allpos = comm.allgather(npos)
+    assert_array_equal(allpos[0], [[0, 0], [0, 1], [1, 0], [1, 1]])
+    assert_array_equal(allpos[1], [[0, 0], [0, 1], [1, 0], [1, 1]])
+
+
+def case_period_empty_ranks(be, comm):
+    """test_domain.py:196-216: degenerate (empty) domains receive nothing"""
+    from pmesh_amd import domain
+    if comm.size < 3:
+        return
+    dcop = domain.GridND([[0, 2, 4, 4], [0, 4]], comm=comm, periodic=True)
+    pos = numpy.array([(0., 0.)])
+    layout = dcop.decompose(pos, smoothing=1.5)
+    p1 = layout.exchange(pos)
+    if comm.rank == 2:
+        assert len(p1) == 0
+    if comm.rank in (0, 1):
+        assert len(p1) == comm.size
+
+
+def case_paint_distributed_equals_serial(be, comm):
+    """test_pm.py:230-264: decompose + exchange + local paint, summed over ranks,
+    equals painting all particles on one block; readout through the layout equals
+    the serial readout."""
+    from pmesh_amd.pm import ParticleMesh
+    from oracle import oracle as O
+    N, L = 12, 24.0
+    rs = numpy.random.RandomState(100 + comm.rank)
+    npart = 300 + 50 * comm.rank
+    pos = rs.uniform(-L, 2 * L, size=(npart, 3))
+    mass = rs.uniform(0.5, 1.5, size=npart)
+    all_pos = numpy.concatenate(comm.allgather(pos), axis=0)
+    all_mass = numpy.concatenate(comm.allgather(mass), axis=0)
+    field = numpy.random.RandomState(5).normal(size=(N, N, N))
+    for resampler, kind in (('cic', 'tunedcic'), ('tsc', 'tunedtsc'), ('pcs', 'tunedpcs')):
+        pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler=resampler)
+        aff = O.Affine(3, scale=1.0 * N / L, period=N)
+        truth = numpy.zeros((N, N, N))
+        O.Window(kind).paint(truth, all_pos, mass=all_mass, transform=aff)
+        layout = pm.decompose(pos)
+        real = pm.paint(pos, mass=mass, layout=layout)
+        full = gather_field(comm, real, (N, N, N))
+        assert_allclose(full, truth, rtol=0, atol=1e-12 * abs(truth).max())
+        # readout with ghosts summed on the way back
+        fld = pm.create('real', value=field[real.slices])
+        got = fld.readout(pos, layout=layout)
+        want = O.Window(kind).readout(field, pos, transform=aff)
+        assert_allclose(got, want, rtol=0, atol=1e-12 * abs(want).max())
+        g1 = fld.readout(pos, layout=layout, gradient=1)
+        w1 = O.Window(kind).readout(field, pos, transform=aff, diffdir=1)
+        assert_allclose(g1, w1, rtol=0, atol=1e-12 * abs(w1).max())
+
+
+def case_slab_fft(be, comm):
+    """r2c / c2r on P ranks == numpy.fft on the gathered mesh, incl. uneven blocks"""
+    from pmesh_amd.pm import ParticleMesh
+    for Nmesh, dtype, tol in (([8, 12, 10], 'f8', 1e-13), ([10, 6, 9], 'f8', 1e-13),
+                              ([9, 7], 'f8', 1e-13), ([16, 8, 8], 'f4', 5e-6)):
+        pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, comm=comm, dtype=dtype, np=[comm.size])
+        data = numpy.random.RandomState(17).normal(size=Nmesh).astype(dtype)
+        real = pm.create('real', value=data[pm.create('real').slices])
+        ck = real.r2c()
+        Nc = list(Nmesh[:-1]) + [Nmesh[-1] // 2 + 1]
+        assert tuple(ck.cshape) == tuple(Nc)
+        full = gather_field(comm, ck, Nc)
+        ref = numpy.fft.rfftn(data.astype('f8')) / numpy.prod(Nmesh)
+        err = numpy.sqrt((abs(full - ref) ** 2).sum() / (abs(ref) ** 2).sum())
+        assert err < tol, (Nmesh, err)
+        assert_array_equal(numpy.asarray(real), data[real.slices])       # input preserved
+        back = ck.c2r()
+        assert numpy.sqrt(((numpy.asarray(back) - data[back.slices]) ** 2).sum() /
+                          max((data[back.slices] ** 2).sum(), 1e-300)) < 4 * tol
+        # in place
+        ck2 = real.r2c(out=Ellipsis)
+        assert real._base in ck2._base
+        full2 = gather_field(comm, ck2, Nc)
+        assert numpy.sqrt((abs(full2 - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < tol
+        back2 = ck2.c2r(out=Ellipsis)
+        assert numpy.sqrt(((numpy.asarray(back2) - data[back2.slices]) ** 2).sum() /
+                          max((data[back2.slices] ** 2).sum(), 1e-300)) < 4 * tol
+        # coordinates of the transposed field match its slices
+        for d in range(len(Nmesh)):
+            assert_array_equal(ck.i[d].cpu().numpy().ravel(),
+                               numpy.arange(ck.slices[d].start, ck.slices[d].stop))
+
+
+def case_cycle(be, comm):
+    """the whole PM cycle on P ranks == the serial oracle cycle"""
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    from oracle import oracle as O
+    N, L = 16, 1000.0
+    allpos = O.synth_uniform(N, L)
+    # each rank starts with an arbitrary share of the particles
+    share = numpy.array_split(numpy.arange(len(allpos)), comm.size)[comm.rank]
+    pos = allpos[share]
+    pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler='cic')
+    layout = pm.decompose(pos)
+    rho = pm.paint(pos, layout=layout)
+    Ntot = comm.allreduce(len(pos))
+    assert Ntot == N ** 3
+    rho[...] *= 1.0 * pm.Nmesh.prod() / Ntot                  # nbody.py:205-207
+    assert abs(rho.cmean() - 1.0) < 1e-12
+    rhok = rho.r2c(out=Ellipsis)
+    f = rhok.apply(Transfer.force(0), out=Ellipsis).c2r(out=Ellipsis).readout(pos, layout=layout)
+    t = O.make_transfer(laplace_pow=-1, grad_dir=0, grad_kind=1)
+    real, ck, back, out = O.pm_cycle(N, L, allpos, kind='tunedcic', transfer=t)
+    want = out[share]
+    assert abs(f - want).max() <= 1e-11 * abs(out).max()
+
+
+CASES = [case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+         case_slab_fft, case_cycle]
+
+
+def main():
+    be, comm = setup()
+    names = sys.argv[1:]
+    for case in CASES:
+        if names and case.__name__ not in names:
+            continue
+        case(be, comm)
+        comm.Barrier()
+        if comm.rank == 0:
+            print('ok', case.__name__, 'on', comm.size, 'ranks', flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

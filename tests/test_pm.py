@@ -1,0 +1,281 @@
+"""ParticleMesh / RealField / ComplexField through the public API of pmesh_amd.pm.
+
+Restates the reference's pmesh/tests/test_pm.py expectations for the hot path
+(cited per test) plus the golden 16^3 PM cycle generated from the compiled
+reference kernels and numpy.fft (tests/golden/cycle16.npz).  Two modes as in
+test_window.py: `-m gpu` runs the HIP kernels + rocFFT, `-m "not gpu"` drives the
+same host code against the CPU oracle.
+"""
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_array_equal, assert_allclose, assert_almost_equal
+
+from pmesh_amd.pm import ParticleMesh, RealField, ComplexField, UntransposedComplexField
+from pmesh_amd.transfer import Transfer
+from pmesh_amd import window
+
+# FFT tolerances: f8 rel-L2 <= 1e-13, f4 <= 5e-6; full cycle f8 <= 1e-11
+def rel_l2(a, b):
+    a = numpy.asarray(a); b = numpy.asarray(b)
+    return numpy.sqrt((abs(a - b) ** 2).sum() / max((abs(b) ** 2).sum(), 1e-300))
+
+
+def test_shapes_and_attributes(be):           # test_pm.py:30-42
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    real = RealField(pm)
+    assert tuple(real.cshape) == (8, 8) and real.csize == 64
+    comp = ComplexField(pm)
+    assert tuple(comp.cshape) == (8, 5) and comp.csize == 40
+    assert pm.ndim == 2 and tuple(pm.Nmesh) == (8, 8) and tuple(pm.BoxSize) == (8.0, 8.0)
+    assert real.dtype == numpy.dtype('f8') and comp.dtype == numpy.dtype('c16')
+    assert real.slices == (slice(0, 8), slice(0, 8))
+
+
+def test_negnyquist(be):                      # test_pm.py:46-53
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    c = pm.create(type='complex')
+    last = c.x[-1].cpu().numpy()
+    assert (last[0][-1] < 0).all()
+    assert (last[0][:-1] >= 0).all()
+
+
+def test_indices(be):                         # test_pm.py:268-275
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f8')
+    comp = pm.create(type='complex')
+    real = pm.create(type='real')
+    assert_almost_equal(comp.x[0].cpu(), [[0], [0.785], [-1.571], [-0.785]], decimal=3)
+    assert_almost_equal(comp.x[1].cpu(), [[0, 0.785, -1.571]], decimal=3)
+    assert_almost_equal(real.x[0].cpu(), [[0], [2], [-4], [-2]], decimal=3)
+    assert_almost_equal(real.x[1].cpu(), [[0, 2, -4, -2]], decimal=3)
+
+
+def test_fft(be):                             # test_pm.py:128-141
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f4')
+    real = pm.create(type='real', value=0)
+    real[...] = 2
+    real[::2, ::2] = -2
+    real3 = real.copy()
+    complex = real.r2c()
+    assert_almost_equal(numpy.asarray(real), numpy.asarray(real3), decimal=7)   # input preserved
+    real2 = complex.c2r()
+    assert_almost_equal(numpy.asarray(real), numpy.asarray(real2), decimal=6)
+
+
+@pytest.mark.parametrize('dtype,tol', [('f8', 1e-13), ('f4', 5e-6)])
+@pytest.mark.parametrize('Nmesh', [[8, 12, 10], [16, 16], [32]])
+def test_fft_contract_vs_numpy(be, dtype, tol, Nmesh):
+    """r2c == rfftn / prod(N); c2r == irfftn * prod(N) (pm.py:692; test_pm.py:422-428)."""
+    pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, dtype=dtype)
+    rs = numpy.random.RandomState(7)
+    data = rs.normal(size=Nmesh).astype(dtype)
+    real = pm.create(type='real', value=data)
+    assert_array_equal(numpy.asarray(real), data)
+    ck = real.r2c()
+    ref = numpy.fft.rfftn(data.astype('f8')) / numpy.prod(Nmesh)
+    assert rel_l2(ck, ref) < tol
+    assert_array_equal(numpy.asarray(real), data)            # PRESERVE_INPUT (pm.py:1335)
+    back = ck.c2r()
+    assert rel_l2(back, data) < 4 * tol
+    assert rel_l2(ck, ref) < tol                             # c2r preserves its input too
+    # untransposed flavour gives the same modes
+    cu = real.r2c(out=UntransposedComplexField(pm))
+    assert rel_l2(cu, ref) < tol
+    assert rel_l2(cu.c2r(), data) < 4 * tol
+
+
+def test_inplace_fft(be):                     # test_pm.py:167-192
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    Npar = 100
+    pos = 1.0 * (numpy.arange(Npar * len(pm.Nmesh))).reshape(-1, len(pm.Nmesh)) * (7, 7)
+    pos %= (pm.Nmesh + 1)
+    layout = pm.decompose(pos)
+    npos = layout.exchange(pos)
+    real = pm.paint(npos)
+    complex = real.r2c()
+    complex2 = real.r2c(out=Ellipsis)
+    assert real._base in complex2._base
+    assert_almost_equal(numpy.asarray(complex), numpy.asarray(complex2), decimal=7)
+    real = complex2.c2r()
+    real2 = complex2.c2r(out=Ellipsis)
+    assert real2._base in complex2._base
+    assert_almost_equal(numpy.asarray(real), numpy.asarray(real2), decimal=7)
+
+
+def test_decompose_paint_equals_serial(be):   # test_pm.py:230-264
+    pm = ParticleMesh(BoxSize=4.0, Nmesh=[4, 4, 4], dtype='f8')
+    pos = pm.generate_uniform_particle_grid(shift=0.5)
+    all_pos = pos.cpu().numpy()
+    for resampler in ['cic', 'tsc', 'pcs']:
+        truth = numpy.zeros(pm.Nmesh, dtype='f8')
+        window.FindResampler(resampler).paint(truth, all_pos, transform=window.Affine(ndim=3, period=4))
+        layout = pm.decompose(pos, smoothing=resampler)
+        npos = layout.exchange(pos)
+        real = pm.paint(npos, resampler=resampler)
+        full = numpy.zeros(pm.Nmesh, dtype='f8')
+        full[real.slices] = numpy.asarray(real)
+        assert_almost_equal(full, truth)
+
+
+def test_real_apply(be):                      # test_pm.py:329-341
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    real = RealField(pm)
+
+    def filter(x, v):
+        xnormp = x.normp()
+        assert_allclose(xnormp.cpu() if hasattr(xnormp, 'cpu') else xnormp,
+                        sum(xi ** 2 for xi in x).cpu() if hasattr(xnormp, 'cpu') else sum(xi ** 2 for xi in x))
+        return x[0] * 10 + x[1]
+    real.apply(filter, out=Ellipsis)
+    for i, x, slab in zip(real.slabs.i, real.slabs.x, real.slabs):
+        assert_array_equal(slab.cpu(), (x[0] * 10 + x[1]).cpu())
+
+
+def test_complex_apply(be):                   # test_pm.py:343-355
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    complex = ComplexField(pm)
+
+    def filter(k, v):
+        return k[0] + k[1] * 1j
+    complex.apply(filter, out=Ellipsis)
+    for i, x, slab in zip(complex.slabs.i, complex.slabs.x, complex.slabs):
+        assert_array_equal(slab.cpu(), (x[0] + x[1] * 1j).cpu())
+
+
+def test_apply_numpy_only_callable_falls_back_to_host(be):
+    """nbody.py's force_transfer calls numpy.sin on the wavenumbers: evaluated on the
+    host slab by slab, as the reference does (pm.py:633-647)."""
+    pm = ParticleMesh(BoxSize=100.0, Nmesh=[8, 8, 8], dtype='f8')
+    rs = numpy.random.RandomState(3)
+    ck = pm.create(type='real', value=rs.normal(size=(8, 8, 8))).r2c()
+
+    def force_transfer(direction):            # examples/nbody.py:162-171
+        def filter(k, v):
+            k2 = sum(ki ** 2 for ki in k)
+            k2[k2 == 0] = 1.0
+            C = (v.BoxSize / v.Nmesh)[direction]
+            w = k[direction] * C
+            kfinite = 1.0 / C * 1 / 6.0 * (8 * numpy.sin(w) - numpy.sin(2 * w))
+            return 1j * kfinite / k2 * v
+        return filter
+    for d in range(3):
+        a = ck.apply(force_transfer(d))
+        b = ck.apply(Transfer.force(d))
+        assert rel_l2(a, b) < 1e-14
+
+
+@pytest.mark.parametrize('dtype,tol', [('f8', 1e-14), ('f4', 1e-6)])
+def test_fused_transfers_match_reference_filters(be, dtype, tol):
+    """Transfer.{dx1,force,potential,lowpass,compensation} == the numpy filters of
+    examples/nbody.py:154-181 and window.get_compensation (window.py:65-80)."""
+    pm = ParticleMesh(BoxSize=[100.0, 80.0, 120.0], Nmesh=[8, 6, 10], dtype=dtype)
+    rs = numpy.random.RandomState(5)
+    ck = pm.create(type='real', value=rs.normal(size=(8, 6, 10))).r2c()
+    v = numpy.asarray(ck).astype('c16')
+    k = [x.cpu().numpy().astype('f8') for x in ck.x]
+    # recompute k in f8 from the indices: the reference casts them to the pm dtype
+    k = [2 * numpy.pi / L * (numpy.where(i.cpu().numpy() >= N // 2, i.cpu().numpy() - N, i.cpu().numpy()))
+         for i, L, N in zip(ck.i, pm.BoxSize, pm.Nmesh)]
+    k2 = sum(ki ** 2.0 for ki in k)
+    k2[k2 == 0] = 1.0
+    for d in range(3):
+        assert rel_l2(ck.apply(Transfer.dx1(d)), 1j * k[d] / k2 * v) < tol
+        C = pm.BoxSize[d] / pm.Nmesh[d]
+        w = k[d] * C
+        kf = 1.0 / C * 1 / 6.0 * (8 * numpy.sin(w) - numpy.sin(2 * w))
+        assert rel_l2(ck.apply(Transfer.force(d)), 1j * kf / k2 * v) < tol
+    assert rel_l2(ck.apply(Transfer.potential()), -1. / k2 * v) < tol
+    kk = sum(ki ** 2.0 for ki in k)
+    assert rel_l2(ck.apply(Transfer.lowpass(3.0)), numpy.exp(-0.5 * kk * 3.0 ** 2) * v) < tol
+    comp = window.TSC.get_compensation()
+    wlist = [ki * L / N for ki, L, N in zip(k, pm.BoxSize, pm.Nmesh)]
+    assert rel_l2(ck.apply(Transfer.compensation('tsc'), kind='circular'), comp(wlist, v)) < tol
+    # in place
+    c2 = ck.copy()
+    r = c2.apply(Transfer.potential(), out=Ellipsis)
+    assert r is c2 and rel_l2(c2, -1. / k2 * v) < tol
+
+
+def test_grid(be):                            # test_pm.py:828-847
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4, 4], dtype='f8')
+    grid = pm.generate_uniform_particle_grid(shift=0.5)
+    assert grid.shape[0] == pm.Nmesh.prod()
+    real = pm.paint(grid)
+    assert_array_equal(numpy.asarray(real), 1.0)
+    grid, id = pm.generate_uniform_particle_grid(shift=0.5, return_id=True)
+    allid = id.cpu().numpy()
+    assert len(numpy.unique(allid)) == len(allid) and allid.max() == len(allid) - 1 and allid.min() == 0
+
+
+def test_grid_shifted(be):                    # test_pm.py:850-867
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4, 4], dtype='f8')
+    grid = pm.generate_uniform_particle_grid(shift=0.5)
+    grid = grid + 4.0
+    layout = pm.decompose(grid)
+    real = pm.paint(grid, layout=layout)
+    assert_allclose(numpy.asarray(real), 1.0)
+    grid = grid - 6.1
+    layout = pm.decompose(grid)
+    real = pm.paint(grid, layout=layout)
+    assert_allclose(numpy.asarray(real), 1.0)
+
+
+def test_field_arithmetic_stays_a_field(be):  # Field.__array_ufunc__, pm.py:169-208
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4, 4], dtype='f8')
+    a = pm.create('real', value=numpy.arange(64.).reshape(4, 4, 4))
+    b = a * 2 + 1
+    assert isinstance(b, RealField)
+    assert_array_equal(numpy.asarray(b), numpy.arange(64.).reshape(4, 4, 4) * 2 + 1)
+    a[...] *= 0.5                              # examples/nbody.py:207
+    assert_array_equal(numpy.asarray(a), numpy.arange(64.).reshape(4, 4, 4) * 0.5)
+    assert abs(a.csum() - 0.5 * 63 * 64 / 2) < 1e-9
+    assert abs(a.cmean() - 0.5 * 63 / 2) < 1e-9
+    assert abs(a.cnorm() - (numpy.asarray(a) ** 2).sum()) < 1e-9
+    c = a.r2c()
+    full = numpy.fft.fftn(numpy.asarray(a)) / 64
+    assert abs(c.cnorm() - (abs(full) ** 2).sum()) < 1e-9           # test_pm.py:681-700
+    assert abs(c.cdot(c).real - (abs(full) ** 2).sum()) < 1e-9
+
+
+@pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs', 'nnb'])
+def test_golden_cycle16(be, golden, name):
+    """paint -> r2c -> transfer -> c2r -> readout against the fixture made with the
+    compiled reference kernels + numpy.fft."""
+    g = golden['cycle16']
+    N, L = int(g['N'][0]), float(g['L'][0])
+    pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype='f8', resampler=name)
+    pos = torch.from_numpy(g['pos']).to(be.device)
+    rho = pm.paint(pos)
+    want = g['%s/paint' % name]
+    assert abs(numpy.asarray(rho) - want).max() <= 1e-12 * max(1.0, abs(want).max())
+    rhok = rho.r2c()
+    assert rel_l2(rhok, g['%s/r2c' % name]) < 1e-13
+    for tname, T in (('dx1_0', Transfer.dx1(0)), ('force_2', Transfer.force(2)),
+                     ('pot', Transfer.potential())):
+        back = rhok.apply(T).c2r()
+        assert rel_l2(back, g['%s/%s/c2r' % (name, tname)]) < 1e-11
+        out = back.readout(pos)
+        assert rel_l2(out.cpu().numpy(), g['%s/%s/readout' % (name, tname)]) < 1e-11
+        out0 = back.readout(pos, gradient=0)
+        assert rel_l2(out0.cpu().numpy(), g['%s/%s/readout_g0' % (name, tname)]) < 1e-11
+    # the in-place chain the benchmark uses gives the same numbers
+    f = pm.paint(pos).r2c(out=Ellipsis).apply(Transfer.dx1(0), out=Ellipsis).c2r(out=Ellipsis).readout(pos)
+    assert rel_l2(f.cpu().numpy(), g['%s/dx1_0/readout' % name]) < 1e-11
+
+
+def test_vjp_compositions(be):                # test_gradient.py: paint/readout adjointness
+    pm = ParticleMesh(BoxSize=4.0, Nmesh=[4, 4, 4], dtype='f8')
+    rs = numpy.random.RandomState(9)
+    pos = rs.uniform(0, 4, size=(50, 3))
+    mass = rs.uniform(0.5, 1.5, size=50)
+    field = pm.create('real', value=rs.normal(size=(4, 4, 4)))
+    # <paint(pos, mass), field> == <mass, readout(field, pos)>
+    lhs = pm.paint(pos, mass=mass).cdot(field)
+    rhs = (mass * field.readout(pos)).sum()
+    assert abs(lhs - rhs) < 1e-12 * abs(rhs)
+    out_pos, out_mass = pm.paint_vjp(field, pos, mass=mass)
+    assert_allclose(out_mass, field.readout(pos))
+    for d in range(3):
+        assert_allclose(out_pos[:, d], field.readout(pos, gradient=d) * mass)
+    out_self, out_pos2 = field.readout_vjp(pos, v=mass)
+    assert_allclose(numpy.asarray(out_self), numpy.asarray(pm.paint(pos, mass=mass)))
