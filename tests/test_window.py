@@ -338,11 +338,12 @@ def test_golden_E_dyadic_bit_exact(be, golden, name):
         aff = Affine(3, period=8)
         real = numpy.zeros((8, 8, 8), dtype=dt)
         W.paint(real, g['E/pos'], mass=g['E/mass'], transform=aff)
-        if dt == 'f8' or name in ('nnb', 'cic'):
+        if (dt == 'f8' and name != 'pcs') or name in ('nnb', 'cic'):
             assert_array_equal(real, g['E/%s/%s/paint' % (name, dt)])
         else:
             # TSC/PCS weights on a 1/16 lattice need > 24 mantissa bits: the f4
-            # canvas rounds per add (quirk Q7), so only the tolerance applies
+            # canvas rounds per add (quirk Q7); PCS weights carry a factor 1/6 and are
+            # never exactly representable: only the tolerance applies there
             check_paint(be, real, g['E/%s/%s/paint' % (name, dt)])
         assert_array_equal(W.readout(g['E/field'].astype(dt), g['E/pos'], transform=aff),
                            g['E/%s/%s/readout' % (name, dt)])
