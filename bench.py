@@ -44,7 +44,7 @@ def algorithmic_bytes(stage, e, pe, nu=1.0):
         'readout': 3 * pe + e + e / nu,        # positions + result + each cell once
         'r2c': 2 * e / nu, 'c2r': 2 * e / nu,  # real in, half-complex out (single pass)
         'apply': 2 * e / nu,                   # complex read + write
-        'zero': e / nu,
+        'zero': e / nu, 'bin': 3 * pe,
     }[stage]
 
 
@@ -176,7 +176,12 @@ def main():
         torch.cuda.synchronize()
         t_decompose = time.perf_counter() - t0
 
-    stages = ['zero', 'paint', 'r2c', 'apply', 'c2r', 'readout']
+    from pmesh_amd import window as _window
+    if args.binned == 0:
+        _window.BINNED = 'never'
+    elif args.binned == 1:
+        _window.BINNED = 'always'
+    stages = ['bin', 'paint', 'r2c', 'apply', 'c2r', 'readout']
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
           for _ in range(args.steps)]
 
@@ -184,10 +189,15 @@ def main():
         def mark(i):
             if marks is not None:
                 marks[i].record()
+        # a new time step: positions are "new", nothing binned or exchanged is reused
+        _window.clear_bin_cache()
+        if layout is not None:
+            layout._memo = None
         mark(0)
-        rho.value.zero_()
+        if layout is None:
+            pm.resampler.prebin(rho.value, pos, pm.affine)      # tile binning, shared by paint+readout
         mark(1)
-        pm.paint(pos, hold=True, layout=layout, out=rho)
+        pm.paint(pos, hold=False, layout=layout, out=rho)        # includes the zero fill
         mark(2)
         rhok = rho.r2c(out=Ellipsis)
         mark(3)

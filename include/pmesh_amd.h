@@ -113,19 +113,29 @@ int pmx_readout(const pmx_painter *p, const void *canvas, const pmx_vec *pos, co
                 const pmx_vec *out, int64_t npart, void *stream);
 
 /* ---- tile-binned paint / readout (device-side acceleration structure) ---- */
-/* A bin plan orders the particles by mesh tile so that paint accumulates each
- * tile in LDS and readout gathers from an LDS-staged tile.  Results equal
- * pmx_paint / pmx_readout up to floating-point summation order. */
+/* A bin plan orders the particles of one batch by mesh tile (an index list per
+ * tile; positions are not copied) so that paint accumulates each tile in LDS
+ * and writes it with plain stores, and readout gathers from an LDS-staged tile.
+ * 3-d meshes, tuned windows (NNB/CIC/TSC/PCS) at native support, no hsml.
+ * Results: readout is bit-identical to pmx_readout; paint equals pmx_paint up
+ * to the order of floating-point additions into a cell.  One plan serves any
+ * number of paint/readout calls on the same positions and geometry (the PM
+ * cycle paints and reads out at the same positions). */
 typedef struct pmx_binplan pmx_binplan;
-int pmx_binplan_create(pmx_binplan **plan, const pmx_painter *p, int64_t max_particles);
+int pmx_binplan_create(pmx_binplan **plan);
 int pmx_binplan_destroy(pmx_binplan *plan);
-/* sort the particle batch by tile; keeps a device copy of the sorted
- * positions (and masses) and the permutation */
-int pmx_binplan_build(pmx_binplan *plan, const pmx_painter *p, const pmx_vec *pos,
-                      const pmx_vec *mass, double mass_scalar, int64_t npart, void *stream);
-int pmx_paint_binned(pmx_binplan *plan, const pmx_painter *p, void *canvas, void *stream);
+/* PMX_OK if (painter, npart) can use the binned kernels */
+int pmx_binplan_supported(const pmx_painter *p, int64_t npart);
+/* bin the batch: tile id + slot per particle, per-tile counts, scan, index lists */
+int pmx_binplan_build(pmx_binplan *plan, const pmx_painter *p, const pmx_vec *pos, int64_t npart,
+                      void *stream);
+/* overwrite != 0: the canvas content is ignored and every cell of the block is
+ * written (paint with hold=False without a separate zero fill, pm.py:1852-1853) */
+int pmx_paint_binned(pmx_binplan *plan, const pmx_painter *p, void *canvas, const pmx_vec *pos,
+                     const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream);
+/* out entries of particles that touch no local cell are not written: zero `out` first */
 int pmx_readout_binned(pmx_binplan *plan, const pmx_painter *p, const void *canvas,
-                       const pmx_vec *out, void *stream);
+                       const pmx_vec *pos, const pmx_vec *out, void *stream);
 
 /* ---- domain decomposition (pmesh/domain.py:561-652 + _domain.pyx:9-122) -- */
 typedef struct pmx_grid {

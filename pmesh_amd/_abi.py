@@ -80,11 +80,12 @@ DEVICE_ONLY = {
     'last_error': (C.c_char_p, []),
     'version': (C.c_int, []),
     'device_count': (C.c_int, []),
-    'binplan_create': (C.c_int, [_P(_vp), _P(Painter), _i64]),
+    'binplan_create': (C.c_int, [_P(_vp)]),
     'binplan_destroy': (C.c_int, [_vp]),
-    'binplan_build': (C.c_int, [_vp, _P(Painter), _P(Vec), _P(Vec), _f64, _i64, _vp]),
-    'paint_binned': (C.c_int, [_vp, _P(Painter), _vp, _vp]),
-    'readout_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _vp]),
+    'binplan_supported': (C.c_int, [_P(Painter), _i64]),
+    'binplan_build': (C.c_int, [_vp, _P(Painter), _P(Vec), _i64, _vp]),
+    'paint_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _f64, _i32, _vp]),
+    'readout_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _vp]),
     'fft_create': (C.c_int, [_P(_vp), _i32, _i32, _i32, _P(_i64), _P(_i64), _i64, _P(_i64), _i64,
                              _i64, _f64, _i32]),
     'fft_execute': (C.c_int, [_vp, _vp, _vp, _vp]),

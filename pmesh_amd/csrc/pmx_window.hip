@@ -22,121 +22,9 @@
 #include <math.h>
 
 #include "pmx_common.h"
+#include "pmx_window_dev.h"
 
 namespace pmx {
-
-__host__ __device__ inline int native_support(int kind)
-{
-    switch (kind) {
-    case PMX_NEAREST: case PMX_TUNED_NNB: return 1;
-    case PMX_LINEAR: case PMX_TUNED_CIC: return 2;
-    case PMX_QUADRATIC: case PMX_TUNED_TSC: return 3;
-    case PMX_CUBIC: case PMX_TUNED_PCS: return 4;
-    }
-    return -1;
-}
-
-struct WInfo {
-    int support;
-    int left;
-    double vfactor, shift;
-};
-
-// pmesh_window_info_init (_window_imp.c:24-47)
-__host__ __device__ inline WInfo winfo_init(int nativesupport, double support)
-{
-    WInfo w;
-    if (support <= 0) {
-        w.support = nativesupport;
-        support = nativesupport;
-    } else {
-        w.support = (int)support;
-        w.support += (support != (double)w.support);
-    }
-    w.left = (w.support - 1) / 2;
-    w.shift = support / 2.0 - w.support / 2;
-    w.vfactor = nativesupport / (1. * support);
-    return w;
-}
-
-__device__ __forceinline__ int wrap1(int i, int64_t n)
-{
-    if (n <= 0) return i;
-    int m = (int)n;
-    int r = i % m;
-    return r < 0 ? r + m : r;
-}
-
-// ---- one axis of SETUP_KERNEL_* (tuned_nnb.h:1-27, tuned_cic.h:1-32,
-//      tuned_tsc.h:1-37, tuned_pcs.h:1-52) ---------------------------------
-template <int KIND> struct Tuned;
-
-template <> struct Tuned<PMX_TUNED_NNB> {
-    static constexpr int S = 1;
-    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
-    {
-        I[0] = (int)floor(X + 0.5);
-        V[0] = (order == 0) ? 1 : 0;
-    }
-};
-
-template <> struct Tuned<PMX_TUNED_CIC> {
-    static constexpr int S = 2;
-    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
-    {
-        I[0] = (int)floor(X);
-        I[1] = I[0] + 1;
-        if (order == 0) {
-            V[1] = X - I[0];
-            V[0] = 1. - V[1];
-        } else {
-            V[1] = scale;
-            V[0] = -scale;
-        }
-    }
-};
-
-template <> struct Tuned<PMX_TUNED_TSC> {
-    static constexpr int S = 3;
-    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
-    {
-        I[1] = (int)floor(X + 0.5);
-        I[0] = I[1] - 1;
-        I[2] = I[1] + 1;
-        if (order == 0) {
-            V[1] = 0.75 - (X - I[1]) * (X - I[1]);
-            V[0] = (1.5 - (X - I[0])) * (1.5 - (X - I[0])) * 0.5;
-            V[2] = (1.5 + (X - I[2])) * (1.5 + (X - I[2])) * 0.5;
-        } else {
-            V[1] = -2 * (X - I[1]) * scale;
-            V[0] = -(1.5 - (X - I[0])) * scale;
-            V[2] = (1.5 + (X - I[2])) * scale;
-        }
-    }
-};
-
-template <> struct Tuned<PMX_TUNED_PCS> {
-    static constexpr int S = 4;
-    __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
-    {
-        I[1] = (int)floor(X);
-        I[0] = I[1] - 1;
-        I[2] = I[1] + 1;
-        I[3] = I[2] + 1;
-        if (order == 0) {
-            V[1] = 1.0 / 6.0 * (4 - 6 * (X - I[1]) * (X - I[1]) + 3 * (X - I[1]) * (X - I[1]) * (X - I[1]));
-            V[2] = 1.0 / 6.0 * (4 - 6 * (X - I[2]) * (X - I[2]) - 3 * (X - I[2]) * (X - I[2]) * (X - I[2]));
-            V[0] = 1.0 / 6.0 * (2 - (X - I[0])) * (2 - (X - I[0])) * (2 - (X - I[0]));
-            V[3] = 1.0 / 6.0 * (2 + (X - I[3])) * (2 + (X - I[3])) * (2 + (X - I[3]));
-        } else {
-            // quirk Q1: no scale factor in the tuned PCS derivative
-            V[1] = +1.0 / 6.0 * (-12 * (X - I[1]) + 9 * (X - I[1]) * (X - I[1]));
-            V[2] = -1.0 / 6.0 * (+12 * (X - I[2]) + 9 * (X - I[2]) * (X - I[2]));
-            V[0] = -1.0 / 2.0 * (2 - (X - I[0])) * (2 - (X - I[0]));
-            V[3] = +1.0 / 2.0 * (2 + (X - I[3])) * (2 + (X - I[3]));
-        }
-    }
-};
 
 template <typename T> __device__ __forceinline__ void canvas_add(char *canvas, int64_t off, double f)
 {

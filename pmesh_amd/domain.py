@@ -116,6 +116,21 @@ class Layout(object):
 
     def _exchange(self, data):
         be = backend.get()
+        # The PM cycle routes the same positions before paint and before every readout
+        # (pm.py:1859, 784): remember the last exchanged device array and hand it back while
+        # the source tensor is unchanged (same storage, same version counter).
+        memo_key = None
+        if is_tensor(data) and data.device == be.device:
+            memo_key = (data.data_ptr(), data._version, tuple(data.shape), data.stride(), data.dtype)
+            memo = getattr(self, '_memo', None)
+            if memo is not None and memo[0] == memo_key:
+                return memo[2]
+        r = self._exchange_impl(be, data)
+        if memo_key is not None:
+            self._memo = (memo_key, data, r)
+        return r
+
+    def _exchange_impl(self, be, data):
         data, host = to_device(data, be.device, 'data', allow_int=True)
         if any(self.comm.allgather(len(data) != self.sendlength)) if self.comm.size > 1 \
                 else len(data) != self.sendlength:

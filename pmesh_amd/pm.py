@@ -933,16 +933,16 @@ class ParticleMesh(object):
         resampler = FindResampler(resampler)
         if out is None:
             out = self.create(type=RealField)
-        if not hold:
-            out.value.zero_()
         if layout is None:
-            resampler.paint(out.value, pos, hsml=hsml, mass=mass, transform=transform, diffdir=gradient)
+            # hold=False: "out.value[...] = 0" (pm.py:1852-1853) is folded into the kernel
+            resampler.paint(out.value, pos, hsml=hsml, mass=mass, transform=transform, diffdir=gradient,
+                            _overwrite=not hold)
             return out
         localpos = layout.exchange(pos)
         localmass = exchange(layout, mass)
         localhsml = exchange(layout, hsml)
         return self.paint(localpos, mass=localmass, hsml=localhsml, resampler=resampler,
-                          transform=transform, hold=True, gradient=gradient, layout=None, out=out)
+                          transform=transform, hold=hold, gradient=gradient, layout=None, out=out)
 
     def paint_jvp(self, pos, mass=1.0, v_pos=None, v_mass=None, resampler=None, transform=None,
                   gradient=None, layout=None, out=None):

@@ -59,6 +59,85 @@ class Affine(object):
         return Affine(self.ndim, self.scale, self.translate + amount, self.period)
 
 
+# ---- tile-binned fast path (csrc/pmx_binned.hip) --------------------------------
+# 'auto'  : use the LDS-tiled kernels when the batch is large, 3-d, on the device and the
+#           window is a tuned one at native support; otherwise the direct kernels.
+# 'never' : always the direct (global-atomic) kernels.  'always': binned whenever legal.
+BINNED = 'auto'
+BINNED_MIN_PARTICLES = 1 << 17
+
+
+class _BinCache(object):
+    """A bin plan (particles ordered by mesh tile) depends only on the positions, the
+    window and the affine/block geometry; the PM cycle paints and reads out at the same
+    positions, so the plan of the last batches is kept and found again by the identity
+    and version counter of the position tensor.  Plans are pooled: no allocation in
+    steady state."""
+    SLOTS = 2
+
+    def __init__(self):
+        self.entries = []     # [key, plan handle, pos tensor (kept alive), built]
+        self.clock = 0
+
+    def _key(self, pos, painter):
+        return (pos.data_ptr(), pos._version, tuple(pos.shape), pos.stride(), pos.dtype,
+                painter.kind, tuple(painter.scale), tuple(painter.translate),
+                tuple(painter.period), tuple(painter.size))
+
+    def lookup(self, be, pos, painter, pv, n):
+        key = self._key(pos, painter)
+        for e in self.entries:
+            if e[0] == key and e[3]:
+                e[4] = self._tick()
+                return e[1]
+        if len(self.entries) < self.SLOTS:
+            plan = C.c_void_p()
+            be.call('binplan_create', C.byref(plan))
+            e = [None, plan, None, False, 0]
+            self.entries.append(e)
+        else:
+            e = min(self.entries, key=lambda q: q[4])
+        e[0], e[2], e[3] = key, pos, False
+        be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
+        e[3] = True
+        e[4] = self._tick()
+        return e[1]
+
+    def _tick(self):
+        self.clock += 1
+        return self.clock
+
+    def clear(self):
+        """forget which batches are binned (the pooled device buffers are kept)"""
+        for e in self.entries:
+            e[0], e[2], e[3] = None, None, False
+
+    def destroy(self, be):
+        for e in self.entries:
+            try:
+                be.call('binplan_destroy', e[1])
+            except Exception:
+                pass
+        self.entries = []
+
+
+_bin_cache = _BinCache()
+
+
+def clear_bin_cache():
+    """Invalidate cached bin plans, e.g. at the start of a time step when positions
+    were rewritten in place through a foreign pointer."""
+    _bin_cache.clear()
+
+
+def _binned_ok(be, painter, pos, n, hs):
+    if BINNED == 'never' or be.name != 'hip' or hs is not None:
+        return False
+    if BINNED == 'auto' and n < BINNED_MIN_PARTICLES:
+        return False
+    return be.lib.pmx_binplan_supported(C.byref(painter), n) == 0
+
+
 # kinds of the reference registry that are table driven (lanczos/acg/db/sym,
 # _window_lanczos.h etc.): outside the hot-path scope table (SURVEY.md 2.1 #5b)
 _UNBUILT = ['lanczos2', 'lanczos3', 'lanczos4', 'lanczos5', 'lanczos6',
@@ -181,7 +260,26 @@ class ResampleWindow(object):
                 hs = hs[0]
         return pos, hs, n
 
-    def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None):
+    def prebin(self, real, pos, transform=None):
+        """Bin a particle batch by mesh tile ahead of paint/readout (device tensors only).
+        Optional: paint and readout bin on demand and share the plan; calling this
+        separately only makes the cost of the binning visible on its own.  Returns True if
+        the tile-binned kernels will be used for this batch."""
+        self._require_built()
+        be = backend.get()
+        if not (is_tensor(real) and is_tensor(pos)):
+            return False
+        canvas = real_view(real)
+        if transform is None:
+            transform = Affine(canvas.dim())
+        p = self._painter(canvas, numpy.zeros(canvas.dim(), dtype=int), transform)
+        n = pos.shape[0]
+        if not (n and _binned_ok(be, p, pos, n, None)):
+            return False
+        _bin_cache.lookup(be, pos, p, vec(pos), n)
+        return True
+
+    def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None, _overwrite=False):
         """
             paint to a field (window.py:106-163).
 
@@ -222,8 +320,15 @@ class ResampleWindow(object):
         p = self._painter(canvas, order, transform)
         pv = vec(pos)
         hv = vec(hs) if hs is not None else None
-        be.call('paint', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv), mass_scalar,
-                vec_ref(hv), n, be.stream())
+        if n and _binned_ok(be, p, pos, n, hs):
+            plan = _bin_cache.lookup(be, pos, p, pv, n)
+            be.call('paint_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv),
+                    mass_scalar, int(bool(_overwrite)), be.stream())
+        else:
+            if _overwrite:
+                canvas.zero_()
+            be.call('paint', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv), mass_scalar,
+                    vec_ref(hv), n, be.stream())
         if writeback is not None:
             writeback()
 
@@ -273,8 +378,14 @@ class ResampleWindow(object):
         pv = vec(pos)
         hv = vec(hs) if hs is not None else None
         ov = vec(dout)
-        be.call('readout', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(hv), C.byref(ov), n,
-                be.stream())
+        if n and _binned_ok(be, p, pos, n, hs):
+            plan = _bin_cache.lookup(be, pos, p, pv, n)
+            dout.zero_()      # particles that touch no local cell are in no tile
+            be.call('readout_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), C.byref(ov),
+                    be.stream())
+        else:
+            be.call('readout', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(hv), C.byref(ov), n,
+                    be.stream())
         if host_out is not None:
             host_out[...] = dout.cpu().numpy()
             return host_out

@@ -1,0 +1,183 @@
+"""The tile-binned (LDS-tiled) paint / readout kernels against the direct kernels,
+the CPU oracle and size-independent properties.  GPU only: the binned path exists
+only in the HIP library (there is nothing to test on the oracle double).
+
+  * readout_binned == pmx_readout bit for bit (same per-particle summation order);
+  * paint_binned == pmx_paint within the f8/f4 tolerance (the order of additions
+    into a cell differs), and bit for bit on dyadic inputs (exact partial sums),
+    which pins the cell indexing of the binning, the tile-local addressing, the
+    owned/halo split and the periodic flush;
+  * slab-local blocks (size < period, translate), non-periodic canvases, particles
+    outside the box, random order, overwrite vs accumulate;
+  * full-size properties at the BASELINE workload: mass conservation, paint
+    linearity, readout of a constant field.
+"""
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_array_equal, assert_allclose
+
+from pmesh_amd import window
+from pmesh_amd.window import Affine, windows
+
+pytestmark = pytest.mark.gpu
+
+TUNED = ['nnb', 'cic', 'tsc', 'pcs']
+
+
+@pytest.fixture
+def hip():
+    from pmesh_amd import backend
+    backend.reset()
+    b = backend.get()
+    old = window.BINNED
+    yield b
+    window.BINNED = old
+    window.clear_bin_cache()
+    backend.reset()
+
+
+def both(W, fn):
+    """run fn under the direct and under the binned kernels"""
+    window.BINNED = 'never'
+    a = fn()
+    window.BINNED = 'always'
+    window.clear_bin_cache()
+    b = fn()
+    return a, b
+
+
+CASES = [
+    # shape, period, scale, translate
+    ((32, 32, 32), (32, 32, 32), 1.0, 0.0),                          # full periodic block
+    ((40, 36, 48), (40, 36, 48), (0.5, 1.0, 0.75), (0.3, 0.0, -0.25)),  # not a multiple of the tile
+    ((20, 48, 48), (64, 48, 48), 1.0, (-16.0, 0.0, 0.0)),            # slab-local block of a bigger mesh
+    ((24, 24, 40), (0, 0, 0), 1.0, 0.0),                             # non periodic
+    ((19, 48, 21), (19, 0, 64), 1.0, (0.0, 2.0, -5.0)),              # mixed
+]
+
+
+@pytest.mark.parametrize('name', TUNED)
+@pytest.mark.parametrize('case', range(len(CASES)))
+def test_binned_equals_direct(hip, oracle, name, case):
+    shape, period, scale, translate = CASES[case]
+    W = windows[name]
+    rs = numpy.random.RandomState(100 + case)
+    n = 20000
+    pos_h = rs.uniform(-40, 110, size=(n, 3))
+    mass_h = rs.uniform(0.5, 1.5, size=n)
+    aff = Affine(3, scale=scale, translate=translate, period=period)
+    oaff = oracle.Affine(3, scale=scale, translate=translate, period=period)
+    for dt, tdt, tol in (('f8', torch.float64, 1e-12), ('f4', torch.float32, 2e-6)):
+        for ptype in ('f8', 'f4'):
+            pos = torch.from_numpy(pos_h.astype(ptype)).to(hip.device)
+            mass = torch.from_numpy(mass_h).to(hip.device)
+            field_h = rs.normal(size=shape).astype(dt)
+            field = torch.from_numpy(field_h).to(hip.device)
+            for diffdir in (None, 1):
+                def paint():
+                    c = torch.zeros(shape, dtype=tdt, device=hip.device)
+                    W.paint(c, pos, mass=mass, diffdir=diffdir, transform=aff)
+                    return c.cpu().numpy()
+                d, b = both(W, paint)
+                s = max(1.0, abs(d).max())
+                assert_allclose(b, d, rtol=0, atol=tol * s)
+                if ptype == 'f8' and diffdir is None and dt == 'f8':
+                    want = numpy.zeros(shape)
+                    oracle.Window(W.kind).paint(want, pos_h, mass=mass_h, transform=oaff)
+                    assert_allclose(b, want, rtol=0, atol=tol * s)
+
+                def readout():
+                    return W.readout(field, pos, diffdir=diffdir, transform=aff).cpu().numpy()
+                d, b = both(W, readout)
+                assert_array_equal(b, d)                  # bit-identical gather
+    # overwrite == zero + accumulate; accumulate really accumulates
+    pos = torch.from_numpy(pos_h).to(hip.device)
+    window.BINNED = 'always'
+    c1 = torch.full(shape, 7.0, dtype=torch.float64, device=hip.device)
+    W.paint(c1, pos, transform=aff, _overwrite=True)
+    c2 = torch.zeros(shape, dtype=torch.float64, device=hip.device)
+    W.paint(c2, pos, transform=aff)
+    assert_allclose(c1.cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=1e-12 * max(1, float(c2.abs().max())))
+    c3 = torch.full(shape, 7.0, dtype=torch.float64, device=hip.device)
+    W.paint(c3, pos, transform=aff)
+    assert_allclose(c3.cpu().numpy(), c2.cpu().numpy() + 7.0, rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize('name', ['nnb', 'cic', 'tsc'])
+def test_binned_dyadic_bit_exact(hip, oracle, name):
+    """positions on a 1/16-cell lattice, small integer masses: exact partial sums =>
+    the binned scatter must reproduce the reference bit for bit (indexing parity)."""
+    W = windows[name]
+    rs = numpy.random.RandomState(4)
+    N = 48
+    pos_h = rs.randint(-64 * 16, 3 * N * 16, size=(50000, 3)) / 16.0
+    mass_h = rs.randint(1, 5, size=len(pos_h)).astype('f8')
+    want = numpy.zeros((N, N, N))
+    oracle.Window(W.kind).paint(want, pos_h, mass=mass_h, transform=oracle.Affine(3, period=N))
+    window.BINNED = 'always'
+    c = torch.zeros((N, N, N), dtype=torch.float64, device=hip.device)
+    W.paint(c, torch.from_numpy(pos_h).to(hip.device), mass=torch.from_numpy(mass_h).to(hip.device),
+            transform=Affine(3, period=N))
+    assert_array_equal(c.cpu().numpy(), want)
+
+
+def test_plan_is_shared_and_invalidated(hip):
+    """paint and readout on the same position tensor share one plan; an in-place change of
+    the positions (version counter) rebuilds it."""
+    W = windows['cic']
+    window.BINNED = 'always'
+    window.clear_bin_cache()
+    rs = numpy.random.RandomState(1)
+    pos = torch.from_numpy(rs.uniform(0, 32, size=(5000, 3))).to(hip.device)
+    aff = Affine(3, period=32)
+    c = torch.zeros((32, 32, 32), dtype=torch.float64, device=hip.device)
+    W.paint(c, pos, transform=aff)
+    built = [e[3] for e in window._bin_cache.entries]
+    W.readout(c, pos, transform=aff)
+    assert [e[3] for e in window._bin_cache.entries] == built
+    keys = [e[0] for e in window._bin_cache.entries]
+    pos += 1.0                                    # in place: version changes
+    c2 = torch.zeros((32, 32, 32), dtype=torch.float64, device=hip.device)
+    W.paint(c2, pos, transform=aff)
+    assert [e[0] for e in window._bin_cache.entries] != keys
+    window.BINNED = 'never'
+    c3 = torch.zeros((32, 32, 32), dtype=torch.float64, device=hip.device)
+    W.paint(c3, pos, transform=aff)
+    assert_allclose(c2.cpu().numpy(), c3.cpu().numpy(), rtol=0, atol=1e-12 * float(c3.abs().max()))
+
+
+@pytest.mark.parametrize('name,dtype', [('cic', 'f8'), ('tsc', 'f4')])
+def test_full_size_properties(hip, name, dtype):
+    """BASELINE sizes (512^3 mesh, 512^3 particles; config 3 in f4): size-independent
+    properties of the tile-binned kernels."""
+    import ctypes as C
+    from pmesh_amd._arrays import vec
+    from pmesh_amd.pm import ParticleMesh
+    window.BINNED = 'auto'
+    N, L = 512, 1000.0
+    tdt = torch.float64 if dtype == 'f8' else torch.float32
+    pos = torch.empty((N ** 3, 3), dtype=tdt, device=hip.device)
+    pv = vec(pos)
+    hip.call('synth_uniform', C.byref(pv), N, L, 42, 0, N ** 3, hip.stream())
+    pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype=dtype, resampler=name)
+    rho = pm.paint(pos)
+    tol = 1e-10 if dtype == 'f8' else 2e-4
+    assert abs(rho.csum(dtype='f8') / N ** 3 - 1.0) < tol           # mass conservation
+    assert float(rho.value.min()) >= 0.0
+    rho2 = pm.paint(pos, mass=2.0)                                   # linearity in the mass
+    assert float((rho2.value - 2 * rho.value).abs().max()) <= (1e-12 if dtype == 'f8' else 1e-5) * float(rho2.value.max())
+    window.BINNED = 'never'                                          # direct == binned at full size
+    rho3 = pm.paint(pos)
+    assert float((rho3.value - rho.value).abs().max()) <= (1e-12 if dtype == 'f8' else 4e-6) * float(rho.value.max())
+    window.BINNED = 'auto'
+    one = pm.create('real', value=1.0)
+    v = one.readout(pos)                                             # partition of unity
+    assert float((v - 1.0).abs().max()) < (1e-14 if dtype == 'f8' else 1e-6)
+    g = one.readout(pos, gradient=0)                                 # gradient of a constant
+    assert float(g.abs().max()) < (1e-12 if dtype == 'f8' else 1e-4)
+    # checksum of checksums: readout of the painted density, weighted back, is symmetric
+    f1 = rho.readout(pos)
+    lhs = float((f1.to(torch.float64)).sum())
+    rhs = float((rho.value.to(torch.float64) ** 2).sum())          # <paint(1), rho> == <1, readout(rho)>
+    assert abs(lhs - rhs) <= (1e-10 if dtype == 'f8' else 1e-3) * abs(rhs)
