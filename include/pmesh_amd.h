@@ -133,7 +133,6 @@ int pmx_binplan_build(pmx_binplan *plan, const pmx_painter *p, const pmx_vec *po
  * written (paint with hold=False without a separate zero fill, pm.py:1852-1853) */
 int pmx_paint_binned(pmx_binplan *plan, const pmx_painter *p, void *canvas, const pmx_vec *pos,
                      const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream);
-/* out entries of particles that touch no local cell are not written: zero `out` first */
 int pmx_readout_binned(pmx_binplan *plan, const pmx_painter *p, const void *canvas,
                        const pmx_vec *pos, const pmx_vec *out, void *stream);
 

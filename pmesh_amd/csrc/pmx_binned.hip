@@ -7,10 +7,10 @@
 // mesh is cut into tiles of T^3 cells; the particles are binned by the tile of
 // their window's base cell (an index list per tile: positions are NOT copied);
 // one workgroup per tile accumulates its (T+S-1)^3 region in LDS with ds_add and
-// writes the T^3 cells it owns with plain coalesced stores; only the S-1 cell
-// deep halo (20 % of the cells for CIC) goes through a staging buffer and global
-// atomics in a second kernel.  Readout stages the tile region in LDS the same
-// way and gathers from there.
+// flushes it once: cells that only this tile can touch (the deep interior, 82 % of
+// a CIC tile) are written with plain coalesced stores, cells that a neighbouring
+// tile's region also covers (the S-1 deep faces) with global atomics.  Readout
+// stages the tile region in LDS the same way and gathers from there.
 //
 // Arithmetic is the same as the direct kernels (same Tuned<KIND>::axis, same
 // left-to-right products): readout is bit-identical to pmx_readout (the
@@ -44,6 +44,7 @@ struct BinGeom {
     int32_t nt[3];        // tiles per axis
     int32_t o[3];         // tile-space offset per axis
     int32_t R;            // region extent per axis = TILE + S - 1
+    int32_t wrapcover[3]; // full periodic axes: cells [0, wrapcover) are also covered by the last tile
     int64_t ntiles;
 };
 
@@ -62,8 +63,7 @@ struct pmx_binplan {
     uint32_t *counts = nullptr; // particles per tile
     int64_t *offsets = nullptr; // exclusive prefix (ntiles + 1)
     size_t cap_tiles = 0;
-    void *halo = nullptr;       // staging for non-owned region cells: ntiles * R^3 elements
-    size_t cap_halo = 0;
+    uint32_t *flags = nullptr;  // [0] != 0: some particle touches no local cell (tid == -1)
 };
 
 namespace pmx {
@@ -98,7 +98,8 @@ __device__ __forceinline__ bool base_cell(const pmx_painter &p, const BinGeom &g
 
 template <int KIND>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
-                                                           int32_t *tid, uint32_t *slot, uint32_t *counts)
+                                                           int32_t *tid, uint32_t *slot, uint32_t *counts,
+                                                           uint32_t *flags)
 {
     const int lane = threadIdx.x & 63;
     for (int64_t base = blockIdx.x * (int64_t)TBLOCK; base < n; base += (int64_t)gridDim.x * TBLOCK) {
@@ -110,18 +111,27 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
             if (base_cell<KIND>(p, g, x, c))
                 t = ((c[0] / TILE) * g.nt[1] + (c[1] / TILE)) * g.nt[2] + (c[2] / TILE);
         }
-        // wave-aggregated atomics: one atomicAdd per distinct tile in the wave
-        uint32_t myslot = 0;
+        // wave-aggregated counting: find the lanes that share my tile (ballots only), then
+        // ONE atomicAdd instruction for the whole wave (the first lane of every group adds the
+        // group's population), i.e. one memory round trip per wave
+        unsigned long long same = 0;
         unsigned long long active = __ballot(t >= 0);
         while (active) {
             int leader = __ffsll((long long)active) - 1;
             int lt = __shfl(t, leader);
-            unsigned long long same = __ballot(t == lt) & active;
+            unsigned long long m = __ballot(t == lt) & active;
+            if (t == lt) same = m;
+            active &= ~m;
+        }
+        uint32_t myslot = 0;
+        if (t >= 0) {
+            int leader = __ffsll((long long)same) - 1;
             uint32_t b = 0;
-            if (lane == leader) b = atomicAdd(&counts[lt], (uint32_t)__popcll(same));
+            if (lane == leader) b = atomicAdd(&counts[t], (uint32_t)__popcll(same));
             b = __shfl(b, leader);
-            if (t == lt) myslot = b + (uint32_t)__popcll(same & (((unsigned long long)1 << lane) - 1));
-            active &= ~same;
+            myslot = b + (uint32_t)__popcll(same & (((unsigned long long)1 << lane) - 1));
+        } else if (i < n) {
+            atomicOr(&flags[0], 1u);
         }
         if (i < n) {
             tid[i] = t;
@@ -166,31 +176,45 @@ __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid,
     }
 }
 
-// classify one region cell of a tile: 0 = dropped, 1 = owned, 2 = halo; *goff = byte offset in the canvas
+// wrap an index that is at most one period outside [0, period) (guaranteed by
+// pmx_binplan_supported: every axis spans at least one tile region)
+__device__ __forceinline__ int wrap_near(int l, int64_t period)
+{
+    if (period > 0) {
+        if (l < 0) l += (int)period;
+        else if (l >= period) l -= (int)period;
+    }
+    return l;
+}
+
+// classify one region cell of a tile: 0 = dropped (outside the local block),
+// 1 = exclusive (no other tile's region covers it: plain store), 2 = shared (atomic add);
+// *goff = byte offset in the canvas
 __device__ __forceinline__ int region_cell(const pmx_painter &p, const BinGeom &g, const int *t, int a, int b, int c,
                                            int64_t *goff)
 {
     int loc[3] = {a, b, c};
-    bool owned = true;
+    bool owned = true, shared = false;
     int64_t off = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         int l = t[d] * TILE - g.o[d] + loc[d];
-        int gidx = l;
-        if (p.period[d] > 0) gidx = wrap1(l, p.period[d]);
+        int gidx = wrap_near(l, p.period[d]);
         if (gidx < 0 || gidx >= p.size[d]) return 0;
         owned = owned && (loc[d] < TILE) && (l >= 0) && (l < p.size[d]);
+        // covered by the lower neighbour's halo, or by the periodic wrap of the last tile
+        shared = shared || (loc[d] < g.S - 1) || (l < g.wrapcover[d]);
         off += gidx * p.strides[d];
     }
     *goff = off;
-    return owned ? 1 : 2;
+    return (owned && !shared) ? 1 : 2;
 }
 
 template <int KIND, typename T>
 __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
-                                                            T *halo, int overwrite)
+                                                            int overwrite)
 {
     constexpr int S = Tuned<KIND>::S;
     constexpr int R = TILE + S - 1;
@@ -205,7 +229,7 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
         }
         const int64_t start = offsets[tile];
         const int count = (int)(offsets[tile + 1] - start);
-        if (count == 0 && !overwrite) continue;   // nothing to add; uniform per workgroup
+        if (count == 0) continue;   // nothing to add (overwrite: the canvas is already zero)
         for (int q = threadIdx.x; q < R * R * R; q += TBLOCK) lds[q] = 0;
         __syncthreads();
         for (int j = threadIdx.x; j < count; j += TBLOCK) {
@@ -237,53 +261,33 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
                 }
         }
         __syncthreads();
-        // flush: owned cells -> canvas (plain, rows along the last axis), halo cells -> staging
-        T *hbase = halo + tile * (int64_t)(R * R * R);
+        // flush: exclusive cells -> plain stores (rows along the last axis), shared cells ->
+        // global atomics.  With `overwrite` the canvas was zero-filled before this kernel.
         for (int q = threadIdx.x; q < R * R * R; q += TBLOCK) {
             int c = q % R, r = q / R;
             int b = r % R, a = r / R;
             int64_t goff;
             int cls = region_cell(p, g, t, a, b, c, &goff);
+            T v = lds[q];
             if (cls == 1) {
                 T *dst = (T *)(canvas + goff);
-                if (overwrite) *dst = lds[q];
-                else *dst += lds[q];
+                if (overwrite) *dst = v;
+                else *dst += v;
             } else if (cls == 2) {
-                hbase[q] = lds[q];
+                if (v != (T)0) unsafeAtomicAdd((T *)(canvas + goff), v);
             }
         }
         __syncthreads();
     }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGeom g, char *canvas, const T *halo,
-                                                            const int64_t *offsets, int overwrite)
+// entries of `out` for particles that are in no tile (they touch no local cell) read 0
+__global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint32_t *flags, const int32_t *tid, int64_t n,
+                                                              DVec out)
 {
-    const int R = g.R;
-    const int R3 = R * R * R;
-    for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        if (!overwrite && offsets[tile + 1] == offsets[tile]) continue;
-        int t[3];
-        {
-            int64_t r = tile;
-            t[2] = (int)(r % g.nt[2]); r /= g.nt[2];
-            t[1] = (int)(r % g.nt[1]); r /= g.nt[1];
-            t[0] = (int)r;
-        }
-        const T *hbase = halo + tile * (int64_t)R3;
-        for (int q = threadIdx.x; q < R3; q += TBLOCK) {
-            int c = q % R, r = q / R;
-            int b = r % R, a = r / R;
-            // interior cells of interior tiles are owned: skip the classification early
-            int64_t goff;
-            int cls = region_cell(p, g, t, a, b, c, &goff);
-            if (cls == 2) {
-                T v = hbase[q];
-                if (v != (T)0) unsafeAtomicAdd((T *)(canvas + goff), v);
-            }
-        }
-    }
+    if (flags[0] == 0) return;   // the common case: nothing was dropped
+    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * TBLOCK)
+        if (tid[i] < 0) out.set(i, 0, 0.0);
 }
 
 template <int KIND, typename T>
@@ -384,7 +388,7 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->list) (void)hipFree(pl->list);
     if (pl->counts) (void)hipFree(pl->counts);
     if (pl->offsets) (void)hipFree(pl->offsets);
-    if (pl->halo) (void)hipFree(pl->halo);
+    if (pl->flags) (void)hipFree(pl->flags);
     delete pl;
     return PMX_OK;
 }
@@ -404,6 +408,10 @@ extern "C" int pmx_binplan_supported(const pmx_painter *p, int64_t npart)
         PMX_REQUIRE(span >= TILE + S - 1, PMX_EUNSUPPORTED, "mesh smaller than a tile region");
         PMX_REQUIRE(p->size[d] >= 1, PMX_EUNSUPPORTED, "empty block");
         PMX_REQUIRE(p->period[d] == 0 || p->size[d] <= p->period[d], PMX_EUNSUPPORTED, "block larger than period");
+        // a block that is almost (but not exactly) the whole period would let a stencil wrap
+        // from below onto cells another tile stores exclusively
+        PMX_REQUIRE(p->period[d] == 0 || p->size[d] == p->period[d] || p->size[d] <= p->period[d] - (S - 1),
+                    PMX_EUNSUPPORTED, "block within S-1 cells of the full period");
     }
     return PMX_OK;
 }
@@ -426,6 +434,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         bool full = p.period[d] > 0 && p.size[d] == p.period[d];
         g.o[d] = full ? 0 : g.S - 1;
         g.nt[d] = (int32_t)((p.size[d] + g.o[d] + TILE - 1) / TILE);
+        g.wrapcover[d] = full ? (int32_t)(g.nt[d] * TILE + g.S - 1 - p.size[d]) : 0;
         g.ntiles *= g.nt[d];
     }
     pl->g = g;
@@ -455,15 +464,17 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         rc = ensure((void **)&pl->offsets, &c2, (size_t)(g.ntiles + 1) * 8); if (rc) return rc;
         pl->cap_tiles = (size_t)(g.ntiles + 1);
     }
+    if (!pl->flags) PMX_HIP_CHECK(hipMalloc((void **)&pl->flags, 16));
+    PMX_HIP_CHECK(hipMemsetAsync(pl->flags, 0, 16, st));
     PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)(g.ntiles + 1) * 4, st));
     DVec dpos = dvec(pos);
     if (npart > 0) {
         unsigned grid = grid_for(npart, TBLOCK);
         switch (p.kind) {
-        case PMX_TUNED_NNB: bin_count_kernel<PMX_TUNED_NNB><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts); break;
-        case PMX_TUNED_CIC: bin_count_kernel<PMX_TUNED_CIC><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts); break;
-        case PMX_TUNED_TSC: bin_count_kernel<PMX_TUNED_TSC><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts); break;
-        default: bin_count_kernel<PMX_TUNED_PCS><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts); break;
+        case PMX_TUNED_NNB: bin_count_kernel<PMX_TUNED_NNB><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
+        case PMX_TUNED_CIC: bin_count_kernel<PMX_TUNED_CIC><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
+        case PMX_TUNED_TSC: bin_count_kernel<PMX_TUNED_TSC><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
+        default: bin_count_kernel<PMX_TUNED_PCS><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
         }
     }
     bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles, pl->offsets);
@@ -479,12 +490,23 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
                           int overwrite, hipStream_t st)
 {
     const BinGeom &g = pl->g;
-    size_t need = (size_t)g.ntiles * g.R * g.R * g.R * sizeof(T);
-    int rc = ensure(&pl->halo, &pl->cap_halo, need);
-    if (rc) return rc;
+    if (overwrite) {
+        // shared cells are accumulated with atomics: start them (and everything else) from zero
+        bool contiguous = p.strides[2] == (int64_t)sizeof(T) && p.strides[1] == p.size[2] * p.strides[2] &&
+                          p.strides[0] == p.size[1] * p.strides[1];
+        if (contiguous) {
+            PMX_HIP_CHECK(hipMemsetAsync(canvas, 0, (size_t)(p.size[0] * p.strides[0]), st));
+        } else {
+            // padded / strided block: zero row by row (2-d memset over the last axis)
+            for (int64_t i = 0; i < p.size[0]; i++)
+                PMX_HIP_CHECK(hipMemset2DAsync((char *)canvas + i * p.strides[0], (size_t)p.strides[1], 0,
+                                               (size_t)(p.size[2] * sizeof(T)), (size_t)p.size[1], st));
+            PMX_REQUIRE(p.strides[2] == (int64_t)sizeof(T), PMX_EUNSUPPORTED,
+                        "overwrite needs a unit-stride last axis");
+        }
+    }
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-    T *halo = (T *)pl->halo;
-#define PT(K) paint_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, halo, overwrite)
+#define PT(K) paint_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, overwrite)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
     case PMX_TUNED_CIC: PT(PMX_TUNED_CIC); break;
@@ -492,8 +514,6 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     default: PT(PMX_TUNED_PCS); break;
     }
 #undef PT
-    if (g.S > 1 || true)
-        halo_merge_kernel<T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->offsets, overwrite);
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }
@@ -524,8 +544,9 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     pmx_painter p = *p_;
     const BinGeom &g = pl->g;
     hipStream_t st = (hipStream_t)stream;
-    // particles that touch no local cell read 0 (they are in no tile)
     DVec dout = dvec(out), dpos = dvec(pos);
+    // particles that touch no local cell are in no tile: they read 0
+    zero_dropped_kernel<<<grid_for(pl->npart, TBLOCK, 1024), TBLOCK, 0, st>>>(pl->flags, pl->tid, pl->npart, dout);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
 #define RT(K, T) readout_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets)
     if (p.canvas_elsize == 8) {

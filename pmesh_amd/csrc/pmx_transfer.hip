@@ -17,31 +17,36 @@ namespace pmx {
 struct TGeom {
     int64_t shape[3], in_strides[3], out_strides[3], start[3], nmesh[3];
     double boxsize[3];
+    double dw[3], nl[3];   // 2 pi / N and N / L per axis
     // memory-order permutation: ax[2] is the fastest-varying axis in memory
     int32_t ax[3];
     int32_t ndim;
 };
 
+// grid.y walks the slowest memory axis, grid.x / threads the flattened two fast axes:
+// 32-bit index arithmetic only, consecutive threads touch consecutive modes.
 template <typename T>
 __global__ void __launch_bounds__(256) transfer_kernel(pmx_transfer t, TGeom g, const char *in, char *out)
 {
-    const int64_t n0 = g.shape[g.ax[0]], n1 = g.shape[g.ax[1]], n2 = g.shape[g.ax[2]];
-    const int64_t total = n0 * n1 * n2;
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
-         q += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t n1 = (uint32_t)g.shape[g.ax[1]], n2 = (uint32_t)g.shape[g.ax[2]];
+    const uint32_t inner = n1 * n2;
+    for (int64_t i0 = blockIdx.y; i0 < g.shape[g.ax[0]]; i0 += gridDim.y)
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < inner; q += gridDim.x * blockDim.x) {
+        const uint32_t i1 = q / n2;
+        const int64_t v0 = i0, v1 = i1, v2 = q - i1 * n2;   // indices in memory order
         int64_t idx[3];
-        int64_t r = q;
-        idx[g.ax[2]] = r % n2; r /= n2;
-        idx[g.ax[1]] = r % n1; r /= n1;
-        idx[g.ax[0]] = r;
+#pragma unroll
+        for (int d = 0; d < 3; d++) idx[d] = (g.ax[0] == d) ? v0 : ((g.ax[1] == d) ? v1 : v2);
         double kk[3] = {0, 0, 0}, ww[3] = {0, 0, 0}, k2 = 0;
-        for (int d = 0; d < g.ndim; d++) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if (d >= g.ndim) break;
             int64_t gi = idx[d] + g.start[d];
             double wi = (double)gi;
             if (gi >= g.nmesh[d] / 2) wi -= g.nmesh[d];
-            wi *= (2 * M_PI / g.nmesh[d]);
+            wi *= g.dw[d];               // 2 pi / N   (pm.py:1217)
             ww[d] = wi;
-            kk[d] = wi * g.nmesh[d] / g.boxsize[d];
+            kk[d] = wi * g.nl[d];        // w N / L    (pm.py:1218)
             k2 += kk[d] * kk[d];
         }
         double re = t.amplitude, im = 0;
@@ -107,6 +112,8 @@ extern "C" int pmx_apply_transfer(const pmx_transfer *t, int32_t ndim, int32_t e
         g.start[d] = on ? start[d] : 0;
         g.nmesh[d] = on ? nmesh[d] : 1;
         g.boxsize[d] = on ? boxsize[d] : 1.0;
+        g.dw[d] = 2 * M_PI / g.nmesh[d];
+        g.nl[d] = g.nmesh[d] / g.boxsize[d];
     }
     // order axes by decreasing output stride so consecutive threads touch
     // consecutive memory whatever the (transposed) layout is
@@ -120,11 +127,14 @@ extern "C" int pmx_apply_transfer(const pmx_transfer *t, int32_t ndim, int32_t e
     for (int a = 0; a < 3; a++) g.ax[a] = ax[a];
     int64_t total = g.shape[0] * g.shape[1] * g.shape[2];
     if (total == 0) return PMX_OK;
+    int64_t inner = g.shape[g.ax[1]] * g.shape[g.ax[2]];
+    PMX_REQUIRE(inner < (1ll << 31), PMX_EUNSUPPORTED, "plane of more than 2^31 modes");
     hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((inner + 255) / 256), (unsigned)(g.shape[g.ax[0]] < 65535 ? g.shape[g.ax[0]] : 65535));
     if (elsize == 8)
-        transfer_kernel<double><<<grid_for(total, 256), 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
+        transfer_kernel<double><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
     else
-        transfer_kernel<float><<<grid_for(total, 256), 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
+        transfer_kernel<float><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }

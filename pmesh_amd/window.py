@@ -358,7 +358,7 @@ class ResampleWindow(object):
         pos, hs, n = self._particles(pos, hsml, be)
         host_out = None
         if out is None:
-            dout = torch.zeros(n, dtype=torch.float64, device=be.device)
+            dout = torch.empty(n, dtype=torch.float64, device=be.device)
             ret_host = not is_tensor(pos_in)
         elif is_tensor(out):
             dout = out
@@ -380,7 +380,6 @@ class ResampleWindow(object):
         ov = vec(dout)
         if n and _binned_ok(be, p, pos, n, hs):
             plan = _bin_cache.lookup(be, pos, p, pv, n)
-            dout.zero_()      # particles that touch no local cell are in no tile
             be.call('readout_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), C.byref(ov),
                     be.stream())
         else:
