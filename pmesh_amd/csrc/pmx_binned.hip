@@ -6,11 +6,13 @@
 // CIC at 512^3 adds 8 x 8 B per particle = 8.6 GB -> 6.9 ms measured.  Here the
 // mesh is cut into tiles of T^3 cells; the particles are binned by the tile of
 // their window's base cell (an index list per tile: positions are NOT copied);
-// one workgroup per tile accumulates its (T+S-1)^3 region in LDS with ds_add and
-// flushes it once: cells that only this tile can touch (the deep interior, 82 % of
-// a CIC tile) are written with plain coalesced stores, cells that a neighbouring
-// tile's region also covers (the S-1 deep faces) with global atomics.  Readout
-// stages the tile region in LDS the same way and gathers from there.
+// one workgroup per tile accumulates its region (tile + S-1 halo cells on the high
+// side of every axis) in LDS with ds_add and writes the cells it owns with plain
+// coalesced stores (256-byte rows); the halo cells (23 % for CIC) are parked in a
+// compact staging buffer and added to their owners by a second kernel with global
+// atomics shaped as contiguous rows.  Tiles are 8 x 16 x 32 cells: long along the
+// contiguous axis so that almost all halo traffic is whole rows.  Readout stages
+// the tile region in LDS the same way and gathers from there.
 //
 // Arithmetic is the same as the direct kernels (same Tuned<KIND>::axis, same
 // left-to-right products): readout is bit-identical to pmx_readout (the
@@ -36,16 +38,43 @@
 
 namespace pmx {
 
-constexpr int TILE = 16;
+constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
+constexpr int TCELLS = T0 * T1 * T2;
 constexpr int TBLOCK = 256;
 
 struct BinGeom {
     int32_t kind, S;
     int32_t nt[3];        // tiles per axis
-    int32_t o[3];         // tile-space offset per axis
-    int32_t R;            // region extent per axis = TILE + S - 1
-    int32_t wrapcover[3]; // full periodic axes: cells [0, wrapcover) are also covered by the last tile
+    int32_t o[3];         // tile-space offset per axis (S-1 unless the axis is the full period)
     int64_t ntiles;
+};
+
+template <int S> struct Region {
+    static constexpr int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
+    static constexpr int CELLS = R0 * R1 * R2;
+    // compact numbering of the halo (region minus the T0 x T1 x T2 box)
+    static constexpr int NA = (S - 1) * R1 * R2;     // a >= T0
+    static constexpr int NB = T0 * (S - 1) * R2;     // a < T0, b >= T1
+    static constexpr int NC = T0 * T1 * (S - 1);     // a < T0, b < T1, c >= T2
+    static constexpr int HALO = NA + NB + NC;
+    __device__ static __forceinline__ int halo_index(int a, int b, int c)
+    {
+        if (a >= T0) return ((a - T0) * R1 + b) * R2 + c;
+        if (b >= T1) return NA + (a * (S - 1) + (b - T1)) * R2 + c;
+        return NA + NB + (a * T1 + b) * (S - 1) + (c - T2);
+    }
+    __device__ static __forceinline__ void halo_decode(int h, int *a, int *b, int *c)
+    {
+        if (h < NA) {
+            *c = h % R2; int r = h / R2; *b = r % R1; *a = T0 + r / R1;
+        } else if (h < NA + NB) {
+            h -= NA;
+            *c = h % R2; int r = h / R2; *b = T1 + r % (S - 1 > 0 ? S - 1 : 1); *a = r / (S - 1 > 0 ? S - 1 : 1);
+        } else {
+            h -= NA + NB;
+            *c = T2 + h % (S - 1 > 0 ? S - 1 : 1); int r = h / (S - 1 > 0 ? S - 1 : 1); *b = r % T1; *a = r / T1;
+        }
+    }
 };
 
 }  // namespace pmx
@@ -56,42 +85,57 @@ struct pmx_binplan {
     int64_t npart = 0;
     bool built = false;
     // device arrays
-    int32_t *tid = nullptr;     // tile id per particle (-1 = dropped)
+    int32_t *tid = nullptr;     // tile id per particle (-1 = touches no local cell)
     uint32_t *slot = nullptr;   // rank of the particle inside its tile
     uint32_t *list = nullptr;   // particle indices, tile major
     size_t cap_part = 0;
     uint32_t *counts = nullptr; // particles per tile
     int64_t *offsets = nullptr; // exclusive prefix (ntiles + 1)
     size_t cap_tiles = 0;
-    uint32_t *flags = nullptr;  // [0] != 0: some particle touches no local cell (tid == -1)
+    uint32_t *flags = nullptr;  // [0] != 0: some particle is in no tile
+    void *halo = nullptr;       // staging of the halo cells: ntiles * Region<S>::HALO elements
+    size_t cap_halo = 0;
 };
 
 namespace pmx {
 
+__device__ __forceinline__ int tile_ext(int d) { return d == 0 ? T0 : (d == 1 ? T1 : T2); }
+
+// true modulo with a fast path for indices within one period of the box
+__device__ __forceinline__ int wrap_fast(int i, int64_t n)
+{
+    if (n <= 0) return i;
+    int m = (int)n;
+    if (i < 0) { i += m; if (i < 0) { i %= m; if (i < 0) i += m; } }
+    else if (i >= m) { i -= m; if (i >= m) i %= m; }
+    return i;
+}
+
+// wrap an index that is at most one period outside [0, period) (guaranteed by
+// pmx_binplan_supported: every axis spans at least one tile region)
+__device__ __forceinline__ int wrap_near(int l, int64_t period)
+{
+    if (period > 0) {
+        if (l < 0) l += (int)period;
+        else if (l >= period) l -= (int)period;
+    }
+    return l;
+}
+
+// first stencil index of a particle along axis d in the local frame (see header);
+// returns false if the particle touches no local cell along this axis
 template <int KIND>
-__device__ __forceinline__ bool base_cell(const pmx_painter &p, const BinGeom &g, const double *x,
-                                          int *c /* tile-space coords */)
+__device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, int *i0w)
 {
     constexpr int S = Tuned<KIND>::S;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        double X = x[d] * p.scale[d] + p.translate[d];
-        if (!(fabs(X) < 1073741824.0)) return false;
-        int I[S];
-        double V[S];
-        Tuned<KIND>::axis(X, 0, 1.0, I, V);
-        int w = wrap1(I[0], p.period[d]);
-        int i0w;
-        if (p.period[d] > 0) {
-            if (w < p.size[d]) i0w = w;
-            else if (w >= p.period[d] - (S - 1)) i0w = w - (int)p.period[d];
-            else return false;
-        } else {
-            if (w < -(S - 1) || w >= p.size[d]) return false;
-            i0w = w;
-        }
-        c[d] = i0w + g.o[d];
-        if (c[d] < 0) return false;
+    int w = wrap_fast(I0, p.period[d]);
+    if (p.period[d] > 0) {
+        if (w < p.size[d]) *i0w = w;
+        else if (w >= p.period[d] - (S - 1)) *i0w = w - (int)p.period[d];
+        else return false;
+    } else {
+        if (w < -(S - 1) || w >= p.size[d]) return false;
+        *i0w = w;
     }
     return true;
 }
@@ -101,15 +145,26 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                                                            int32_t *tid, uint32_t *slot, uint32_t *counts,
                                                            uint32_t *flags)
 {
+    constexpr int S = Tuned<KIND>::S;
     const int lane = threadIdx.x & 63;
     for (int64_t base = blockIdx.x * (int64_t)TBLOCK; base < n; base += (int64_t)gridDim.x * TBLOCK) {
         int64_t i = base + threadIdx.x;
         int t = -1;
         if (i < n) {
-            double x[3] = {pos.get(i, 0), pos.get(i, 1), pos.get(i, 2)};
-            int c[3];
-            if (base_cell<KIND>(p, g, x, c))
-                t = ((c[0] / TILE) * g.nt[1] + (c[1] / TILE)) * g.nt[2] + (c[2] / TILE);
+            bool ok = true;
+            int tt[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                double X = pos.get(i, d) * p.scale[d] + p.translate[d];
+                ok = ok && (fabs(X) < 1073741824.0);   // NaN / out of int range: dropped
+                int I[S];
+                double V[S];
+                Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
+                int i0w = 0;
+                ok = ok && local_base<KIND>(p, d, I[0], &i0w);
+                tt[d] = (i0w + g.o[d]) / tile_ext(d);
+            }
+            if (ok) t = (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
         }
         // wave-aggregated counting: find the lanes that share my tile (ballots only), then
         // ONE atomicAdd instruction for the whole wave (the first lane of every group adds the
@@ -123,16 +178,12 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
             if (t == lt) same = m;
             active &= ~m;
         }
-        uint32_t myslot = 0;
-        if (t >= 0) {
-            int leader = __ffsll((long long)same) - 1;
-            uint32_t b = 0;
-            if (lane == leader) b = atomicAdd(&counts[t], (uint32_t)__popcll(same));
-            b = __shfl(b, leader);
-            myslot = b + (uint32_t)__popcll(same & (((unsigned long long)1 << lane) - 1));
-        } else if (i < n) {
-            atomicOr(&flags[0], 1u);
-        }
+        uint32_t b = 0;
+        const int leader = t >= 0 ? __ffsll((long long)same) - 1 : lane;
+        if (t >= 0 && lane == leader) b = atomicAdd(&counts[t], (uint32_t)__popcll(same));
+        b = __shfl(b, leader);
+        uint32_t myslot = b + (uint32_t)__popcll(same & (((unsigned long long)1 << lane) - 1));
+        if (t < 0 && i < n) atomicOr(&flags[0], 1u);
         if (i < n) {
             tid[i] = t;
             slot[i] = myslot;
@@ -176,78 +227,73 @@ __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid,
     }
 }
 
-// wrap an index that is at most one period outside [0, period) (guaranteed by
-// pmx_binplan_supported: every axis spans at least one tile region)
-__device__ __forceinline__ int wrap_near(int l, int64_t period)
+__device__ __forceinline__ void tile_coords(const BinGeom &g, int64_t tile, int *t)
 {
-    if (period > 0) {
-        if (l < 0) l += (int)period;
-        else if (l >= period) l -= (int)period;
-    }
-    return l;
+    int64_t r = tile;
+    t[2] = (int)(r % g.nt[2]); r /= g.nt[2];
+    t[1] = (int)(r % g.nt[1]); r /= g.nt[1];
+    t[0] = (int)r;
 }
 
-// classify one region cell of a tile: 0 = dropped (outside the local block),
-// 1 = exclusive (no other tile's region covers it: plain store), 2 = shared (atomic add);
-// *goff = byte offset in the canvas
-__device__ __forceinline__ int region_cell(const pmx_painter &p, const BinGeom &g, const int *t, int a, int b, int c,
-                                           int64_t *goff)
+// region cell (a, b, c) of tile t -> canvas byte offset; false if it lies outside the block
+__device__ __forceinline__ bool region_cell(const pmx_painter &p, const BinGeom &g, const int *t, int a, int b, int c,
+                                            int64_t *goff)
 {
     int loc[3] = {a, b, c};
-    bool owned = true, shared = false;
     int64_t off = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        int l = t[d] * TILE - g.o[d] + loc[d];
+        int l = t[d] * tile_ext(d) - g.o[d] + loc[d];
         int gidx = wrap_near(l, p.period[d]);
-        if (gidx < 0 || gidx >= p.size[d]) return 0;
-        owned = owned && (loc[d] < TILE) && (l >= 0) && (l < p.size[d]);
-        // covered by the lower neighbour's halo, or by the periodic wrap of the last tile
-        shared = shared || (loc[d] < g.S - 1) || (l < g.wrapcover[d]);
+        if (gidx < 0 || gidx >= p.size[d]) return false;
         off += gidx * p.strides[d];
     }
     *goff = off;
-    return (owned && !shared) ? 1 : 2;
+    return true;
+}
+
+// per-particle setup shared by paint and readout: weights and local base of the stencil
+template <int KIND>
+__device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGeom &g, const int *t, DVec pos,
+                                               int64_t i, double (*V)[Tuned<KIND>::S], int *lb)
+{
+    constexpr int S = Tuned<KIND>::S;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        double X = pos.get(i, d) * p.scale[d] + p.translate[d];
+        int I[S];
+        Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
+        int w = wrap_fast(I[0], p.period[d]);
+        int i0w = w;
+        if (p.period[d] > 0 && w >= p.size[d]) i0w = w - (int)p.period[d];
+        lb[d] = i0w + g.o[d] - t[d] * tile_ext(d);
+    }
 }
 
 template <int KIND, typename T>
 __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
-                                                            int overwrite)
+                                                            T *halo, int overwrite)
 {
     constexpr int S = Tuned<KIND>::S;
-    constexpr int R = TILE + S - 1;
-    __shared__ T lds[R * R * R];
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    __shared__ T lds[Rg::CELLS];
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         int t[3];
-        {
-            int64_t r = tile;
-            t[2] = (int)(r % g.nt[2]); r /= g.nt[2];
-            t[1] = (int)(r % g.nt[1]); r /= g.nt[1];
-            t[0] = (int)r;
-        }
+        tile_coords(g, tile, t);
         const int64_t start = offsets[tile];
         const int count = (int)(offsets[tile + 1] - start);
-        if (count == 0) continue;   // nothing to add (overwrite: the canvas is already zero)
-        for (int q = threadIdx.x; q < R * R * R; q += TBLOCK) lds[q] = 0;
+        if (count == 0 && !overwrite) continue;   // nothing to add; uniform per workgroup
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TBLOCK) lds[q] = 0;
         __syncthreads();
         for (int j = threadIdx.x; j < count; j += TBLOCK) {
             int64_t i = list[start + j];
-            double x[3] = {pos.get(i, 0), pos.get(i, 1), pos.get(i, 2)};
             double m = mass.data ? mass.get(i, 0) : mass_scalar;
             int lb[3];
             double V[3][S];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                double X = x[d] * p.scale[d] + p.translate[d];
-                int I[S];
-                Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
-                int w = wrap1(I[0], p.period[d]);
-                int i0w = w;
-                if (p.period[d] > 0 && w >= p.size[d]) i0w = w - (int)p.period[d];
-                lb[d] = i0w + g.o[d] - t[d] * TILE;
-            }
+            particle_setup<KIND>(p, g, t, pos, i, V, lb);
 #pragma unroll
             for (int a = 0; a < S; a++) V[0][a] *= m;
 #pragma unroll
@@ -255,29 +301,65 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
 #pragma unroll
                 for (int b = 0; b < S; b++) {
                     double fb = V[0][a] * V[1][b];
-                    int rowoff = ((lb[0] + a) * R + (lb[1] + b)) * R + lb[2];
+                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
 #pragma unroll
                     for (int c = 0; c < S; c++) unsafeAtomicAdd(&lds[rowoff + c], (T)(fb * V[2][c]));
                 }
         }
         __syncthreads();
-        // flush: exclusive cells -> plain stores (rows along the last axis), shared cells ->
-        // global atomics.  With `overwrite` the canvas was zero-filled before this kernel.
-        for (int q = threadIdx.x; q < R * R * R; q += TBLOCK) {
-            int c = q % R, r = q / R;
-            int b = r % R, a = r / R;
+        // owned box -> canvas, plain stores in rows of T2 cells
+        for (int q = threadIdx.x; q < TCELLS; q += TBLOCK) {
+            int c = q % T2, r = q / T2;
+            int b = r % T1, a = r / T1;
             int64_t goff;
-            int cls = region_cell(p, g, t, a, b, c, &goff);
-            T v = lds[q];
-            if (cls == 1) {
+            // cells of the box below 0 / beyond the block exist only on non-periodic or slab
+            // axes and are dropped there (no wrap reaches them: pmx_binplan_supported)
+            bool in = true;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                int l = t[d] * tile_ext(d) - g.o[d] + (d == 0 ? a : (d == 1 ? b : c));
+                in = in && l >= 0 && l < p.size[d];
+            }
+            if (in && region_cell(p, g, t, a, b, c, &goff)) {
+                T v = lds[(a * R1 + b) * R2 + c];
                 T *dst = (T *)(canvas + goff);
                 if (overwrite) *dst = v;
                 else *dst += v;
-            } else if (cls == 2) {
-                if (v != (T)0) unsafeAtomicAdd((T *)(canvas + goff), v);
+            }
+        }
+        // halo -> staging (compact numbering, contiguous writes)
+        if (S > 1) {
+            T *hbase = halo + tile * (int64_t)Rg::HALO;
+            for (int h = threadIdx.x; h < Rg::HALO; h += TBLOCK) {
+                int a, b, c;
+                Rg::halo_decode(h, &a, &b, &c);
+                hbase[h] = lds[(a * R1 + b) * R2 + c];
             }
         }
         __syncthreads();
+    }
+}
+
+// second pass: add every tile's halo cells to their owners.  Runs after ALL owned boxes
+// are stored (kernel boundary), so the atomics never race with a plain store.
+template <int S, typename T>
+__global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGeom g, char *canvas, const T *halo,
+                                                            const int64_t *offsets)
+{
+    using Rg = Region<S>;
+    for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        if (offsets[tile + 1] == offsets[tile]) continue;   // empty tile: its halo is zero
+        int t[3];
+        tile_coords(g, tile, t);
+        const T *hbase = halo + tile * (int64_t)Rg::HALO;
+        for (int h = threadIdx.x; h < Rg::HALO; h += TBLOCK) {
+            T v = hbase[h];
+            if (v == (T)0) continue;
+            int a, b, c;
+            Rg::halo_decode(h, &a, &b, &c);
+            int64_t goff;
+            if (region_cell(p, g, t, a, b, c, &goff)) unsafeAtomicAdd((T *)(canvas + goff), v);
+        }
     }
 }
 
@@ -296,49 +378,35 @@ __global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, Bin
                                                               const int64_t *offsets)
 {
     constexpr int S = Tuned<KIND>::S;
-    constexpr int R = TILE + S - 1;
-    __shared__ T lds[R * R * R];
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    __shared__ T lds[Rg::CELLS];
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t start = offsets[tile];
         const int count = (int)(offsets[tile + 1] - start);
         if (count == 0) continue;
         int t[3];
-        {
-            int64_t r = tile;
-            t[2] = (int)(r % g.nt[2]); r /= g.nt[2];
-            t[1] = (int)(r % g.nt[1]); r /= g.nt[1];
-            t[0] = (int)r;
-        }
-        for (int q = threadIdx.x; q < R * R * R; q += TBLOCK) {
-            int c = q % R, r = q / R;
-            int b = r % R, a = r / R;
+        tile_coords(g, tile, t);
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TBLOCK) {
+            int c = q % R2, r = q / R2;
+            int b = r % R1, a = r / R1;
             int64_t goff;
-            int cls = region_cell(p, g, t, a, b, c, &goff);
-            lds[q] = cls ? *(const T *)(canvas + goff) : (T)0;   // outside the block reads as 0
+            bool in = region_cell(p, g, t, a, b, c, &goff);
+            lds[q] = in ? *(const T *)(canvas + goff) : (T)0;   // outside the block reads as 0
         }
         __syncthreads();
         for (int j = threadIdx.x; j < count; j += TBLOCK) {
             int64_t i = list[start + j];
-            double x[3] = {pos.get(i, 0), pos.get(i, 1), pos.get(i, 2)};
             int lb[3];
             double V[3][S];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                double X = x[d] * p.scale[d] + p.translate[d];
-                int I[S];
-                Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
-                int w = wrap1(I[0], p.period[d]);
-                int i0w = w;
-                if (p.period[d] > 0 && w >= p.size[d]) i0w = w - (int)p.period[d];
-                lb[d] = i0w + g.o[d] - t[d] * TILE;
-            }
+            particle_setup<KIND>(p, g, t, pos, i, V, lb);
             double value = 0;
 #pragma unroll
             for (int a = 0; a < S; a++)
 #pragma unroll
                 for (int b = 0; b < S; b++) {
                     double fb = V[0][a] * V[1][b];
-                    int rowoff = ((lb[0] + a) * R + (lb[1] + b)) * R + lb[2];
+                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
 #pragma unroll
                     for (int c = 0; c < S; c++) value += (double)lds[rowoff + c] * (fb * V[2][c]);
                 }
@@ -369,6 +437,12 @@ static bool same_geometry(const pmx_painter &a, const pmx_painter &b)
     return true;
 }
 
+static int halo_cells(int S)
+{
+    int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
+    return R0 * R1 * R2 - TCELLS;
+}
+
 }  // namespace pmx
 
 using namespace pmx;
@@ -389,6 +463,7 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->counts) (void)hipFree(pl->counts);
     if (pl->offsets) (void)hipFree(pl->offsets);
     if (pl->flags) (void)hipFree(pl->flags);
+    if (pl->halo) (void)hipFree(pl->halo);
     delete pl;
     return PMX_OK;
 }
@@ -401,17 +476,24 @@ extern "C" int pmx_binplan_supported(const pmx_painter *p, int64_t npart)
     PMX_REQUIRE(p->kind >= PMX_TUNED_NNB && p->kind <= PMX_TUNED_PCS, PMX_EUNSUPPORTED, "tuned windows only");
     PMX_REQUIRE(p->support <= 0 || p->support == native_support(p->kind), PMX_EUNSUPPORTED, "native support only");
     PMX_REQUIRE(npart < (int64_t)4294967295ll, PMX_EUNSUPPORTED, "more than 2^32 particles per rank");
-    int S = native_support(p->kind);
+    const int S = native_support(p->kind);
+    const int T[3] = {T0, T1, T2};
     for (int d = 0; d < 3; d++) {
-        // every region cell must map to a distinct canvas cell
-        int64_t span = p->period[d] > 0 ? p->period[d] : p->size[d];
-        PMX_REQUIRE(span >= TILE + S - 1, PMX_EUNSUPPORTED, "mesh smaller than a tile region");
         PMX_REQUIRE(p->size[d] >= 1, PMX_EUNSUPPORTED, "empty block");
         PMX_REQUIRE(p->period[d] == 0 || p->size[d] <= p->period[d], PMX_EUNSUPPORTED, "block larger than period");
-        // a block that is almost (but not exactly) the whole period would let a stencil wrap
-        // from below onto cells another tile stores exclusively
-        PMX_REQUIRE(p->period[d] == 0 || p->size[d] == p->period[d] || p->size[d] <= p->period[d] - (S - 1),
-                    PMX_EUNSUPPORTED, "block within S-1 cells of the full period");
+        // every region cell must map to a distinct canvas cell
+        int64_t span = p->period[d] > 0 ? p->period[d] : p->size[d];
+        PMX_REQUIRE(span >= T[d] + S - 1, PMX_EUNSUPPORTED, "mesh smaller than a tile region");
+        if (p->period[d] > 0 && p->size[d] == p->period[d]) {
+            // full periodic axis: the last tile's halo wraps onto tile 0; the owned boxes must
+            // tile the axis exactly
+            PMX_REQUIRE(p->size[d] % T[d] == 0, PMX_EUNSUPPORTED, "periodic axis is not a multiple of the tile");
+        } else if (p->period[d] > 0) {
+            // a block within S-1 cells of the full period would let a stencil wrap from below
+            // onto cells owned by another tile
+            PMX_REQUIRE(p->size[d] <= p->period[d] - (S - 1), PMX_EUNSUPPORTED,
+                        "block within S-1 cells of the full period");
+        }
     }
     return PMX_OK;
 }
@@ -425,16 +507,15 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     PMX_REQUIRE(npart == 0 || (vec_ok(pos) && pos->ncol >= 3), PMX_EINVAL, "pos must be (n, >=3) f4/f8");
     hipStream_t st = (hipStream_t)stream;
     pmx_painter p = *p_;
+    const int T[3] = {T0, T1, T2};
     BinGeom g;
     g.kind = p.kind;
     g.S = native_support(p.kind);
-    g.R = TILE + g.S - 1;
     g.ntiles = 1;
     for (int d = 0; d < 3; d++) {
         bool full = p.period[d] > 0 && p.size[d] == p.period[d];
         g.o[d] = full ? 0 : g.S - 1;
-        g.nt[d] = (int32_t)((p.size[d] + g.o[d] + TILE - 1) / TILE);
-        g.wrapcover[d] = full ? (int32_t)(g.nt[d] * TILE + g.S - 1 - p.size[d]) : 0;
+        g.nt[d] = (int32_t)((p.size[d] + g.o[d] + T[d] - 1) / T[d]);
         g.ntiles *= g.nt[d];
     }
     pl->g = g;
@@ -442,8 +523,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     pl->npart = npart;
     pl->built = false;
     size_t np1 = (size_t)(npart > 0 ? npart : 1);
-    size_t cp = pl->cap_part;
-    if (np1 * 4 > cp) {
+    if (np1 * 4 > pl->cap_part) {
         size_t c1 = 0, c2 = 0, c3 = 0;
         if (pl->tid) (void)hipFree(pl->tid);
         if (pl->slot) (void)hipFree(pl->slot);
@@ -454,8 +534,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         rc = ensure((void **)&pl->list, &c3, np1 * 4); if (rc) return rc;
         pl->cap_part = np1 * 4;
     }
-    size_t ct = pl->cap_tiles;
-    if ((size_t)(g.ntiles + 1) > ct) {
+    if ((size_t)(g.ntiles + 1) > pl->cap_tiles) {
         size_t c1 = 0, c2 = 0;
         if (pl->counts) (void)hipFree(pl->counts);
         if (pl->offsets) (void)hipFree(pl->offsets);
@@ -470,12 +549,14 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     DVec dpos = dvec(pos);
     if (npart > 0) {
         unsigned grid = grid_for(npart, TBLOCK);
+#define BC(K) bin_count_kernel<K><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags)
         switch (p.kind) {
-        case PMX_TUNED_NNB: bin_count_kernel<PMX_TUNED_NNB><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
-        case PMX_TUNED_CIC: bin_count_kernel<PMX_TUNED_CIC><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
-        case PMX_TUNED_TSC: bin_count_kernel<PMX_TUNED_TSC><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
-        default: bin_count_kernel<PMX_TUNED_PCS><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); break;
+        case PMX_TUNED_NNB: BC(PMX_TUNED_NNB); break;
+        case PMX_TUNED_CIC: BC(PMX_TUNED_CIC); break;
+        case PMX_TUNED_TSC: BC(PMX_TUNED_TSC); break;
+        default: BC(PMX_TUNED_PCS); break;
         }
+#undef BC
     }
     bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles, pl->offsets);
     if (npart > 0)
@@ -490,30 +571,21 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
                           int overwrite, hipStream_t st)
 {
     const BinGeom &g = pl->g;
-    if (overwrite) {
-        // shared cells are accumulated with atomics: start them (and everything else) from zero
-        bool contiguous = p.strides[2] == (int64_t)sizeof(T) && p.strides[1] == p.size[2] * p.strides[2] &&
-                          p.strides[0] == p.size[1] * p.strides[1];
-        if (contiguous) {
-            PMX_HIP_CHECK(hipMemsetAsync(canvas, 0, (size_t)(p.size[0] * p.strides[0]), st));
-        } else {
-            // padded / strided block: zero row by row (2-d memset over the last axis)
-            for (int64_t i = 0; i < p.size[0]; i++)
-                PMX_HIP_CHECK(hipMemset2DAsync((char *)canvas + i * p.strides[0], (size_t)p.strides[1], 0,
-                                               (size_t)(p.size[2] * sizeof(T)), (size_t)p.size[1], st));
-            PMX_REQUIRE(p.strides[2] == (int64_t)sizeof(T), PMX_EUNSUPPORTED,
-                        "overwrite needs a unit-stride last axis");
-        }
-    }
+    size_t need = (size_t)g.ntiles * (size_t)halo_cells(g.S) * sizeof(T);
+    int rc = ensure(&pl->halo, &pl->cap_halo, need > 0 ? need : 16);
+    if (rc) return rc;
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-#define PT(K) paint_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, overwrite)
+    T *halo = (T *)pl->halo;
+#define PT(K) paint_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, halo, overwrite)
+#define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->offsets)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
-    case PMX_TUNED_CIC: PT(PMX_TUNED_CIC); break;
-    case PMX_TUNED_TSC: PT(PMX_TUNED_TSC); break;
-    default: PT(PMX_TUNED_PCS); break;
+    case PMX_TUNED_CIC: PT(PMX_TUNED_CIC); HM(2); break;
+    case PMX_TUNED_TSC: PT(PMX_TUNED_TSC); HM(3); break;
+    default: PT(PMX_TUNED_PCS); HM(4); break;
     }
 #undef PT
+#undef HM
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }

@@ -49,12 +49,16 @@ def both(W, fn):
 
 CASES = [
     # shape, period, scale, translate
-    ((32, 32, 32), (32, 32, 32), 1.0, 0.0),                          # full periodic block
-    ((40, 36, 48), (40, 36, 48), (0.5, 1.0, 0.75), (0.3, 0.0, -0.25)),  # not a multiple of the tile
-    ((20, 48, 48), (64, 48, 48), 1.0, (-16.0, 0.0, 0.0)),            # slab-local block of a bigger mesh
-    ((24, 24, 40), (0, 0, 0), 1.0, 0.0),                             # non periodic
-    ((19, 48, 21), (19, 0, 64), 1.0, (0.0, 2.0, -5.0)),              # mixed
+    ((64, 64, 64), (64, 64, 64), 1.0, 0.0),                              # full periodic block
+    ((40, 48, 96), (40, 48, 96), (0.5, 1.0, 0.75), (0.3, 0.0, -0.25)),   # anisotropic, several tiles
+    ((24, 48, 64), (96, 48, 64), 1.0, (-32.0, 0.0, 0.0)),                # slab-local block of a bigger mesh
+    ((24, 40, 70), (0, 0, 0), 1.0, 0.0),                                 # non periodic, ragged tiles
+    ((20, 48, 45), (64, 0, 128), 1.0, (0.0, 2.0, -5.0)),                 # mixed
 ]
+
+
+def assert_binned_ran():
+    assert any(e[3] for e in window._bin_cache.entries), 'the tile-binned path was not taken'
 
 
 @pytest.mark.parametrize('name', TUNED)
@@ -80,6 +84,7 @@ def test_binned_equals_direct(hip, oracle, name, case):
                     W.paint(c, pos, mass=mass, diffdir=diffdir, transform=aff)
                     return c.cpu().numpy()
                 d, b = both(W, paint)
+                assert_binned_ran()
                 s = max(1.0, abs(d).max())
                 assert_allclose(b, d, rtol=0, atol=tol * s)
                 if ptype == 'f8' and diffdir is None and dt == 'f8':
@@ -110,7 +115,7 @@ def test_binned_dyadic_bit_exact(hip, oracle, name):
     the binned scatter must reproduce the reference bit for bit (indexing parity)."""
     W = windows[name]
     rs = numpy.random.RandomState(4)
-    N = 48
+    N = 64
     pos_h = rs.randint(-64 * 16, 3 * N * 16, size=(50000, 3)) / 16.0
     mass_h = rs.randint(1, 5, size=len(pos_h)).astype('f8')
     want = numpy.zeros((N, N, N))
@@ -119,6 +124,7 @@ def test_binned_dyadic_bit_exact(hip, oracle, name):
     c = torch.zeros((N, N, N), dtype=torch.float64, device=hip.device)
     W.paint(c, torch.from_numpy(pos_h).to(hip.device), mass=torch.from_numpy(mass_h).to(hip.device),
             transform=Affine(3, period=N))
+    assert_binned_ran()
     assert_array_equal(c.cpu().numpy(), want)
 
 
@@ -129,20 +135,21 @@ def test_plan_is_shared_and_invalidated(hip):
     window.BINNED = 'always'
     window.clear_bin_cache()
     rs = numpy.random.RandomState(1)
-    pos = torch.from_numpy(rs.uniform(0, 32, size=(5000, 3))).to(hip.device)
-    aff = Affine(3, period=32)
-    c = torch.zeros((32, 32, 32), dtype=torch.float64, device=hip.device)
+    pos = torch.from_numpy(rs.uniform(0, 64, size=(5000, 3))).to(hip.device)
+    aff = Affine(3, period=64)
+    c = torch.zeros((64, 64, 64), dtype=torch.float64, device=hip.device)
     W.paint(c, pos, transform=aff)
+    assert_binned_ran()
     built = [e[3] for e in window._bin_cache.entries]
     W.readout(c, pos, transform=aff)
     assert [e[3] for e in window._bin_cache.entries] == built
     keys = [e[0] for e in window._bin_cache.entries]
     pos += 1.0                                    # in place: version changes
-    c2 = torch.zeros((32, 32, 32), dtype=torch.float64, device=hip.device)
+    c2 = torch.zeros((64, 64, 64), dtype=torch.float64, device=hip.device)
     W.paint(c2, pos, transform=aff)
     assert [e[0] for e in window._bin_cache.entries] != keys
     window.BINNED = 'never'
-    c3 = torch.zeros((32, 32, 32), dtype=torch.float64, device=hip.device)
+    c3 = torch.zeros((64, 64, 64), dtype=torch.float64, device=hip.device)
     W.paint(c3, pos, transform=aff)
     assert_allclose(c2.cpu().numpy(), c3.cpu().numpy(), rtol=0, atol=1e-12 * float(c3.abs().max()))
 
