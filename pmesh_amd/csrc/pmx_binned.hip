@@ -41,6 +41,7 @@ namespace pmx {
 constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
 constexpr int TCELLS = T0 * T1 * T2;
 constexpr int TBLOCK = 256;
+constexpr int UNROLL = 4;             // particles in flight per lane in the tile kernels
 
 struct BinGeom {
     int32_t kind, S;
@@ -254,13 +255,13 @@ __device__ __forceinline__ bool region_cell(const pmx_painter &p, const BinGeom 
 
 // per-particle setup shared by paint and readout: weights and local base of the stencil
 template <int KIND>
-__device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGeom &g, const int *t, DVec pos,
-                                               int64_t i, double (*V)[Tuned<KIND>::S], int *lb)
+__device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGeom &g, const int *t,
+                                               const double *x, double (*V)[Tuned<KIND>::S], int *lb)
 {
     constexpr int S = Tuned<KIND>::S;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        double X = pos.get(i, d) * p.scale[d] + p.translate[d];
+        double X = x[d] * p.scale[d] + p.translate[d];
         int I[S];
         Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
         int w = wrap_fast(I[0], p.period[d]);
@@ -288,23 +289,41 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
         if (count == 0 && !overwrite) continue;   // nothing to add; uniform per workgroup
         for (int q = threadIdx.x; q < Rg::CELLS; q += TBLOCK) lds[q] = 0;
         __syncthreads();
-        for (int j = threadIdx.x; j < count; j += TBLOCK) {
-            int64_t i = list[start + j];
-            double m = mass.data ? mass.get(i, 0) : mass_scalar;
-            int lb[3];
-            double V[3][S];
-            particle_setup<KIND>(p, g, t, pos, i, V, lb);
+        // UNROLL particles per thread and trip: all index and position loads are issued before
+        // the first use, so several dependent gathers are in flight per lane
+        for (int j0 = threadIdx.x; j0 < count; j0 += TBLOCK * UNROLL) {
+            int64_t idx[UNROLL];
+            double x[UNROLL][3], m[UNROLL];
 #pragma unroll
-            for (int a = 0; a < S; a++) V[0][a] *= m;
+            for (int u = 0; u < UNROLL; u++) {
+                int j = j0 + u * TBLOCK;
+                idx[u] = j < count ? (int64_t)list[start + j] : -1;
+            }
 #pragma unroll
-            for (int a = 0; a < S; a++)
-#pragma unroll
-                for (int b = 0; b < S; b++) {
-                    double fb = V[0][a] * V[1][b];
-                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
-#pragma unroll
-                    for (int c = 0; c < S; c++) unsafeAtomicAdd(&lds[rowoff + c], (T)(fb * V[2][c]));
+            for (int u = 0; u < UNROLL; u++) {
+                if (idx[u] >= 0) {
+                    x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
+                    m[u] = mass.data ? mass.get(idx[u], 0) : mass_scalar;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                if (idx[u] < 0) continue;
+                int lb[3];
+                double V[3][S];
+                particle_setup<KIND>(p, g, t, x[u], V, lb);
+#pragma unroll
+                for (int a = 0; a < S; a++) V[0][a] *= m[u];
+#pragma unroll
+                for (int a = 0; a < S; a++)
+#pragma unroll
+                    for (int b = 0; b < S; b++) {
+                        double fb = V[0][a] * V[1][b];
+                        int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
+#pragma unroll
+                        for (int c = 0; c < S; c++) unsafeAtomicAdd(&lds[rowoff + c], (T)(fb * V[2][c]));
+                    }
+            }
         }
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
@@ -387,6 +406,7 @@ __global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, Bin
         if (count == 0) continue;
         int t[3];
         tile_coords(g, tile, t);
+#pragma unroll 4
         for (int q = threadIdx.x; q < Rg::CELLS; q += TBLOCK) {
             int c = q % R2, r = q / R2;
             int b = r % R1, a = r / R1;
@@ -395,22 +415,38 @@ __global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, Bin
             lds[q] = in ? *(const T *)(canvas + goff) : (T)0;   // outside the block reads as 0
         }
         __syncthreads();
-        for (int j = threadIdx.x; j < count; j += TBLOCK) {
-            int64_t i = list[start + j];
-            int lb[3];
-            double V[3][S];
-            particle_setup<KIND>(p, g, t, pos, i, V, lb);
-            double value = 0;
+        for (int j0 = threadIdx.x; j0 < count; j0 += TBLOCK * UNROLL) {
+            int64_t idx[UNROLL];
+            double x[UNROLL][3];
 #pragma unroll
-            for (int a = 0; a < S; a++)
+            for (int u = 0; u < UNROLL; u++) {
+                int j = j0 + u * TBLOCK;
+                idx[u] = j < count ? (int64_t)list[start + j] : -1;
+            }
 #pragma unroll
-                for (int b = 0; b < S; b++) {
-                    double fb = V[0][a] * V[1][b];
-                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
-#pragma unroll
-                    for (int c = 0; c < S; c++) value += (double)lds[rowoff + c] * (fb * V[2][c]);
+            for (int u = 0; u < UNROLL; u++) {
+                if (idx[u] >= 0) {
+                    x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
                 }
-            out.set(i, 0, value);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                if (idx[u] < 0) continue;
+                int lb[3];
+                double V[3][S];
+                particle_setup<KIND>(p, g, t, x[u], V, lb);
+                double value = 0;
+#pragma unroll
+                for (int a = 0; a < S; a++)
+#pragma unroll
+                    for (int b = 0; b < S; b++) {
+                        double fb = V[0][a] * V[1][b];
+                        int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
+#pragma unroll
+                        for (int c = 0; c < S; c++) value += (double)lds[rowoff + c] * (fb * V[2][c]);
+                    }
+                out.set(idx[u], 0, value);
+            }
         }
         __syncthreads();
     }

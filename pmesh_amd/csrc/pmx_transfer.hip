@@ -25,7 +25,9 @@ struct TGeom {
 
 // grid.y walks the slowest memory axis, grid.x / threads the flattened two fast axes:
 // 32-bit index arithmetic only, consecutive threads touch consecutive modes.
-template <typename T>
+// SIMPLE: no Gaussian, no deconvolution, spectral or no gradient — the transfers of the PM
+// cycle proper (dx1, potential): no transcendental code, few registers, high occupancy.
+template <typename T, bool SIMPLE>
 __global__ void __launch_bounds__(256) transfer_kernel(pmx_transfer t, TGeom g, const char *in, char *out)
 {
     const uint32_t n1 = (uint32_t)g.shape[g.ax[1]], n2 = (uint32_t)g.shape[g.ax[2]];
@@ -53,10 +55,11 @@ __global__ void __launch_bounds__(256) transfer_kernel(pmx_transfer t, TGeom g, 
         if (t.laplace_pow) {
             double qq = (k2 == 0) ? 1.0 : k2;
             if (t.laplace_pow == -1) re *= 1.0 / qq;
-            else re *= pow(qq, (double)t.laplace_pow);
+            else if (t.laplace_pow == 1) re *= qq;
+            else if (!SIMPLE) re *= pow(qq, (double)t.laplace_pow);
         }
-        if (t.gauss_r != 0) re *= exp(-0.5 * k2 * t.gauss_r * t.gauss_r);
-        if (t.deconv_pow) {
+        if (!SIMPLE && t.gauss_r != 0) re *= exp(-0.5 * k2 * t.gauss_r * t.gauss_r);
+        if (!SIMPLE && t.deconv_pow) {
             for (int d = 0; d < g.ndim; d++) {
                 double x = 0.5 * ww[d];
                 double s;
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(256) transfer_kernel(pmx_transfer t, TGeom g, 
         if (t.grad_dir >= 0) {
             int d = t.grad_dir;
             double D;
-            if (t.grad_kind == 0) D = kk[d];
+            if (SIMPLE || t.grad_kind == 0) D = kk[d];
             else {
                 double C = g.boxsize[d] / g.nmesh[d];
                 double w = kk[d] * C;
@@ -131,10 +134,15 @@ extern "C" int pmx_apply_transfer(const pmx_transfer *t, int32_t ndim, int32_t e
     PMX_REQUIRE(inner < (1ll << 31), PMX_EUNSUPPORTED, "plane of more than 2^31 modes");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((inner + 255) / 256), (unsigned)(g.shape[g.ax[0]] < 65535 ? g.shape[g.ax[0]] : 65535));
-    if (elsize == 8)
-        transfer_kernel<double><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
-    else
-        transfer_kernel<float><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
+    bool simple = t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
+                  t->laplace_pow >= -1 && t->laplace_pow <= 1;
+    if (elsize == 8) {
+        if (simple) transfer_kernel<double, true><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
+        else transfer_kernel<double, false><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
+    } else {
+        if (simple) transfer_kernel<float, true><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
+        else transfer_kernel<float, false><<<grid, 256, 0, st>>>(*t, g, (const char *)in, (char *)out);
+    }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }
