@@ -242,7 +242,13 @@ def main():
         dom = max(single, key=single.get)
         units = nloc
         ach = algorithmic_bytes(dom, e, pe, nu) * units / (single[dom] * 1e-3) / 1e9
-        kname = {'paint': 'paint_tuned_kernel', 'readout': 'readout_tuned_kernel', 'apply': 'transfer_kernel'}[dom]
+        binned = any(e[3] for e in _window._bin_cache.entries)
+        if binned:
+            kname = {'paint': 'paint_tile_kernel+halo_merge_kernel', 'readout': 'readout_tile_kernel',
+                     'apply': 'transfer_kernel'}[dom]
+        else:
+            kname = {'paint': 'paint_tuned_kernel', 'readout': 'readout_tuned_kernel',
+                     'apply': 'transfer_kernel'}[dom]
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):

@@ -8,10 +8,12 @@ PFFT = serial FFTW per rank + MPI all-to-all transposes.  Here
   in-place layout; the forward normalisation 1/prod(Nmesh) (pm.py:692) is the
   plan's scale factor, so no extra pass over the mesh;
 * P ranks, slab decomposition (``np=[P]``): batched 2-D R2C over the local
-  planes -> pack kernel -> RCCL all-to-all over xGMI -> unpack kernel -> batched
-  1-D C2C along the formerly distributed axis.  The complex field comes out
-  "transposed" (axis 1 distributed, memory order (n1_local, N0, N2c)), which is
-  PFFT's TRANSPOSED_OUT and the reference's default ``ComplexField``.
+  planes -> pack kernel (split axis 1 by destination) -> RCCL all-to-all over
+  xGMI, received straight into the output buffer -> ONE strided batched 1-D C2C
+  along axis 0.  The complex field comes out "transposed": axis 1 is
+  distributed (PFFT's TRANSPOSED_OUT, the reference's default ``ComplexField``)
+  and the local block (N0, n1_local, N2c) is plain C order, because the blocks
+  that arrive from the P ranks are exactly its row ranges — no unpack pass.
 
 Partitions are block distributions with block = ceil(N / P) (FFTW-MPI / PFFT
 default): rank r owns [r*block, min((r+1)*block, N)).
@@ -107,14 +109,7 @@ class Partition(object):
         padded[-1] = 2 * int(Nc[-1])
         self.i_strides = _c_strides(padded)
         self.i_alloc = int(numpy.prod(padded, dtype='i8'))
-        if oax == 1:
-            # memory order (n1_local, N0, N2c[, ...]) : swap the two leading axes
-            mshape = [int(self.local_o_shape[1]), int(self.local_o_shape[0])] + \
-                     [int(x) for x in self.local_o_shape[2:]]
-            ms = _c_strides(mshape)
-            self.o_strides = [ms[1], ms[0]] + ms[2:]
-        else:
-            self.o_strides = _c_strides([int(x) for x in self.local_o_shape])
+        self.o_strides = _c_strides([int(x) for x in self.local_o_shape])
         self.o_alloc = int(numpy.prod(self.local_o_shape, dtype='i8'))
         # one buffer serves both views (in-place transforms)
         self.alloc_reals = max(self.i_alloc, 2 * self.o_alloc, 2)
@@ -249,43 +244,39 @@ class Plan(object):
                                      plane_r, inner_strides_c, plane_c, n0loc, norm, False)
             if n0loc:
                 be.fft_execute(self._native('stage1', make1), bufin.storage, W0)
-            # 2. pack by destination rank, 3. all-to-all, 4. unpack into (n1loc, N0, n2)
+            # 2. pack by destination rank; 3. all-to-all straight into the output buffer: the
+            #    block from rank s is rows [e0[s], e0[s+1]) of the local (N0, n1loc, n2) array
             be.slab_pack(W0, W1, n0loc, N1c, n2, e1, elb)
-            comm.alltoall(W1[:nsend], W2[:nrecv], send_splits, recv_splits)
             out = bufout.storage
-            be.slab_unpack(W2, out, e0, n1loc, n2, elb)
-            # 5. 1-D C2C along N0 (stride n2), batched over the n2 trailing modes, per local row
+            comm.alltoall(W1[:nsend], out[:nrecv], send_splits, recv_splits)
+            # 4. one strided, batched 1-D C2C along axis 0 (stride n1loc*n2, batch n1loc*n2)
+            nb = n1loc * n2
+
             def make2():
-                return be.fft_create(_abi.PMX_FFT_C2C_FWD, self.elsize, [N0], [n2], 1, [n2], 1, n2,
+                return be.fft_create(_abi.PMX_FFT_C2C_FWD, self.elsize, [N0], [nb], 1, [nb], 1, nb,
                                      1.0, True)
-            if n1loc:
-                plan2 = self._native('stage2', make2)
-                for j in range(n1loc):
-                    row = out[2 * j * N0 * n2:]
-                    be.fft_execute(plan2, row, row)
+            if nb:
+                be.fft_execute(self._native('stage2', make2), out, out)
         else:
             # the backward pass works on a copy so that c2r preserves its input
             ncplx = 2 * n1loc * N0 * n2
             W0[:ncplx].copy_(bufin.storage[:ncplx])
+            nb = n1loc * n2
 
             def make2():
-                return be.fft_create(_abi.PMX_FFT_C2C_BWD, self.elsize, [N0], [n2], 1, [n2], 1, n2,
+                return be.fft_create(_abi.PMX_FFT_C2C_BWD, self.elsize, [N0], [nb], 1, [nb], 1, nb,
                                      1.0, True)
-            if n1loc:
-                plan2 = self._native('stage2', make2)
-                for j in range(n1loc):
-                    row = W0[2 * j * N0 * n2:]
-                    be.fft_execute(plan2, row, row)
-            # (n1loc, N0, n2) -> blocks by source rank; all-to-all back; blocks -> (n0loc, N1c, n2)
-            be.slab_unpack(W0, W1, e0, n1loc, n2, elb, inverse=True)
-            comm.alltoall(W1[:nrecv], W2[:nsend], recv_splits, send_splits)
-            be.slab_pack(W2, W0, n0loc, N1c, n2, e1, elb, inverse=True)
+            if nb:
+                be.fft_execute(self._native('stage2', make2), W0, W0)
+            # row ranges go back to their owners; blocks -> (n0loc, N1c, n2)
+            comm.alltoall(W0[:nrecv], W1[:nsend], recv_splits, send_splits)
+            be.slab_pack(W1, W2, n0loc, N1c, n2, e1, elb, inverse=True)
 
             def make1():
                 return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, inner_real, inner_strides_c,
                                      plane_c, inner_strides_r, plane_r, n0loc, 1.0, False)
             if n0loc:
-                be.fft_execute(self._native('stage1', make1), W0, bufout.storage)
+                be.fft_execute(self._native('stage1', make1), W2, bufout.storage)
 
     def destroy(self):
         try:

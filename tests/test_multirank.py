@@ -50,3 +50,17 @@ def test_multirank_rccl():
         pytest.skip('needs at least 2 GPUs (the 1-GPU box runs the single-rank suite)')
     out = _launch(min(n, 8), 'hip')
     assert 'ok case_cycle' in out
+
+
+@pytest.mark.parametrize('nproc', [2, 4, 8])
+def test_multirank_threads(be, nproc):
+    """The same cases with the ranks as threads of this process (tests/thread_comm.py).
+    Under -m gpu this drives the real HIP kernels and the rocFFT stage plans of the slab
+    FFT for P = 2, 4, 8 on a single device; under -m "not gpu" the oracle double."""
+    from tests import mp_cases, thread_comm
+
+    def body(comm):
+        for case in mp_cases.CASES:
+            case(be, comm)
+            comm.Barrier()
+    thread_comm.run_ranks(nproc, body)
