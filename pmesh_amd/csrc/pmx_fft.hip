@@ -27,6 +27,9 @@ struct pmx_fft {
 
 namespace pmx {
 static std::once_flag g_rocfft_once;
+// rocFFT plan creation (kernel generation + caches) is not safe to run concurrently from
+// several host threads: serialise it.  Execution is lock-free.
+static std::mutex g_plan_mutex;
 
 #define PMX_FFT_CHECK(expr)                                                              \
     do {                                                                                 \
@@ -51,6 +54,7 @@ extern "C" int pmx_fft_create(pmx_fft **out, int32_t kind, int32_t elsize, int32
     PMX_REQUIRE(elsize == 4 || elsize == 8, PMX_EINVAL, "elsize must be 4 or 8");
     PMX_REQUIRE(kind >= PMX_FFT_R2C && kind <= PMX_FFT_C2C_BWD, PMX_EINVAL, "bad transform kind");
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+    std::lock_guard<std::mutex> plan_lock(g_plan_mutex);
 
     rocfft_transform_type tt;
     rocfft_array_type it, ot;
