@@ -273,10 +273,28 @@ class Plan(object):
             be.slab_pack(W1, W2, n0loc, N1c, n2, e1, elb, inverse=True)
 
             def make1():
-                return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, inner_real, inner_strides_c,
-                                     plane_c, inner_strides_r, plane_r, n0loc, 1.0, False)
+                try:
+                    return ('padded', be.fft_create(_abi.PMX_FFT_C2R, self.elsize, inner_real,
+                                                    inner_strides_c, plane_c, inner_strides_r, plane_r,
+                                                    n0loc, 1.0, False))
+                except backend.PmxError:
+                    # rocFFT 7.2 rejects out-of-place C2R into a padded real layout for 2-d
+                    # lengths <= 64 (its single-kernel 2-d path); meshes that small are test
+                    # cases only: transform into a dense buffer and copy the rows over
+                    dense = _c_strides(inner_real)
+                    nreal = int(numpy.prod(inner_real, dtype='i8'))
+                    return ('dense', be.fft_create(_abi.PMX_FFT_C2R, self.elsize, inner_real,
+                                                   inner_strides_c, plane_c, dense, nreal, n0loc, 1.0,
+                                                   False))
             if n0loc:
-                be.fft_execute(self._native('stage1', make1), W2, bufout.storage)
+                mode, plan1 = self._native('stage1', make1)
+                if mode == 'padded':
+                    be.fft_execute(plan1, W2, bufout.storage)
+                else:
+                    be.fft_execute(plan1, W2, W1)
+                    shape = [n0loc] + inner_real
+                    dst = torch.as_strided(bufout.storage, shape, [plane_r] + list(inner_strides_r))
+                    dst.copy_(W1[:int(numpy.prod(shape, dtype='i8'))].view(shape))
 
     def destroy(self):
         try:
@@ -284,6 +302,8 @@ class Plan(object):
         except Exception:
             return
         for plan in self._plans.values():
+            if isinstance(plan, tuple):
+                plan = plan[1]
             try:
                 be.fft_destroy(plan)
             except Exception:
