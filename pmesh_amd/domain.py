@@ -132,8 +132,9 @@ class Layout(object):
 
     def _exchange_impl(self, be, data):
         data, host = to_device(data, be.device, 'data', allow_int=True)
-        if any(self.comm.allgather(len(data) != self.sendlength)) if self.comm.size > 1 \
-                else len(data) != self.sendlength:
+        # the reference allgathers this check (domain.py:177-179); a local raise is enough here
+        # and keeps a host-side object collective out of every exchange
+        if len(data) != self.sendlength:
             raise ValueError('the length of data does not match that used to build the layout')
         trailing = tuple(data.shape[1:])
         row_bytes = data.element_size()
