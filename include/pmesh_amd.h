@@ -169,6 +169,17 @@ int pmx_take_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const
 int pmx_scatter_add(const void *values, int32_t elsize, int32_t ncol, const void *indices,
                     int32_t index_elsize, int64_t nrows, void *out, int64_t nout, void *stream);
 
+/* closed-form transfer functions T(k); see pmx_apply_transfer below */
+typedef struct pmx_transfer {
+    double amplitude;     /* real prefactor */
+    int32_t laplace_pow;  /* multiply by (k^2)^laplace_pow, k^2(0) := 1 (nbody.py:156-157); 0 = off */
+    int32_t grad_dir;     /* -1 = off; else multiply by i * D(k_dir) */
+    int32_t grad_kind;    /* 0: D = k (dx1_transfer nbody.py:154-160);
+                             1: D = (8 sin w - sin 2w)/(6 C), w = k C, C = L/N (force_transfer 162-171) */
+    int32_t deconv_pow;   /* divide by prod_d sinc(w_d/2)^deconv_pow (window.py:65-80); 0 = off */
+    double gauss_r;       /* multiply by exp(-0.5 k^2 r^2) (lowpass_transfer nbody.py:177-181); 0 = off */
+} pmx_transfer;
+
 /* ---- FFT (replaces pfft.Plan / plan.execute, pm.py:1429-1434, 689, 1017) -- */
 typedef enum pmx_fft_kind { PMX_FFT_R2C = 0, PMX_FFT_C2R = 1, PMX_FFT_C2C_FWD = 2, PMX_FFT_C2C_BWD = 3 } pmx_fft_kind;
 typedef struct pmx_fft pmx_fft;
@@ -181,6 +192,19 @@ int pmx_fft_create(pmx_fft **plan, int32_t kind, int32_t elsize, int32_t ndim, c
                    int64_t batch, double scale, int32_t inplace);
 int pmx_fft_execute(pmx_fft *plan, void *in, void *out, void *stream);
 int pmx_fft_destroy(pmx_fft *plan);
+
+/* Batched strided ("column") complex FFT, in place, power-of-two lengths 64..1024, with the
+ * columns resident in LDS (csrc/pmx_colfft.hip): the passes of a 3-d transform along the
+ * non-contiguous axes.  `data` is an (A, N, B) complex array in C order; the transform runs
+ * along the middle axis.  inverse = 0: exp(-i k x); 1: exp(+i k x); unnormalised, the result
+ * is multiplied by `scale`.  transfer != NULL fuses ComplexField.apply (pm.py:1047-1070)
+ * into the load of the axis-0 pass: A must be 1, B = n1*n2, element (i0, i1, i2) of the
+ * local block starting at global index start[] is multiplied by T(k) first (closed forms
+ * without transcendentals only: laplace_pow in -1..1, spectral gradient). */
+int pmx_colfft_supported(int64_t n, int32_t elsize);
+int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
+               double scale, const pmx_transfer *transfer, int64_t n1, int64_t n2,
+               const int64_t *start, const int64_t *nmesh, const double *boxsize, void *stream);
 
 /* Local transposes either side of the slab all-to-all (PFFT's global transpose).
  * pack:   src (n0, n1, n2) C order -> P contiguous blocks, block r = (n0, n1 range of r, n2)
@@ -199,15 +223,6 @@ int pmx_slab_unpack_t(const void *src, void *dst, int64_t n0, int64_t n1, int64_
 
 /* ---- apply-transfer (Field.apply, pm.py:617-648, with the transfer functions
  * of examples/nbody.py:154-181 and pmesh/transfer.py fused) ---------------- */
-typedef struct pmx_transfer {
-    double amplitude;     /* real prefactor */
-    int32_t laplace_pow;  /* multiply by (k^2)^laplace_pow, k^2(0) := 1 (nbody.py:156-157); 0 = off */
-    int32_t grad_dir;     /* -1 = off; else multiply by i * D(k_dir) */
-    int32_t grad_kind;    /* 0: D = k (dx1_transfer nbody.py:154-160);
-                             1: D = (8 sin w - sin 2w)/(6 C), w = k C, C = L/N (force_transfer 162-171) */
-    int32_t deconv_pow;   /* divide by prod_d sinc(w_d/2)^deconv_pow (window.py:65-80); 0 = off */
-    double gauss_r;       /* multiply by exp(-0.5 k^2 r^2) (lowpass_transfer nbody.py:177-181); 0 = off */
-} pmx_transfer;
 
 /* out[m] = T(k(m)) * in[m] over a local complex block of logical shape
  * shape[0..ndim) starting at global index start[], with byte strides; k_d =

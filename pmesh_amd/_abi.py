@@ -90,6 +90,9 @@ DEVICE_ONLY = {
                              _i64, _f64, _i32]),
     'fft_execute': (C.c_int, [_vp, _vp, _vp, _vp]),
     'fft_destroy': (C.c_int, [_vp]),
+    'colfft_supported': (C.c_int, [_i64, _i32]),
+    'colfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
+                         _P(_i64), _P(_f64), _vp]),
     'slab_pack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
     'slab_unpack': (C.c_int, [_vp, _vp, _P(_i64), _i32, _i64, _i64, _i32, _vp]),
     'slab_pack_t': (C.c_int, [_vp, _vp, _P(_i64), _i32, _i64, _i64, _i32, _vp]),

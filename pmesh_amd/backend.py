@@ -88,6 +88,17 @@ class HipBackend(object):
     def fft_destroy(self, plan):
         self.call('fft_destroy', plan)
 
+    # -- LDS-resident column FFT -----------------------------------------
+    def colfft_supported(self, n, elsize):
+        return self.lib.pmx_colfft_supported(int(n), int(elsize)) == 0
+
+    def colfft(self, elsize, inverse, data, A, N, B, scale=1.0, transfer=None, n1=1, n2=1,
+               start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
+        """in-place FFT along the middle axis of the (A, N, B) complex array in `data`"""
+        self.call('colfft', elsize, int(bool(inverse)), data.data_ptr(), A, N, B, float(scale),
+                  C.byref(transfer) if transfer is not None else None, n1, n2,
+                  _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3), self.stream())
+
     # -- slab transposes --------------------------------------------------
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
         name = 'slab_unpack_t' if inverse else 'slab_pack'

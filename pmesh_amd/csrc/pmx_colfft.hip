@@ -1,0 +1,376 @@
+// pmx_colfft.hip — batched, strided ("column") complex FFT of power-of-two length,
+// in place, with whole columns resident in LDS.
+//
+// Why: in a 3-d transform of an (N0, N1, N2c) array the passes along axes 1 and 0 walk
+// the array with a stride of one row / one plane.  rocFFT's kernels for that shape
+// (`..._sbcc_...`, 4 columns = 64-byte rows per workgroup) reach 2.9 TB/s and over-fetch
+// ~30 % at 512^3 (profiles/, PMC FETCH_SIZE); they are 2/3 of the r2c/c2r time, which
+// in turn is 44 % of the PM cycle.  Here one workgroup owns W adjacent columns
+// (W x 16 B = 128-256 byte rows: full DRAM bursts), loads them once, runs a Stockham
+// radix-8/4/2 FFT entirely in LDS, and stores them once: one read + one write of the
+// array per pass, nothing else.  The transform of the PM cycle is completed by rocFFT's
+// unit-stride R2C/C2R along the contiguous axis (which already runs near the copy rate).
+//
+// Array view: (A, N, B) complex, C order; the FFT runs along the middle axis (stride B),
+// batched over A (stride N*B) and B.  Axis-1 pass of (N0, N1, N2c): A=N0, N=N1, B=N2c;
+// axis-0 pass: A=1, N=N0, B=N1*N2c.  Unnormalised in both directions; `scale`
+// multiplies the result (the forward transform of the cycle carries 1/prod(Nmesh),
+// pmesh/pm.py:692).  An optional transfer function (same closed forms as
+// pmx_transfer.hip, SIMPLE variant) can be applied while loading, which folds
+// ComplexField.apply into the first pass of c2r.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "pmx_common.h"
+
+namespace pmx {
+
+template <typename T> struct cpx { T x, y; };
+
+template <typename T> __device__ __forceinline__ cpx<T> cmul(cpx<T> a, cpx<T> b)
+{
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <typename T> __device__ __forceinline__ cpx<T> cadd(cpx<T> a, cpx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T> __device__ __forceinline__ cpx<T> csub(cpx<T> a, cpx<T> b) { return {a.x - b.x, a.y - b.y}; }
+// multiply by -i (forward) or +i (inverse)
+template <typename T, bool INV> __device__ __forceinline__ cpx<T> rot90(cpx<T> a)
+{
+    if (INV) return {-a.y, a.x};
+    return {a.y, -a.x};
+}
+
+template <typename T, bool INV> __device__ __forceinline__ void fft2(cpx<T> *v)
+{
+    cpx<T> a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+
+template <typename T, bool INV> __device__ __forceinline__ void fft4(cpx<T> *v)
+{
+    cpx<T> a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
+    cpx<T> c = cadd(v[1], v[3]), d = rot90<T, INV>(csub(v[1], v[3]));
+    v[0] = cadd(a, c);
+    v[2] = csub(a, c);
+    v[1] = cadd(b, d);
+    v[3] = csub(b, d);
+}
+
+// in-register DFT of 8 points, natural order in and out
+template <typename T, bool INV> __device__ __forceinline__ void fft8(cpx<T> *v)
+{
+    const T h = (T)0.70710678118654752440;
+    // radix-2 stage: pairs (k, k+4)
+    cpx<T> a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    cpx<T> a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    cpx<T> a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    cpx<T> a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    // twiddles w8^k on the odd half: w8 = exp(-+ i pi/4)
+    {
+        cpx<T> t = a5;   // * w8^1
+        if (INV) a5 = {h * (t.x - t.y), h * (t.x + t.y)};
+        else a5 = {h * (t.x + t.y), h * (t.y - t.x)};
+        a6 = rot90<T, INV>(a6);   // * w8^2 = -+ i
+        t = a7;          // * w8^3
+        if (INV) a7 = {-h * (t.x + t.y), h * (t.x - t.y)};
+        else a7 = {h * (t.y - t.x), -h * (t.x + t.y)};
+    }
+    // two DFT-4: even outputs from a0..a3, odd outputs from a4..a7
+    cpx<T> e[4] = {a0, a1, a2, a3}, o[4] = {a4, a5, a6, a7};
+    fft4<T, INV>(e);
+    fft4<T, INV>(o);
+    v[0] = e[0]; v[2] = e[1]; v[4] = e[2]; v[6] = e[3];
+    v[1] = o[0]; v[3] = o[1]; v[5] = o[2]; v[7] = o[3];
+}
+
+template <typename T, bool INV, int R> __device__ __forceinline__ void fftR(cpx<T> *v)
+{
+    if (R == 8) fft8<T, INV>(v);
+    else if (R == 4) fft4<T, INV>(v);
+    else fft2<T, INV>(v);
+}
+
+struct ColGeom {
+    int64_t A, B;          // outer and inner batch extents
+    int32_t N, logN;
+    double scale;
+    // optional fused transfer (APPLY): global index bookkeeping of the (N0, n1, N2c) block
+    pmx_transfer t;
+    int32_t n1, n2;        // B = n1 * n2 for the axis-0 pass
+    int64_t start[3], nmesh[3];
+    double dw[3], nl[3];
+};
+
+// One pass of the Stockham autosort FFT over the LDS-resident tile.
+// Column layout in LDS: element n of column c at buf[n * LDW + c].
+template <typename T, bool INV, int R, int W, int LDW>
+__device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int N, int Ns, int tpc /*threads per column*/,
+                                              int col, int tj)
+{
+    // every thread handles (N/R)/tpc butterflies of its column
+    const int nb = N / R;
+    const int per = nb / tpc;
+    cpx<T> v[4][8];   // up to 4 butterflies of radix <= 8 per thread (tpc = N/8, R = 2 -> 4)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (q >= per) break;
+        int j = tj + q * tpc;
+        int k = j % Ns;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cpx<T> x = buf[(j + r * nb) * LDW + col];
+            if (r > 0 && Ns > 1) {
+                // twiddle exp(-+ 2 pi i r k / (Ns R)) from the length-N table
+                int m = r * k * (N / (Ns * R));
+                cpx<T> w = tw[m];
+                if (INV) w.y = -w.y;
+                x = cmul(x, w);
+            }
+            v[q][r] = x;
+        }
+        fftR<T, INV, R>(v[q]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (q >= per) break;
+        int j = tj + q * tpc;
+        int k = j % Ns;
+        int base = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; r++) buf[(base + r * Ns) * LDW + col] = v[q][r];
+    }
+    __syncthreads();
+}
+
+template <typename T> __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, int64_t b, cpx<T> v)
+{
+    // mode (i0, i1, i2) of the local block, i1 i2 from the flattened inner index
+    int64_t i1 = b / g.n2, i2 = b - i1 * g.n2;
+    int64_t idx[3] = {i0, i1, i2};
+    double kk[3], k2 = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        int64_t gi = idx[d] + g.start[d];
+        double wi = (double)gi;
+        if (gi >= g.nmesh[d] / 2) wi -= g.nmesh[d];
+        wi *= g.dw[d];
+        kk[d] = wi * g.nl[d];
+        k2 += kk[d] * kk[d];
+    }
+    double re = g.t.amplitude, im = 0;
+    if (g.t.laplace_pow) {
+        double qq = (k2 == 0) ? 1.0 : k2;
+        if (g.t.laplace_pow == -1) re *= 1.0 / qq;
+        else if (g.t.laplace_pow == 1) re *= qq;
+    }
+    if (g.t.grad_dir >= 0) {
+        double D = g.t.grad_dir == 0 ? kk[0] : (g.t.grad_dir == 1 ? kk[1] : kk[2]);
+        im = re * D;
+        re = 0;
+    }
+    double ar = v.x, ai = v.y;
+    return {(T)(re * ar - im * ai), (T)(re * ai + im * ar)};
+}
+
+// radices per log2(N): products of 8/4/2, largest first
+template <int LOGN> struct Radices;
+template <> struct Radices<6>  { static constexpr int n = 2; static constexpr int r[4] = {8, 8, 1, 1}; };
+template <> struct Radices<7>  { static constexpr int n = 3; static constexpr int r[4] = {8, 4, 4, 1}; };
+template <> struct Radices<8>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 4, 1}; };
+template <> struct Radices<9>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 8, 1}; };
+template <> struct Radices<10> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
+template <> struct Radices<11> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
+
+template <typename T, int LOGN, int W, bool INV, bool APPLY>
+__global__ void __launch_bounds__((1 << LOGN) / 8 * W) colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int TPC = N / 8;            // threads per column
+    constexpr int NT = TPC * W;           // threads per workgroup
+    constexpr int LDW = W + 1;            // padded row: column accesses spread over banks
+    extern __shared__ __align__(16) unsigned char smem[];
+    cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
+    cpx<T> *tw = buf + N * LDW;
+    const int tid = threadIdx.x;
+    for (int n = tid; n < N; n += NT) tw[n] = twiddle[n];
+
+    const int64_t tilesB = (g.B + W - 1) / W;
+    const int64_t ntiles = g.A * tilesB;
+    const int lc = tid % W, lr = tid / W;     // loader mapping: W consecutive lanes = one row segment
+    const int col = tid / TPC, tj = tid % TPC; // compute mapping: TPC consecutive lanes = one column
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
+        cpx<T> *base = data + a * (int64_t)N * g.B + b0;
+        const bool colok = b0 + lc < g.B;
+        __syncthreads();
+        // load: rows of W complex (W*sizeof(cpx) contiguous bytes)
+#pragma unroll 8
+        for (int n = lr; n < N; n += NT / W) {
+            cpx<T> v = {0, 0};
+            if (colok) {
+                v = base[(int64_t)n * g.B + lc];
+                if (APPLY) v = apply_simple<T>(g, n, b0 + lc, v);
+            }
+            buf[n * LDW + lc] = v;
+        }
+        __syncthreads();
+        int Ns = 1;
+        using Rd = Radices<LOGN>;
+        // passes (compile-time radices)
+        if (Rd::r[0] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+        Ns *= Rd::r[0];
+        if (Rd::n > 1) {
+            if (Rd::r[1] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            Ns *= Rd::r[1];
+        }
+        if (Rd::n > 2) {
+            if (Rd::r[2] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            Ns *= Rd::r[2];
+        }
+        if (Rd::n > 3) {
+            if (Rd::r[3] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            Ns *= Rd::r[3];
+        }
+        // store
+        const T sc = (T)g.scale;
+#pragma unroll 8
+        for (int n = lr; n < N; n += NT / W) {
+            if (colok) {
+                cpx<T> v = buf[n * LDW + lc];
+                v.x *= sc;
+                v.y *= sc;
+                base[(int64_t)n * g.B + lc] = v;
+            }
+        }
+    }
+}
+
+// twiddle tables exp(-2 pi i m / N), one per (N, precision, device), created on first use
+struct TwKey { int n, es, dev; bool operator<(const TwKey &o) const { return n != o.n ? n < o.n : (es != o.es ? es < o.es : dev < o.dev); } };
+static std::map<TwKey, void *> g_tw;
+static std::mutex g_tw_mutex;
+
+static int get_twiddles(int N, int es, void **out, hipStream_t st)
+{
+    int dev = 0;
+    PMX_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    TwKey key{N, es, dev};
+    auto it = g_tw.find(key);
+    if (it != g_tw.end()) { *out = it->second; return PMX_OK; }
+    void *d = nullptr;
+    PMX_HIP_CHECK(hipMalloc(&d, (size_t)N * 2 * es));
+    if (es == 8) {
+        std::vector<double> h(2 * N);
+        for (int m = 0; m < N; m++) { h[2 * m] = cos(-2.0 * M_PI * m / N); h[2 * m + 1] = sin(-2.0 * M_PI * m / N); }
+        PMX_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> h(2 * N);
+        for (int m = 0; m < N; m++) { h[2 * m] = (float)cos(-2.0 * M_PI * m / N); h[2 * m + 1] = (float)sin(-2.0 * M_PI * m / N); }
+        PMX_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    g_tw[key] = d;
+    *out = d;
+    return PMX_OK;
+}
+
+template <typename T, int LOGN, int W>
+static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int NT = N / 8 * W;
+    size_t lds = (size_t)(N * (W + 1) + N) * sizeof(cpx<T>);
+    int64_t tiles = g.A * ((g.B + W - 1) / W);
+    unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
+#define LAUNCH(INV, AP)                                                                                        \
+    do {                                                                                                       \
+        auto k = colfft_kernel<T, LOGN, W, INV, AP>;                                                           \
+        PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        k<<<grid, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                                       \
+    } while (0)
+    if (inverse) { if (apply) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (apply) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+template <typename T, int W>
+static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
+{
+    switch (g.logN) {
+    case 6: return launch_colfft<T, 6, W>(g, data, tw, inverse, apply, st);
+    case 7: return launch_colfft<T, 7, W>(g, data, tw, inverse, apply, st);
+    case 8: return launch_colfft<T, 8, W>(g, data, tw, inverse, apply, st);
+    case 9: return launch_colfft<T, 9, W>(g, data, tw, inverse, apply, st);
+    case 10: return launch_colfft<T, 10, W>(g, data, tw, inverse, apply, st);
+    }
+    set_error("pmx_colfft: length 2^%d is not built", g.logN);
+    return PMX_EUNSUPPORTED;
+}
+
+}  // namespace pmx
+
+using namespace pmx;
+
+// PMX_OK if a column FFT of length n (element size elsize = 4|8 per component) is built
+extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
+{
+    if (elsize != 4 && elsize != 8) return PMX_EINVAL;
+    if (n < 64 || n > 1024 || (n & (n - 1))) return PMX_EUNSUPPORTED;
+    return PMX_OK;
+}
+
+// In-place FFT along the middle axis of the (A, N, B) complex array `data`.
+// inverse: 0 forward (exp(-i..)), 1 backward; result multiplied by `scale`.
+// t == NULL: plain transform.  t != NULL (SIMPLE transfers only: no gauss/deconv, spectral
+// gradient, laplace_pow in -1..1): A must be 1 and B = n1*n2; element (i0, i1, i2) is
+// multiplied by T(k) before the transform, with the index bookkeeping of pmx_apply_transfer.
+extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
+                          double scale, const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
+                          const int64_t *nmesh, const double *boxsize, void *stream)
+{
+    int rc = pmx_colfft_supported(N, elsize);
+    if (rc) { set_error("pmx_colfft: unsupported length %lld", (long long)N); return rc; }
+    PMX_REQUIRE(data != nullptr && A >= 0 && B >= 0, PMX_EINVAL, "bad arguments");
+    if (A == 0 || B == 0) return PMX_OK;
+    ColGeom g;
+    g.A = A; g.B = B; g.N = (int32_t)N; g.scale = scale;
+    g.logN = 0;
+    while ((1ll << g.logN) < N) g.logN++;
+    g.n1 = 1; g.n2 = 1;
+    bool apply = t != nullptr;
+    if (apply) {
+        PMX_REQUIRE(A == 1 && n1 * n2 == B, PMX_EINVAL, "fused transfer needs the axis-0 pass of one block");
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
+                    t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
+                    PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
+        g.t = *t;
+        g.n1 = (int32_t)n1; g.n2 = (int32_t)n2;
+        for (int d = 0; d < 3; d++) {
+            g.start[d] = start[d]; g.nmesh[d] = nmesh[d];
+            g.dw[d] = 2 * M_PI / nmesh[d];
+            g.nl[d] = nmesh[d] / boxsize[d];
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)N, elsize, &tw, st);
+    if (rc) return rc;
+    // W columns per workgroup: 256-byte rows where LDS allows two workgroups per CU
+    if (elsize == 8) {
+        if (N <= 256) return dispatch_logn<double, 16>(g, data, tw, inverse != 0, apply, st);
+        return dispatch_logn<double, 8>(g, data, tw, inverse != 0, apply, st);
+    }
+    if (N <= 512) return dispatch_logn<float, 16>(g, data, tw, inverse != 0, apply, st);
+    return dispatch_logn<float, 8>(g, data, tw, inverse != 0, apply, st);
+}

@@ -25,6 +25,12 @@ from . import _abi, backend
 from ._arrays import torch_dtype
 
 
+# 'auto': 3-d transforms whose axis-0/1 lengths are powers of two in 64..1024 run as
+# rocFFT (unit-stride R2C/C2R along the contiguous axis) + the LDS-resident column FFT of
+# csrc/pmx_colfft.hip along the other two; 'never': everything through rocFFT.
+COLFFT = 'auto'
+
+
 def split_size_2d(s):
     """pfft.split_size_2d: the most square factorisation a*d = s with a <= d."""
     a = int(s ** 0.5) + 1
@@ -176,19 +182,37 @@ class Plan(object):
             self._plans[key] = maker()
         return self._plans[key]
 
-    def execute(self, bufin, bufout):
+    def execute(self, bufin, bufout, transfer=None):
         p = self.partition
         if p.nproc == 1:
-            self._execute_local(bufin, bufout)
+            self._execute_local(bufin, bufout, transfer)
         else:
+            if transfer is not None:
+                raise NotImplementedError('fused transfer on several ranks')
             self._execute_slab(bufin, bufout)
 
-    def _execute_local(self, bufin, bufout):
+    def can_fuse(self):
+        """True if execute(..., transfer=) can fold a transfer function into the transform"""
+        p = self.partition
+        if self.forward or p.nproc != 1 or p.ndim != 3:
+            return False
+        return self._use_colfft(backend.get(), [int(x) for x in p.Nmesh[:2]])
+
+    def _use_colfft(self, be, lengths):
+        if COLFFT == 'never' or not hasattr(be, 'colfft'):
+            return False
+        return all(be.colfft_supported(n, self.elsize) for n in lengths)
+
+    def _execute_local(self, bufin, bufout, transfer=None):
         be = backend.get()
         p = self.partition
         n = [int(x) for x in p.Nmesh]
         norm = 1.0 / float(numpy.prod(p.Nmesh, dtype='f8'))
         inplace = bufin.storage.data_ptr() == bufout.storage.data_ptr()
+        if p.ndim == 3 and self._use_colfft(be, n[:2]):
+            return self._execute_local_hybrid(be, bufin, bufout, inplace, transfer)
+        if transfer is not None:
+            raise NotImplementedError('fused transfer needs the column-FFT path')
 
         def make():
             if self.forward:
@@ -198,6 +222,38 @@ class Plan(object):
                                  p.i_strides, p.i_alloc, 1, 1.0, inplace)
         plan = self._native(('local', inplace), make)
         be.fft_execute(plan, bufin.storage, bufout.storage)
+
+    def _execute_local_hybrid(self, be, bufin, bufout, inplace, transfer):
+        """3-d transform on one rank: rocFFT along the contiguous axis, column FFTs along
+        axes 1 and 0 (one read + one write of the array per pass)."""
+        p = self.partition
+        N0, N1, N2 = [int(x) for x in p.Nmesh]
+        N2c = N2 // 2 + 1
+        norm = 1.0 / float(N0) / float(N1) / float(N2)
+        rows = N0 * N1
+        if self.forward:
+            def make():
+                return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, [N2], [1], 2 * N2c, [1], N2c,
+                                     rows, 1.0, inplace)
+            be.fft_execute(self._native(('z', inplace), make), bufin.storage, bufout.storage)
+            out = bufout.storage
+            be.colfft(self.elsize, False, out, N0, N1, N2c)
+            be.colfft(self.elsize, False, out, 1, N0, N1 * N2c, scale=norm)
+        else:
+            # in place on the complex data (c2r(out=...) made `bufin` a copy when needed)
+            src = bufin.storage
+            if transfer is not None:
+                t, start, nmesh, boxsize = transfer
+                be.colfft(self.elsize, True, src, 1, N0, N1 * N2c, transfer=t, n1=N1, n2=N2c,
+                          start=start, nmesh=nmesh, boxsize=boxsize)
+            else:
+                be.colfft(self.elsize, True, src, 1, N0, N1 * N2c)
+            be.colfft(self.elsize, True, src, N0, N1, N2c)
+
+            def make():
+                return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, [N2], [1], N2c, [1], 2 * N2c,
+                                     rows, 1.0, inplace)
+            be.fft_execute(self._native(('z', inplace), make), src, bufout.storage)
 
     def _execute_slab(self, bufin, bufout):
         """Slab-decomposed 3-D (or 2-D) transform with one global transpose."""

@@ -561,8 +561,14 @@ class BaseComplexField(Field):
             r.apply(lambda k, y: y * metric(k.normp() ** 0.5), out=Ellipsis)
         return r
 
-    def c2r(self, out=None):
-        """ complex to real transformation, unnormalised (pm.py:987-1019). """
+    def c2r(self, out=None, transfer=None):
+        """ complex to real transformation, unnormalised (pm.py:987-1019).
+
+            transfer : optional :class:`pmesh_amd.transfer.Transfer` (an extension): the
+            result is ``self.apply(transfer).c2r(out)``, with the multiplication fused into
+            the first pass of the inverse transform when the column-FFT path is active
+            (the complex field is then read once less).  `self` is left untouched unless
+            the transform is in place (``out=Ellipsis``). """
         if out is None:
             out = RealField(self.pm)
         if is_inplace(out):
@@ -579,7 +585,17 @@ class BaseComplexField(Field):
             src = self.pm.create(type=_gettype(self), base=out._base, value=self.value)
             inplace = True
         plan = self.pm.plans[('ipbackward' if inplace else 'backward') + T]
-        plan.execute(src._base, out._base)
+        fused = None
+        if transfer is not None:
+            if not isinstance(transfer, Transfer):
+                raise TypeError('transfer must be a pmesh_amd.transfer.Transfer')
+            if self.pm.comm.size == 1 and transfer.fusable() and plan.can_fuse():
+                fused = (transfer._cstruct(), src.start, src.Nmesh, src.BoxSize)
+            elif src is self and not inplace:
+                src = self.apply(transfer)            # several ranks: the slab path copies anyway
+            else:
+                src.apply(transfer, out=Ellipsis)
+        plan.execute(src._base, out._base, transfer=fused)
         return out
 
     def r2c_vjp(v, out=None):

@@ -66,6 +66,11 @@ class Transfer(object):
         from .window import FindResampler
         return cls(deconv_pow=FindResampler(resampler).nativesupport)
 
+    def fusable(self):
+        """closed forms without transcendentals can ride on the first pass of c2r"""
+        return (self.gauss_r == 0.0 and self.deconv_pow == 0 and -1 <= self.laplace_pow <= 1 and
+                (self.grad_dir < 0 or self.grad_kind == 'spectral'))
+
     def _cstruct(self):
         t = _abi.Transfer()
         t.amplitude = self.amplitude

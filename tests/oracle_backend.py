@@ -91,6 +91,23 @@ class OracleBackend(object):
     def fft_destroy(self, plan):
         pass
 
+    # ---- column FFT (numpy restatement of csrc/pmx_colfft.hip) ------------
+    def colfft_supported(self, n, elsize):
+        n = int(n)
+        return 64 <= n <= 1024 and (n & (n - 1)) == 0
+
+    def colfft(self, elsize, inverse, data, A, N, B, scale=1.0, transfer=None, n1=1, n2=1,
+               start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
+        cdt = 'c8' if elsize == 4 else 'c16'
+        arr = data.detach().numpy().reshape(-1).view(cdt)[:A * N * B].reshape(A, N, B)
+        x = arr.astype('c16')
+        if transfer is not None:
+            blk = numpy.ascontiguousarray(x.reshape(N, n1, n2))
+            blk = O.apply_transfer(transfer, blk, start, nmesh, boxsize)
+            x = blk.reshape(A, N, B)
+        y = numpy.fft.ifft(x, axis=1) * N if inverse else numpy.fft.fft(x, axis=1)
+        arr[...] = y * scale
+
     # ---- slab transposes (numpy restatement of csrc/pmx_fft.hip kernels) ----
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
         cdt = 'c8' if elbytes == 8 else 'c16'

@@ -279,3 +279,51 @@ def test_vjp_compositions(be):                # test_gradient.py: paint/readout 
         assert_allclose(out_pos[:, d], field.readout(pos, gradient=d) * mass)
     out_self, out_pos2 = field.readout_vjp(pos, v=mass)
     assert_allclose(numpy.asarray(out_self), numpy.asarray(pm.paint(pos, mass=mass)))
+
+
+@pytest.mark.parametrize('dtype,tol', [('f8', 1e-13), ('f4', 5e-6)])
+@pytest.mark.parametrize('Nmesh', [[64, 64, 64], [128, 64, 20], [64, 256, 34]])
+def test_fft_column_path_vs_numpy(be, dtype, tol, Nmesh):
+    """The hybrid 3-d transform (rocFFT along the contiguous axis + LDS-resident column FFTs,
+    csrc/pmx_colfft.hip) obeys the same contract and equals the all-rocFFT path."""
+    from pmesh_amd import fft as _fft
+    rs = numpy.random.RandomState(21)
+    data = rs.normal(size=Nmesh).astype(dtype)
+    ref = numpy.fft.rfftn(data.astype('f8')) / numpy.prod(Nmesh)
+    res = {}
+    for mode in ('auto', 'never'):
+        _fft.COLFFT = mode
+        try:
+            pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, dtype=dtype)
+            real = pm.create(type='real', value=data)
+            ck = real.r2c()
+            assert rel_l2(ck, ref) < tol
+            assert_array_equal(numpy.asarray(real), data)
+            assert rel_l2(ck.c2r(), data) < 4 * tol
+            ck2 = real.r2c(out=Ellipsis)
+            assert rel_l2(ck2, ref) < tol
+            assert rel_l2(ck2.c2r(out=Ellipsis), data) < 4 * tol
+            res[mode] = numpy.asarray(ck)
+        finally:
+            _fft.COLFFT = 'auto'
+    assert rel_l2(res['auto'], res['never']) < 2 * tol
+
+
+@pytest.mark.parametrize('dtype,tol', [('f8', 1e-13), ('f4', 5e-6)])
+def test_c2r_with_fused_transfer(be, dtype, tol):
+    """c2r(transfer=T) == apply(T).c2r(): fused into the first column pass where possible,
+    composed otherwise; `self` is preserved unless the transform is in place."""
+    Nmesh = [64, 64, 40]
+    pm = ParticleMesh(BoxSize=[100.0, 80.0, 120.0], Nmesh=Nmesh, dtype=dtype)
+    rs = numpy.random.RandomState(8)
+    ck = pm.create(type='real', value=rs.normal(size=Nmesh).astype(dtype)).r2c()
+    before = numpy.asarray(ck).copy()
+    for T in (Transfer.dx1(0), Transfer.dx1(2), Transfer.potential(), Transfer(amplitude=2.5),
+              Transfer.force(1), Transfer.lowpass(4.0)):
+        want = numpy.asarray(ck.apply(T).c2r())
+        got = numpy.asarray(ck.c2r(transfer=T))
+        assert rel_l2(got, want) < 10 * tol
+        assert_array_equal(numpy.asarray(ck), before)
+        c2 = ck.copy()
+        got2 = numpy.asarray(c2.c2r(out=Ellipsis, transfer=T))
+        assert rel_l2(got2, want) < 10 * tol
