@@ -62,6 +62,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-mesh', type=int, default=256)
     ap.add_argument('--binned', type=int, default=-1, help='1/0 force the tile-binned kernels on/off')
+    ap.add_argument('--colfft', type=int, default=1, help='0: all-rocFFT 3-d transforms; 1: LDS column FFT')
+    ap.add_argument('--fuse-apply', type=int, default=1,
+                    help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
     return ap.parse_args()
 
 
@@ -181,6 +184,9 @@ def main():
         _window.BINNED = 'never'
     elif args.binned == 1:
         _window.BINNED = 'always'
+    from pmesh_amd import fft as _fft
+    if args.colfft == 0:
+        _fft.COLFFT = 'never'
     stages = ['bin', 'paint', 'r2c', 'apply', 'c2r', 'readout']
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
           for _ in range(args.steps)]
@@ -201,9 +207,10 @@ def main():
         mark(2)
         rhok = rho.r2c(out=Ellipsis)
         mark(3)
-        rhok.apply(transfer, out=Ellipsis)
+        if not args.fuse_apply:
+            rhok.apply(transfer, out=Ellipsis)
         mark(4)
-        back = rhok.c2r(out=Ellipsis)
+        back = rhok.c2r(out=Ellipsis, transfer=transfer if args.fuse_apply else None)
         mark(5)
         f = back.readout(pos, gradient=args.gradient, layout=layout)
         mark(6)
@@ -271,7 +278,8 @@ def main():
                                       args.window.upper(), 'fp64' if args.dtype == 'f8' else 'fp32',
                                       '' if args.gradient is None else ' (gradient %d)' % args.gradient),
                        'decomposition': 'single GPU' if world == 1 else 'slab np=[%d], particle exchange included' % world,
-                       'particles': ntot},
+                       'particles': ntot, 'apply': 'fused into c2r' if args.fuse_apply else 'separate kernel',
+                       'fft': 'rocFFT z + LDS column FFT' if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'decompose_ms': round(1e3 * t_decompose, 3),
             'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu) for s in
