@@ -6,7 +6,7 @@
 // (`..._sbcc_...`, 4 columns = 64-byte rows per workgroup) reach 2.9 TB/s and over-fetch
 // ~30 % at 512^3 (profiles/, PMC FETCH_SIZE); they are 2/3 of the r2c/c2r time, which
 // in turn is 44 % of the PM cycle.  Here one workgroup owns W adjacent columns
-// (W x 16 B = 128-256 byte rows: full DRAM bursts), loads them once, runs a Stockham
+// (one 128-byte row segment per row: 8 double or 16 float columns), loads them once, runs a Stockham
 // radix-8/4/2 FFT entirely in LDS, and stores them once: one read + one write of the
 // array per pass, nothing else.  The transform of the PM cycle is completed by rocFFT's
 // unit-stride R2C/C2R along the contiguous axis (which already runs near the copy rate).
@@ -106,9 +106,22 @@ struct ColGeom {
     double dw[3], nl[3];
 };
 
-// One pass of the Stockham autosort FFT over the LDS-resident tile.
-// Column layout in LDS: element n of column c at buf[n * LDW + c].
-template <typename T, bool INV, int R, int W, int LDW>
+// LDS layout: one row of the tile = W columns = 128 bytes = half a bank row.  Rows 2m and
+// 2m+1 share bank row m; WHICH half a row takes is XOR-swizzled with bits 3, 6, 9 of the
+// row number, so that the row sets a wave touches in every Stockham pass (consecutive rows
+// when reading, rows 8 or 64 apart when writing) always split evenly over the two halves:
+// all passes are bank-conflict free without padding.
+template <typename T> __device__ __forceinline__ int lds_index(int row, int col)
+{
+    constexpr int W = 128 / (int)sizeof(cpx<T>);
+    int half = (row ^ (row >> 3) ^ (row >> 6) ^ (row >> 9)) & 1;
+    return ((row >> 1) * 2 + half) * W + col;
+}
+
+// One pass of the Stockham autosort FFT over the LDS-resident tile.  Lane mapping: the W
+// columns of a row are W consecutive lanes (col fastest), so a wave works on 64/W
+// butterflies of all W columns at once.
+template <typename T, bool INV, int R>
 __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int N, int Ns, int tpc /*threads per column*/,
                                               int col, int tj)
 {
@@ -123,7 +136,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
         int k = j % Ns;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            cpx<T> x = buf[(j + r * nb) * LDW + col];
+            cpx<T> x = buf[lds_index<T>(j + r * nb, col)];
             if (r > 0 && Ns > 1) {
                 // twiddle exp(-+ 2 pi i r k / (Ns R)) from the length-N table
                 int m = r * k * (N / (Ns * R));
@@ -143,7 +156,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
         int k = j % Ns;
         int base = (j - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; r++) buf[(base + r * Ns) * LDW + col] = v[q][r];
+        for (int r = 0; r < R; r++) buf[lds_index<T>(base + r * Ns, col)] = v[q][r];
     }
     __syncthreads();
 }
@@ -151,8 +164,9 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
 template <typename T> __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, int64_t b, cpx<T> v)
 {
     // mode (i0, i1, i2) of the local block, i1 i2 from the flattened inner index
-    int64_t i1 = b / g.n2, i2 = b - i1 * g.n2;
-    int64_t idx[3] = {i0, i1, i2};
+    const uint32_t ub = (uint32_t)b, un2 = (uint32_t)g.n2;
+    const uint32_t i1 = ub / un2, i2 = ub - i1 * un2;
+    int64_t idx[3] = {i0, (int64_t)i1, (int64_t)i2};
     double kk[3], k2 = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -187,68 +201,73 @@ template <> struct Radices<9>  { static constexpr int n = 3; static constexpr in
 template <> struct Radices<10> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
 template <> struct Radices<11> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
 
-template <typename T, int LOGN, int W, bool INV, bool APPLY>
-__global__ void __launch_bounds__((1 << LOGN) / 8 * W) colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
+template <typename T, int LOGN, bool INV, bool APPLY>
+__global__ void __launch_bounds__((1 << LOGN) / 8 * (128 / (int)sizeof(cpx<T>)))
+colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 {
     constexpr int N = 1 << LOGN;
-    constexpr int TPC = N / 8;            // threads per column
-    constexpr int NT = TPC * W;           // threads per workgroup
-    constexpr int LDW = W + 1;            // padded row: column accesses spread over banks
+    constexpr int W = 128 / (int)sizeof(cpx<T>);   // columns per tile: 128-byte rows
+    constexpr int TPC = N / 8;                     // threads per column
+    constexpr int NT = TPC * W;                    // threads per workgroup
     extern __shared__ __align__(16) unsigned char smem[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
-    cpx<T> *tw = buf + N * LDW;
+    cpx<T> *tw = buf + N * W;
     const int tid = threadIdx.x;
     for (int n = tid; n < N; n += NT) tw[n] = twiddle[n];
 
     const int64_t tilesB = (g.B + W - 1) / W;
     const int64_t ntiles = g.A * tilesB;
-    const int lc = tid % W, lr = tid / W;     // loader mapping: W consecutive lanes = one row segment
-    const int col = tid / TPC, tj = tid % TPC; // compute mapping: TPC consecutive lanes = one column
+    const int col = tid % W, tj = tid / W;   // W consecutive lanes = one 128-byte row segment
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
         cpx<T> *base = data + a * (int64_t)N * g.B + b0;
-        const bool colok = b0 + lc < g.B;
+        const bool colok = b0 + col < g.B;
         __syncthreads();
-        // load: rows of W complex (W*sizeof(cpx) contiguous bytes)
-#pragma unroll 8
-        for (int n = lr; n < N; n += NT / W) {
-            cpx<T> v = {0, 0};
-            if (colok) {
-                v = base[(int64_t)n * g.B + lc];
-                if (APPLY) v = apply_simple<T>(g, n, b0 + lc, v);
-            }
-            buf[n * LDW + lc] = v;
+        // load: 8 rows per thread, all loads issued before the first LDS store
+        cpx<T> ld[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int n = tj + u * TPC;
+            ld[u] = colok ? base[(int64_t)n * g.B + col] : cpx<T>{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int n = tj + u * TPC;
+            cpx<T> v = ld[u];
+            if (APPLY && colok) v = apply_simple<T>(g, n, b0 + col, v);
+            buf[lds_index<T>(n, col)] = v;
         }
         __syncthreads();
         int Ns = 1;
         using Rd = Radices<LOGN>;
         // passes (compile-time radices)
-        if (Rd::r[0] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+        if (Rd::r[0] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
         Ns *= Rd::r[0];
         if (Rd::n > 1) {
-            if (Rd::r[1] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[1] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
-            if (Rd::r[2] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[2] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
-            if (Rd::r[3] == 8) stockham_pass<T, INV, 8, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, W, LDW>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[3] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[3];
         }
         // store
         const T sc = (T)g.scale;
-#pragma unroll 8
-        for (int n = lr; n < N; n += NT / W) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int n = tj + u * TPC;
             if (colok) {
-                cpx<T> v = buf[n * LDW + lc];
+                cpx<T> v = buf[lds_index<T>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
-                base[(int64_t)n * g.B + lc] = v;
+                base[(int64_t)n * g.B + col] = v;
             }
         }
     }
@@ -283,17 +302,18 @@ static int get_twiddles(int N, int es, void **out, hipStream_t st)
     return PMX_OK;
 }
 
-template <typename T, int LOGN, int W>
+template <typename T, int LOGN>
 static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
 {
     constexpr int N = 1 << LOGN;
+    constexpr int W = 128 / (int)sizeof(cpx<T>);
     constexpr int NT = N / 8 * W;
-    size_t lds = (size_t)(N * (W + 1) + N) * sizeof(cpx<T>);
+    size_t lds = (size_t)(N * W + N) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
-        auto k = colfft_kernel<T, LOGN, W, INV, AP>;                                                           \
+        auto k = colfft_kernel<T, LOGN, INV, AP>;                                                              \
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         k<<<grid, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                                       \
     } while (0)
@@ -304,15 +324,15 @@ static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inve
     return PMX_OK;
 }
 
-template <typename T, int W>
+template <typename T>
 static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
 {
     switch (g.logN) {
-    case 6: return launch_colfft<T, 6, W>(g, data, tw, inverse, apply, st);
-    case 7: return launch_colfft<T, 7, W>(g, data, tw, inverse, apply, st);
-    case 8: return launch_colfft<T, 8, W>(g, data, tw, inverse, apply, st);
-    case 9: return launch_colfft<T, 9, W>(g, data, tw, inverse, apply, st);
-    case 10: return launch_colfft<T, 10, W>(g, data, tw, inverse, apply, st);
+    case 6: return launch_colfft<T, 6>(g, data, tw, inverse, apply, st);
+    case 7: return launch_colfft<T, 7>(g, data, tw, inverse, apply, st);
+    case 8: return launch_colfft<T, 8>(g, data, tw, inverse, apply, st);
+    case 9: return launch_colfft<T, 9>(g, data, tw, inverse, apply, st);
+    case 10: return launch_colfft<T, 10>(g, data, tw, inverse, apply, st);
     }
     set_error("pmx_colfft: length 2^%d is not built", g.logN);
     return PMX_EUNSUPPORTED;
@@ -326,7 +346,7 @@ using namespace pmx;
 extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
-    if (n < 64 || n > 1024 || (n & (n - 1))) return PMX_EUNSUPPORTED;
+    if (n < 64 || n > (elsize == 8 ? 1024 : 512) || (n & (n - 1))) return PMX_EUNSUPPORTED;
     return PMX_OK;
 }
 
@@ -350,7 +370,8 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     g.n1 = 1; g.n2 = 1;
     bool apply = t != nullptr;
     if (apply) {
-        PMX_REQUIRE(A == 1 && n1 * n2 == B, PMX_EINVAL, "fused transfer needs the axis-0 pass of one block");
+        PMX_REQUIRE(A == 1 && n1 * n2 == B && B < (1ll << 31), PMX_EINVAL,
+                    "fused transfer needs the axis-0 pass of one block");
         PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
                     t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
                     PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
@@ -366,11 +387,8 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     void *tw = nullptr;
     rc = get_twiddles((int)N, elsize, &tw, st);
     if (rc) return rc;
-    // W columns per workgroup: 256-byte rows where LDS allows two workgroups per CU
-    if (elsize == 8) {
-        if (N <= 256) return dispatch_logn<double, 16>(g, data, tw, inverse != 0, apply, st);
-        return dispatch_logn<double, 8>(g, data, tw, inverse != 0, apply, st);
-    }
-    if (N <= 512) return dispatch_logn<float, 16>(g, data, tw, inverse != 0, apply, st);
-    return dispatch_logn<float, 8>(g, data, tw, inverse != 0, apply, st);
+    if (elsize == 8) return dispatch_logn<double>(g, data, tw, inverse != 0, apply, st);
+    // float: 16 columns x 8 B = 128-byte rows; 1024 threads at N = 512, so N <= 512 only
+    PMX_REQUIRE(N <= 512, PMX_EUNSUPPORTED, "single precision column FFT is built up to length 512");
+    return dispatch_logn<float>(g, data, tw, inverse != 0, apply, st);
 }

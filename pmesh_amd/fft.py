@@ -67,7 +67,7 @@ class Partition(object):
     """The local blocks of the real ("i") and complex ("o") meshes
     (pfft.Partition; attributes used by pm.py:237-242, 1185-1187, 1209-1211, 1450-1453)."""
 
-    def __init__(self, Nmesh, procmesh, transposed, is_c2c=False):
+    def __init__(self, Nmesh, procmesh, transposed, is_c2c=False, itemsize=8):
         self.Nmesh = numpy.array(Nmesh, dtype='intp')
         self.ndim = len(self.Nmesh)
         self.procmesh = procmesh
@@ -110,13 +110,25 @@ class Partition(object):
         self.local_o_shape = numpy.array([(e[r + 1] - e[r]) if d == oax else e[-1]
                                           for d, e in enumerate(self.o_edges)], dtype='intp')
         # memory layout, in elements
-        # real: padded in place: last axis has 2*(N/2+1) reals
+        # complex rows: N2c modes; on one rank the row pitch of 3-d meshes is rounded up to a
+        # whole number of 128-byte lines (8 complex128 / 16 complex64) so that every row of
+        # the array, and every tile row of the column FFT and of the window kernels, starts
+        # on a line boundary.  Consumers are stride agnostic (as in the reference, pm.py:97).
+        pitch_c = int(Nc[-1])
+        if P == 1 and nd == 3:
+            q = 128 // (2 * itemsize)
+            pitch_c = -(-pitch_c // q) * q
+        self.pitch_c = pitch_c
+        # real: padded in place: the last axis has 2*pitch_c reals
         padded = list(self.local_i_shape)
-        padded[-1] = 2 * int(Nc[-1])
+        padded[-1] = 2 * pitch_c
         self.i_strides = _c_strides(padded)
         self.i_alloc = int(numpy.prod(padded, dtype='i8'))
-        self.o_strides = _c_strides([int(x) for x in self.local_o_shape])
-        self.o_alloc = int(numpy.prod(self.local_o_shape, dtype='i8'))
+        oshape_mem = [int(x) for x in self.local_o_shape]
+        if pitch_c != int(Nc[-1]):
+            oshape_mem[-1] = pitch_c
+        self.o_strides = _c_strides(oshape_mem)
+        self.o_alloc = int(numpy.prod(oshape_mem, dtype='i8'))
         # one buffer serves both views (in-place transforms)
         self.alloc_reals = max(self.i_alloc, 2 * self.o_alloc, 2)
         if P > 1:
@@ -228,7 +240,7 @@ class Plan(object):
         axes 1 and 0 (one read + one write of the array per pass)."""
         p = self.partition
         N0, N1, N2 = [int(x) for x in p.Nmesh]
-        N2c = N2 // 2 + 1
+        N2c = p.pitch_c                       # row pitch in complex elements (>= N2/2+1)
         norm = 1.0 / float(N0) / float(N1) / float(N2)
         rows = N0 * N1
         if self.forward:

@@ -769,8 +769,8 @@ class ParticleMesh(object):
 
         procmesh = _fft.ProcMesh(self.np, comm) if len(self.np) else _fft.ProcMesh([1], comm)
         plans = OrderedDict()
-        plans['partitionT'] = _fft.Partition(self.Nmesh, procmesh, transposed=True)
-        plans['partitionU'] = _fft.Partition(self.Nmesh, procmesh, transposed=False)
+        plans['partitionT'] = _fft.Partition(self.Nmesh, procmesh, transposed=True, itemsize=dtype.itemsize)
+        plans['partitionU'] = _fft.Partition(self.Nmesh, procmesh, transposed=False, itemsize=dtype.itemsize)
         for T in 'TU':
             part = plans['partition' + T]
             plans['forward' + T] = _fft.Plan(part, True, dtype, inplace=False)
