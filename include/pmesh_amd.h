@@ -206,6 +206,14 @@ int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N
                double scale, const pmx_transfer *transfer, int64_t n1, int64_t n2,
                const int64_t *start, const int64_t *nmesh, const double *boxsize, void *stream);
 
+/* Real <-> half-complex transform along the contiguous axis, in place, with the rows
+ * resident in LDS (csrc/pmx_colfft.hip): `nrows` rows of n reals (n a power of two in
+ * 128..1024) at a pitch of `pitch` complex elements <-> n/2+1 modes.  inverse = 0: r2c,
+ * 1: c2r; unnormalised, times `scale`. */
+int pmx_rowfft_supported(int64_t n, int32_t elsize);
+int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
+               double scale, void *stream);
+
 /* Local transposes either side of the slab all-to-all (PFFT's global transpose).
  * pack:   src (n0, n1, n2) C order -> P contiguous blocks, block r = (n0, n1 range of r, n2)
  * unpack: P blocks, block s = (n0 range of s, n1loc, n2) -> dst (n1loc, n0tot, n2) C order

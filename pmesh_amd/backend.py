@@ -99,6 +99,14 @@ class HipBackend(object):
                   C.byref(transfer) if transfer is not None else None, n1, n2,
                   _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3), self.stream())
 
+    def rowfft_supported(self, n, elsize):
+        return self.lib.pmx_rowfft_supported(int(n), int(elsize)) == 0
+
+    def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0):
+        """in-place r2c / c2r of `nrows` rows of n reals at a pitch of `pitch` complex elements"""
+        self.call('rowfft', elsize, int(bool(inverse)), data.data_ptr(), nrows, n, pitch, float(scale),
+                  self.stream())
+
     # -- slab transposes --------------------------------------------------
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
         name = 'slab_unpack_t' if inverse else 'slab_pack'

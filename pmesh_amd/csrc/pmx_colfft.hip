@@ -115,7 +115,9 @@ template <typename T> __device__ __forceinline__ int lds_index(int row, int col)
 {
     constexpr int W = 128 / (int)sizeof(cpx<T>);
     int half = (row ^ (row >> 3) ^ (row >> 6) ^ (row >> 9)) & 1;
-    return ((row >> 1) * 2 + half) * W + col;
+    // the column slot is rotated by the row number: a wave that walks along a column
+    // (the transposing load/store of the row kernel) then also spreads over all banks
+    return ((row >> 1) * 2 + half) * W + ((col + row) & (W - 1));
 }
 
 // One pass of the Stockham autosort FFT over the LDS-resident tile.  Lane mapping: the W
@@ -123,7 +125,7 @@ template <typename T> __device__ __forceinline__ int lds_index(int row, int col)
 // butterflies of all W columns at once.
 template <typename T, bool INV, int R>
 __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int N, int Ns, int tpc /*threads per column*/,
-                                              int col, int tj)
+                                              int col, int tj, int twstride = 1)
 {
     // every thread handles (N/R)/tpc butterflies of its column
     const int nb = N / R;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
             if (r > 0 && Ns > 1) {
                 // twiddle exp(-+ 2 pi i r k / (Ns R)) from the length-N table
                 int m = r * k * (N / (Ns * R));
-                cpx<T> w = tw[m];
+                cpx<T> w = tw[m * twstride];
                 if (INV) w.y = -w.y;
                 x = cmul(x, w);
             }
@@ -161,22 +163,34 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
     __syncthreads();
 }
 
-template <typename T> __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, int64_t b, cpx<T> v)
+// Fused transfer (SIMPLE forms).  The wavenumbers along axes 1 and 2 depend only on the
+// column, so they are computed once per tile and thread; per element only axis 0 remains.
+struct ColK { double k1, k2, k12sq; };
+
+__device__ __forceinline__ double kcoord(const ColGeom &g, int d, int64_t i)
 {
-    // mode (i0, i1, i2) of the local block, i1 i2 from the flattened inner index
+    int64_t gi = i + g.start[d];
+    double wi = (double)gi;
+    if (gi >= g.nmesh[d] / 2) wi -= g.nmesh[d];
+    wi *= g.dw[d];
+    return wi * g.nl[d];
+}
+
+__device__ __forceinline__ ColK column_k(const ColGeom &g, int64_t b)
+{
     const uint32_t ub = (uint32_t)b, un2 = (uint32_t)g.n2;
     const uint32_t i1 = ub / un2, i2 = ub - i1 * un2;
-    int64_t idx[3] = {i0, (int64_t)i1, (int64_t)i2};
-    double kk[3], k2 = 0;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        int64_t gi = idx[d] + g.start[d];
-        double wi = (double)gi;
-        if (gi >= g.nmesh[d] / 2) wi -= g.nmesh[d];
-        wi *= g.dw[d];
-        kk[d] = wi * g.nl[d];
-        k2 += kk[d] * kk[d];
-    }
+    ColK c;
+    c.k1 = kcoord(g, 1, i1);
+    c.k2 = kcoord(g, 2, i2);
+    c.k12sq = c.k1 * c.k1 + c.k2 * c.k2;
+    return c;
+}
+
+template <typename T> __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, const ColK &c, cpx<T> v)
+{
+    const double k0 = kcoord(g, 0, i0);
+    const double k2 = k0 * k0 + c.k12sq;
     double re = g.t.amplitude, im = 0;
     if (g.t.laplace_pow) {
         double qq = (k2 == 0) ? 1.0 : k2;
@@ -184,7 +198,7 @@ template <typename T> __device__ __forceinline__ cpx<T> apply_simple(const ColGe
         else if (g.t.laplace_pow == 1) re *= qq;
     }
     if (g.t.grad_dir >= 0) {
-        double D = g.t.grad_dir == 0 ? kk[0] : (g.t.grad_dir == 1 ? kk[1] : kk[2]);
+        double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.k1 : c.k2);
         im = re * D;
         re = 0;
     }
@@ -222,6 +236,8 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
         cpx<T> *base = data + a * (int64_t)N * g.B + b0;
         const bool colok = b0 + col < g.B;
+        ColK ck = {0, 0, 0};
+        if (APPLY && colok) ck = column_k(g, b0 + col);
         __syncthreads();
         // load: 8 rows per thread, all loads issued before the first LDS store
         cpx<T> ld[8];
@@ -234,7 +250,7 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         for (int u = 0; u < 8; u++) {
             int n = tj + u * TPC;
             cpx<T> v = ld[u];
-            if (APPLY && colok) v = apply_simple<T>(g, n, b0 + col, v);
+            if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
             buf[lds_index<T>(n, col)] = v;
         }
         __syncthreads();
@@ -268,6 +284,124 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
                 v.x *= sc;
                 v.y *= sc;
                 base[(int64_t)n * g.B + col] = v;
+            }
+        }
+    }
+}
+
+// ---- unit-stride real <-> half-complex row transform (the contiguous axis) ----------
+// In place on rows of N = 2M reals (row pitch `pitch` complex = 2*pitch reals) <-> M+1
+// complex modes.  A workgroup takes W rows, reads them as M complex z[m] = x[2m] + i x[2m+1],
+// transposes them into the same LDS tile the column kernel uses (row r of the batch is
+// "column" r of the tile), runs the M-point Stockham FFT and splits even/odd:
+//   X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) w^k (Z[k] - conj Z[M-k]),   w = exp(-2 pi i / N)
+// (inverse: Z[k] = (X[k] + conj X[M-k]) + i conj(w)^k (X[k] - conj X[M-k]), then the inverse
+// FFT; unnormalised like rocFFT's C2R).  One read and one write of the array.
+template <typename T, int LOGM, bool INV>
+__global__ void __launch_bounds__((1 << LOGM) / 8 * (128 / (int)sizeof(cpx<T>)))
+rowfft_kernel(cpx<T> *data, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */)
+{
+    constexpr int M = 1 << LOGM;
+    constexpr int W = 128 / (int)sizeof(cpx<T>);
+    constexpr int TPC = M / 8;
+    constexpr int NT = TPC * W;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
+    cpx<T> *tw = buf + M * W;          // 2M entries: exp(-2 pi i m / 2M)
+    cpx<T> *xm = tw + 2 * M;           // W entries: the Nyquist mode X[M] of every row
+    const int tid = threadIdx.x;
+    for (int n = tid; n < 2 * M; n += NT) tw[n] = twiddle[n];
+    const int col = tid % W, tj = tid / W;
+    const T sc = (T)scale;
+    const int64_t ntiles = (nrows + W - 1) / W;
+    using Rd = Radices<LOGM>;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * W;
+        __syncthreads();
+        // load W rows, consecutive lanes along the row
+        cpx<T> ld[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int flat = tid + u * NT;
+            int r = flat / M, n = flat % M;
+            ld[u] = (r0 + r < nrows) ? data[(r0 + r) * pitch + n] : cpx<T>{0, 0};
+        }
+        if (INV && tid < W) xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int flat = tid + u * NT;
+            buf[lds_index<T>(flat % M, flat / M)] = ld[u];
+        }
+        __syncthreads();
+        if (INV) {
+            // X -> Z, pairs (k, M-k) handled together, in place
+            for (int q = tid; q < W * (M / 2 + 1); q += NT) {
+                int r = q / (M / 2 + 1), k = q % (M / 2 + 1);
+                int k2 = M - k;
+                cpx<T> xk = buf[lds_index<T>(k, r)];
+                cpx<T> xq = (k == 0) ? xm[r] : buf[lds_index<T>(k2, r)];
+                // A = xk + conj(xq), D = xk - conj(xq)
+                cpx<T> A = {xk.x + xq.x, xk.y - xq.y}, D = {xk.x - xq.x, xk.y + xq.y};
+                cpx<T> w = tw[k];
+                w.y = -w.y;                                  // conj(w)^k = exp(+2 pi i k / N)
+                cpx<T> B = cmul(w, D);
+                buf[lds_index<T>(k, r)] = {A.x - B.y, A.y + B.x};            // A + i B
+                if (k != 0 && k2 != k) {
+                    // Z[M-k] = conj(A) + i conj(w')... computed from the same pair:
+                    // A' = xq + conj(xk) = conj(A),  D' = xq - conj(xk) = -conj(D),  w' = exp(+2 pi i (M-k)/N) = -conj(w)
+                    cpx<T> Ac = {A.x, -A.y};
+                    cpx<T> Dc = {-D.x, D.y};
+                    cpx<T> wc = {-w.x, w.y};
+                    cpx<T> Bc = cmul(wc, Dc);
+                    buf[lds_index<T>(k2, r)] = {Ac.x - Bc.y, Ac.y + Bc.x};
+                }
+            }
+            __syncthreads();
+        }
+        int Ns = 1;
+        if (Rd::r[0] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
+        Ns *= Rd::r[0];
+        if (Rd::n > 1) {
+            if (Rd::r[1] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4>(buf, tw, M, Ns, TPC, col, tj, 2);
+            Ns *= Rd::r[1];
+        }
+        if (Rd::n > 2) {
+            if (Rd::r[2] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4>(buf, tw, M, Ns, TPC, col, tj, 2);
+            Ns *= Rd::r[2];
+        }
+        if (Rd::n > 3) {
+            if (Rd::r[3] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4>(buf, tw, M, Ns, TPC, col, tj, 2);
+            Ns *= Rd::r[3];
+        }
+        if (!INV) {
+            // Z -> X for k = 0..M, consecutive lanes along the row
+            for (int q = tid; q < W * (M + 1); q += NT) {
+                int r = q / (M + 1), k = q % (M + 1);
+                if (r0 + r >= nrows) continue;
+                cpx<T> zk = buf[lds_index<T>(k & (M - 1), r)];
+                cpx<T> zq = buf[lds_index<T>((M - k) & (M - 1), r)];
+                cpx<T> E = {(T)0.5 * (zk.x + zq.x), (T)0.5 * (zk.y - zq.y)};       // (zk + conj zq)/2
+                cpx<T> D = {(T)0.5 * (zk.x - zq.x), (T)0.5 * (zk.y + zq.y)};       // (zk - conj zq)/2
+                cpx<T> w = (k == M) ? cpx<T>{(T)-1, (T)0} : tw[k];
+                cpx<T> wd = cmul(w, D);
+                // X = E - i * w * D
+                cpx<T> X = {E.x + wd.y, E.y - wd.x};
+                X.x *= sc; X.y *= sc;
+                data[(r0 + r) * pitch + k] = X;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int flat = tid + u * NT;
+                int r = flat / M, n = flat % M;
+                if (r0 + r < nrows) {
+                    cpx<T> v = buf[lds_index<T>(n, r)];
+                    v.x *= sc; v.y *= sc;
+                    data[(r0 + r) * pitch + n] = v;
+                }
             }
         }
     }
@@ -338,9 +472,74 @@ static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inve
     return PMX_EUNSUPPORTED;
 }
 
+template <typename T, int LOGM>
+static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
+                         hipStream_t st)
+{
+    constexpr int M = 1 << LOGM;
+    constexpr int W = 128 / (int)sizeof(cpx<T>);
+    constexpr int NT = M / 8 * W;
+    size_t lds = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>);
+    int64_t tiles = (nrows + W - 1) / W;
+    unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
+    if (inverse) {
+        auto k = rowfft_kernel<T, LOGM, true>;
+        PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw);
+    } else {
+        auto k = rowfft_kernel<T, LOGM, false>;
+        PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw);
+    }
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+template <typename T>
+static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, double scale, const void *tw,
+                         bool inverse, hipStream_t st)
+{
+    switch (logm) {
+    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, st);
+    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, st);
+    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, st);
+    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, st);
+    }
+    set_error("pmx_rowfft: length 2^%d is not built", logm + 1);
+    return PMX_EUNSUPPORTED;
+}
+
 }  // namespace pmx
 
 using namespace pmx;
+
+// PMX_OK if the real row transform of length n (n reals <-> n/2+1 modes) is built
+extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
+{
+    if (elsize != 4 && elsize != 8) return PMX_EINVAL;
+    if (n < 128 || n > 1024 || (n & (n - 1))) return PMX_EUNSUPPORTED;
+    return PMX_OK;
+}
+
+// In-place real <-> half-complex transform of `nrows` rows of n reals (inverse = 0: r2c,
+// n reals -> n/2+1 modes; 1: c2r), row pitch `pitch` COMPLEX elements (>= n/2+1), result
+// multiplied by `scale`; unnormalised in both directions.
+extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
+                          double scale, void *stream)
+{
+    int rc = pmx_rowfft_supported(n, elsize);
+    if (rc) { set_error("pmx_rowfft: unsupported length %lld", (long long)n); return rc; }
+    PMX_REQUIRE(data != nullptr && nrows >= 0 && pitch >= n / 2 + 1, PMX_EINVAL, "bad arguments");
+    if (nrows == 0) return PMX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)n, elsize, &tw, st);
+    if (rc) return rc;
+    int logm = 0;
+    while ((2ll << logm) < n) logm++;
+    if (elsize == 8) return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, st);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, st);
+}
 
 // PMX_OK if a column FFT of length n (element size elsize = 4|8 per component) is built
 extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)

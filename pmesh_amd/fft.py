@@ -243,11 +243,15 @@ class Plan(object):
         N2c = p.pitch_c                       # row pitch in complex elements (>= N2/2+1)
         norm = 1.0 / float(N0) / float(N1) / float(N2)
         rows = N0 * N1
+        own_rows = inplace and be.rowfft_supported(N2, self.elsize)
         if self.forward:
-            def make():
-                return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, [N2], [1], 2 * N2c, [1], N2c,
-                                     rows, 1.0, inplace)
-            be.fft_execute(self._native(('z', inplace), make), bufin.storage, bufout.storage)
+            if own_rows:
+                be.rowfft(self.elsize, False, bufin.storage, rows, N2, N2c)
+            else:
+                def make():
+                    return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, [N2], [1], 2 * N2c, [1], N2c,
+                                         rows, 1.0, inplace)
+                be.fft_execute(self._native(('z', inplace), make), bufin.storage, bufout.storage)
             out = bufout.storage
             be.colfft(self.elsize, False, out, N0, N1, N2c)
             be.colfft(self.elsize, False, out, 1, N0, N1 * N2c, scale=norm)
@@ -261,11 +265,13 @@ class Plan(object):
             else:
                 be.colfft(self.elsize, True, src, 1, N0, N1 * N2c)
             be.colfft(self.elsize, True, src, N0, N1, N2c)
-
-            def make():
-                return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, [N2], [1], N2c, [1], 2 * N2c,
-                                     rows, 1.0, inplace)
-            be.fft_execute(self._native(('z', inplace), make), src, bufout.storage)
+            if own_rows:
+                be.rowfft(self.elsize, True, src, rows, N2, N2c)
+            else:
+                def make():
+                    return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, [N2], [1], N2c, [1], 2 * N2c,
+                                         rows, 1.0, inplace)
+                be.fft_execute(self._native(('z', inplace), make), src, bufout.storage)
 
     def _execute_slab(self, bufin, bufout):
         """Slab-decomposed 3-D (or 2-D) transform with one global transpose."""

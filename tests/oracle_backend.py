@@ -108,6 +108,22 @@ class OracleBackend(object):
         y = numpy.fft.ifft(x, axis=1) * N if inverse else numpy.fft.fft(x, axis=1)
         arr[...] = y * scale
 
+    def rowfft_supported(self, n, elsize):
+        n = int(n)
+        return 128 <= n <= 1024 and (n & (n - 1)) == 0
+
+    def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0):
+        rdt, cdt = ('f4', 'c8') if elsize == 4 else ('f8', 'c16')
+        flat = data.detach().numpy().reshape(-1)
+        real = flat.view(rdt)[:nrows * 2 * pitch].reshape(nrows, 2 * pitch)
+        cplx = flat.view(cdt)[:nrows * pitch].reshape(nrows, pitch)
+        if inverse:
+            x = numpy.fft.irfft(cplx[:, :n // 2 + 1].astype('c16'), n=n, axis=1) * n
+            real[:, :n] = x * scale
+        else:
+            y = numpy.fft.rfft(real[:, :n].astype('f8'), axis=1)
+            cplx[:, :n // 2 + 1] = y * scale
+
     # ---- slab transposes (numpy restatement of csrc/pmx_fft.hip kernels) ----
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
         cdt = 'c8' if elbytes == 8 else 'c16'
