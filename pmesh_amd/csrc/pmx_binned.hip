@@ -141,22 +141,52 @@ __device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, 
     return true;
 }
 
-template <int KIND>
+// DENSE: positions are a contiguous (n, 3) array.  A lane-per-particle load of 3 elements
+// at a 24-byte stride touches three times the cache lines per instruction that a dense
+// load does (the kernel is address-path bound, not bandwidth bound), so the block copies
+// its 256 rows with 16-byte-per-lane loads into LDS and every lane picks its row there.
+template <int KIND, bool DENSE>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
                                                            int32_t *tid, uint32_t *slot, uint32_t *counts,
                                                            uint32_t *flags)
 {
     constexpr int S = Tuned<KIND>::S;
     const int lane = threadIdx.x & 63;
+    __shared__ __align__(16) unsigned char stage[DENSE ? TBLOCK * 24 : 16];
     for (int64_t base = blockIdx.x * (int64_t)TBLOCK; base < n; base += (int64_t)gridDim.x * TBLOCK) {
         int64_t i = base + threadIdx.x;
         int t = -1;
+        double xin[3] = {0, 0, 0};
+        if (DENSE) {
+            const int rowb = 3 * pos.elsize;
+            const int64_t left = n - base;
+            const int nbytes = (int)((left < TBLOCK ? left : TBLOCK) * rowb);
+            const char *src = pos.data + base * rowb;
+            __syncthreads();
+            const int n16 = nbytes & ~15;
+            for (int off = threadIdx.x * 16; off < n16; off += TBLOCK * 16)
+                *(uint4 *)(stage + off) = *(const uint4 *)(src + off);
+            for (int off = n16 + threadIdx.x * 4; off < nbytes; off += TBLOCK * 4)
+                *(uint32_t *)(stage + off) = *(const uint32_t *)(src + off);
+            __syncthreads();
+            if (i < n) {
+                if (pos.elsize == 8) {
+                    const double *r = (const double *)stage + 3 * threadIdx.x;
+                    xin[0] = r[0]; xin[1] = r[1]; xin[2] = r[2];
+                } else {
+                    const float *r = (const float *)stage + 3 * threadIdx.x;
+                    xin[0] = r[0]; xin[1] = r[1]; xin[2] = r[2];
+                }
+            }
+        } else if (i < n) {
+            xin[0] = pos.get(i, 0); xin[1] = pos.get(i, 1); xin[2] = pos.get(i, 2);
+        }
         if (i < n) {
             bool ok = true;
             int tt[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                double X = pos.get(i, d) * p.scale[d] + p.translate[d];
+                double X = xin[d] * p.scale[d] + p.translate[d];
                 ok = ok && (fabs(X) < 1073741824.0);   // NaN / out of int range: dropped
                 int I[S];
                 double V[S];
@@ -588,7 +618,14 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     DVec dpos = dvec(pos);
     if (npart > 0) {
         unsigned grid = grid_for(npart, TBLOCK);
-#define BC(K) bin_count_kernel<K><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags)
+        // contiguous (n, 3) rows on a 16-byte boundary take the dense staging path
+        const bool dense = pos->stride1 == pos->elsize && pos->stride0 == 3 * (int64_t)pos->elsize &&
+                           (((uintptr_t)pos->data) & 15) == 0;
+#define BC(K)                                                                                                   \
+    do {                                                                                                        \
+        if (dense) bin_count_kernel<K, true><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); \
+        else bin_count_kernel<K, false><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags);      \
+    } while (0)
         switch (p.kind) {
         case PMX_TUNED_NNB: BC(PMX_TUNED_NNB); break;
         case PMX_TUNED_CIC: BC(PMX_TUNED_CIC); break;
