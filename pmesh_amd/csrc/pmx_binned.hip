@@ -151,16 +151,15 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                                                            uint32_t *flags)
 {
     constexpr int S = Tuned<KIND>::S;
+    constexpr int U = 4;    // particle chunks per trip: U independent load -> atomic chains per wave
     const int lane = threadIdx.x & 63;
-    __shared__ __align__(16) unsigned char stage[DENSE ? TBLOCK * 24 : 16];
-    for (int64_t base = blockIdx.x * (int64_t)TBLOCK; base < n; base += (int64_t)gridDim.x * TBLOCK) {
-        int64_t i = base + threadIdx.x;
-        int t = -1;
-        double xin[3] = {0, 0, 0};
+    __shared__ __align__(16) unsigned char stage[DENSE ? U * TBLOCK * 24 : 16];
+    for (int64_t base = blockIdx.x * (int64_t)(TBLOCK * U); base < n; base += (int64_t)gridDim.x * TBLOCK * U) {
+        double xin[U][3];
         if (DENSE) {
             const int rowb = 3 * pos.elsize;
             const int64_t left = n - base;
-            const int nbytes = (int)((left < TBLOCK ? left : TBLOCK) * rowb);
+            const int nbytes = (int)((left < TBLOCK * U ? left : TBLOCK * U) * rowb);
             const char *src = pos.data + base * rowb;
             __syncthreads();
             const int n16 = nbytes & ~15;
@@ -169,55 +168,79 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
             for (int off = n16 + threadIdx.x * 4; off < nbytes; off += TBLOCK * 4)
                 *(uint32_t *)(stage + off) = *(const uint32_t *)(src + off);
             __syncthreads();
-            if (i < n) {
-                if (pos.elsize == 8) {
-                    const double *r = (const double *)stage + 3 * threadIdx.x;
-                    xin[0] = r[0]; xin[1] = r[1]; xin[2] = r[2];
-                } else {
-                    const float *r = (const float *)stage + 3 * threadIdx.x;
-                    xin[0] = r[0]; xin[1] = r[1]; xin[2] = r[2];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int row = u * TBLOCK + threadIdx.x;
+                if (base + row < n) {
+                    if (pos.elsize == 8) {
+                        const double *r = (const double *)stage + 3 * row;
+                        xin[u][0] = r[0]; xin[u][1] = r[1]; xin[u][2] = r[2];
+                    } else {
+                        const float *r = (const float *)stage + 3 * row;
+                        xin[u][0] = r[0]; xin[u][1] = r[1]; xin[u][2] = r[2];
+                    }
                 }
             }
-        } else if (i < n) {
-            xin[0] = pos.get(i, 0); xin[1] = pos.get(i, 1); xin[2] = pos.get(i, 2);
-        }
-        if (i < n) {
-            bool ok = true;
-            int tt[3];
+        } else {
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                double X = xin[d] * p.scale[d] + p.translate[d];
-                ok = ok && (fabs(X) < 1073741824.0);   // NaN / out of int range: dropped
-                int I[S];
-                double V[S];
-                Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
-                int i0w = 0;
-                ok = ok && local_base<KIND>(p, d, I[0], &i0w);
-                tt[d] = (i0w + g.o[d]) / tile_ext(d);
+            for (int u = 0; u < U; u++) {
+                int64_t i = base + u * TBLOCK + threadIdx.x;
+                if (i < n) { xin[u][0] = pos.get(i, 0); xin[u][1] = pos.get(i, 1); xin[u][2] = pos.get(i, 2); }
             }
-            if (ok) t = (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
         }
-        // wave-aggregated counting: find the lanes that share my tile (ballots only), then
-        // ONE atomicAdd instruction for the whole wave (the first lane of every group adds the
-        // group's population), i.e. one memory round trip per wave
-        unsigned long long same = 0;
-        unsigned long long active = __ballot(t >= 0);
-        while (active) {
-            int leader = __ffsll((long long)active) - 1;
-            int lt = __shfl(t, leader);
-            unsigned long long m = __ballot(t == lt) & active;
-            if (t == lt) same = m;
-            active &= ~m;
+        int t[U];
+        unsigned long long same[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + u * TBLOCK + threadIdx.x;
+            t[u] = -1;
+            if (i < n) {
+                bool ok = true;
+                int tt[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    double X = xin[u][d] * p.scale[d] + p.translate[d];
+                    ok = ok && (fabs(X) < 1073741824.0);   // NaN / out of int range: dropped
+                    int I[S];
+                    double V[S];
+                    Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
+                    int i0w = 0;
+                    ok = ok && local_base<KIND>(p, d, I[0], &i0w);
+                    tt[d] = (i0w + g.o[d]) / tile_ext(d);
+                }
+                if (ok) t[u] = (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+            }
+            // wave-aggregated counting: find the lanes that share my tile (ballots only)
+            same[u] = 0;
+            unsigned long long active = __ballot(t[u] >= 0);
+            while (active) {
+                int leader = __ffsll((long long)active) - 1;
+                int lt = __shfl(t[u], leader);
+                unsigned long long m = __ballot(t[u] == lt) & active;
+                if (t[u] == lt) same[u] = m;
+                active &= ~m;
+            }
         }
-        uint32_t b = 0;
-        const int leader = t >= 0 ? __ffsll((long long)same) - 1 : lane;
-        if (t >= 0 && lane == leader) b = atomicAdd(&counts[t], (uint32_t)__popcll(same));
-        b = __shfl(b, leader);
-        uint32_t myslot = b + (uint32_t)__popcll(same & (((unsigned long long)1 << lane) - 1));
-        if (t < 0 && i < n) atomicOr(&flags[0], 1u);
-        if (i < n) {
-            tid[i] = t;
-            slot[i] = myslot;
+        // ONE atomicAdd instruction per chunk for the whole wave (the first lane of every
+        // group adds the group's population); the U atomics are in flight together
+        uint32_t b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            b[u] = 0;
+            const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+            if (t[u] >= 0 && lane == leader) b[u] = atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + u * TBLOCK + threadIdx.x;
+            const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+            uint32_t bb = __shfl(b[u], leader);
+            uint32_t myslot = bb + (uint32_t)__popcll(same[u] & (((unsigned long long)1 << lane) - 1));
+            if (i < n) {
+                if (t[u] < 0) atomicOr(&flags[0], 1u);
+                tid[i] = t[u];
+                slot[i] = myslot;
+            }
         }
     }
 }
@@ -617,7 +640,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)(g.ntiles + 1) * 4, st));
     DVec dpos = dvec(pos);
     if (npart > 0) {
-        unsigned grid = grid_for(npart, TBLOCK);
+        unsigned grid = grid_for((npart + 3) / 4, TBLOCK);
         // contiguous (n, 3) rows on a 16-byte boundary take the dense staging path
         const bool dense = pos->stride1 == pos->elsize && pos->stride0 == 3 * (int64_t)pos->elsize &&
                            (((uintptr_t)pos->data) & 15) == 0;
