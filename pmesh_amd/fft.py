@@ -311,6 +311,45 @@ class Plan(object):
         plane_c = N1c * n2
         nsend, nrecv = sum(send_splits), sum(recv_splits)
 
+        same = bufin.storage.data_ptr() == bufout.storage.data_ptr()
+        own = (nd == 3 and COLFFT != 'never' and hasattr(be, 'colfft') and
+               be.rowfft_supported(int(p.Nmesh[2]), self.elsize) and
+               be.colfft_supported(int(p.Nmesh[1]), self.elsize) and be.colfft_supported(N0, self.elsize))
+        if own:
+            # the LDS-resident row / column kernels of csrc/pmx_colfft.hip, all in place
+            N1, N2 = int(p.Nmesh[1]), int(p.Nmesh[2])
+            N2c = n2
+            nb = n1loc * N2c
+            if self.forward:
+                X = bufin.storage
+                if not same:
+                    nreal = n0loc * N1 * 2 * N2c
+                    W0[:nreal].copy_(bufin.storage[:nreal])     # r2c preserves its input
+                    X = W0
+                if n0loc:
+                    be.rowfft(self.elsize, False, X, n0loc * N1, N2, N2c)
+                    be.colfft(self.elsize, False, X, n0loc, N1, N2c, scale=norm)
+                be.slab_pack(X, W1, n0loc, N1c, n2, e1, elb)
+                out = bufout.storage
+                comm.alltoall(W1[:nsend], out[:nrecv], send_splits, recv_splits)
+                if nb:
+                    be.colfft(self.elsize, False, out, 1, N0, nb)
+            else:
+                S = bufin.storage
+                if not same:
+                    ncplx = 2 * n1loc * N0 * n2
+                    W0[:ncplx].copy_(bufin.storage[:ncplx])     # c2r preserves its input
+                    S = W0
+                if nb:
+                    be.colfft(self.elsize, True, S, 1, N0, nb)
+                comm.alltoall(S[:nrecv], W1[:nsend], recv_splits, send_splits)
+                Y = bufout.storage
+                be.slab_pack(W1, Y, n0loc, N1c, n2, e1, elb, inverse=True)
+                if n0loc:
+                    be.colfft(self.elsize, True, Y, n0loc, N1, N2c)
+                    be.rowfft(self.elsize, True, Y, n0loc * N1, N2, N2c)
+            return
+
         if self.forward:
             # 1. local (nd-1)-D R2C over the n0loc planes: real (padded) -> W0 (n0loc, N1c, n2)
             def make1():

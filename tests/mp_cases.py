@@ -125,8 +125,12 @@ def case_paint_distributed_equals_serial(be, comm):
 def case_slab_fft(be, comm):
     """r2c / c2r on P ranks == numpy.fft on the gathered mesh, incl. uneven blocks"""
     from pmesh_amd.pm import ParticleMesh
-    for Nmesh, dtype, tol in (([8, 12, 10], 'f8', 1e-13), ([10, 6, 9], 'f8', 1e-13),
-                              ([9, 7], 'f8', 1e-13), ([16, 8, 8], 'f4', 5e-6)):
+    cases = [([8, 12, 10], 'f8', 1e-13), ([10, 6, 9], 'f8', 1e-13), ([9, 7], 'f8', 1e-13),
+             ([16, 8, 8], 'f4', 5e-6),
+             ([64, 64, 128], 'f8', 1e-13)]        # power-of-two: the LDS row/column kernels
+    if be.name == 'hip':
+        cases += [([64, 128, 128], 'f4', 5e-6), ([128, 64, 256], 'f8', 1e-13)]
+    for Nmesh, dtype, tol in cases:
         pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, comm=comm, dtype=dtype, np=[comm.size])
         data = numpy.random.RandomState(17).normal(size=Nmesh).astype(dtype)
         real = pm.create('real', value=data[pm.create('real').slices])
