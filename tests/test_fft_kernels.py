@@ -1,0 +1,71 @@
+"""The LDS-resident row / column FFT kernels (csrc/pmx_colfft.hip) on their own,
+against numpy.fft, for every length they are built for, both precisions, ragged
+batch sizes (tiles with fewer than W columns / rows), scaling and the fused transfer.
+Runs against the HIP library under -m gpu and against the numpy double otherwise
+(which then only checks the test itself and the host plumbing)."""
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from pmesh_amd import _abi
+
+
+def rel(a, b):
+    return numpy.sqrt((abs(a - b) ** 2).sum() / max((abs(b) ** 2).sum(), 1e-300))
+
+
+@pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
+@pytest.mark.parametrize('N', [64, 128, 256, 512, 1024])
+def test_colfft_lengths(be, elsize, tol, N):
+    if not be.colfft_supported(N, elsize):
+        pytest.skip('length not built for this precision')
+    cdt = 'c16' if elsize == 8 else 'c8'
+    rs = numpy.random.RandomState(N)
+    for A, B in ((1, 37), (3, 8), (2, 129)):
+        x = (rs.normal(size=(A, N, B)) + 1j * rs.normal(size=(A, N, B))).astype(cdt)
+        for inverse in (False, True):
+            t = torch.view_as_real(torch.from_numpy(x.copy())).reshape(-1).to(be.device)
+            be.colfft(elsize, inverse, t, A, N, B, scale=0.5)
+            got = t.cpu().numpy().view(cdt).reshape(A, N, B)
+            want = (numpy.fft.ifft(x.astype('c16'), axis=1) * N if inverse else numpy.fft.fft(x.astype('c16'), axis=1)) * 0.5
+            assert rel(got, want) < tol * numpy.log2(N), (N, A, B, inverse)
+
+
+@pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
+@pytest.mark.parametrize('n', [128, 256, 512, 1024])
+def test_rowfft_lengths(be, elsize, tol, n):
+    if not be.rowfft_supported(n, elsize):
+        pytest.skip('length not built for this precision')
+    rdt, cdt = ('f8', 'c16') if elsize == 8 else ('f4', 'c8')
+    rs = numpy.random.RandomState(n)
+    for nrows, pitch in ((5, n // 2 + 1), (19, n // 2 + 8)):
+        buf = numpy.zeros((nrows, 2 * pitch), dtype=rdt)
+        x = rs.normal(size=(nrows, n)).astype(rdt)
+        buf[:, :n] = x
+        t = torch.from_numpy(buf.copy()).reshape(-1).to(be.device)
+        be.rowfft(elsize, False, t, nrows, n, pitch, scale=2.0)
+        got = t.cpu().numpy().view(cdt).reshape(nrows, pitch)[:, :n // 2 + 1]
+        want = numpy.fft.rfft(x.astype('f8'), axis=1) * 2.0
+        assert rel(got, want) < tol * numpy.log2(n)
+        # and back (unnormalised: n * x)
+        be.rowfft(elsize, True, t, nrows, n, pitch, scale=1.0 / (2.0 * n))
+        back = t.cpu().numpy().reshape(nrows, 2 * pitch)[:, :n]
+        assert rel(back, x) < 2 * tol * numpy.log2(n)
+
+
+def test_colfft_fused_transfer(be, oracle):
+    """element (i0, i1, i2) * T(k) before the inverse axis-0 pass == apply_transfer + ifft"""
+    N0, n1, n2 = 64, 6, 9
+    nmesh = (N0, 12, 16)
+    box = (100.0, 50.0, 70.0)
+    start = (0, 3, 0)
+    rs = numpy.random.RandomState(5)
+    x = rs.normal(size=(N0, n1, n2)) + 1j * rs.normal(size=(N0, n1, n2))
+    for t in (oracle.make_transfer(laplace_pow=-1, grad_dir=1), oracle.make_transfer(amplitude=-2.0, laplace_pow=-1),
+              oracle.make_transfer(laplace_pow=1, grad_dir=0), oracle.make_transfer(grad_dir=2)):
+        want = numpy.fft.ifft(oracle.apply_transfer(t, x.copy(), start, nmesh, box), axis=0) * N0
+        d = torch.view_as_real(torch.from_numpy(x.copy())).reshape(-1).to(be.device)
+        be.colfft(8, True, d, 1, N0, n1 * n2, transfer=t, n1=n1, n2=n2, start=start, nmesh=nmesh, boxsize=box)
+        got = d.cpu().numpy().view('c16').reshape(N0, n1, n2)
+        assert rel(got, want) < 1e-14
