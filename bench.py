@@ -118,12 +118,15 @@ def cpu_baseline_run(args, cores):
         # jitter is +-0.4 cells: particles of lattice planes [a-S, b+S) can touch the slab
         lo, hi = a - S, b + S
         parts = []
-        if lo < 0:
+        if P == 1:
+            parts, lo, hi = [pos], 0, 0                      # the slab is the whole period: no ghosts
+        elif lo < 0:
             parts.append(pos[(lo % n) * n * n:])
             lo = 0
         top = min(hi, n)
-        parts.append(pos[lo * n * n:top * n * n])
-        if hi > n:
+        if P > 1:
+            parts.append(pos[lo * n * n:top * n * n])
+        if P > 1 and hi > n:
             parts.append(pos[:(hi - n) * n * n])
         for q in parts:
             if len(q):
