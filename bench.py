@@ -71,6 +71,10 @@ def parse():
 def cpu_baseline(args):
     """Time the reference path on ONE core and on ALL cores of the host and report the faster
     (some hosts — sandboxes, SMT siblings, cgroup quotas — do not scale with threads)."""
+    import copy
+    warm = copy.copy(args)
+    warm.cpu_sample_mesh = 32
+    cpu_baseline_run(warm, 1)                  # load libraries, touch the allocator
     one = cpu_baseline_run(args, 1)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     if cores <= 1:
