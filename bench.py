@@ -80,7 +80,17 @@ def cpu_baseline(args):
     if cores <= 1:
         return one
     try:
-        many = cpu_baseline_run(args, cores)
+        big = copy.copy(args)
+        # with many cores the bounded sample is the workload itself (mesh^3 particles):
+        # ~1 s of wall time, tens of core-seconds; it needs ~10 GB of host memory
+        try:
+            import psutil
+            mem_ok = psutil.virtual_memory().available > 24e9
+        except Exception:
+            mem_ok = False
+        if cores >= 16 and mem_ok:
+            big.cpu_sample_mesh = min(args.mesh, 512)
+        many = cpu_baseline_run(big, cores)
     except Exception as ex:
         one['sample'] += '; the %d-core run failed: %r' % (cores, ex)
         return one
