@@ -46,8 +46,8 @@ class SelfComm(object):
     def alltoall(self, send, recv):
         recv.copy_(send)
 
-    def split(self, color, key):
-        return self
+    def subgroups(self, rank_lists):
+        return [self for _ in rank_lists]
 
 
 class TorchComm(object):
@@ -122,6 +122,20 @@ class TorchComm(object):
         else:
             self._dist.all_to_all_single(recv, send, output_split_sizes=list(recv_splits),
                                          input_split_sizes=list(send_splits), group=self.group)
+
+
+def _torch_subgroups(self, rank_lists):
+    """one communicator per rank list (every rank creates every group, in the same order, as
+    torch.distributed requires); entries this rank is not a member of are None"""
+    out = []
+    for ranks in rank_lists:
+        granks = ranks if self.group is None else [self._dist.get_global_rank(self.group, r) for r in ranks]
+        g = self._dist.new_group(ranks=granks)
+        out.append(TorchComm(group=g) if self.rank in ranks else None)
+    return out
+
+
+TorchComm.subgroups = _torch_subgroups
 
 
 def default_comm():

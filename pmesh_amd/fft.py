@@ -61,6 +61,19 @@ class ProcMesh(object):
             raise ValueError('process mesh %s does not match the communicator size %d' % (self.np, comm.size))
         self.this = numpy.unravel_index(comm.rank, self.np) if len(self.np) else ()
         self.rank = comm.rank
+        self._sub = None
+
+    def subcomms(self):
+        """(row communicator: the P1 ranks sharing my p0, column communicator: the P0 ranks
+        sharing my p1) of a 2-d process mesh; created once, collectively."""
+        if self._sub is None:
+            P0, P1 = self.np
+            p0, p1 = [int(x) for x in self.this]
+            rows = [[q0 * P1 + q1 for q1 in range(P1)] for q0 in range(P0)]
+            cols = [[q0 * P1 + q1 for q0 in range(P0)] for q1 in range(P1)]
+            groups = self.comm.subgroups(rows + cols)
+            self._sub = (groups[p0], groups[P0 + p1])
+        return self._sub
 
 
 class Partition(object):
@@ -78,12 +91,18 @@ class Partition(object):
         if is_c2c:
             raise NotImplementedError('complex-to-complex meshes (dtype c8/c16) are outside the '
                                       'PM-cycle scope built so far')
-        if len(np_) > 1 and P > 1 and min(np_) > 1:
-            raise NotImplementedError('pencil decompositions (np=%s) are not built yet; use np=[%d]'
-                                      % (np_, P))
         if nd == 1 and P > 1:
             raise ValueError("Running 1d transforms on multiple ranks is not supported")
         self.nproc = P
+        self.pencil = len(np_) == 2 and P > 1 and min(np_) > 1
+        if self.pencil:
+            if nd != 3:
+                raise ValueError('a 2-d process mesh needs a 3-d mesh')
+            if not transposed:
+                # built lazily: only the transposed ("ComplexField") layout exists for pencils
+                self._unsupported = 'untransposed complex fields on a pencil decomposition'
+            self._init_pencil(np_, itemsize)
+            return
         r = procmesh.comm.rank
         Nc = self.Nmesh.copy()
         Nc[-1] = Nc[-1] // 2 + 1
@@ -136,6 +155,41 @@ class Partition(object):
             n0loc = int(self.local_i_shape[0])
             mid = n0loc * int(numpy.prod(Nc[1:], dtype='i8'))
             self.alloc_reals = max(self.alloc_reals, 2 * mid)
+
+
+def _pencil_init(self, np_, itemsize):
+    """2-d process mesh (P0, P1), rank = p0*P1 + p1 (C order).
+    real    : (N0/P0, N1/P1, N2)        axes 0, 1 distributed
+    complex : (N0, N1/P0, N2c/P1)       axes 1, 2 distributed ("transposed out", PFFT's layout
+              for 3-d r2c on a 2-d process mesh), local block in C order."""
+    P0, P1 = int(np_[0]), int(np_[1])
+    p0, p1 = [int(x) for x in self.procmesh.this]
+    N0, N1, N2 = [int(x) for x in self.Nmesh]
+    N2c = N2 // 2 + 1
+    self.P0, self.P1, self.p0, self.p1 = P0, P1, p0, p1
+    self.cshape_o = numpy.array([N0, N1, N2c], dtype='intp')
+    self.i_edges = [block_edges(N0, P0), block_edges(N1, P1), numpy.array([0, N2], dtype='intp')]
+    self.local_i_start = numpy.array([self.i_edges[0][p0], self.i_edges[1][p1], 0], dtype='intp')
+    self.local_i_shape = numpy.array([self.i_edges[0][p0 + 1] - self.i_edges[0][p0],
+                                      self.i_edges[1][p1 + 1] - self.i_edges[1][p1], N2], dtype='intp')
+    self.o_axis = None
+    self.o_edges = [numpy.array([0, N0], dtype='intp'), block_edges(N1, P0), block_edges(N2c, P1)]
+    self.local_o_start = numpy.array([0, self.o_edges[1][p0], self.o_edges[2][p1]], dtype='intp')
+    self.local_o_shape = numpy.array([N0, self.o_edges[1][p0 + 1] - self.o_edges[1][p0],
+                                      self.o_edges[2][p1 + 1] - self.o_edges[2][p1]], dtype='intp')
+    self.pitch_c = N2c
+    n0l, n1l = int(self.local_i_shape[0]), int(self.local_i_shape[1])
+    padded = [n0l, n1l, 2 * N2c]
+    self.i_strides = _c_strides(padded)
+    self.i_alloc = n0l * n1l * 2 * N2c
+    oshape = [int(x) for x in self.local_o_shape]
+    self.o_strides = _c_strides(oshape)
+    self.o_alloc = int(numpy.prod(oshape, dtype='i8'))
+    mid = n0l * N1 * oshape[2]                         # (n0loc, N1, n2cloc) between the transposes
+    self.alloc_reals = max(self.i_alloc, 2 * self.o_alloc, 2 * mid, 2)
+
+
+Partition._init_pencil = _pencil_init
 
 
 def _c_strides(shape):
@@ -201,7 +255,108 @@ class Plan(object):
         else:
             if transfer is not None:
                 raise NotImplementedError('fused transfer on several ranks')
-            self._execute_slab(bufin, bufout)
+            if getattr(p, 'pencil', False):
+                self._execute_pencil(bufin, bufout)
+            else:
+                self._execute_slab(bufin, bufout)
+
+    # ---- single stages on (A, N, B) / row arrays: own LDS kernels, rocFFT otherwise ----
+    def _row(self, be, buf, nrows, n, pitch, inverse):
+        """in-place r2c (inverse False) / c2r of nrows rows of n reals at `pitch` complex"""
+        if nrows == 0:
+            return
+        if COLFFT != 'never' and hasattr(be, 'rowfft') and be.rowfft_supported(n, self.elsize):
+            be.rowfft(self.elsize, inverse, buf, nrows, n, pitch)
+            return
+
+        def make():
+            if inverse:
+                return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, [n], [1], pitch, [1], 2 * pitch,
+                                     nrows, 1.0, True)
+            return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, [n], [1], 2 * pitch, [1], pitch,
+                                 nrows, 1.0, True)
+        be.fft_execute(self._native(('row', inverse, nrows, n, pitch), make), buf, buf)
+
+    def _col(self, be, buf, A, N, B, inverse, scale=1.0):
+        """in-place C2C along the middle axis of the (A, N, B) complex array in buf"""
+        if A == 0 or B == 0:
+            return
+        if COLFFT != 'never' and hasattr(be, 'colfft') and be.colfft_supported(N, self.elsize):
+            be.colfft(self.elsize, inverse, buf, A, N, B, scale=scale)
+            return
+        kind = _abi.PMX_FFT_C2C_BWD if inverse else _abi.PMX_FFT_C2C_FWD
+
+        def make():
+            return be.fft_create(kind, self.elsize, [N], [B], 1, [B], 1, B, scale, True)
+        plan = self._native(('col', inverse, N, B, scale), make)
+        for a in range(A):
+            sub = buf[2 * a * N * B:]
+            be.fft_execute(plan, sub, sub)
+
+    def _execute_pencil(self, bufin, bufout):
+        """Pencil-decomposed 3-d transform: two transposes, on the row and the column
+        sub-communicators of the (P0, P1) process mesh (PFFT's scheme for np=[P0, P1])."""
+        be = backend.get()
+        p = self.partition
+        if getattr(p, '_unsupported', None):
+            raise NotImplementedError(p._unsupported)
+        rowc, colc = p.procmesh.subcomms()
+        P0, P1 = p.P0, p.P1
+        N0, N1, N2 = [int(x) for x in p.Nmesh]
+        N2c = N2 // 2 + 1
+        n0l, n1l = int(p.local_i_shape[0]), int(p.local_i_shape[1])
+        m1, m2 = int(p.local_o_shape[1]), int(p.local_o_shape[2])      # complex local extents
+        e1i = [int(x) for x in p.i_edges[1]]      # axis 1 by P1 (real side)
+        e0i = [int(x) for x in p.i_edges[0]]      # axis 0 by P0
+        e1o = [int(x) for x in p.o_edges[1]]      # axis 1 by P0 (complex side)
+        e2o = [int(x) for x in p.o_edges[2]]      # axis 2 by P1
+        elb = 2 * self.elsize
+        norm = 1.0 / float(N0) / float(N1) / float(N2)
+        rdt = bufin.storage.dtype
+        need = max(2 * n0l * n1l * N2c, 2 * n0l * N1 * m2, 2 * N0 * m1 * m2, 2)
+        if self._work is None or self._work[0].numel() < need or self._work[0].dtype != rdt:
+            self._work = [torch.empty(need, dtype=rdt, device=bufin.storage.device) for _ in range(3)]
+        W0, W1, W2 = self._work
+        same = bufin.storage.data_ptr() == bufout.storage.data_ptr()
+        # transpose 1 (row group, P1 ranks): (n0l, n1l, N2c) <-> (n0l, N1, m2)
+        s1 = [2 * n0l * n1l * (e2o[q + 1] - e2o[q]) for q in range(P1)]
+        r1 = [2 * n0l * (e1i[q + 1] - e1i[q]) * m2 for q in range(P1)]
+        # transpose 2 (column group, P0 ranks): (n0l, N1, m2) <-> (N0, m1, m2)
+        s2 = [2 * n0l * (e1o[q + 1] - e1o[q]) * m2 for q in range(P0)]
+        r2 = [2 * (e0i[q + 1] - e0i[q]) * m1 * m2 for q in range(P0)]
+        if self.forward:
+            X = bufin.storage
+            if not same:
+                nreal = n0l * n1l * 2 * N2c
+                W0[:nreal].copy_(bufin.storage[:nreal])
+                X = W0
+            self._row(be, X, n0l * n1l, N2, N2c, False)
+            be.slab_pack(X, W1, n0l * n1l, N2c, 1, e2o, elb)                 # split the last axis
+            rowc.alltoall(W1[:sum(s1)], W2[:sum(r1)], s1, r1)
+            Y = X if X is W0 else W0
+            be.slab_pack(W2, Y, n0l, N1, m2, e1i, elb, inverse=True)        # blocks -> (n0l, N1, m2)
+            self._col(be, Y, n0l, N1, m2, False)
+            be.slab_pack(Y, W1, n0l, N1, m2, e1o, elb)                      # split axis 1 by P0
+            out = bufout.storage
+            colc.alltoall(W1[:sum(s2)], out[:sum(r2)], s2, r2)              # row ranges of (N0, m1, m2)
+            self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
+        else:
+            S = bufin.storage
+            if not same:
+                ncplx = 2 * N0 * m1 * m2
+                W0[:ncplx].copy_(bufin.storage[:ncplx])
+                S = W0
+            self._col(be, S, 1, N0, m1 * m2, True)
+            colc.alltoall(S[:sum(r2)], W1[:sum(s2)], r2, s2)
+            Y = W2
+            be.slab_pack(W1, Y, n0l, N1, m2, e1o, elb, inverse=True)
+            self._col(be, Y, n0l, N1, m2, True)
+            be.slab_pack(Y, W1, n0l, N1, m2, e1i, elb)
+            Z = S if S is W0 else W0
+            rowc.alltoall(W1[:sum(r1)], Z[:sum(s1)], r1, s1)
+            out = bufout.storage
+            be.slab_pack(Z, out, n0l * n1l, N2c, 1, e2o, elb, inverse=True)
+            self._row(be, out, n0l * n1l, N2, N2c, True)
 
     def can_fuse(self):
         """True if execute(..., transfer=) can fold a transfer function into the transform"""

@@ -753,7 +753,7 @@ class ParticleMesh(object):
             else:
                 np = []
         self.np = list(np)
-        self._use_padded = len(self.np) != len(Nmesh)
+        self._use_padded = True
         dtype = numpy.dtype(dtype)
         if dtype not in (numpy.dtype('f8'), numpy.dtype('f4')):
             if dtype in (numpy.dtype('complex128'), numpy.dtype('complex64')):

@@ -184,7 +184,56 @@ def case_cycle(be, comm):
     assert abs(f - want).max() <= 1e-11 * abs(out).max()
 
 
-CASES = [case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+def case_pencil(be, comm):
+    """pencil decomposition np=[P0, P1] (pm.py:1319-1325; config 5): r2c / c2r == numpy.fft on
+    the gathered mesh, even and uneven blocks, and the whole cycle == the serial oracle"""
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    from oracle import oracle as O
+    shapes = {4: [2, 2], 6: [2, 3], 8: [2, 4]}
+    if comm.size not in shapes:
+        return
+    np_ = shapes[comm.size]
+    cases = [([8, 12, 10], 'f8', 1e-13), ([10, 9, 14], 'f8', 1e-13), ([64, 64, 128], 'f8', 1e-13)]
+    if be.name == 'hip':
+        cases += [([128, 64, 128], 'f4', 5e-6)]
+    for Nmesh, dtype, tol in cases:
+        pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, comm=comm, dtype=dtype, np=np_)
+        data = numpy.random.RandomState(23).normal(size=Nmesh).astype(dtype)
+        real = pm.create('real', value=data[pm.create('real').slices])
+        ck = real.r2c()
+        Nc = list(Nmesh[:-1]) + [Nmesh[-1] // 2 + 1]
+        assert tuple(ck.cshape) == tuple(Nc)
+        full = gather_field(comm, ck, Nc)
+        ref = numpy.fft.rfftn(data.astype('f8')) / numpy.prod(Nmesh)
+        err = numpy.sqrt((abs(full - ref) ** 2).sum() / (abs(ref) ** 2).sum())
+        assert err < tol, (Nmesh, err)
+        assert_array_equal(numpy.asarray(real), data[real.slices])
+        back = ck.c2r()
+        loc = data[back.slices]
+        assert numpy.sqrt(((numpy.asarray(back) - loc) ** 2).sum() / max((loc ** 2).sum(), 1e-300)) < 4 * tol
+        ck2 = real.r2c(out=Ellipsis)
+        full2 = gather_field(comm, ck2, Nc)
+        assert numpy.sqrt((abs(full2 - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < tol
+        back2 = ck2.c2r(out=Ellipsis)
+        loc = data[back2.slices]
+        assert numpy.sqrt(((numpy.asarray(back2) - loc) ** 2).sum() / max((loc ** 2).sum(), 1e-300)) < 4 * tol
+    # the cycle on pencils
+    N, L = 16, 1000.0
+    allpos = O.synth_uniform(N, L)
+    share = numpy.array_split(numpy.arange(len(allpos)), comm.size)[comm.rank]
+    pos = allpos[share]
+    pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler='tsc', np=np_)
+    layout = pm.decompose(pos)
+    rho = pm.paint(pos, layout=layout)
+    assert abs(rho.csum() - N ** 3) < 1e-8
+    f = rho.r2c(out=Ellipsis).apply(Transfer.dx1(1), out=Ellipsis).c2r(out=Ellipsis).readout(pos, layout=layout)
+    t = O.make_transfer(laplace_pow=-1, grad_dir=1, grad_kind=0)
+    real, ck, back, out = O.pm_cycle(N, L, allpos, kind='tunedtsc', transfer=t)
+    assert abs(f - out[share]).max() <= 1e-11 * abs(out).max()
+
+
+CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_slab_fft, case_cycle]
 
 

@@ -81,6 +81,25 @@ class ThreadComm(object):
         self.shared.barrier.wait()
 
 
+def _thread_subgroups(self, rank_lists):
+    """sub-communicators over subsets of the thread ranks (shared state created by rank 0)"""
+    key = tuple(tuple(r) for r in rank_lists)
+    sh = self.shared
+    if self.rank == 0:
+        with sh.lock:
+            if not hasattr(sh, 'subs'):
+                sh.subs = {}
+            sh.subs[key] = [_Shared(len(r)) for r in rank_lists]
+    sh.barrier.wait()
+    subs = sh.subs[key]
+    sh.barrier.wait()
+    return [ThreadComm(subs[i], r.index(self.rank)) if self.rank in r else None
+            for i, r in enumerate(rank_lists)]
+
+
+ThreadComm.subgroups = _thread_subgroups
+
+
 def run_ranks(size, fn):
     """run fn(comm) on `size` threads; re-raises the first failure"""
     shared = _Shared(size)
