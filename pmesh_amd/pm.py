@@ -736,8 +736,7 @@ class ParticleMesh(object):
             resampler : string or ResampleWindow, the default window
             np : the process mesh; None -> slab decomposition [comm.size] of the first axis
                 (the reference defaults 3-d meshes to a pencil pfft.split_size_2d(size),
-                pm.py:1319-1325; the pencil FFT is not built yet and every consumer is
-                partition agnostic)
+                pm.py:1319-1325; pass np=[P0, P1] for a pencil decomposition)
             Nmesh : tuple or alike; len(Nmesh) is the dimension of the system.
         """
         if comm is None:
