@@ -87,11 +87,11 @@ struct pmx_binplan {
     bool built = false;
     // device arrays
     int32_t *tid = nullptr;     // tile id per particle (-1 = touches no local cell)
-    uint32_t *slot = nullptr;   // rank of the particle inside its tile
     uint32_t *list = nullptr;   // particle indices, tile major
     size_t cap_part = 0;
     uint32_t *counts = nullptr; // particles per tile
     int64_t *offsets = nullptr; // exclusive prefix (ntiles + 1)
+    unsigned long long *cursor = nullptr;   // next free slot per tile while scattering
     size_t cap_tiles = 0;
     uint32_t *flags = nullptr;  // [0] != 0: some particle is in no tile
     void *halo = nullptr;       // staging of the halo cells: ntiles * Region<S>::HALO elements
@@ -147,8 +147,7 @@ __device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, 
 // its 256 rows with 16-byte-per-lane loads into LDS and every lane picks its row there.
 template <int KIND, bool DENSE>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
-                                                           int32_t *tid, uint32_t *slot, uint32_t *counts,
-                                                           uint32_t *flags)
+                                                           int32_t *tid, uint32_t *counts, uint32_t *flags)
 {
     constexpr int S = Tuned<KIND>::S;
     constexpr int U = 4;    // particle chunks per trip: U independent load -> atomic chains per wave
@@ -222,31 +221,24 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
             }
         }
         // ONE atomicAdd instruction per chunk for the whole wave (the first lane of every
-        // group adds the group's population); the U atomics are in flight together
-        uint32_t b[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            b[u] = 0;
-            const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
-            if (t[u] >= 0 && lane == leader) b[u] = atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
-        }
+        // group adds the group's population): no return value is needed here, the slots are
+        // handed out by bin_scatter_kernel
 #pragma unroll
         for (int u = 0; u < U; u++) {
             int64_t i = base + u * TBLOCK + threadIdx.x;
             const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
-            uint32_t bb = __shfl(b[u], leader);
-            uint32_t myslot = bb + (uint32_t)__popcll(same[u] & (((unsigned long long)1 << lane) - 1));
+            if (t[u] >= 0 && lane == leader) atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
             if (i < n) {
                 if (t[u] < 0) atomicOr(&flags[0], 1u);
                 tid[i] = t[u];
-                slot[i] = myslot;
             }
         }
     }
 }
 
 // exclusive scan of counts -> offsets[ntiles+1]; one workgroup
-__global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets)
+__global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
+                                                        unsigned long long *cursor)
 {
     __shared__ int64_t sh[1024];
     __shared__ int64_t carry;
@@ -264,7 +256,10 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, 
             __syncthreads();
         }
         int64_t incl = sh[threadIdx.x];
-        if (i < ntiles) offsets[i] = carry + incl - v;
+        if (i < ntiles) {
+            offsets[i] = carry + incl - v;
+            cursor[i] = (unsigned long long)(carry + incl - v);
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry += incl;
         __syncthreads();
@@ -272,12 +267,42 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, 
     if (threadIdx.x == 0) offsets[ntiles] = carry;
 }
 
-__global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, const uint32_t *slot,
-                                                             const int64_t *offsets, int64_t n, uint32_t *list)
+__global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
+                                                             uint32_t *list)
 {
-    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * TBLOCK) {
-        int t = tid[i];
-        if (t >= 0) list[offsets[t] + slot[i]] = (uint32_t)i;
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = blockIdx.x * (int64_t)(TBLOCK * U); base < n; base += (int64_t)gridDim.x * TBLOCK * U) {
+        int t[U];
+        unsigned long long same[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + u * TBLOCK + threadIdx.x;
+            t[u] = i < n ? tid[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            same[u] = 0;
+            unsigned long long active = __ballot(t[u] >= 0);
+            while (active) {
+                int leader = __ffsll((long long)active) - 1;
+                int lt = __shfl(t[u], leader);
+                unsigned long long m = __ballot(t[u] == lt) & active;
+                if (t[u] == lt) same[u] = m;
+                active &= ~m;
+            }
+            b[u] = 0;
+            const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+            if (t[u] >= 0 && lane == leader) b[u] = atomicAdd(&cursor[t[u]], (unsigned long long)__popcll(same[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + u * TBLOCK + threadIdx.x;
+            const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+            unsigned long long bb = __shfl(b[u], leader);
+            if (t[u] >= 0)
+                list[bb + (unsigned long long)__popcll(same[u] & (((unsigned long long)1 << lane) - 1))] = (uint32_t)i;
+        }
     }
 }
 
@@ -553,10 +578,10 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
 {
     if (!pl) return PMX_OK;
     if (pl->tid) (void)hipFree(pl->tid);
-    if (pl->slot) (void)hipFree(pl->slot);
     if (pl->list) (void)hipFree(pl->list);
     if (pl->counts) (void)hipFree(pl->counts);
     if (pl->offsets) (void)hipFree(pl->offsets);
+    if (pl->cursor) (void)hipFree(pl->cursor);
     if (pl->flags) (void)hipFree(pl->flags);
     if (pl->halo) (void)hipFree(pl->halo);
     delete pl;
@@ -619,23 +644,23 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     pl->built = false;
     size_t np1 = (size_t)(npart > 0 ? npart : 1);
     if (np1 * 4 > pl->cap_part) {
-        size_t c1 = 0, c2 = 0, c3 = 0;
+        size_t c1 = 0, c3 = 0;
         if (pl->tid) (void)hipFree(pl->tid);
-        if (pl->slot) (void)hipFree(pl->slot);
         if (pl->list) (void)hipFree(pl->list);
-        pl->tid = nullptr; pl->slot = nullptr; pl->list = nullptr; pl->cap_part = 0;
+        pl->tid = nullptr; pl->list = nullptr; pl->cap_part = 0;
         rc = ensure((void **)&pl->tid, &c1, np1 * 4); if (rc) return rc;
-        rc = ensure((void **)&pl->slot, &c2, np1 * 4); if (rc) return rc;
         rc = ensure((void **)&pl->list, &c3, np1 * 4); if (rc) return rc;
         pl->cap_part = np1 * 4;
     }
     if ((size_t)(g.ntiles + 1) > pl->cap_tiles) {
-        size_t c1 = 0, c2 = 0;
+        size_t c1 = 0, c2 = 0, c3 = 0;
         if (pl->counts) (void)hipFree(pl->counts);
         if (pl->offsets) (void)hipFree(pl->offsets);
-        pl->counts = nullptr; pl->offsets = nullptr; pl->cap_tiles = 0;
+        if (pl->cursor) (void)hipFree(pl->cursor);
+        pl->counts = nullptr; pl->offsets = nullptr; pl->cursor = nullptr; pl->cap_tiles = 0;
         rc = ensure((void **)&pl->counts, &c1, (size_t)(g.ntiles + 1) * 4); if (rc) return rc;
         rc = ensure((void **)&pl->offsets, &c2, (size_t)(g.ntiles + 1) * 8); if (rc) return rc;
+        rc = ensure((void **)&pl->cursor, &c3, (size_t)(g.ntiles + 1) * 8); if (rc) return rc;
         pl->cap_tiles = (size_t)(g.ntiles + 1);
     }
     if (!pl->flags) PMX_HIP_CHECK(hipMalloc((void **)&pl->flags, 16));
@@ -649,8 +674,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                            (((uintptr_t)pos->data) & 15) == 0;
 #define BC(K)                                                                                                   \
     do {                                                                                                        \
-        if (dense) bin_count_kernel<K, true><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags); \
-        else bin_count_kernel<K, false><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->slot, pl->counts, pl->flags);      \
+        if (dense) bin_count_kernel<K, true><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, pl->flags); \
+        else bin_count_kernel<K, false><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, pl->flags);      \
     } while (0)
         switch (p.kind) {
         case PMX_TUNED_NNB: BC(PMX_TUNED_NNB); break;
@@ -660,9 +685,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         }
 #undef BC
     }
-    bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles, pl->offsets);
+    bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles, pl->offsets, pl->cursor);
     if (npart > 0)
-        bin_scatter_kernel<<<grid_for(npart, TBLOCK), TBLOCK, 0, st>>>(pl->tid, pl->slot, pl->offsets, npart, pl->list);
+        bin_scatter_kernel<<<grid_for((npart + 3) / 4, TBLOCK), TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list);
     PMX_HIP_CHECK(hipGetLastError());
     pl->built = true;
     return PMX_OK;
