@@ -20,6 +20,7 @@
 // ComplexField.apply into the first pass of c2r.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -111,9 +112,14 @@ struct ColGeom {
 // row number, so that the row sets a wave touches in every Stockham pass (consecutive rows
 // when reading, rows 8 or 64 apart when writing) always split evenly over the two halves:
 // all passes are bank-conflict free without padding.
-template <typename T> __device__ __forceinline__ int lds_index(int row, int col)
+template <typename T, int RB = 128> __device__ __forceinline__ int lds_index(int row, int col)
 {
-    constexpr int W = 128 / (int)sizeof(cpx<T>);
+    constexpr int W = RB / (int)sizeof(cpx<T>);
+    if (RB == 256) {
+        // a tile row is a whole bank row: any set of rows is conflict free; the column slot is
+        // still rotated by the row number for the transposing accesses
+        return row * W + ((col + row) & (W - 1));
+    }
     int half = (row ^ (row >> 3) ^ (row >> 6) ^ (row >> 9)) & 1;
     // the column slot is rotated by the row number: a wave that walks along a column
     // (the transposing load/store of the row kernel) then also spreads over all banks
@@ -123,7 +129,7 @@ template <typename T> __device__ __forceinline__ int lds_index(int row, int col)
 // One pass of the Stockham autosort FFT over the LDS-resident tile.  Lane mapping: the W
 // columns of a row are W consecutive lanes (col fastest), so a wave works on 64/W
 // butterflies of all W columns at once.
-template <typename T, bool INV, int R>
+template <typename T, bool INV, int R, int RB = 128>
 __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int N, int Ns, int tpc /*threads per column*/,
                                               int col, int tj, int twstride = 1)
 {
@@ -138,7 +144,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
         int k = j % Ns;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            cpx<T> x = buf[lds_index<T>(j + r * nb, col)];
+            cpx<T> x = buf[lds_index<T, RB>(j + r * nb, col)];
             if (r > 0 && Ns > 1) {
                 // twiddle exp(-+ 2 pi i r k / (Ns R)) from the length-N table
                 int m = r * k * (N / (Ns * R));
@@ -158,7 +164,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
         int k = j % Ns;
         int base = (j - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; r++) buf[lds_index<T>(base + r * Ns, col)] = v[q][r];
+        for (int r = 0; r < R; r++) buf[lds_index<T, RB>(base + r * Ns, col)] = v[q][r];
     }
     __syncthreads();
 }
@@ -215,12 +221,12 @@ template <> struct Radices<9>  { static constexpr int n = 3; static constexpr in
 template <> struct Radices<10> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
 template <> struct Radices<11> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
 
-template <typename T, int LOGN, bool INV, bool APPLY>
-__global__ void __launch_bounds__((1 << LOGN) / 8 * (128 / (int)sizeof(cpx<T>)))
+template <typename T, int LOGN, bool INV, bool APPLY, int RB>
+__global__ void __launch_bounds__((1 << LOGN) / 8 * (RB / (int)sizeof(cpx<T>)))
 colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 {
     constexpr int N = 1 << LOGN;
-    constexpr int W = 128 / (int)sizeof(cpx<T>);   // columns per tile: 128-byte rows
+    constexpr int W = RB / (int)sizeof(cpx<T>);    // columns per tile: RB-byte row segments
     constexpr int TPC = N / 8;                     // threads per column
     constexpr int NT = TPC * W;                    // threads per workgroup
     extern __shared__ __align__(16) unsigned char smem[];
@@ -251,27 +257,27 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
             int n = tj + u * TPC;
             cpx<T> v = ld[u];
             if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
-            buf[lds_index<T>(n, col)] = v;
+            buf[lds_index<T, RB>(n, col)] = v;
         }
         __syncthreads();
         int Ns = 1;
         using Rd = Radices<LOGN>;
         // passes (compile-time radices)
-        if (Rd::r[0] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
+        if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
         Ns *= Rd::r[0];
         if (Rd::n > 1) {
-            if (Rd::r[1] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
-            if (Rd::r[2] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
-            if (Rd::r[3] == 8) stockham_pass<T, INV, 8>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[3];
         }
         // store
@@ -280,7 +286,7 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         for (int u = 0; u < 8; u++) {
             int n = tj + u * TPC;
             if (colok) {
-                cpx<T> v = buf[lds_index<T>(n, col)];
+                cpx<T> v = buf[lds_index<T, RB>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
                 base[(int64_t)n * g.B + col] = v;
@@ -436,18 +442,18 @@ static int get_twiddles(int N, int es, void **out, hipStream_t st)
     return PMX_OK;
 }
 
-template <typename T, int LOGN>
+template <typename T, int LOGN, int RB>
 static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
 {
     constexpr int N = 1 << LOGN;
-    constexpr int W = 128 / (int)sizeof(cpx<T>);
+    constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = N / 8 * W;
     size_t lds = (size_t)(N * W + N) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
-        auto k = colfft_kernel<T, LOGN, INV, AP>;                                                              \
+        auto k = colfft_kernel<T, LOGN, INV, AP, RB>;                                                          \
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         k<<<grid, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                                       \
     } while (0)
@@ -458,15 +464,27 @@ static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inve
     return PMX_OK;
 }
 
+// wide = 256-byte row segments (one workgroup per CU at N = 512 in double): used for the
+// axis-0 pass, whose rows are a whole plane apart (fewer, longer DRAM bursts)
 template <typename T>
-static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
+static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, bool wide,
+                         hipStream_t st)
 {
+    constexpr bool can_wide = sizeof(T) == 8;
+    if (wide && can_wide) {
+        switch (g.logN) {
+        case 6: return launch_colfft<T, 6, 256>(g, data, tw, inverse, apply, st);
+        case 7: return launch_colfft<T, 7, 256>(g, data, tw, inverse, apply, st);
+        case 8: return launch_colfft<T, 8, 256>(g, data, tw, inverse, apply, st);
+        case 9: return launch_colfft<T, 9, 256>(g, data, tw, inverse, apply, st);
+        }
+    }
     switch (g.logN) {
-    case 6: return launch_colfft<T, 6>(g, data, tw, inverse, apply, st);
-    case 7: return launch_colfft<T, 7>(g, data, tw, inverse, apply, st);
-    case 8: return launch_colfft<T, 8>(g, data, tw, inverse, apply, st);
-    case 9: return launch_colfft<T, 9>(g, data, tw, inverse, apply, st);
-    case 10: return launch_colfft<T, 10>(g, data, tw, inverse, apply, st);
+    case 6: return launch_colfft<T, 6, 128>(g, data, tw, inverse, apply, st);
+    case 7: return launch_colfft<T, 7, 128>(g, data, tw, inverse, apply, st);
+    case 8: return launch_colfft<T, 8, 128>(g, data, tw, inverse, apply, st);
+    case 9: return launch_colfft<T, 9, 128>(g, data, tw, inverse, apply, st);
+    case 10: return launch_colfft<T, 10, 128>(g, data, tw, inverse, apply, st);
     }
     set_error("pmx_colfft: length 2^%d is not built", g.logN);
     return PMX_EUNSUPPORTED;
@@ -586,8 +604,9 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     void *tw = nullptr;
     rc = get_twiddles((int)N, elsize, &tw, st);
     if (rc) return rc;
-    if (elsize == 8) return dispatch_logn<double>(g, data, tw, inverse != 0, apply, st);
+    const bool wide = getenv("PMX_COLFFT_WIDE") ? atoi(getenv("PMX_COLFFT_WIDE")) != 0 : false;
+    if (elsize == 8) return dispatch_logn<double>(g, data, tw, inverse != 0, apply, wide && A == 1, st);
     // float: 16 columns x 8 B = 128-byte rows; 1024 threads at N = 512, so N <= 512 only
     PMX_REQUIRE(N <= 512, PMX_EUNSUPPORTED, "single precision column FFT is built up to length 512");
-    return dispatch_logn<float>(g, data, tw, inverse != 0, apply, st);
+    return dispatch_logn<float>(g, data, tw, inverse != 0, apply, false, st);
 }
