@@ -214,20 +214,19 @@ int pmx_rowfft_supported(int64_t n, int32_t elsize);
 int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
                double scale, void *stream);
 
-/* Local transposes either side of the slab all-to-all (PFFT's global transpose).
- * pack:   src (n0, n1, n2) C order -> P contiguous blocks, block r = (n0, n1 range of r, n2)
- * unpack: P blocks, block s = (n0 range of s, n1loc, n2) -> dst (n1loc, n0tot, n2) C order
- * Elements are `elbytes` wide (8 = complex64, 16 = complex128). */
+/* Local transpose next to the all-to-all of a distributed FFT (PFFT's global transpose).
+ * pmx_slab_pack  : src (n0, n1, n2) C order -> nparts contiguous blocks, block r = (n0,
+ *                  n1 range [n1_offsets[r], n1_offsets[r+1]), n2): the send buffer of an
+ *                  all-to-all that redistributes axis 1.
+ * pmx_slab_unpack: the inverse (blocks -> (n0, n1, n2)): what the reverse all-to-all delivers.
+ * The blocks an all-to-all delivers for axis 0 are row ranges of the destination array
+ * and need no kernel.  Elements are `elbytes` wide (8 = complex64, 16 = complex128). */
 int pmx_slab_pack(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
-                  const int64_t *n1_offsets /* host, P+1 */, int32_t nparts, int32_t elbytes,
+                  const int64_t *n1_offsets /* host, nparts+1 */, int32_t nparts, int32_t elbytes,
                   void *stream);
-int pmx_slab_unpack(const void *src, void *dst, const int64_t *n0_offsets /* host, P+1 */,
-                    int32_t nparts, int64_t n1loc, int64_t n2, int32_t elbytes, void *stream);
-/* inverse pair used by c2r */
-int pmx_slab_pack_t(const void *src, void *dst, const int64_t *n0_offsets, int32_t nparts,
-                    int64_t n1loc, int64_t n2, int32_t elbytes, void *stream);
-int pmx_slab_unpack_t(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
-                      const int64_t *n1_offsets, int32_t nparts, int32_t elbytes, void *stream);
+int pmx_slab_unpack(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
+                    const int64_t *n1_offsets /* host, nparts+1 */, int32_t nparts, int32_t elbytes,
+                    void *stream);
 
 /* ---- apply-transfer (Field.apply, pm.py:617-648, with the transfer functions
  * of examples/nbody.py:154-181 and pmesh/transfer.py fused) ---------------- */

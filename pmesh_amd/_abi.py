@@ -96,9 +96,7 @@ DEVICE_ONLY = {
     'rowfft_supported': (C.c_int, [_i64, _i32]),
     'rowfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _vp]),
     'slab_pack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
-    'slab_unpack': (C.c_int, [_vp, _vp, _P(_i64), _i32, _i64, _i64, _i32, _vp]),
-    'slab_pack_t': (C.c_int, [_vp, _vp, _P(_i64), _i32, _i64, _i64, _i32, _vp]),
-    'slab_unpack_t': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
+    'slab_unpack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
 }
 
 

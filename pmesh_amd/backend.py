@@ -109,14 +109,9 @@ class HipBackend(object):
 
     # -- slab transposes --------------------------------------------------
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
-        name = 'slab_unpack_t' if inverse else 'slab_pack'
-        self.call(name, src.data_ptr(), dst.data_ptr(), n0, n1, n2, _abi.i64arr(n1_offsets),
-                  len(n1_offsets) - 1, elbytes, self.stream())
-
-    def slab_unpack(self, src, dst, n0_offsets, n1loc, n2, elbytes, inverse=False):
-        name = 'slab_pack_t' if inverse else 'slab_unpack'
-        self.call(name, src.data_ptr(), dst.data_ptr(), _abi.i64arr(n0_offsets),
-                  len(n0_offsets) - 1, n1loc, n2, elbytes, self.stream())
+        """(n0, n1, n2) -> blocks by n1 range (inverse: blocks -> (n0, n1, n2))"""
+        self.call('slab_unpack' if inverse else 'slab_pack', src.data_ptr(), dst.data_ptr(), n0, n1, n2,
+                  _abi.i64arr(n1_offsets), len(n1_offsets) - 1, elbytes, self.stream())
 
 
 _current = None

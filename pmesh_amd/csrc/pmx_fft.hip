@@ -7,7 +7,7 @@
 // forward normalisation 1/prod(Nmesh) of pm.py:692 folded into the plan's
 // scale factor so no separate pass over the mesh is needed) and the global
 // transpose is an RCCL all-to-all issued by the host layer between
-// pmx_slab_pack and pmx_slab_unpack.
+// pmx_slab_pack (before) / pmx_slab_unpack (after the reverse exchange).
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
@@ -145,26 +145,6 @@ __global__ void __launch_bounds__(256) slab_pack_kernel(const E *src, E *dst, in
     }
 }
 
-// blocks s = (n0[s]..n0[s+1], n1loc, n2) concatenated -> dst (n1loc, n0tot, n2)
-template <typename E>
-__global__ void __launch_bounds__(256) slab_unpack_kernel(const E *src, E *dst, Offs o, int64_t n1loc,
-                                                          int64_t n2, bool inverse)
-{
-    const int64_t n0tot = o.v[o.n];
-    const int64_t total = n0tot * n1loc * n2;
-    // iterate in dst order (j, i, k) so that writes coalesce
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
-         q += (int64_t)gridDim.x * blockDim.x) {
-        int64_t k = q % n2, r = q / n2;
-        int64_t i = r % n0tot, j = r / n0tot;
-        int part = 0;
-        while (i >= o.v[part + 1]) part++;
-        int64_t p = o.v[part] * n1loc * n2 + ((i - o.v[part]) * n1loc + j) * n2 + k;
-        if (!inverse) dst[q] = src[p];
-        else dst[p] = src[q];
-    }
-}
-
 struct alignas(8) E8 { float a, b; };
 struct alignas(16) E16 { double a, b; };
 
@@ -198,45 +178,14 @@ static int slab_pack_impl(const void *src, void *dst, int64_t n0, int64_t n1, in
     return PMX_OK;
 }
 
-static int slab_unpack_impl(const void *src, void *dst, const int64_t *n0_offsets, int32_t nparts,
-                            int64_t n1loc, int64_t n2, int32_t elbytes, void *stream, bool inverse)
-{
-    PMX_REQUIRE(elbytes == 8 || elbytes == 16, PMX_EINVAL, "elbytes must be 8 or 16");
-    Offs o;
-    int rc = load_offs(o, n0_offsets, nparts);
-    if (rc) return rc;
-    int64_t total = o.v[nparts] * n1loc * n2;
-    if (total == 0) return PMX_OK;
-    hipStream_t st = (hipStream_t)stream;
-    if (elbytes == 16)
-        slab_unpack_kernel<E16><<<grid_for(total, 256), 256, 0, st>>>((const E16 *)src, (E16 *)dst, o, n1loc, n2, inverse);
-    else
-        slab_unpack_kernel<E8><<<grid_for(total, 256), 256, 0, st>>>((const E8 *)src, (E8 *)dst, o, n1loc, n2, inverse);
-    PMX_HIP_CHECK(hipGetLastError());
-    return PMX_OK;
-}
-
 extern "C" int pmx_slab_pack(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
                              const int64_t *n1_offsets, int32_t nparts, int32_t elbytes, void *stream)
 {
     return slab_pack_impl(src, dst, n0, n1, n2, n1_offsets, nparts, elbytes, stream, false);
 }
 
-extern "C" int pmx_slab_unpack(const void *src, void *dst, const int64_t *n0_offsets,
-                               int32_t nparts, int64_t n1loc, int64_t n2, int32_t elbytes, void *stream)
-{
-    return slab_unpack_impl(src, dst, n0_offsets, nparts, n1loc, n2, elbytes, stream, false);
-}
-
-// c2r direction: dst (n1loc, n0tot, n2) -> blocks, then blocks -> (n0, n1, n2)
-extern "C" int pmx_slab_pack_t(const void *src, void *dst, const int64_t *n0_offsets,
-                               int32_t nparts, int64_t n1loc, int64_t n2, int32_t elbytes, void *stream)
-{
-    return slab_unpack_impl(src, dst, n0_offsets, nparts, n1loc, n2, elbytes, stream, true);
-}
-
-extern "C" int pmx_slab_unpack_t(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
-                                 const int64_t *n1_offsets, int32_t nparts, int32_t elbytes, void *stream)
+extern "C" int pmx_slab_unpack(const void *src, void *dst, int64_t n0, int64_t n1, int64_t n2,
+                               const int64_t *n1_offsets, int32_t nparts, int32_t elbytes, void *stream)
 {
     return slab_pack_impl(src, dst, n0, n1, n2, n1_offsets, nparts, elbytes, stream, true);
 }

@@ -137,19 +137,6 @@ class OracleBackend(object):
             else:
                 blk[...] = full[:, a:b, :]
 
-    def slab_unpack(self, src, dst, n0_offsets, n1loc, n2, elbytes, inverse=False):
-        cdt = 'c8' if elbytes == 8 else 'c16'
-        n0tot = int(n0_offsets[-1])
-        full = (src if inverse else dst).detach().numpy().reshape(-1).view(cdt)[:n0tot * n1loc * n2].reshape(n1loc, n0tot, n2)
-        blocks = (dst if inverse else src).detach().numpy().reshape(-1).view(cdt)
-        for s in range(len(n0_offsets) - 1):
-            a, b = int(n0_offsets[s]), int(n0_offsets[s + 1])
-            blk = blocks[a * n1loc * n2:b * n1loc * n2].reshape(b - a, n1loc, n2)
-            if inverse:
-                blk[...] = full[:, a:b, :].transpose(1, 0, 2)
-            else:
-                full[:, a:b, :] = blk.transpose(1, 0, 2)
-
 
 def install():
     return backend.use(OracleBackend())
