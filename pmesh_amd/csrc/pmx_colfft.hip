@@ -464,21 +464,12 @@ static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inve
     return PMX_OK;
 }
 
-// wide = 256-byte row segments (one workgroup per CU at N = 512 in double): used for the
-// axis-0 pass, whose rows are a whole plane apart (fewer, longer DRAM bursts)
+// (A 256-byte-row variant, RB = 256 with one workgroup per CU, was measured for the axis-0
+// pass, whose rows are a whole plane apart: no gain at 512^3 — 1.42 vs 1.44 ms forward, and
+// the fused-transfer pass got slower — so only the 128-byte tiles are instantiated.)
 template <typename T>
-static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, bool wide,
-                         hipStream_t st)
+static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
 {
-    constexpr bool can_wide = sizeof(T) == 8;
-    if (wide && can_wide) {
-        switch (g.logN) {
-        case 6: return launch_colfft<T, 6, 256>(g, data, tw, inverse, apply, st);
-        case 7: return launch_colfft<T, 7, 256>(g, data, tw, inverse, apply, st);
-        case 8: return launch_colfft<T, 8, 256>(g, data, tw, inverse, apply, st);
-        case 9: return launch_colfft<T, 9, 256>(g, data, tw, inverse, apply, st);
-        }
-    }
     switch (g.logN) {
     case 6: return launch_colfft<T, 6, 128>(g, data, tw, inverse, apply, st);
     case 7: return launch_colfft<T, 7, 128>(g, data, tw, inverse, apply, st);
@@ -604,9 +595,8 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     void *tw = nullptr;
     rc = get_twiddles((int)N, elsize, &tw, st);
     if (rc) return rc;
-    const bool wide = getenv("PMX_COLFFT_WIDE") ? atoi(getenv("PMX_COLFFT_WIDE")) != 0 : false;
-    if (elsize == 8) return dispatch_logn<double>(g, data, tw, inverse != 0, apply, wide && A == 1, st);
+    if (elsize == 8) return dispatch_logn<double>(g, data, tw, inverse != 0, apply, st);
     // float: 16 columns x 8 B = 128-byte rows; 1024 threads at N = 512, so N <= 512 only
     PMX_REQUIRE(N <= 512, PMX_EUNSUPPORTED, "single precision column FFT is built up to length 512");
-    return dispatch_logn<float>(g, data, tw, inverse != 0, apply, false, st);
+    return dispatch_logn<float>(g, data, tw, inverse != 0, apply, st);
 }

@@ -423,6 +423,20 @@ class RealField(Field):
         plan.execute(self._base, out._base)
         return out
 
+    def ctranspose(self, axes):
+        """ Collectively transpose a RealField: the coordinates are replaced according to the
+            new set of axes (pm.py:696-723; as in the reference, through a nearest-neighbour
+            readout and paint of one particle per mesh point). """
+        assert len(numpy.unique(axes)) == self.ndim
+        assert numpy.max(axes) == self.ndim - 1
+        axes = numpy.array(axes, dtype='intp')
+        pm = self.pm.reshape(BoxSize=self.BoxSize[axes], Nmesh=self.Nmesh[axes])
+        q = self.pm.generate_uniform_particle_grid(shift=0)
+        v = self.readout(q, resampler='nnb')
+        q = q[..., torch.as_tensor(axes, device=q.device)].contiguous()
+        layout = pm.decompose(q, smoothing='nnb')
+        return pm.paint(q, mass=v, resampler='nnb', layout=layout)
+
     def csum(self, dtype=None):
         """ Collective sum of the entire mesh (pm.py:725-739). """
         s = self.value.sum(dtype=torch_dtype(dtype) if dtype is not None else None)
@@ -1000,6 +1014,45 @@ class ParticleMesh(object):
             else:
                 out_mass[...] = r
         return out_pos, out_mass
+
+
+def _pm_upsample(self, source, resampler=None, keep_mean=False):
+    """ Resample an image with the upsample method: read out the value of the image at the
+        pixel positions of this pm (pm.py:1937-1986).  keep_mean conserves the mean rather than
+        the total mass in the overlapped region.  Returns a new RealField. """
+    assert isinstance(source, RealField)
+    q = self.mesh_coordinates(dtype=self.dtype)
+    # transform from my mesh to source's mesh
+    transform = Affine(self.ndim, translate=-source.start, scale=1.0 * source.Nmesh / self.Nmesh,
+                       period=source.Nmesh)
+    # quirk Q5: the reference computes the layout twice; the second, with a hard-coded
+    # smoothing of 1.6, is the one that is used (pm.py:1971-1972)
+    layout = source.pm.decompose(q, smoothing=1.6, transform=transform)
+    f = source.readout(q, resampler=resampler, layout=layout, transform=transform)
+    if not keep_mean:
+        f = f * float((source.pm.Nmesh.prod() / source.pm.BoxSize.prod()) /
+                      (self.Nmesh.prod() / self.BoxSize.prod()))
+    # all are on the grid. NGB is faster, and no need to decompose
+    return self.paint(q, mass=f, resampler='nnb', transform=self.affine_grid)
+
+
+def _pm_downsample(self, source, resampler=None, keep_mean=False):
+    """ Resample an image with the downsample method: paint the value of the image at the
+        pixel positions of the source (pm.py:1988-2027).  Returns a new RealField. """
+    assert isinstance(source, RealField)
+    q = source.pm.mesh_coordinates(dtype=self.dtype)
+    f = source.readout(q, resampler='nnb', transform=source.pm.affine_grid)
+    # transform from source's mesh to my mesh
+    transform = self.affine_grid.rescale(1.0 * self.Nmesh / source.Nmesh)
+    if keep_mean:
+        f = f / float((source.pm.Nmesh.prod() / source.pm.BoxSize.prod()) /
+                      (self.Nmesh.prod() / self.BoxSize.prod()))
+    layout = self.decompose(q, smoothing=resampler, transform=transform)
+    return self.paint(q, mass=f, layout=layout, resampler=resampler, transform=transform)
+
+
+ParticleMesh.upsample = _pm_upsample
+ParticleMesh.downsample = _pm_downsample
 
 
 def _smoke_cycle(O):

@@ -327,3 +327,34 @@ def test_c2r_with_fused_transfer(be, dtype, tol):
         c2 = ck.copy()
         got2 = numpy.asarray(c2.c2r(out=Ellipsis, transfer=T))
         assert rel_l2(got2, want) < 10 * tol
+
+
+def test_real_resample(be):                   # test_pm.py:458-470
+    pmh = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    pml = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f8')
+    reall = pml.create(type='real')
+    reall.apply(lambda i, v: (i[0] % 2) * (i[1] % 2), kind='index', out=Ellipsis)
+    for resampler in ['nearest', 'cic', 'tsc', 'cubic']:
+        realh = pmh.upsample(reall, resampler=resampler, keep_mean=False)
+        reall2 = pml.downsample(realh, resampler=resampler)
+        assert_almost_equal(reall.csum(), realh.csum())
+        assert_almost_equal(reall.csum(), reall2.csum())
+    # nearest up then down is the identity on the coarse mesh
+    realh = pmh.upsample(reall, resampler='nearest', keep_mean=True)
+    assert_allclose(numpy.asarray(realh)[::2, ::2], numpy.asarray(reall))
+
+
+def test_transpose(be):                       # test_pm.py:754-776
+    pm = ParticleMesh(BoxSize=[8.0, 16.0, 32.0], Nmesh=[4, 6, 8], dtype='f8')
+    rs = numpy.random.RandomState(1234)
+    comp1 = pm.create('real', value=rs.normal(size=(4, 6, 8)))
+    comp1t = comp1.ctranspose([0, 1, 2])
+    assert_array_equal(comp1t.Nmesh, comp1.Nmesh)
+    assert_array_equal(comp1t.BoxSize, comp1.BoxSize)
+    assert_allclose(comp1t.cnorm(), comp1.cnorm())
+    comp1t = comp1.ctranspose([1, 2, 0])
+    assert_array_equal(comp1t.Nmesh, comp1.Nmesh[[1, 2, 0]])
+    assert_array_equal(comp1t.BoxSize, comp1.BoxSize[[1, 2, 0]])
+    assert_allclose(numpy.asarray(comp1t), numpy.asarray(comp1).transpose(1, 2, 0))
+    comp1ttt = comp1t.ctranspose([1, 2, 0]).ctranspose([1, 2, 0])
+    assert_allclose(numpy.asarray(comp1ttt), numpy.asarray(comp1))
