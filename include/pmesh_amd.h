@@ -44,7 +44,7 @@ typedef enum pmx_status {
 } pmx_status;
 
 /* Window kinds on the path (pmesh/_window_imp.h:4-28; window.py:230-255).
- * The table-driven kinds (lanczos/acg/db/sym) are outside the scope table. */
+ * The wavelet kinds (db/sym) are not built. */
 typedef enum pmx_window_kind {
     PMX_NEAREST = 0,   /* PMESH_PAINTER_NEAREST   */
     PMX_LINEAR = 1,    /* PMESH_PAINTER_LINEAR    */
@@ -53,7 +53,10 @@ typedef enum pmx_window_kind {
     PMX_TUNED_NNB = 4, /* PMESH_PAINTER_TUNED_NNB */
     PMX_TUNED_CIC = 5, /* PMESH_PAINTER_TUNED_CIC */
     PMX_TUNED_TSC = 6, /* PMESH_PAINTER_TUNED_TSC */
-    PMX_TUNED_PCS = 7  /* PMESH_PAINTER_TUNED_PCS */
+    PMX_TUNED_PCS = 7, /* PMESH_PAINTER_TUNED_PCS */
+    /* table driven (generic path only; need pmx_window_set_table first) */
+    PMX_LANCZOS2 = 8, PMX_LANCZOS3 = 9, PMX_LANCZOS4 = 10, PMX_LANCZOS5 = 11, PMX_LANCZOS6 = 12,
+    PMX_ACG2 = 13, PMX_ACG3 = 14, PMX_ACG4 = 15, PMX_ACG5 = 16, PMX_ACG6 = 17
 } pmx_window_kind;
 
 /* The geometric part of `struct PMeshPainter` (pmesh/_window_imp.h:48-62):
@@ -92,6 +95,10 @@ int pmx_device_count(void);
 /* pmesh_painter_init + pmesh_window_info_init (_window_imp.c:24-47, 246-459):
  * native support and effective integer support of (kind, support). */
 int pmx_window_info(int32_t kind, int32_t support, int32_t *nativesupport, int32_t *eff_support);
+/* Register the lookup table of a table-driven kind on the current device (the reference
+ * compiles them in: pmesh/_window_lanczos.h, _window_acg.h; `_<name>_kernel/_diff` there):
+ * n values on [0, (n-1)*step], HOST array, linear interpolation.  Once per device and kind. */
+int pmx_window_set_table(int32_t kind, const double *values, int32_t n, double step);
 /* pmesh_painter_get_fwindow (_window_imp.c:473-485) for n circular
  * frequencies; HOST arrays (tiny, init-time). */
 int pmx_fwindow(int32_t kind, int32_t support, const double *w, int64_t n, double *out);

@@ -35,6 +35,16 @@ static int ref_type(int kind)
     case PMX_TUNED_CIC: return PMESH_PAINTER_TUNED_CIC;
     case PMX_TUNED_TSC: return PMESH_PAINTER_TUNED_TSC;
     case PMX_TUNED_PCS: return PMESH_PAINTER_TUNED_PCS;
+    case PMX_LANCZOS2: return PMESH_PAINTER_LANCZOS2;
+    case PMX_LANCZOS3: return PMESH_PAINTER_LANCZOS3;
+    case PMX_LANCZOS4: return PMESH_PAINTER_LANCZOS4;
+    case PMX_LANCZOS5: return PMESH_PAINTER_LANCZOS5;
+    case PMX_LANCZOS6: return PMESH_PAINTER_LANCZOS6;
+    case PMX_ACG2: return PMESH_PAINTER_ACG2;
+    case PMX_ACG3: return PMESH_PAINTER_ACG3;
+    case PMX_ACG4: return PMESH_PAINTER_ACG4;
+    case PMX_ACG5: return PMESH_PAINTER_ACG5;
+    case PMX_ACG6: return PMESH_PAINTER_ACG6;
     }
     return kind - 100; /* kind >= 100: raw reference enum value (lanczos, acg, ...) */
 }

@@ -17,7 +17,10 @@ STATUS_NAMES = {0: 'PMX_OK', 1: 'PMX_EINVAL', 2: 'PMX_EUNSUPPORTED', 3: 'PMX_EHI
 KINDS = {
     'nearest': 0, 'linear': 1, 'quadratic': 2, 'cubic': 3,
     'tunednnb': 4, 'tunedcic': 5, 'tunedtsc': 6, 'tunedpcs': 7,
+    'lanczos2': 8, 'lanczos3': 9, 'lanczos4': 10, 'lanczos5': 11, 'lanczos6': 12,
+    'acg2': 13, 'acg3': 14, 'acg4': 15, 'acg5': 16, 'acg6': 17,
 }
+TABLE_KINDS = [k for k, v in KINDS.items() if v >= 8]
 
 PMX_FFT_R2C, PMX_FFT_C2R, PMX_FFT_C2C_FWD, PMX_FFT_C2C_BWD = range(4)
 
@@ -80,6 +83,7 @@ DEVICE_ONLY = {
     'last_error': (C.c_char_p, []),
     'version': (C.c_int, []),
     'device_count': (C.c_int, []),
+    'window_set_table': (C.c_int, [_i32, _P(_f64), _i32, _f64]),
     'binplan_create': (C.c_int, [_P(_vp)]),
     'binplan_destroy': (C.c_int, [_vp]),
     'binplan_supported': (C.c_int, [_P(Painter), _i64]),

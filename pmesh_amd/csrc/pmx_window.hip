@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <mutex>
+
 #include "pmx_common.h"
 #include "pmx_window_dev.h"
 
@@ -131,6 +133,38 @@ __global__ void __launch_bounds__(256) readout_tuned_kernel(pmx_painter p, const
     }
 }
 
+// lookup table of a table-driven window (device pointer)
+struct TableD {
+    const double *v;
+    int n;
+    double step;
+};
+
+// `_<name>_kernel` of the generated headers (makelanczos.py:20-30): linear interpolation
+__device__ inline double table_kernel(const TableD &t, double x)
+{
+    x = fabs(x);
+    double f = x / t.step;
+    int i = (int)f;
+    if (i < 0) return 0;
+    if (i >= t.n - 1) return 0;
+    f -= i;
+    return t.v[i] * (1 - f) + t.v[i + 1] * f;
+}
+
+// `_<name>_diff` (makelanczos.py:31-46): slope of the table segment
+__device__ inline double table_diff(const TableD &t, double x)
+{
+    double factor;
+    if (x >= 0) factor = 1;
+    else { factor = -1; x = -x; }
+    int i = (int)(x / t.step);
+    if (i < 0) return 0;
+    if (i >= t.n - 1) return 0;
+    double f = t.v[i + 1] - t.v[i];
+    return factor * f / t.step;
+}
+
 // ---- analytic kernels of the generic path (_window_imp.c:108-236) ---------
 __device__ inline double k_eval(int kind, double x)
 {
@@ -200,11 +234,11 @@ __device__ double tuned_dispatch(const pmx_painter &p, char *canvas, const doubl
 template <typename T, bool PAINT>
 __global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canvas, DVec pos,
                                                       DVec mass, double mass_scalar, DVec hsml,
-                                                      DVec out, int64_t n)
+                                                      DVec out, int64_t n, TableD tab)
 {
     const int nd = p.ndim;
     const int ns = native_support(p.kind);
-    const bool tuned = p.kind >= PMX_TUNED_NNB;
+    const bool tuned = p.kind >= PMX_TUNED_NNB && p.kind <= PMX_TUNED_PCS;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         double x[PMX_MAXDIM];
@@ -226,7 +260,10 @@ __global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canva
                 double dx = g - ipos[d];
                 for (int j = 0; j < w.support; j++) {
                     double xx = (dx - j) * w.vfactor;
-                    if (p.order[d] == 0) k[d][j] = k_eval(p.kind, xx) * w.vfactor;
+                    if (tab.v) {
+                        if (p.order[d] == 0) k[d][j] = table_kernel(tab, xx) * w.vfactor;
+                        else k[d][j] = table_diff(tab, xx) * p.scale[d] * w.vfactor * w.vfactor;
+                    } else if (p.order[d] == 0) k[d][j] = k_eval(p.kind, xx) * w.vfactor;
                     else k[d][j] = d_eval(p.kind, xx) * p.scale[d] * w.vfactor * w.vfactor;
                 }
             }
@@ -323,15 +360,52 @@ static void launch_readout_kind(const pmx_painter &p, const void *canvas, DVec p
 // true if every particle takes the tuned fast path
 static bool is_fast(const pmx_painter &p, const pmx_vec *hsml)
 {
-    if (p.kind < PMX_TUNED_NNB) return false;
+    if (p.kind < PMX_TUNED_NNB || p.kind > PMX_TUNED_PCS) return false;
     if (hsml && hsml->data) return false;
     WInfo w = winfo_init(native_support(p.kind), (double)p.support);
     return w.support == native_support(p.kind);
 }
 
+// device tables of the table-driven kinds, per device
+struct TableSlot { double *v = nullptr; int n = 0; double step = 0; };
+static TableSlot g_tables[16][PMX_ACG6 + 1];
+static std::mutex g_tables_mutex;
+
+static int lookup_table(int kind, TableD *t)
+{
+    t->v = nullptr; t->n = 0; t->step = 0;
+    if (kind < PMX_LANCZOS2) return PMX_OK;
+    int dev = 0;
+    PMX_HIP_CHECK(hipGetDevice(&dev));
+    PMX_REQUIRE(dev < 16, PMX_EUNSUPPORTED, "device index above 15");
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    const TableSlot &sl = g_tables[dev][kind];
+    PMX_REQUIRE(sl.v != nullptr, PMX_EINVAL, "table-driven window used before pmx_window_set_table");
+    t->v = sl.v; t->n = sl.n; t->step = sl.step;
+    return PMX_OK;
+}
+
 }  // namespace pmx
 
 using namespace pmx;
+
+extern "C" int pmx_window_set_table(int32_t kind, const double *values, int32_t n, double step)
+{
+    PMX_REQUIRE(kind >= PMX_LANCZOS2 && kind <= PMX_ACG6, PMX_EINVAL, "not a table-driven window kind");
+    PMX_REQUIRE(values != nullptr && n >= 2 && step > 0, PMX_EINVAL, "bad table");
+    int dev = 0;
+    PMX_HIP_CHECK(hipGetDevice(&dev));
+    PMX_REQUIRE(dev < 16, PMX_EUNSUPPORTED, "device index above 15");
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    TableSlot &sl = g_tables[dev][kind];
+    if (sl.v) (void)hipFree(sl.v);
+    sl.v = nullptr;
+    PMX_HIP_CHECK(hipMalloc((void **)&sl.v, sizeof(double) * n));
+    PMX_HIP_CHECK(hipMemcpy(sl.v, values, sizeof(double) * n, hipMemcpyHostToDevice));
+    sl.n = n;
+    sl.step = step;
+    return PMX_OK;
+}
 
 extern "C" int pmx_window_info(int32_t kind, int32_t support, int32_t *nativesupport,
                                int32_t *eff_support)
@@ -359,6 +433,10 @@ extern "C" int pmx_fwindow(int32_t kind, int32_t support, const double *w, int64
     int ns = native_support(kind);
     PMX_REQUIRE(ns > 0, PMX_EUNSUPPORTED, "window kind not built");
     WInfo wi = winfo_init(ns, (double)support);
+    if (kind >= PMX_LANCZOS2) {
+        for (int64_t i = 0; i < n; i++) out[i] = 1.0;   // fwindow == NULL: "not implemented" (_window_imp.c:482-484)
+        return PMX_OK;
+    }
     for (int64_t i = 0; i < n; i++) {
         // pmesh_painter_get_fwindow (_window_imp.c:473-485): sinc^p at w / vfactor
         double t = sinc_unnormed(0.5 * (w[i] / wi.vfactor));
@@ -385,15 +463,18 @@ extern "C" int pmx_paint(const pmx_painter *p_, void *canvas, const pmx_vec *pos
     p.support = winfo_init(native_support(p.kind), (double)p.support).support;
     hipStream_t st = (hipStream_t)stream;
     DVec dpos = dvec(pos), dmass = dvec(mass), dh = dvec(hsml), none = dvec(nullptr);
+    TableD tab;
+    rc = lookup_table(p.kind, &tab);
+    if (rc) return rc;
     if (is_fast(*p_, hsml)) {
         if (p.canvas_elsize == 8) launch_paint_kind<double>(p, canvas, dpos, dmass, mass_scalar, npart, st);
         else launch_paint_kind<float>(p, canvas, dpos, dmass, mass_scalar, npart, st);
     } else {
         dim3 block(256), grid(grid_for(npart, 256));
         if (p.canvas_elsize == 8)
-            general_kernel<double, true><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart);
+            general_kernel<double, true><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart, tab);
         else
-            general_kernel<float, true><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart);
+            general_kernel<float, true><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart, tab);
     }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -413,15 +494,18 @@ extern "C" int pmx_readout(const pmx_painter *p_, const void *canvas, const pmx_
     p.support = winfo_init(native_support(p.kind), (double)p.support).support;
     hipStream_t st = (hipStream_t)stream;
     DVec dpos = dvec(pos), dh = dvec(hsml), dout = dvec(out), none = dvec(nullptr);
+    TableD tab;
+    rc = lookup_table(p.kind, &tab);
+    if (rc) return rc;
     if (is_fast(*p_, hsml)) {
         if (p.canvas_elsize == 8) launch_readout_kind<double>(p, canvas, dpos, dout, npart, st);
         else launch_readout_kind<float>(p, canvas, dpos, dout, npart, st);
     } else {
         dim3 block(256), grid(grid_for(npart, 256));
         if (p.canvas_elsize == 8)
-            general_kernel<double, false><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart);
+            general_kernel<double, false><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart, tab);
         else
-            general_kernel<float, false><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart);
+            general_kernel<float, false><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart, tab);
     }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;

@@ -16,6 +16,9 @@ __host__ __device__ inline int native_support(int kind)
     case PMX_QUADRATIC: case PMX_TUNED_TSC: return 3;
     case PMX_CUBIC: case PMX_TUNED_PCS: return 4;
     }
+    // table driven: lanczos n has support 2n, acg n has support n (_window_lanczos.h:2057, _window_acg.h:2057)
+    if (kind >= PMX_LANCZOS2 && kind <= PMX_LANCZOS6) return 2 * (kind - PMX_LANCZOS2 + 2);
+    if (kind >= PMX_ACG2 && kind <= PMX_ACG6) return kind - PMX_ACG2 + 2;
     return -1;
 }
 

@@ -138,10 +138,10 @@ def _binned_ok(be, painter, pos, n, hs):
     return be.lib.pmx_binplan_supported(C.byref(painter), n) == 0
 
 
-# kinds of the reference registry that are table driven (lanczos/acg/db/sym,
-# _window_lanczos.h etc.): outside the hot-path scope table (SURVEY.md 2.1 #5b)
-_UNBUILT = ['lanczos2', 'lanczos3', 'lanczos4', 'lanczos5', 'lanczos6',
-            'acg2', 'acg3', 'acg4', 'acg5', 'acg6', 'db6', 'db12', 'db20', 'sym6', 'sym12', 'sym20']
+# wavelet kinds of the reference registry (_window_wavelets.h, generated with PyWavelets):
+# not built.  lanczos / acg are table driven too and ARE built (pmesh_amd/_tables.py).
+_UNBUILT = ['db6', 'db12', 'db20', 'sym6', 'sym12', 'sym20']
+_TABLES_SENT = set()
 
 
 class ResampleWindow(object):
@@ -161,7 +161,11 @@ class ResampleWindow(object):
         if kind not in _abi.KINDS:
             raise ValueError('unknown window kind %r' % (kind,))
         self._k = _abi.KINDS[kind]
-        native = {0: 1, 4: 1, 1: 2, 5: 2, 2: 3, 6: 3, 3: 4, 7: 4}[self._k]
+        if kind in _abi.TABLE_KINDS:
+            from . import _tables
+            native = _tables.table(kind)[2]
+        else:
+            native = {0: 1, 4: 1, 1: 2, 5: 2, 2: 3, 6: 3, 3: 4, 7: 4}[self._k]
         # pmesh_window_info_init (_window_imp.c:24-47): support <= 0 means native
         self.nativesupport = native
         self.support = native if support <= 0 else int(support)
@@ -170,9 +174,18 @@ class ResampleWindow(object):
     def _require_built(self):
         if self._k is None:
             raise NotImplementedError(
-                "window kind %r is table driven (lanczos/acg/wavelet) and is outside the "
-                "GPU hot path built so far; use nnb/cic/tsc/pcs or nearest/linear/quadratic/cubic"
-                % (self.kind,))
+                "window kind %r (wavelet tables) is not built; use nnb/cic/tsc/pcs, "
+                "nearest/linear/quadratic/cubic, lanczos2-6 or acg2-6" % (self.kind,))
+        if self.kind in _abi.TABLE_KINDS:
+            be = backend.get()
+            key = (id(be), self._k)
+            if key not in _TABLES_SENT:
+                from . import _tables
+                values, step, _ = _tables.table(self.kind)
+                values = numpy.ascontiguousarray(values, dtype='f8')
+                be.call('window_set_table', self._k, values.ctypes.data_as(C.POINTER(C.c_double)),
+                        len(values), float(step))
+                _TABLES_SENT.add(key)
 
     def resize(self, support):
         """ Change the support of the window, returning a new window. """
@@ -402,6 +415,11 @@ def FindResampler(window):
 
 
 windows = dict(
+    LANCZOS2=ResampleWindow(kind="lanczos2"), LANCZOS3=ResampleWindow(kind="lanczos3"),
+    LANCZOS4=ResampleWindow(kind="lanczos4"), LANCZOS5=ResampleWindow(kind="lanczos5"),
+    LANCZOS6=ResampleWindow(kind="lanczos6"),
+    ACG2=ResampleWindow(kind="acg2"), ACG3=ResampleWindow(kind="acg3"), ACG4=ResampleWindow(kind="acg4"),
+    ACG5=ResampleWindow(kind="acg5"), ACG6=ResampleWindow(kind="acg6"),
     NEAREST=ResampleWindow(kind="nearest"),
     LINEAR=ResampleWindow(kind="linear"),
     NNB=ResampleWindow(kind="tunednnb"),

@@ -408,3 +408,86 @@ def test_device_tensors_in_place(be):
     canvas_t = torch.zeros((8, 8, 8), dtype=torch.float64, device=be.device).permute(2, 0, 1)
     CIC.paint(canvas_t, tpos, mass=tmass, transform=Affine(3, period=8))
     check_paint(be, canvas_t.cpu().numpy(), expect)
+
+
+# ---- table-driven windows (lanczos / acg) ------------------------------------------
+
+def test_lanczos2(be):                        # test_window.py:202-213
+    real = numpy.zeros((4, 4))
+    windows['lanczos2'].paint(real, [[1.5, 1.5]])
+    assert_allclose(real,
+      [[0.003977, -0.035797, -0.035797, 0.003977],
+       [-0.035797, 0.322173, 0.322173, -0.035797],
+       [-0.035797, 0.322173, 0.322173, -0.035797],
+       [0.003977, -0.035797, -0.035797, 0.003977]], atol=1e-5)
+    assert windows['lanczos2'].support == 4
+    a = numpy.zeros(1000)                     # test_lanczos_resize :215-219
+    windows['lanczos2'].resize(400).paint(a, [[500.5]])
+    b = numpy.zeros(1000)
+    windows['lanczos3'].resize(400).paint(b, [[500.5]])
+    assert abs(a.sum() - 1) < 1e-3 and abs(b.sum() - 1) < 1e-3
+
+
+def test_acg(be):                             # test_window.py:279-285
+    real = numpy.zeros((4))
+    windows['acg3'].paint(real, [[2.1]], 1.0)
+    assert_allclose(real, [0., 0.21347228, 0.52014034, 0.30805789])
+
+
+def test_tables_equal_reference(oracle):
+    """pmesh_amd/_tables.py regenerates the reference's generated headers: one particle
+    painted through the compiled reference sweeps the kernel; the interpolated table must
+    reproduce it exactly."""
+    if not oracle.have_ref():
+        pytest.skip('oracle/_ref not built')
+    from pmesh_amd import _tables, _abi
+    for kind in _abi.TABLE_KINDS:
+        values, step, ns = _tables.table(kind)
+        W = oracle.Window(_abi.KINDS[kind], which='ref')
+        assert W.nativesupport == ns and W.support == ns
+        for x0 in (0.0, 0.123456789, 0.5, 0.987654321):
+            n = ns + 4
+            real = numpy.zeros(n)
+            W.paint(real, [[n // 2 + x0]])
+            # the same numbers from the table (generic path of _window_generics.h:21-72)
+            left = (ns - 1) // 2
+            shift = ns / 2.0 - ns // 2
+            g = n // 2 + x0
+            ipos = int(numpy.floor(g + shift)) - left
+            want = numpy.zeros(n)
+            for i in range(ns):
+                x = abs((g - ipos) - i)
+                f = x / step
+                j = int(f)
+                k = 0.0 if j >= len(values) - 1 else values[j] * (1 - (f - j)) + values[j + 1] * (f - j)
+                want[ipos + i] += 1.0 * k
+            assert_array_equal(real, want)
+
+
+@pytest.mark.parametrize('name', ['lanczos2', 'lanczos3', 'lanczos6', 'acg2', 'acg5'])
+def test_table_windows_vs_compiled_reference(be, oracle, name):
+    """paint / readout / gradients / hsml of the table-driven kinds == the reference's
+    compiled kernels (oracle/_ref) on random particles."""
+    if not oracle.have_ref():
+        pytest.skip('oracle/_ref not built')
+    from pmesh_amd import _abi
+    rs = numpy.random.RandomState(77)
+    shape, period = (9, 14, 16), (18, 14, 16)
+    pos = rs.uniform(-5, 30, size=(300, 3))
+    mass = rs.uniform(0.5, 1.5, size=300)
+    hsml = rs.uniform(0.6, 1.7, size=300)
+    field = rs.normal(size=shape)
+    W = windows[name]
+    R = oracle.Window(_abi.KINDS[name], which='ref')
+    aff = Affine(3, scale=[0.5, 1.0, 0.9], translate=[-2, 0, 0.3], period=period)
+    oaff = oracle.Affine(3, scale=[0.5, 1.0, 0.9], translate=[-2, 0, 0.3], period=period)
+    for d in (None, 1):
+        for h in (None, hsml):
+            got = numpy.zeros(shape)
+            want = numpy.zeros(shape)
+            W.paint(got, pos, mass=mass, hsml=h, diffdir=d, transform=aff)
+            R.paint(want, pos, mass=mass, hsml=h, diffdir=d, transform=oaff)
+            check_paint(be, got, want)
+            check_readout(be, W.readout(field, pos, hsml=h, diffdir=d, transform=aff),
+                          R.readout(field, pos, hsml=h, diffdir=d, transform=oaff))
+    assert_array_equal(W.get_fwindow([0.0, 1.0]), [1.0, 1.0])      # "not implemented" -> 1
