@@ -249,23 +249,31 @@ __global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canva
         double value = 0;
         if (tuned && w.support == ns) {
             value = tuned_dispatch<T, PAINT>(p, canvas, x, m);
-        } else if (w.support <= PMX_MAXSUPPORT) {
+        } else {
+            // weights are tabulated per particle up to PMX_MAXSUPPORT points per axis and
+            // evaluated on the fly beyond (the reference sizes its table dynamically,
+            // _window_generics.h:24; test_lanczos_resize uses support 400)
+            const bool cached = w.support <= PMX_MAXSUPPORT;
             int ipos[PMX_MAXDIM];
+            double dxs[PMX_MAXDIM];
             double k[PMX_MAXDIM][PMX_MAXSUPPORT];
             bool finite = true;
+            auto weight = [&](int d, int j) -> double {
+                double xx = (dxs[d] - j) * w.vfactor;
+                if (tab.v) {
+                    if (p.order[d] == 0) return table_kernel(tab, xx) * w.vfactor;
+                    return table_diff(tab, xx) * p.scale[d] * w.vfactor * w.vfactor;
+                }
+                if (p.order[d] == 0) return k_eval(p.kind, xx) * w.vfactor;
+                return d_eval(p.kind, xx) * p.scale[d] * w.vfactor * w.vfactor;
+            };
             for (int d = 0; d < nd; d++) {
                 double g = x[d] * p.scale[d] + p.translate[d];
                 if (!(fabs(g) < 1073741824.0)) { finite = false; break; }
                 ipos[d] = (int)(floor(g + w.shift) - w.left);
-                double dx = g - ipos[d];
-                for (int j = 0; j < w.support; j++) {
-                    double xx = (dx - j) * w.vfactor;
-                    if (tab.v) {
-                        if (p.order[d] == 0) k[d][j] = table_kernel(tab, xx) * w.vfactor;
-                        else k[d][j] = table_diff(tab, xx) * p.scale[d] * w.vfactor * w.vfactor;
-                    } else if (p.order[d] == 0) k[d][j] = k_eval(p.kind, xx) * w.vfactor;
-                    else k[d][j] = d_eval(p.kind, xx) * p.scale[d] * w.vfactor * w.vfactor;
-                }
+                dxs[d] = g - ipos[d];
+                if (cached)
+                    for (int j = 0; j < w.support; j++) k[d][j] = weight(d, j);
             }
             if (finite) {
                 int rel[PMX_MAXDIM] = {0, 0, 0};
@@ -276,7 +284,7 @@ __global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canva
                     bool outside = false;
                     for (int d = 0; d < nd; d++) {
                         int r = rel[d];
-                        kernel *= k[d][r];
+                        kernel *= cached ? k[d][r] : weight(d, r);
                         int t = wrap1(ipos[d] + r, p.period[d]);
                         if (t >= p.size[d] || t < 0) { outside = true; break; }
                         ind += p.strides[d] * t;
