@@ -63,6 +63,11 @@ def parse():
     ap.add_argument('--cpu-sample-mesh', type=int, default=256)
     ap.add_argument('--binned', type=int, default=-1, help='1/0 force the tile-binned kernels on/off')
     ap.add_argument('--colfft', type=int, default=1, help='0: all-rocFFT 3-d transforms; 1: LDS column FFT')
+    ap.add_argument('--exchange', type=int, default=0,
+                    help='1: route the particles through a decompose() layout even on one rank')
+    ap.add_argument('--ghosts-only', type=int, default=1,
+                    help='0: the literal exchange-everything scheme of the reference for paint/readout '
+                         'with a layout; 1: own particles in place, only ghosts travel')
     ap.add_argument('--fuse-apply', type=int, default=1,
                     help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
     return ap.parse_args()
@@ -250,7 +255,10 @@ def main():
 
     layout = None
     t_decompose = 0.0
-    if world > 1:
+    if not args.ghosts_only:
+        from pmesh_amd import pm as _pm
+        _pm.GHOSTS_ONLY = 'never'
+    if world > 1 or args.exchange:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         layout = pm.decompose(pos)
@@ -277,8 +285,9 @@ def main():
         _window.clear_bin_cache()
         if layout is not None:
             layout._memo = None
+            layout._memo_remote = None
         mark(0)
-        if layout is None:
+        if layout is None or args.ghosts_only:
             pm.resampler.prebin(rho.value, pos, pm.affine)      # tile binning, shared by paint+readout
         mark(1)
         pm.paint(pos, hold=False, layout=layout, out=rho)        # includes the zero fill
@@ -327,7 +336,7 @@ def main():
         dom = max(single, key=single.get)
         units = nloc
         ach = algorithmic_bytes(dom, e, pe, nu) * units / (single[dom] * 1e-3) / 1e9
-        binned = any(e[3] for e in _window._bin_cache.entries)
+        binned = any(e[3] for e in _window.bin_cache().entries)
         if binned:
             kname = {'paint': 'paint_tile_kernel+halo_merge_kernel', 'readout': 'readout_tile_kernel',
                      'apply': 'transfer_kernel'}[dom]
@@ -355,7 +364,9 @@ def main():
                                       'hashed jitter' if args.data == 'uniform' else "Zel'dovich plane waves",
                                       args.window.upper(), 'fp64' if args.dtype == 'f8' else 'fp32',
                                       '' if args.gradient is None else ' (gradient %d)' % args.gradient),
-                       'decomposition': 'single GPU' if world == 1 else 'slab np=[%d], particle exchange included' % world,
+                       'decomposition': ('single GPU' if world == 1 else
+                                         'slab np=[%d], particle exchange included (%s)'
+                                         % (world, 'ghosts only' if args.ghosts_only else 'all particles')),
                        'particles': ntot, 'apply': 'fused into c2r' if args.fuse_apply else 'separate kernel',
                        'fft': 'rocFFT z + LDS column FFT' if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},

@@ -172,7 +172,8 @@ int pmx_take_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const
                   int32_t index_elsize, int64_t nrows, void *dst, void *stream);
 /* Layout.gather mode='sum' (domain.py:294-295, bincountv 26-48):
  * out[i*ncol + c] = sum over j with indices[j] == i of values[j*ncol + c], for all
- * i < nout (rows that receive nothing become 0, as numpy.bincount does). */
+ * i < nout (rows that receive nothing become 0, as numpy.bincount does).
+ * nout = 0: `out` is not cleared first — the rows are added into what it already holds. */
 int pmx_scatter_add(const void *values, int32_t elsize, int32_t ncol, const void *indices,
                     int32_t index_elsize, int64_t nrows, void *out, int64_t nout, void *stream);
 
@@ -212,6 +213,14 @@ int pmx_colfft_supported(int64_t n, int32_t elsize);
 int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
                double scale, const pmx_transfer *transfer, int64_t n1, int64_t n2,
                const int64_t *start, const int64_t *nmesh, const double *boxsize, void *stream);
+
+/* The axis-1 column pass of a slab-decomposed transform fused with the pack / unpack that
+ * brackets PFFT's global transpose (what pmx_slab_pack does, for equal power-of-two ranges):
+ * inverse = 0: src plain (A, N, B) -> dst "split": block r = lines [r*nsplit, (r+1)*nsplit)
+ * as one contiguous (A, nsplit, B) array, i.e. the all-to-all send buffer; inverse = 1: src
+ * split (the receive buffer) -> dst plain.  Out of place; unnormalised, times `scale`. */
+int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N,
+                     int64_t B, int64_t nsplit, double scale, void *stream);
 
 /* Real <-> half-complex transform along the contiguous axis, in place, with the rows
  * resident in LDS (csrc/pmx_colfft.hip): `nrows` rows of n reals (n a power of two in

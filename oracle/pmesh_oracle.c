@@ -628,6 +628,17 @@ int pmo_scatter_add(const void *values, int32_t elsize, int32_t ncol, const void
                     int32_t index_elsize, int64_t nrows, void *out, int64_t nout, void *stream)
 {
     (void)stream;
+    if (nout == 0) {        /* accumulate into what `out` already holds (include/pmesh_amd.h) */
+        for (int64_t j = 0; j < nrows; j++) {
+            int64_t i = index_elsize == 8 ? ((const int64_t *)indices)[j] : ((const int32_t *)indices)[j];
+            if (i < 0) return PMX_EINVAL;
+            for (int c = 0; c < ncol; c++) {
+                if (elsize == 8) ((double *)out)[i * ncol + c] += ((const double *)values)[j * ncol + c];
+                else ((float *)out)[i * ncol + c] += ((const float *)values)[j * ncol + c];
+            }
+        }
+        return PMX_OK;
+    }
     double *acc = (double *)calloc((size_t)(nout * ncol) + 1, sizeof(double));
     if (!acc) return PMX_ENOMEM;
     for (int64_t j = 0; j < nrows; j++) {

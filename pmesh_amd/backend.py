@@ -99,6 +99,11 @@ class HipBackend(object):
                   C.byref(transfer) if transfer is not None else None, n1, n2,
                   _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3), self.stream())
 
+    def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0):
+        """column FFT fused with the slab pack (forward: plain -> split) / unpack (inverse)"""
+        self.call('colfft_split', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), A, N, B,
+                  int(nsplit), float(scale), self.stream())
+
     def rowfft_supported(self, n, elsize):
         return self.lib.pmx_rowfft_supported(int(n), int(elsize)) == 0
 

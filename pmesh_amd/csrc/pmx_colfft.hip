@@ -96,9 +96,19 @@ template <typename T, bool INV, int R> __device__ __forceinline__ void fftR(cpx<
     else fft2<T, INV>(v);
 }
 
+// Addressing of element (a, n, b): a*sa + (n >> sh)*shi + (n & mask)*B + b.  The plain
+// (A, N, B) array is sh = 31, mask = ~0, sa = N*B.  The "split" layout of the slab transpose
+// cuts axis N into N/nl ranges of nl = 1 << sh lines, one contiguous (A, nl, B) block per
+// range (= per destination rank): sa = nl*B, shi = A*nl*B, mask = nl-1.
+struct ColAddr {
+    int64_t sa, shi;
+    int32_t sh, mask;
+};
+
 struct ColGeom {
     int64_t A, B;          // outer and inner batch extents
     int32_t N, logN;
+    ColAddr in, out;
     double scale;
     // optional fused transfer (APPLY): global index bookkeeping of the (N0, n1, N2c) block
     pmx_transfer t;
@@ -223,7 +233,7 @@ template <> struct Radices<11> { static constexpr int n = 4; static constexpr in
 
 template <typename T, int LOGN, bool INV, bool APPLY, int RB>
 __global__ void __launch_bounds__((1 << LOGN) / 8 * (RB / (int)sizeof(cpx<T>)))
-colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
+colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 {
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);    // columns per tile: RB-byte row segments
@@ -240,7 +250,8 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
     const int col = tid % W, tj = tid / W;   // W consecutive lanes = one 128-byte row segment
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
-        cpx<T> *base = data + a * (int64_t)N * g.B + b0;
+        const cpx<T> *ibase = src + a * g.in.sa + b0;
+        cpx<T> *obase = dst + a * g.out.sa + b0;
         const bool colok = b0 + col < g.B;
         ColK ck = {0, 0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
@@ -250,7 +261,8 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             int n = tj + u * TPC;
-            ld[u] = colok ? base[(int64_t)n * g.B + col] : cpx<T>{0, 0};
+            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.B + col]
+                          : cpx<T>{0, 0};
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -289,7 +301,7 @@ colfft_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
                 cpx<T> v = buf[lds_index<T, RB>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
-                base[(int64_t)n * g.B + col] = v;
+                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.B + col] = v;
             }
         }
     }
@@ -443,7 +455,8 @@ static int get_twiddles(int N, int es, void **out, hipStream_t st)
 }
 
 template <typename T, int LOGN, int RB>
-static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
+static int launch_colfft(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
+                         hipStream_t st)
 {
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);
@@ -455,7 +468,7 @@ static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inve
     do {                                                                                                       \
         auto k = colfft_kernel<T, LOGN, INV, AP, RB>;                                                          \
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k<<<grid, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                                       \
+        k<<<grid, NT, lds, st>>>(g, (const cpx<T> *)src, (cpx<T> *)dst, (const cpx<T> *)tw);                   \
     } while (0)
     if (inverse) { if (apply) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (apply) LAUNCH(false, true); else LAUNCH(false, false); }
@@ -468,14 +481,15 @@ static int launch_colfft(const ColGeom &g, void *data, const void *tw, bool inve
 // pass, whose rows are a whole plane apart: no gain at 512^3 — 1.42 vs 1.44 ms forward, and
 // the fused-transfer pass got slower — so only the 128-byte tiles are instantiated.)
 template <typename T>
-static int dispatch_logn(const ColGeom &g, void *data, const void *tw, bool inverse, bool apply, hipStream_t st)
+static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
+                         hipStream_t st)
 {
     switch (g.logN) {
-    case 6: return launch_colfft<T, 6, 128>(g, data, tw, inverse, apply, st);
-    case 7: return launch_colfft<T, 7, 128>(g, data, tw, inverse, apply, st);
-    case 8: return launch_colfft<T, 8, 128>(g, data, tw, inverse, apply, st);
-    case 9: return launch_colfft<T, 9, 128>(g, data, tw, inverse, apply, st);
-    case 10: return launch_colfft<T, 10, 128>(g, data, tw, inverse, apply, st);
+    case 6: return launch_colfft<T, 6, 128>(g, src, dst, tw, inverse, apply, st);
+    case 7: return launch_colfft<T, 7, 128>(g, src, dst, tw, inverse, apply, st);
+    case 8: return launch_colfft<T, 8, 128>(g, src, dst, tw, inverse, apply, st);
+    case 9: return launch_colfft<T, 9, 128>(g, src, dst, tw, inverse, apply, st);
+    case 10: return launch_colfft<T, 10, 128>(g, src, dst, tw, inverse, apply, st);
     }
     set_error("pmx_colfft: length 2^%d is not built", g.logN);
     return PMX_EUNSUPPORTED;
@@ -550,6 +564,13 @@ extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t n
     return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, st);
 }
 
+static ColAddr plain_addr(int64_t N, int64_t B)
+{
+    ColAddr a;
+    a.sa = N * B; a.shi = 0; a.sh = 31; a.mask = 0x7fffffff;
+    return a;
+}
+
 // PMX_OK if a column FFT of length n (element size elsize = 4|8 per component) is built
 extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 {
@@ -576,6 +597,7 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     g.logN = 0;
     while ((1ll << g.logN) < N) g.logN++;
     g.n1 = 1; g.n2 = 1;
+    g.in = g.out = plain_addr(N, B);
     bool apply = t != nullptr;
     if (apply) {
         PMX_REQUIRE(A == 1 && n1 * n2 == B && B < (1ll << 31), PMX_EINVAL,
@@ -595,8 +617,46 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     void *tw = nullptr;
     rc = get_twiddles((int)N, elsize, &tw, st);
     if (rc) return rc;
-    if (elsize == 8) return dispatch_logn<double>(g, data, tw, inverse != 0, apply, st);
+    if (elsize == 8) return dispatch_logn<double>(g, data, data, tw, inverse != 0, apply, st);
     // float: 16 columns x 8 B = 128-byte rows; 1024 threads at N = 512, so N <= 512 only
     PMX_REQUIRE(N <= 512, PMX_EUNSUPPORTED, "single precision column FFT is built up to length 512");
-    return dispatch_logn<float>(g, data, tw, inverse != 0, apply, st);
+    return dispatch_logn<float>(g, data, data, tw, inverse != 0, apply, st);
+}
+
+// The axis-1 pass of a slab-decomposed transform fused with the pack / unpack around the
+// global transpose (the work of pmx_slab_pack for equal, power-of-two ranges of nsplit lines):
+//   inverse = 0: src is the plain (A, N, B) array; dst receives the transform in split
+//                layout, block r = lines [r*nsplit, (r+1)*nsplit) as a contiguous (A, nsplit, B)
+//                array — the send buffer of the all-to-all;
+//   inverse = 1: src is that split layout (the receive buffer), dst the plain (A, N, B) array.
+// src and dst must not overlap.
+extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A,
+                                int64_t N, int64_t B, int64_t nsplit, double scale, void *stream)
+{
+    int rc = pmx_colfft_supported(N, elsize);
+    if (rc) { set_error("pmx_colfft_split: unsupported length %lld", (long long)N); return rc; }
+    PMX_REQUIRE(src != nullptr && dst != nullptr && src != dst && A >= 0 && B >= 0, PMX_EINVAL, "bad arguments");
+    PMX_REQUIRE(nsplit >= 1 && nsplit <= N && (nsplit & (nsplit - 1)) == 0, PMX_EUNSUPPORTED,
+                "nsplit must be a power of two <= N");
+    if (A == 0 || B == 0) return PMX_OK;
+    ColGeom g;
+    g.A = A; g.B = B; g.N = (int32_t)N; g.scale = scale;
+    g.logN = 0;
+    while ((1ll << g.logN) < N) g.logN++;
+    g.n1 = 1; g.n2 = 1;
+    ColAddr split;
+    split.sh = 0;
+    while ((1ll << split.sh) < nsplit) split.sh++;
+    split.mask = (int32_t)(nsplit - 1);
+    split.sa = nsplit * B;
+    split.shi = A * nsplit * B;
+    g.in = inverse ? split : plain_addr(N, B);
+    g.out = inverse ? plain_addr(N, B) : split;
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)N, elsize, &tw, st);
+    if (rc) return rc;
+    if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, false, st);
+    PMX_REQUIRE(N <= 512, PMX_EUNSUPPORTED, "single precision column FFT is built up to length 512");
+    return dispatch_logn<float>(g, src, dst, tw, inverse != 0, false, st);
 }

@@ -455,6 +455,13 @@ extern "C" int pmx_fwindow(int32_t kind, int32_t support, const double *w, int64
     return PMX_OK;
 }
 
+static bool canvas_empty(const pmx_painter &p)
+{
+    for (int d = 0; d < p.ndim; d++)
+        if (p.size[d] == 0) return true;
+    return false;
+}
+
 extern "C" int pmx_paint(const pmx_painter *p_, void *canvas, const pmx_vec *pos,
                          const pmx_vec *mass, double mass_scalar, const pmx_vec *hsml,
                          int64_t npart, void *stream)
@@ -462,6 +469,7 @@ extern "C" int pmx_paint(const pmx_painter *p_, void *canvas, const pmx_vec *pos
     int rc = check_painter(p_);
     if (rc) return rc;
     if (npart == 0) return PMX_OK;  // empty pos: no-op
+    if (canvas_empty(*p_)) return PMX_OK;  // a rank that holds no cells: every contribution is outside
     PMX_REQUIRE(canvas != nullptr, PMX_EINVAL, "canvas is NULL");
     PMX_REQUIRE(vec_ok(pos) && pos->ncol >= p_->ndim, PMX_EINVAL, "pos must be (n, >=ndim) f4/f8");
     PMX_REQUIRE(!mass || !mass->data || vec_ok(mass), PMX_EINVAL, "mass must be f4/f8");
@@ -494,7 +502,8 @@ extern "C" int pmx_readout(const pmx_painter *p_, const void *canvas, const pmx_
     int rc = check_painter(p_);
     if (rc) return rc;
     if (npart == 0) return PMX_OK;
-    PMX_REQUIRE(canvas != nullptr, PMX_EINVAL, "canvas is NULL");
+    // an empty block has no storage: the kernels then write 0 for every particle (all cells outside)
+    PMX_REQUIRE(canvas != nullptr || canvas_empty(*p_), PMX_EINVAL, "canvas is NULL");
     PMX_REQUIRE(vec_ok(pos) && pos->ncol >= p_->ndim, PMX_EINVAL, "pos must be (n, >=ndim) f4/f8");
     PMX_REQUIRE(vec_ok(out), PMX_EINVAL, "out must be f4/f8");
     PMX_REQUIRE(!hsml || !hsml->data || vec_ok(hsml), PMX_EINVAL, "hsml must be f4/f8");

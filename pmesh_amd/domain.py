@@ -157,6 +157,83 @@ class Layout(object):
             self.comm.alltoallv(buffer, self.sendcounts, recvbuffer, self.recvcounts)
         return recvbuffer.cpu().numpy() if host else recvbuffer
 
+    # ---- ghosts-only routing --------------------------------------------------------
+    # The rows a rank sends to itself are usually almost all of them (particles live on the
+    # rank that owns their cells; only the ghosts within the smoothing length of a domain
+    # face and the migrating few travel).  paint/readout with a layout therefore work on the
+    # caller's own array in place and exchange only the rows bound for *other* ranks; the
+    # two methods below are that remote half of exchange()/gather(mode='sum').
+    def _remote(self, be):
+        rem = getattr(self, '_remote_tables', None)
+        if rem is None:
+            r = self.comm.rank
+            s0 = int(self.sendoffsets[r])
+            s1 = s0 + int(self.sendcounts[r])
+            idx = torch.cat([self.indices[:s0], self.indices[s1:]]) if s1 > s0 else self.indices
+            sc = self.sendcounts.copy()
+            rc = self.recvcounts.copy()
+            sc[r] = 0
+            rc[r] = 0
+            rem = self._remote_tables = (idx.contiguous(), sc, rc, int(sc.sum()), int(rc.sum()))
+        return rem
+
+    @property
+    def remote_recvlength(self):
+        return self._remote(backend.get())[4]
+
+    def exchange_remote(self, data):
+        """ rows of `data` received from the other ranks (ordered by source rank) """
+        be = backend.get()
+        idx, sc, rc, nsend, nrecv = self._remote(be)
+        data, host = to_device(data, be.device, 'data', allow_int=True)
+        if len(data) != self.sendlength:
+            raise ValueError('the length of data does not match that used to build the layout')
+        memo_key = (data.data_ptr(), data._version, tuple(data.shape), data.stride(), data.dtype)
+        memo = getattr(self, '_memo_remote', None)
+        if memo is not None and memo[0] == memo_key:
+            return memo[2]
+        trailing = tuple(data.shape[1:])
+        row_bytes = data.element_size()
+        for s in trailing:
+            row_bytes *= s
+        if data.dim() > 1 and not data[0:1].is_contiguous() and data.shape[0] > 0:
+            data = data.contiguous()
+        buffer = torch.empty((nsend,) + trailing, dtype=data.dtype, device=be.device)
+        if nsend:
+            if row_bytes % 4:
+                raise TypeError('rows must be a multiple of 4 bytes')
+            stride0 = data.stride(0) * data.element_size() if data.shape[0] > 1 else row_bytes
+            be.call('take_rows', data.data_ptr(), stride0, row_bytes, idx.data_ptr(),
+                    idx.element_size(), nsend, buffer.data_ptr(), be.stream())
+        recvbuffer = torch.empty((nrecv,) + trailing, dtype=data.dtype, device=be.device)
+        if self.comm.size > 1:
+            self.comm.alltoallv(buffer, sc, recvbuffer, rc)
+        self._memo_remote = (memo_key, data, recvbuffer)
+        return recvbuffer
+
+    def gather_remote_add(self, data, out):
+        """ send the per-ghost results `data` (rows as exchange_remote delivered them) back to
+        their owners and add them into `out` (one row per original item) in place """
+        be = backend.get()
+        idx, sc, rc, nsend, nrecv = self._remote(be)
+        if len(data) != nrecv:
+            raise ValueError('the length of data does not match result of exchange_remote')
+        if self.comm.size == 1:
+            return out
+        data = data.contiguous()
+        back = torch.empty((nsend,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
+        self.comm.alltoallv(data, rc, back, sc)
+        if nsend:
+            if back.dtype != out.dtype:
+                back = back.to(out.dtype)
+            ncol = 1
+            for s in back.shape[1:]:
+                ncol *= s
+            # nout = 0: accumulate into `out` without clearing it (include/pmesh_amd.h)
+            be.call('scatter_add', back.data_ptr(), back.element_size(), ncol, idx.data_ptr(),
+                    idx.element_size(), nsend, out.data_ptr(), 0, be.stream())
+        return out
+
     def gather(self, data, mode='sum', out=None):
         """
         Pull the data from other ranks back to its original hosting rank (domain.py:208-318).

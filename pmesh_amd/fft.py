@@ -253,12 +253,12 @@ class Plan(object):
         if p.nproc == 1:
             self._execute_local(bufin, bufout, transfer)
         else:
-            if transfer is not None:
-                raise NotImplementedError('fused transfer on several ranks')
             if getattr(p, 'pencil', False):
+                if transfer is not None:
+                    raise NotImplementedError('fused transfer on a pencil decomposition')
                 self._execute_pencil(bufin, bufout)
             else:
-                self._execute_slab(bufin, bufout)
+                self._execute_slab(bufin, bufout, transfer)
 
     # ---- single stages on (A, N, B) / row arrays: own LDS kernels, rocFFT otherwise ----
     def _row(self, be, buf, nrows, n, pitch, inverse):
@@ -361,9 +361,20 @@ class Plan(object):
     def can_fuse(self):
         """True if execute(..., transfer=) can fold a transfer function into the transform"""
         p = self.partition
-        if self.forward or p.nproc != 1 or p.ndim != 3:
+        if self.forward or p.ndim != 3:
             return False
+        if p.nproc != 1:
+            return (not getattr(p, 'pencil', False)) and p.transposed and self._slab_own(backend.get())
         return self._use_colfft(backend.get(), [int(x) for x in p.Nmesh[:2]])
+
+    def _slab_own(self, be):
+        """True when every local stage of the slab transform runs on the LDS row/column
+        kernels of csrc/pmx_colfft.hip"""
+        p = self.partition
+        return (p.ndim == 3 and COLFFT != 'never' and hasattr(be, 'colfft') and
+                be.rowfft_supported(int(p.Nmesh[2]), self.elsize) and
+                be.colfft_supported(int(p.Nmesh[1]), self.elsize) and
+                be.colfft_supported(int(p.Nmesh[0]), self.elsize))
 
     def _use_colfft(self, be, lengths):
         if COLFFT == 'never' or not hasattr(be, 'colfft'):
@@ -428,7 +439,7 @@ class Plan(object):
                                          rows, 1.0, inplace)
                 be.fft_execute(self._native(('z', inplace), make), src, bufout.storage)
 
-    def _execute_slab(self, bufin, bufout):
+    def _execute_slab(self, bufin, bufout, transfer=None):
         """Slab-decomposed 3-D (or 2-D) transform with one global transpose."""
         be = backend.get()
         p = self.partition
@@ -467,9 +478,9 @@ class Plan(object):
         nsend, nrecv = sum(send_splits), sum(recv_splits)
 
         same = bufin.storage.data_ptr() == bufout.storage.data_ptr()
-        own = (nd == 3 and COLFFT != 'never' and hasattr(be, 'colfft') and
-               be.rowfft_supported(int(p.Nmesh[2]), self.elsize) and
-               be.colfft_supported(int(p.Nmesh[1]), self.elsize) and be.colfft_supported(N0, self.elsize))
+        own = self._slab_own(be)
+        if transfer is not None and (not own or self.forward):
+            raise NotImplementedError('fused transfer needs the column-FFT path of c2r')
         if own:
             # the LDS-resident row / column kernels of csrc/pmx_colfft.hip, all in place
             N1, N2 = int(p.Nmesh[1]), int(p.Nmesh[2])
@@ -481,10 +492,17 @@ class Plan(object):
                     nreal = n0loc * N1 * 2 * N2c
                     W0[:nreal].copy_(bufin.storage[:nreal])     # r2c preserves its input
                     X = W0
+                # equal power-of-two ranges of axis 1: the pack rides on the column pass
+                fuse_pack = (hasattr(be, 'colfft_split') and n1loc * P == N1 and
+                             n1loc & (n1loc - 1) == 0 and all(e1[r + 1] - e1[r] == n1loc for r in range(P)))
                 if n0loc:
                     be.rowfft(self.elsize, False, X, n0loc * N1, N2, N2c)
-                    be.colfft(self.elsize, False, X, n0loc, N1, N2c, scale=norm)
-                be.slab_pack(X, W1, n0loc, N1c, n2, e1, elb)
+                    if fuse_pack:
+                        be.colfft_split(self.elsize, False, X, W1, n0loc, N1, N2c, n1loc, scale=norm)
+                    else:
+                        be.colfft(self.elsize, False, X, n0loc, N1, N2c, scale=norm)
+                if not (fuse_pack and n0loc):
+                    be.slab_pack(X, W1, n0loc, N1c, n2, e1, elb)
                 out = bufout.storage
                 comm.alltoall(W1[:nsend], out[:nrecv], send_splits, recv_splits)
                 if nb:
@@ -495,14 +513,25 @@ class Plan(object):
                     ncplx = 2 * n1loc * N0 * n2
                     W0[:ncplx].copy_(bufin.storage[:ncplx])     # c2r preserves its input
                     S = W0
-                if nb:
+                if nb and transfer is not None:
+                    # the local block is (N0, n1loc, N2c) at global start (0, o_start[1], 0)
+                    t, start, nmesh, boxsize = transfer
+                    be.colfft(self.elsize, True, S, 1, N0, nb, transfer=t, n1=n1loc, n2=N2c,
+                              start=start, nmesh=nmesh, boxsize=boxsize)
+                elif nb:
                     be.colfft(self.elsize, True, S, 1, N0, nb)
                 comm.alltoall(S[:nrecv], W1[:nsend], recv_splits, send_splits)
                 Y = bufout.storage
-                be.slab_pack(W1, Y, n0loc, N1c, n2, e1, elb, inverse=True)
-                if n0loc:
-                    be.colfft(self.elsize, True, Y, n0loc, N1, N2c)
+                fuse_pack = (hasattr(be, 'colfft_split') and n1loc * P == N1 and
+                             n1loc & (n1loc - 1) == 0 and all(e1[r + 1] - e1[r] == n1loc for r in range(P)))
+                if fuse_pack and n0loc:
+                    be.colfft_split(self.elsize, True, W1, Y, n0loc, N1, N2c, n1loc)
                     be.rowfft(self.elsize, True, Y, n0loc * N1, N2, N2c)
+                else:
+                    be.slab_pack(W1, Y, n0loc, N1c, n2, e1, elb, inverse=True)
+                    if n0loc:
+                        be.colfft(self.elsize, True, Y, n0loc, N1, N2c)
+                        be.rowfft(self.elsize, True, Y, n0loc * N1, N2, N2c)
             return
 
         if self.forward:

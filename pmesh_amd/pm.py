@@ -462,6 +462,23 @@ class RealField(Field):
         resampler = FindResampler(resampler)
         if layout is None:
             return resampler.readout(self.value, pos, hsml=hsml, out=out, transform=transform, diffdir=gradient)
+        if _ghosts_only(layout, resampler, transform, hsml):
+            # partial sums of the caller's own particles straight from the local block, plus
+            # the partial sums of their ghosts on other ranks added on the way back
+            be = backend.get()
+            dpos, host = to_device(pos, be.device, 'pos')
+            res = resampler.readout(self.value, dpos, transform=transform, diffdir=gradient)
+            if layout.comm.size > 1:
+                rpos = layout.exchange_remote(dpos)
+                rres = resampler.readout(self.value, rpos, transform=transform, diffdir=gradient)
+                layout.gather_remote_add(rres, res)
+            if out is not None:
+                if is_tensor(out):
+                    out.copy_(res)
+                else:
+                    out[...] = res.cpu().numpy()
+                return out
+            return res.cpu().numpy() if host else res
         localpos = layout.exchange(pos)
         localhsml = exchange(layout, hsml)
         localresult = self.readout(localpos, hsml=localhsml, resampler=resampler, transform=transform,
@@ -603,7 +620,7 @@ class BaseComplexField(Field):
         if transfer is not None:
             if not isinstance(transfer, Transfer):
                 raise TypeError('transfer must be a pmesh_amd.transfer.Transfer')
-            if self.pm.comm.size == 1 and transfer.fusable() and plan.can_fuse():
+            if transfer.fusable() and plan.can_fuse():
                 fused = (transfer._cstruct(), src.start, src.Nmesh, src.BoxSize)
             elif src is self and not inplace:
                 src = self.apply(transfer)            # several ranks: the slab path copies anyway
@@ -669,6 +686,32 @@ def _mul(a, b):
     if is_tensor(b) and not is_tensor(a):
         a = torch.as_tensor(numpy.asarray(a), device=b.device)
     return a * b
+
+
+#: 'auto': paint/readout with a layout keep the caller's own particles in place and exchange
+#: only the ghosts when the layout's routing covers the window; 'never': always the literal
+#: exchange -> local operation -> gather of the reference (pm.py:1857-1868, 783-791)
+GHOSTS_ONLY = 'auto'
+
+
+def _is_scalar(value):
+    return value is None or numpy.isscalar(value) or (hasattr(value, 'ndim') and value.ndim == 0)
+
+
+def _ghosts_only(layout, resampler, transform, hsml):
+    """ True when painting/reading the caller's own array in place plus the ghosts received
+    from other ranks is the same set of (particle, cell) contributions as the reference's
+    exchange-everything scheme: the layout must have been built by ParticleMesh.decompose for
+    the same scaling and with a smoothing that covers the window (then a particle that was
+    *not* routed to this rank cannot touch the local block, and one that was routed to its
+    own rank is painted exactly once, in place). """
+    route = getattr(layout, '_route', None)
+    if GHOSTS_ONLY == 'never' or route is None or hsml is not None:
+        return False
+    smoothing, scale = route
+    if tuple(float(x) for x in numpy.asarray(transform.scale).ravel()) != scale:
+        return False
+    return bool(numpy.all(smoothing >= 0.5 * resampler.support))
 
 
 def exchange(layout, value):
@@ -941,7 +984,12 @@ class ParticleMesh(object):
             transform = self.affine
         # Transform from simulation unit to global grid unit: transform0(x) = scale * x; the
         # shift is local per processor, thus not used.  The scaling runs inside the kernel.
-        return self.domain.decompose(pos, smoothing=smoothing, _scale=transform.scale)
+        layout = self.domain.decompose(pos, smoothing=smoothing, _scale=transform.scale)
+        # what the routing guarantees (see _ghosts_only): every particle was sent to every rank
+        # that holds a cell within `smoothing` cells of it
+        layout._route = (numpy.broadcast_to(numpy.asarray(smoothing, dtype='f8'), (self.ndim,)).copy(),
+                         tuple(float(x) for x in numpy.asarray(transform.scale).ravel()))
+        return layout
 
     def paint(self, pos, hsml=None, mass=1.0, resampler=None, transform=None, hold=False,
               gradient=None, layout=None, out=None):
@@ -966,6 +1014,23 @@ class ParticleMesh(object):
             # hold=False: "out.value[...] = 0" (pm.py:1852-1853) is folded into the kernel
             resampler.paint(out.value, pos, hsml=hsml, mass=mass, transform=transform, diffdir=gradient,
                             _overwrite=not hold)
+            return out
+        if _ghosts_only(layout, resampler, transform, hsml):
+            # the caller's own particles are painted where they lie (those whose window misses
+            # the local block fall under the drop-outside rule, _window_generics.h:144-167);
+            # only the ghosts received from other ranks are exchanged
+            be = backend.get()
+            dpos, _ = to_device(pos, be.device, 'pos')
+            dmass = mass
+            if not _is_scalar(mass):
+                dmass, _ = to_device(mass, be.device, 'mass')
+            resampler.paint(out.value, dpos, mass=dmass, transform=transform, diffdir=gradient,
+                            _overwrite=not hold)
+            if layout.remote_recvlength or layout.comm.size > 1:
+                rpos = layout.exchange_remote(dpos)
+                rmass = dmass if _is_scalar(mass) else layout.exchange_remote(dmass)
+                if len(rpos):
+                    resampler.paint(out.value, rpos, mass=rmass, transform=transform, diffdir=gradient)
             return out
         localpos = layout.exchange(pos)
         localmass = exchange(layout, mass)

@@ -11,6 +11,8 @@ of pmesh/_window.pyx:128-205.
 """
 import ctypes as C
 
+import threading
+
 import numpy
 import torch
 
@@ -65,6 +67,11 @@ class Affine(object):
 # 'never' : always the direct (global-atomic) kernels.  'always': binned whenever legal.
 BINNED = 'auto'
 BINNED_MIN_PARTICLES = 1 << 17
+# 'auto' also asks for a minimum mean density (particles per cell of the local block): the
+# binned kernels pay a fixed cost per mesh tile, the direct ones per (particle x window
+# point).  Measured break-even on a 64 x 512 x 512 block (scripts/thresh_probe.py):
+# CIC 2^20 particles, PCS 2^17; thin ghost bands at a slab face sit well below both.
+BINNED_MIN_DENSITY = {1: 0.06, 2: 0.06, 3: 0.02, 4: 0.008}
 
 
 class _BinCache(object):
@@ -121,20 +128,35 @@ class _BinCache(object):
         self.entries = []
 
 
-_bin_cache = _BinCache()
+_bin_tls = threading.local()
+
+
+def bin_cache():
+    """the calling thread's plan cache (a plan is mutable device state: one cache per host
+    thread keeps concurrent callers from rebuilding each other's plans)"""
+    c = getattr(_bin_tls, 'cache', None)
+    if c is None:
+        c = _bin_tls.cache = _BinCache()
+    return c
 
 
 def clear_bin_cache():
     """Invalidate cached bin plans, e.g. at the start of a time step when positions
     were rewritten in place through a foreign pointer."""
-    _bin_cache.clear()
+    bin_cache().clear()
 
 
 def _binned_ok(be, painter, pos, n, hs):
     if BINNED == 'never' or be.name != 'hip' or hs is not None:
         return False
-    if BINNED == 'auto' and n < BINNED_MIN_PARTICLES:
-        return False
+    if BINNED == 'auto':
+        if n < BINNED_MIN_PARTICLES:
+            return False
+        cells = 1
+        for d in range(painter.ndim):
+            cells *= int(painter.size[d])
+        if n < BINNED_MIN_DENSITY.get(int(painter.support), 0.008) * cells:
+            return False
     return be.lib.pmx_binplan_supported(C.byref(painter), n) == 0
 
 
@@ -289,7 +311,7 @@ class ResampleWindow(object):
         n = pos.shape[0]
         if not (n and _binned_ok(be, p, pos, n, None)):
             return False
-        _bin_cache.lookup(be, pos, p, vec(pos), n)
+        bin_cache().lookup(be, pos, p, vec(pos), n)
         return True
 
     def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None, _overwrite=False):
@@ -334,7 +356,7 @@ class ResampleWindow(object):
         pv = vec(pos)
         hv = vec(hs) if hs is not None else None
         if n and _binned_ok(be, p, pos, n, hs):
-            plan = _bin_cache.lookup(be, pos, p, pv, n)
+            plan = bin_cache().lookup(be, pos, p, pv, n)
             be.call('paint_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv),
                     mass_scalar, int(bool(_overwrite)), be.stream())
         else:
@@ -392,7 +414,7 @@ class ResampleWindow(object):
         hv = vec(hs) if hs is not None else None
         ov = vec(dout)
         if n and _binned_ok(be, p, pos, n, hs):
-            plan = _bin_cache.lookup(be, pos, p, pv, n)
+            plan = bin_cache().lookup(be, pos, p, pv, n)
             be.call('readout_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), C.byref(ov),
                     be.stream())
         else:

@@ -122,6 +122,49 @@ def case_paint_distributed_equals_serial(be, comm):
         assert_allclose(g1, w1, rtol=0, atol=1e-12 * abs(w1).max())
 
 
+def case_ghosts_only_equals_literal(be, comm):
+    """paint/readout with a layout: own particles in place + ghosts only (pm._ghosts_only) gives
+    the same field / values as the reference's literal exchange -> local op -> gather
+    (pm.py:1857-1868, 783-791); layouts that do not cover the window take the literal path."""
+    from pmesh_amd import pm as PM
+    N, L = 16, 8.0
+    rs = numpy.random.RandomState(7 + comm.rank)
+    npart = 257 + 31 * comm.rank
+    pos = rs.uniform(-0.5 * L, 1.5 * L, size=(npart, 3))
+    mass = rs.uniform(0.5, 1.5, size=npart)
+    field = numpy.random.RandomState(5).normal(size=(N, N, N))
+    for resampler in ('nnb', 'cic', 'tsc', 'pcs'):
+        pm = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler=resampler)
+        layout = pm.decompose(pos)
+        assert PM._ghosts_only(layout, pm.resampler, pm.affine, None)
+        fld = pm.create('real', value=field[pm.create('real').slices])
+        res = {}
+        for mode in ('auto', 'never'):
+            comm.Barrier()              # thread ranks share the module: switch in step
+            PM.GHOSTS_ONLY = mode
+            comm.Barrier()
+            try:
+                a = pm.paint(pos, mass=mass, layout=layout)
+                b = pm.paint(pos, mass=mass, layout=layout, gradient=2, hold=True, out=a.copy())
+                r0 = fld.readout(pos, layout=layout)
+                r1 = fld.readout(pos, layout=layout, gradient=0)
+            finally:
+                comm.Barrier()
+                PM.GHOSTS_ONLY = 'auto'
+            res[mode] = [numpy.asarray(x.value.cpu()) if hasattr(x, 'value') else numpy.asarray(x)
+                         for x in (a, b, r0, r1)]
+        for x, y in zip(res['auto'], res['never']):
+            assert_allclose(x, y, rtol=0, atol=1e-12 * max(1.0, abs(y).max()))
+    # a layout narrower than the window, or one built for another scaling, is not eligible
+    pm = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler='pcs')
+    narrow = pm.decompose(pos, smoothing=0.5)
+    assert not PM._ghosts_only(narrow, pm.resampler, pm.affine, None)
+    assert not PM._ghosts_only(pm.decompose(pos), pm.resampler, pm.affine, numpy.ones(npart))
+    assert PM._ghosts_only(narrow, PM.FindResampler('nnb'), pm.affine, None)
+    a = pm.paint(pos, layout=narrow)        # literal path: runs, conserves what was routed
+    assert numpy.isfinite(a.csum())
+
+
 def case_slab_fft(be, comm):
     """r2c / c2r on P ranks == numpy.fft on the gathered mesh, incl. uneven blocks"""
     from pmesh_amd.pm import ParticleMesh
@@ -157,6 +200,27 @@ def case_slab_fft(be, comm):
         for d in range(len(Nmesh)):
             assert_array_equal(ck.i[d].cpu().numpy().ravel(),
                                numpy.arange(ck.slices[d].start, ck.slices[d].stop))
+
+
+def case_fused_transfer_slab(be, comm):
+    """c2r(transfer=T) on a slab decomposition (T folded into the first column pass of the
+    inverse transform) == apply(T).c2r(), and leaves the complex field untouched out of place"""
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    Nmesh = [64, 64, 128]
+    pm = ParticleMesh(BoxSize=[3.0, 2.0, 5.0], Nmesh=Nmesh, comm=comm, dtype='f8', np=[comm.size])
+    data = numpy.random.RandomState(23).normal(size=Nmesh)
+    ck = pm.create('real', value=data[pm.create('real').slices]).r2c()
+    for T in (Transfer.dx1(0), Transfer.dx1(1), Transfer.potential(), Transfer.force(2)):
+        assert pm.plans['backwardT'].can_fuse()
+        before = numpy.asarray(ck.value.cpu()).copy()
+        want = numpy.asarray(ck.apply(T).c2r().value.cpu())
+        got = numpy.asarray(ck.c2r(transfer=T).value.cpu())
+        assert_allclose(numpy.asarray(ck.value.cpu()), before, rtol=0, atol=0)
+        scale = comm.allreduce(float(abs(want).max()) if want.size else 0.0, op='max')
+        assert_allclose(got, want, rtol=0, atol=1e-12 * scale)
+        got2 = numpy.asarray(ck.copy().c2r(out=Ellipsis, transfer=T).value.cpu())
+        assert_allclose(got2, want, rtol=0, atol=1e-12 * scale)
 
 
 def case_cycle(be, comm):
@@ -234,7 +298,7 @@ def case_pencil(be, comm):
 
 
 CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
-         case_slab_fft, case_cycle]
+         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_cycle]
 
 
 def main():

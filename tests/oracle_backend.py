@@ -121,6 +121,18 @@ class OracleBackend(object):
         y = numpy.fft.ifft(x, axis=1) * N if inverse else numpy.fft.fft(x, axis=1)
         arr[...] = y * scale
 
+    def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0):
+        cdt = 'c8' if elsize == 4 else 'c16'
+        s = src.detach().numpy().reshape(-1).view(cdt)[:A * N * B]
+        d = dst.detach().numpy().reshape(-1).view(cdt)[:A * N * B]
+        R = N // nsplit
+        if inverse:
+            x = s.reshape(R, A, nsplit, B).transpose(1, 0, 2, 3).reshape(A, N, B).astype('c16')
+            d.reshape(A, N, B)[...] = numpy.fft.ifft(x, axis=1) * N * scale
+        else:
+            y = numpy.fft.fft(s.reshape(A, N, B).astype('c16'), axis=1) * scale
+            d.reshape(R, A, nsplit, B)[...] = y.reshape(A, R, nsplit, B).transpose(1, 0, 2, 3)
+
     def rowfft_supported(self, n, elsize):
         n = int(n)
         return 128 <= n <= 1024 and (n & (n - 1)) == 0

@@ -58,7 +58,7 @@ CASES = [
 
 
 def assert_binned_ran():
-    assert any(e[3] for e in window._bin_cache.entries), 'the tile-binned path was not taken'
+    assert any(e[3] for e in window.bin_cache().entries), 'the tile-binned path was not taken'
 
 
 @pytest.mark.parametrize('name', TUNED)
@@ -140,14 +140,14 @@ def test_plan_is_shared_and_invalidated(hip):
     c = torch.zeros((64, 64, 64), dtype=torch.float64, device=hip.device)
     W.paint(c, pos, transform=aff)
     assert_binned_ran()
-    built = [e[3] for e in window._bin_cache.entries]
+    built = [e[3] for e in window.bin_cache().entries]
     W.readout(c, pos, transform=aff)
-    assert [e[3] for e in window._bin_cache.entries] == built
-    keys = [e[0] for e in window._bin_cache.entries]
+    assert [e[3] for e in window.bin_cache().entries] == built
+    keys = [e[0] for e in window.bin_cache().entries]
     pos += 1.0                                    # in place: version changes
     c2 = torch.zeros((64, 64, 64), dtype=torch.float64, device=hip.device)
     W.paint(c2, pos, transform=aff)
-    assert [e[0] for e in window._bin_cache.entries] != keys
+    assert [e[0] for e in window.bin_cache().entries] != keys
     window.BINNED = 'never'
     c3 = torch.zeros((64, 64, 64), dtype=torch.float64, device=hip.device)
     W.paint(c3, pos, transform=aff)

@@ -54,6 +54,38 @@ def test_rowfft_lengths(be, elsize, tol, n):
         assert rel(back, x) < 2 * tol * numpy.log2(n)
 
 
+@pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
+@pytest.mark.parametrize('N,nsplit', [(64, 8), (128, 64), (256, 1), (512, 64), (64, 64)])
+def test_colfft_split(be, elsize, tol, N, nsplit):
+    """the axis-1 pass fused with the slab pack (forward) / unpack (inverse): the split layout
+    is [range r][a][line in range][b], exactly what slab_pack builds from the plain array"""
+    if not be.colfft_supported(N, elsize):
+        pytest.skip('length not built for this precision')
+    cdt = 'c16' if elsize == 8 else 'c8'
+    rs = numpy.random.RandomState(N + nsplit)
+    R = N // nsplit
+    for A, B in ((3, 9), (1, 33)):
+        x = (rs.normal(size=(A, N, B)) + 1j * rs.normal(size=(A, N, B))).astype(cdt)
+        src = torch.view_as_real(torch.from_numpy(x.copy())).reshape(-1).to(be.device)
+        dst = torch.zeros_like(src)
+        be.colfft_split(elsize, False, src, dst, A, N, B, nsplit, scale=0.25)
+        got = dst.cpu().numpy().view(cdt).reshape(R, A, nsplit, B)
+        want = (numpy.fft.fft(x.astype('c16'), axis=1) * 0.25).reshape(A, R, nsplit, B).transpose(1, 0, 2, 3)
+        assert rel(got, want) < tol * numpy.log2(N)
+        assert numpy.array_equal(src.cpu().numpy().view(cdt).reshape(A, N, B), x)     # input preserved
+        # the same as the plain pass followed by slab_pack
+        if R <= 64:         # slab_pack takes at most 64 ranges (PMX_MAXRANKS)
+            plain = src.clone()
+            be.colfft(elsize, False, plain, A, N, B, scale=0.25)
+            packed = torch.zeros_like(plain)
+            be.slab_pack(plain, packed, A, N, B, [r * nsplit for r in range(R + 1)], 2 * elsize)
+            assert numpy.array_equal(packed.cpu().numpy(), dst.cpu().numpy())
+        # inverse: split -> plain, undoing the forward up to N * scale
+        back = torch.zeros_like(src)
+        be.colfft_split(elsize, True, dst, back, A, N, B, nsplit, scale=4.0 / N)
+        assert rel(back.cpu().numpy().view(cdt).reshape(A, N, B), x) < 2 * tol * numpy.log2(N)
+
+
 def test_colfft_fused_transfer(be, oracle):
     """element (i0, i1, i2) * T(k) before the inverse axis-0 pass == apply_transfer + ifft"""
     N0, n1, n2 = 64, 6, 9
