@@ -42,6 +42,9 @@ constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 
 constexpr int TCELLS = T0 * T1 * T2;
 constexpr int TBLOCK = 256;
 constexpr int UNROLL = 4;             // particles in flight per lane in the tile kernels
+#ifndef PMX_ONEPASS_U
+#define PMX_ONEPASS_U 2
+#endif
 
 struct BinGeom {
     int32_t kind, S;
@@ -89,13 +92,21 @@ struct pmx_binplan {
     int32_t *tid = nullptr;     // tile id per particle (-1 = touches no local cell)
     uint32_t *list = nullptr;   // particle indices, tile major
     size_t cap_part = 0;
-    uint32_t *counts = nullptr; // particles per tile
-    int64_t *offsets = nullptr; // exclusive prefix (ntiles + 1)
+    size_t cap_list = 0;        // entries of `list`: npart + slack (see slot_capacity)
+    uint32_t *counts = nullptr; // particles per tile; entry [ntiles] = particles that touch no local cell
+    int64_t *offsets = nullptr; // first list slot of every tile (ntiles + 2 entries): tile t owns
+                                // slots [offsets[t], offsets[t+1]), of which counts[t] are used
     unsigned long long *cursor = nullptr;   // next free slot per tile while scattering
     size_t cap_tiles = 0;
-    uint32_t *flags = nullptr;  // [0] != 0: some particle is in no tile
+    uint32_t *flags = nullptr;  // [0] != 0: the single-pass build ran out of slots in some tile
+    uint32_t *host_flag = nullptr;          // pinned, device-visible: overflows seen so far
     void *halo = nullptr;       // staging of the halo cells: ntiles * Region<S>::HALO elements
     size_t cap_halo = 0;
+    // history for the single-pass build: the slot ranges of the previous build of the same
+    // geometry and particle count are reused (particles move little between time steps)
+    bool have_history = false;
+    uint32_t seen_overflows = 0;
+    int distrust = 0, skip = 0;  // back-off after an overflow
 };
 
 namespace pmx {
@@ -145,13 +156,29 @@ __device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, 
 // at a 24-byte stride touches three times the cache lines per instruction that a dense
 // load does (the kernel is address-path bound, not bandwidth bound), so the block copies
 // its 256 rows with 16-byte-per-lane loads into LDS and every lane picks its row there.
-template <int KIND, bool DENSE>
+// slots reserved for a tile that held c particles: a quarter more plus a constant, so that the
+// next build of slowly moving particles can reuse the ranges (single pass, see bin_onepass)
+__host__ __device__ __forceinline__ int64_t slot_capacity(int64_t c) { return c + (c >> 2) + 64; }
+
+// MODE 0: count pass of the two-pass build: tid[i] = tile, counts[tile]++.
+// MODE 1: single-pass build into the slot ranges of the previous build: the wave-aggregated
+//         atomic returns the first free slot of the group; particle i goes to
+//         list[offsets[tile] + slot] unless the tile's range is full (-> flags[0], host_flag).
+// Particles that touch no local cell go to bucket `ntiles`.  gate != NULL: do nothing unless
+// *gate != 0 (the fallback launches after a single-pass build are always enqueued and only
+// run if it overflowed — no host synchronisation).
+template <int KIND, bool DENSE, int MODE>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
-                                                           int32_t *tid, uint32_t *counts, uint32_t *flags)
+                                                           int32_t *tid, uint32_t *counts, uint32_t *flags,
+                                                           const int64_t *offsets, uint32_t *list,
+                                                           uint32_t *host_flag, const uint32_t *gate)
 {
     constexpr int S = Tuned<KIND>::S;
-    constexpr int U = 4;    // particle chunks per trip: U independent load -> atomic chains per wave
+    // particle chunks per trip: U independent load -> atomic chains per wave.  The single-pass
+    // mode waits for its atomics to return: fewer registers / less LDS per block, more waves
+    constexpr int U = MODE == 1 ? PMX_ONEPASS_U : 4;
     const int lane = threadIdx.x & 63;
+    if (gate != nullptr && *gate == 0) return;
     __shared__ __align__(16) unsigned char stage[DENSE ? U * TBLOCK * 24 : 16];
     for (int64_t base = blockIdx.x * (int64_t)(TBLOCK * U); base < n; base += (int64_t)gridDim.x * TBLOCK * U) {
         double xin[U][3];
@@ -207,7 +234,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                     ok = ok && local_base<KIND>(p, d, I[0], &i0w);
                     tt[d] = (i0w + g.o[d]) / tile_ext(d);
                 }
-                if (ok) t[u] = (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+                t[u] = ok ? (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2] : (int)g.ntiles;
             }
             // wave-aggregated counting: find the lanes that share my tile (ballots only)
             same[u] = 0;
@@ -221,32 +248,57 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
             }
         }
         // ONE atomicAdd instruction per chunk for the whole wave (the first lane of every
-        // group adds the group's population): no return value is needed here, the slots are
-        // handed out by bin_scatter_kernel
+        // group adds the group's population)
+        if (MODE == 0) {
+            // no return value needed: the slots are handed out by bin_scatter_kernel
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            int64_t i = base + u * TBLOCK + threadIdx.x;
-            const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
-            if (t[u] >= 0 && lane == leader) atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
-            if (i < n) {
-                if (t[u] < 0) atomicOr(&flags[0], 1u);
-                tid[i] = t[u];
+            for (int u = 0; u < U; u++) {
+                int64_t i = base + u * TBLOCK + threadIdx.x;
+                const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+                if (t[u] >= 0 && lane == leader) atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
+                if (i < n) tid[i] = t[u];
+            }
+        } else {
+            uint32_t b[U];
+            int64_t o0[U], o1[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+                b[u] = 0; o0[u] = 0; o1[u] = 0;
+                if (t[u] >= 0 && lane == leader) {
+                    b[u] = atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
+                    o0[u] = offsets[t[u]];
+                    o1[u] = offsets[t[u] + 1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int64_t i = base + u * TBLOCK + threadIdx.x;
+                const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+                const uint32_t bb = __shfl(b[u], leader);
+                const int64_t start = __shfl(o0[u], leader), end = __shfl(o1[u], leader);
+                if (t[u] >= 0) {
+                    int64_t slot = start + bb + __popcll(same[u] & (((unsigned long long)1 << lane) - 1));
+                    if (slot < end) list[slot] = (uint32_t)i;
+                    else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
+                }
             }
         }
     }
 }
 
-// exclusive scan of counts -> offsets[ntiles+1]; one workgroup
+// exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup
 __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
-                                                        unsigned long long *cursor)
+                                                        unsigned long long *cursor, const uint32_t *gate)
 {
     __shared__ int64_t sh[1024];
     __shared__ int64_t carry;
+    if (gate != nullptr && *gate == 0) return;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int64_t base = 0; base < ntiles; base += 1024) {
         int64_t i = base + threadIdx.x;
-        int64_t v = i < ntiles ? counts[i] : 0;
+        int64_t v = i < ntiles ? slot_capacity(counts[i]) : 0;
         sh[threadIdx.x] = v;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {
@@ -268,10 +320,11 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, 
 }
 
 __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
-                                                             uint32_t *list)
+                                                             uint32_t *list, const uint32_t *gate)
 {
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
+    if (gate != nullptr && *gate == 0) return;
     for (int64_t base = blockIdx.x * (int64_t)(TBLOCK * U); base < n; base += (int64_t)gridDim.x * TBLOCK * U) {
         int t[U];
         unsigned long long same[U], b[U];
@@ -304,6 +357,13 @@ __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid,
                 list[bb + (unsigned long long)__popcll(same[u] & (((unsigned long long)1 << lane) - 1))] = (uint32_t)i;
         }
     }
+}
+
+__global__ void __launch_bounds__(TBLOCK) bin_zero_kernel(uint32_t *counts, int64_t nbuckets, const uint32_t *gate)
+{
+    if (*gate == 0) return;
+    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < nbuckets; i += (int64_t)gridDim.x * TBLOCK)
+        counts[i] = 0;
 }
 
 __device__ __forceinline__ void tile_coords(const BinGeom &g, int64_t tile, int *t)
@@ -353,7 +413,7 @@ template <int KIND, typename T>
 __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
-                                                            T *halo, int overwrite)
+                                                            const uint32_t *counts, T *halo, int overwrite)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
@@ -366,7 +426,7 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
         int t[3];
         tile_coords(g, tile, t);
         const int64_t start = offsets[tile];
-        const int count = (int)(offsets[tile + 1] - start);
+        const int count = (int)counts[tile];
         if (count == 0 && !overwrite) continue;   // nothing to add; uniform per workgroup
         for (int q = threadIdx.x; q < Rg::CELLS; q += TBLOCK) lds[q] = 0;
         __syncthreads();
@@ -447,11 +507,11 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
 // at 512^3: the strided single-cell faces cost a read-modify-write of a whole sector each.)
 template <int S, typename T>
 __global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGeom g, char *canvas, const T *halo,
-                                                            const int64_t *offsets)
+                                                            const uint32_t *counts)
 {
     using Rg = Region<S>;
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        if (offsets[tile + 1] == offsets[tile]) continue;   // empty tile: its halo is zero
+        if (counts[tile] == 0) continue;   // empty tile: its halo is zero
         int t[3];
         tile_coords(g, tile, t);
         const T *hbase = halo + tile * (int64_t)Rg::HALO;
@@ -467,18 +527,19 @@ __global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGe
 }
 
 // entries of `out` for particles that are in no tile (they touch no local cell) read 0
-__global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint32_t *flags, const int32_t *tid, int64_t n,
-                                                              DVec out)
+__global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint32_t *list, const int64_t *offsets,
+                                                              const uint32_t *counts, int64_t ntiles, DVec out)
 {
-    if (flags[0] == 0) return;   // the common case: nothing was dropped
-    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * TBLOCK)
-        if (tid[i] < 0) out.set(i, 0, 0.0);
+    const int64_t n = counts[ntiles];   // the common case: nothing was dropped
+    const int64_t start = offsets[ntiles];
+    for (int64_t j = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * TBLOCK)
+        out.set((int64_t)list[start + j], 0, 0.0);
 }
 
 template <int KIND, typename T>
 __global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                               DVec pos, DVec out, const uint32_t *list,
-                                                              const int64_t *offsets)
+                                                              const int64_t *offsets, const uint32_t *counts)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
@@ -486,7 +547,7 @@ __global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, Bin
     __shared__ T lds[Rg::CELLS];
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t start = offsets[tile];
-        const int count = (int)(offsets[tile + 1] - start);
+        const int count = (int)counts[tile];
         if (count == 0) continue;
         int t[3];
         tile_coords(g, tile, t);
@@ -583,6 +644,7 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->offsets) (void)hipFree(pl->offsets);
     if (pl->cursor) (void)hipFree(pl->cursor);
     if (pl->flags) (void)hipFree(pl->flags);
+    if (pl->host_flag) (void)hipHostFree(pl->host_flag);
     if (pl->halo) (void)hipFree(pl->halo);
     delete pl;
     return PMX_OK;
@@ -638,58 +700,107 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         g.nt[d] = (int32_t)((p.size[d] + g.o[d] + T[d] - 1) / T[d]);
         g.ntiles *= g.nt[d];
     }
+    // The slot ranges of the previous build can be reused when it was for the same geometry
+    // and particle count (a time-stepping caller: particles move a fraction of a tile per
+    // step) and reuse has not just failed (back-off after an overflow).
+    bool reuse = pl->built && pl->have_history && pl->npart == npart && npart > 0 &&
+                 same_geometry(p, pl->painter) && pl->g.ntiles == g.ntiles;
+    if (pl->host_flag) {
+        uint32_t seen = *(volatile uint32_t *)pl->host_flag;   // stale at worst: a hint only
+        if (seen != pl->seen_overflows) {
+            pl->seen_overflows = seen;
+            pl->distrust = pl->distrust ? (pl->distrust < 64 ? 2 * pl->distrust : 64) : 1;
+            pl->skip = pl->distrust;
+        }
+    }
+    if (reuse && pl->skip > 0) {
+        pl->skip--;
+        reuse = false;
+    }
     pl->g = g;
     pl->painter = p;
     pl->npart = npart;
     pl->built = false;
+    const int64_t nbuckets = g.ntiles + 1;            // + the bucket of particles in no tile
     size_t np1 = (size_t)(npart > 0 ? npart : 1);
-    if (np1 * 4 > pl->cap_part) {
+    // every bucket reserves slot_capacity(count) <= 1.25 count + 64 slots
+    size_t nlist = np1 + np1 / 4 + 64 * (size_t)nbuckets + 64;
+    if (np1 * 4 > pl->cap_part || nlist > pl->cap_list) {
         size_t c1 = 0, c3 = 0;
         if (pl->tid) (void)hipFree(pl->tid);
         if (pl->list) (void)hipFree(pl->list);
-        pl->tid = nullptr; pl->list = nullptr; pl->cap_part = 0;
+        pl->tid = nullptr; pl->list = nullptr; pl->cap_part = 0; pl->cap_list = 0;
         rc = ensure((void **)&pl->tid, &c1, np1 * 4); if (rc) return rc;
-        rc = ensure((void **)&pl->list, &c3, np1 * 4); if (rc) return rc;
+        rc = ensure((void **)&pl->list, &c3, nlist * 4); if (rc) return rc;
         pl->cap_part = np1 * 4;
+        pl->cap_list = nlist;
+        reuse = false;
     }
-    if ((size_t)(g.ntiles + 1) > pl->cap_tiles) {
+    if ((size_t)(nbuckets + 1) > pl->cap_tiles) {
         size_t c1 = 0, c2 = 0, c3 = 0;
         if (pl->counts) (void)hipFree(pl->counts);
         if (pl->offsets) (void)hipFree(pl->offsets);
         if (pl->cursor) (void)hipFree(pl->cursor);
         pl->counts = nullptr; pl->offsets = nullptr; pl->cursor = nullptr; pl->cap_tiles = 0;
-        rc = ensure((void **)&pl->counts, &c1, (size_t)(g.ntiles + 1) * 4); if (rc) return rc;
-        rc = ensure((void **)&pl->offsets, &c2, (size_t)(g.ntiles + 1) * 8); if (rc) return rc;
-        rc = ensure((void **)&pl->cursor, &c3, (size_t)(g.ntiles + 1) * 8); if (rc) return rc;
-        pl->cap_tiles = (size_t)(g.ntiles + 1);
+        rc = ensure((void **)&pl->counts, &c1, (size_t)(nbuckets + 1) * 4); if (rc) return rc;
+        rc = ensure((void **)&pl->offsets, &c2, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
+        rc = ensure((void **)&pl->cursor, &c3, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
+        pl->cap_tiles = (size_t)(nbuckets + 1);
+        reuse = false;
     }
     if (!pl->flags) PMX_HIP_CHECK(hipMalloc((void **)&pl->flags, 16));
+    if (!pl->host_flag) {
+        PMX_HIP_CHECK(hipHostMalloc((void **)&pl->host_flag, 64, hipHostMallocMapped));
+        *pl->host_flag = 0;
+    }
     PMX_HIP_CHECK(hipMemsetAsync(pl->flags, 0, 16, st));
-    PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)(g.ntiles + 1) * 4, st));
+    PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)nbuckets * 4, st));
     DVec dpos = dvec(pos);
     if (npart > 0) {
-        unsigned grid = grid_for((npart + 3) / 4, TBLOCK);
+        const unsigned full_grid = grid_for((npart + 3) / 4, TBLOCK);
+        const unsigned small_grid = full_grid < 2048 ? full_grid : 2048;   // gated launches: cheap to skip
         // contiguous (n, 3) rows on a 16-byte boundary take the dense staging path
         const bool dense = pos->stride1 == pos->elsize && pos->stride0 == 3 * (int64_t)pos->elsize &&
                            (((uintptr_t)pos->data) & 15) == 0;
-#define BC(K)                                                                                                   \
+#define BC(K, MODE, GRID, GATE)                                                                                 \
     do {                                                                                                        \
-        if (dense) bin_count_kernel<K, true><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, pl->flags); \
-        else bin_count_kernel<K, false><<<grid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, pl->flags);      \
+        if (dense) bin_count_kernel<K, true, MODE><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE);                                         \
+        else bin_count_kernel<K, false, MODE><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE);                                         \
     } while (0)
-        switch (p.kind) {
-        case PMX_TUNED_NNB: BC(PMX_TUNED_NNB); break;
-        case PMX_TUNED_CIC: BC(PMX_TUNED_CIC); break;
-        case PMX_TUNED_TSC: BC(PMX_TUNED_TSC); break;
-        default: BC(PMX_TUNED_PCS); break;
+#define BCK(MODE, GRID, GATE)                                                                                   \
+    do {                                                                                                        \
+        switch (p.kind) {                                                                                       \
+        case PMX_TUNED_NNB: BC(PMX_TUNED_NNB, MODE, GRID, GATE); break;                                         \
+        case PMX_TUNED_CIC: BC(PMX_TUNED_CIC, MODE, GRID, GATE); break;                                         \
+        case PMX_TUNED_TSC: BC(PMX_TUNED_TSC, MODE, GRID, GATE); break;                                         \
+        default: BC(PMX_TUNED_PCS, MODE, GRID, GATE); break;                                                    \
+        }                                                                                                       \
+    } while (0)
+        const uint32_t *nogate = nullptr;
+        if (reuse) {
+            // single pass into the previous slot ranges; if a tile overflowed (flags[0]) the
+            // exact two-pass build below runs, otherwise its kernels return at once
+            BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
+            const uint32_t *gate = pl->flags;
+            bin_zero_kernel<<<64, TBLOCK, 0, st>>>(pl->counts, nbuckets, gate);
+            BCK(0, small_grid, gate);
+            bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, gate);
+            bin_scatter_kernel<<<small_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, gate);
+        } else {
+            BCK(0, full_grid, nogate);
+            bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate);
+            bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate);
         }
+#undef BCK
 #undef BC
+    } else {
+        bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nullptr);
     }
-    bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles, pl->offsets, pl->cursor);
-    if (npart > 0)
-        bin_scatter_kernel<<<grid_for((npart + 3) / 4, TBLOCK), TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list);
     PMX_HIP_CHECK(hipGetLastError());
     pl->built = true;
+    pl->have_history = npart > 0;
     return PMX_OK;
 }
 
@@ -703,8 +814,8 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     if (rc) return rc;
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
     T *halo = (T *)pl->halo;
-#define PT(K) paint_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, halo, overwrite)
-#define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->offsets)
+#define PT(K) paint_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite)
+#define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
     case PMX_TUNED_CIC: PT(PMX_TUNED_CIC); HM(2); break;
@@ -745,9 +856,9 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     hipStream_t st = (hipStream_t)stream;
     DVec dout = dvec(out), dpos = dvec(pos);
     // particles that touch no local cell are in no tile: they read 0
-    zero_dropped_kernel<<<grid_for(pl->npart, TBLOCK, 1024), TBLOCK, 0, st>>>(pl->flags, pl->tid, pl->npart, dout);
+    zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-#define RT(K, T) readout_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets)
+#define RT(K, T) readout_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
     if (p.canvas_elsize == 8) {
         switch (p.kind) {
         case PMX_TUNED_NNB: RT(PMX_TUNED_NNB, double); break;

@@ -83,7 +83,7 @@ class _BinCache(object):
     SLOTS = 2
 
     def __init__(self):
-        self.entries = []     # [key, plan handle, pos tensor (kept alive), built]
+        self.entries = []     # [key, plan handle, pos tensor (kept alive), built, clock, shape]
         self.clock = 0
 
     def _key(self, pos, painter):
@@ -97,14 +97,22 @@ class _BinCache(object):
             if e[0] == key and e[3]:
                 e[4] = self._tick()
                 return e[1]
-        if len(self.entries) < self.SLOTS:
+        # a plan that last served the same geometry and particle count rebuilds in a single
+        # pass over the positions (csrc/pmx_binned.hip: slot ranges of the previous build)
+        shape = key[2:] + (n,)
+        # free: invalidated entries and those built for an older version of this very tensor
+        free = [e for e in self.entries if not e[3] or (e[0] is not None and e[0][0] == key[0])]
+        like = [e for e in free if e[5] == shape]
+        if like:
+            e = min(like, key=lambda q: q[4])
+        elif len(self.entries) < self.SLOTS:
             plan = C.c_void_p()
             be.call('binplan_create', C.byref(plan))
-            e = [None, plan, None, False, 0]
+            e = [None, plan, None, False, 0, None]
             self.entries.append(e)
         else:
-            e = min(self.entries, key=lambda q: q[4])
-        e[0], e[2], e[3] = key, pos, False
+            e = min(free or [q for q in self.entries if q[5] == shape] or self.entries, key=lambda q: q[4])
+        e[0], e[2], e[3], e[5] = key, pos, False, shape
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
         e[3] = True
         e[4] = self._tick()
