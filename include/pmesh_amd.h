@@ -208,11 +208,15 @@ int pmx_fft_destroy(pmx_fft *plan);
  * is multiplied by `scale`.  transfer != NULL fuses ComplexField.apply (pm.py:1047-1070)
  * into the load of the axis-0 pass: A must be 1, B = n1*n2, element (i0, i1, i2) of the
  * local block starting at global index start[] is multiplied by T(k) first (closed forms
- * without transcendentals only: laplace_pow in -1..1, spectral gradient). */
+ * without transcendentals only: laplace_pow in -1..1, spectral gradient).
+ * a_stride / n_stride (complex elements, 0 = dense): stride between successive a (>= N*B) and,
+ * for A == 1, between successive lines n (>= B) — the padded plane stride of the one-rank
+ * complex layout. */
 int pmx_colfft_supported(int64_t n, int32_t elsize);
 int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
-               double scale, const pmx_transfer *transfer, int64_t n1, int64_t n2,
-               const int64_t *start, const int64_t *nmesh, const double *boxsize, void *stream);
+               double scale, const pmx_transfer *transfer, int64_t n1, int64_t n2, const int64_t *start,
+               const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride,
+               void *stream);
 
 /* The axis-1 column pass of a slab-decomposed transform fused with the pack / unpack that
  * brackets PFFT's global transpose (what pmx_slab_pack does, for equal power-of-two ranges):
@@ -225,10 +229,12 @@ int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst
 /* Real <-> half-complex transform along the contiguous axis, in place, with the rows
  * resident in LDS (csrc/pmx_colfft.hip): `nrows` rows of n reals (n a power of two in
  * 128..1024) at a pitch of `pitch` complex elements <-> n/2+1 modes.  inverse = 0: r2c,
- * 1: c2r; unnormalised, times `scale`. */
+ * 1: c2r; unnormalised, times `scale`.  rows_per_plane > 0: row r starts at
+ * (r / rows_per_plane) * plane_pitch + (r % rows_per_plane) * pitch complex elements (padded
+ * plane stride; rows_per_plane a multiple of 8 (f8) / 16 (f4)); 0: r * pitch. */
 int pmx_rowfft_supported(int64_t n, int32_t elsize);
 int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
-               double scale, void *stream);
+               double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream);
 
 /* Local transpose next to the all-to-all of a distributed FFT (PFFT's global transpose).
  * pmx_slab_pack  : src (n0, n1, n2) C order -> nparts contiguous blocks, block r = (n0,

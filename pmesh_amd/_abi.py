@@ -96,10 +96,10 @@ DEVICE_ONLY = {
     'fft_destroy': (C.c_int, [_vp]),
     'colfft_supported': (C.c_int, [_i64, _i32]),
     'colfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
-                         _P(_i64), _P(_f64), _vp]),
+                         _P(_i64), _P(_f64), _i64, _i64, _vp]),
     'colfft_split': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _vp]),
     'rowfft_supported': (C.c_int, [_i64, _i32]),
-    'rowfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _vp]),
+    'rowfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp]),
     'slab_pack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
     'slab_unpack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),
 }

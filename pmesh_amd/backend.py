@@ -93,11 +93,13 @@ class HipBackend(object):
         return self.lib.pmx_colfft_supported(int(n), int(elsize)) == 0
 
     def colfft(self, elsize, inverse, data, A, N, B, scale=1.0, transfer=None, n1=1, n2=1,
-               start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
-        """in-place FFT along the middle axis of the (A, N, B) complex array in `data`"""
+               start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0), a_stride=0, n_stride=0):
+        """in-place FFT along the middle axis of the (A, N, B) complex array in `data`
+        (a_stride / n_stride: padded strides between successive a / lines n, 0 = dense)"""
         self.call('colfft', elsize, int(bool(inverse)), data.data_ptr(), A, N, B, float(scale),
                   C.byref(transfer) if transfer is not None else None, n1, n2,
-                  _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3), self.stream())
+                  _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3),
+                  int(a_stride), int(n_stride), self.stream())
 
     def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0):
         """column FFT fused with the slab pack (forward: plain -> split) / unpack (inverse)"""
@@ -107,10 +109,11 @@ class HipBackend(object):
     def rowfft_supported(self, n, elsize):
         return self.lib.pmx_rowfft_supported(int(n), int(elsize)) == 0
 
-    def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0):
-        """in-place r2c / c2r of `nrows` rows of n reals at a pitch of `pitch` complex elements"""
+    def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0, rows_per_plane=0, plane_pitch=0):
+        """in-place r2c / c2r of `nrows` rows of n reals at a pitch of `pitch` complex elements
+        (rows_per_plane > 0: planes of that many rows, `plane_pitch` complex elements apart)"""
         self.call('rowfft', elsize, int(bool(inverse)), data.data_ptr(), nrows, n, pitch, float(scale),
-                  self.stream())
+                  int(rows_per_plane), int(plane_pitch), self.stream())
 
     # -- slab transposes --------------------------------------------------
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):

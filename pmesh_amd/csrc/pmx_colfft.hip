@@ -96,12 +96,13 @@ template <typename T, bool INV, int R> __device__ __forceinline__ void fftR(cpx<
     else fft2<T, INV>(v);
 }
 
-// Addressing of element (a, n, b): a*sa + (n >> sh)*shi + (n & mask)*B + b.  The plain
-// (A, N, B) array is sh = 31, mask = ~0, sa = N*B.  The "split" layout of the slab transpose
+// Addressing of element (a, n, b): a*sa + (n >> sh)*shi + (n & mask)*sn + b.  The plain
+// (A, N, B) array is sh = 31, mask = ~0, sa = N*B, sn = B (or padded strides: the one-rank
+// complex layout pads its plane stride, see fft.py).  The "split" layout of the slab transpose
 // cuts axis N into N/nl ranges of nl = 1 << sh lines, one contiguous (A, nl, B) block per
 // range (= per destination rank): sa = nl*B, shi = A*nl*B, mask = nl-1.
 struct ColAddr {
-    int64_t sa, shi;
+    int64_t sa, shi, sn;   // sn: stride between successive lines n (B when dense)
     int32_t sh, mask;
 };
 
@@ -261,7 +262,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             int n = tj + u * TPC;
-            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.B + col]
+            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + col]
                           : cpx<T>{0, 0};
         }
 #pragma unroll
@@ -301,7 +302,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
                 cpx<T> v = buf[lds_index<T, RB>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
-                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.B + col] = v;
+                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn + col] = v;
             }
         }
     }
@@ -317,7 +318,8 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 // FFT; unnormalised like rocFFT's C2R).  One read and one write of the array.
 template <typename T, int LOGM, bool INV>
 __global__ void __launch_bounds__((1 << LOGM) / 8 * (128 / (int)sizeof(cpx<T>)))
-rowfft_kernel(cpx<T> *data, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */)
+rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
+              int64_t rpp, int64_t plane_extra)
 {
     constexpr int M = 1 << LOGM;
     constexpr int W = 128 / (int)sizeof(cpx<T>);
@@ -335,6 +337,9 @@ rowfft_kernel(cpx<T> *data, int64_t nrows, int64_t pitch, double scale, const cp
     using Rd = Radices<LOGM>;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * W;
+        // rows are grouped in planes of rpp rows (a multiple of W: a tile never straddles two
+        // planes) whose stride exceeds rpp*pitch by plane_extra elements
+        cpx<T> *data = data_ + (rpp > 0 ? (r0 / rpp) * plane_extra : 0);
         __syncthreads();
         // load W rows, consecutive lanes along the row
         cpx<T> ld[8];
@@ -358,6 +363,10 @@ rowfft_kernel(cpx<T> *data, int64_t nrows, int64_t pitch, double scale, const cp
                 int k2 = M - k;
                 cpx<T> xk = buf[lds_index<T>(k, r)];
                 cpx<T> xq = (k == 0) ? xm[r] : buf[lds_index<T>(k2, r)];
+                // the DC and Nyquist modes of a real row are real: their imaginary parts are
+                // ignored, as FFTW's c2r (behind PFFT) and numpy.fft.irfft do — it matters for
+                // spectra that are not exactly Hermitian, e.g. after i k / k^2 on the Nyquist planes
+                if (k == 0) { xk.y = 0; xq.y = 0; }
                 // A = xk + conj(xq), D = xk - conj(xq)
                 cpx<T> A = {xk.x + xq.x, xk.y - xq.y}, D = {xk.x - xq.x, xk.y + xq.y};
                 cpx<T> w = tw[k];
@@ -497,7 +506,7 @@ static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const voi
 
 template <typename T, int LOGM>
 static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
-                         hipStream_t st)
+                         int64_t rpp, int64_t plane_extra, hipStream_t st)
 {
     constexpr int M = 1 << LOGM;
     constexpr int W = 128 / (int)sizeof(cpx<T>);
@@ -508,11 +517,11 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     if (inverse) {
         auto k = rowfft_kernel<T, LOGM, true>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra);
     } else {
         auto k = rowfft_kernel<T, LOGM, false>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra);
     }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -520,13 +529,13 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
 
 template <typename T>
 static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, double scale, const void *tw,
-                         bool inverse, hipStream_t st)
+                         bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st)
 {
     switch (logm) {
-    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, st);
-    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, st);
-    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, st);
-    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, st);
+    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     }
     set_error("pmx_rowfft: length 2^%d is not built", logm + 1);
     return PMX_EUNSUPPORTED;
@@ -548,11 +557,19 @@ extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
 // n reals -> n/2+1 modes; 1: c2r), row pitch `pitch` COMPLEX elements (>= n/2+1), result
 // multiplied by `scale`; unnormalised in both directions.
 extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
-                          double scale, void *stream)
+                          double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream)
 {
     int rc = pmx_rowfft_supported(n, elsize);
     if (rc) { set_error("pmx_rowfft: unsupported length %lld", (long long)n); return rc; }
     PMX_REQUIRE(data != nullptr && nrows >= 0 && pitch >= n / 2 + 1, PMX_EINVAL, "bad arguments");
+    int64_t plane_extra = 0;
+    if (rows_per_plane > 0) {
+        // row r lives at (r / rows_per_plane) * plane_pitch + (r % rows_per_plane) * pitch
+        PMX_REQUIRE(plane_pitch >= rows_per_plane * pitch, PMX_EINVAL, "plane_pitch smaller than a dense plane");
+        PMX_REQUIRE(rows_per_plane % (128 / (2 * elsize)) == 0, PMX_EUNSUPPORTED,
+                    "rows_per_plane must be a multiple of the rows of a tile");
+        plane_extra = plane_pitch - rows_per_plane * pitch;
+    }
     if (nrows == 0) return PMX_OK;
     hipStream_t st = (hipStream_t)stream;
     void *tw = nullptr;
@@ -560,14 +577,15 @@ extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t n
     if (rc) return rc;
     int logm = 0;
     while ((2ll << logm) < n) logm++;
-    if (elsize == 8) return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, st);
-    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, st);
+    if (elsize == 8)
+        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
 }
 
 static ColAddr plain_addr(int64_t N, int64_t B)
 {
     ColAddr a;
-    a.sa = N * B; a.shi = 0; a.sh = 31; a.mask = 0x7fffffff;
+    a.sa = N * B; a.shi = 0; a.sn = B; a.sh = 31; a.mask = 0x7fffffff;
     return a;
 }
 
@@ -586,7 +604,8 @@ extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 // multiplied by T(k) before the transform, with the index bookkeeping of pmx_apply_transfer.
 extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
                           double scale, const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
-                          const int64_t *nmesh, const double *boxsize, void *stream)
+                          const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride,
+                          void *stream)
 {
     int rc = pmx_colfft_supported(N, elsize);
     if (rc) { set_error("pmx_colfft: unsupported length %lld", (long long)N); return rc; }
@@ -598,6 +617,12 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     while ((1ll << g.logN) < N) g.logN++;
     g.n1 = 1; g.n2 = 1;
     g.in = g.out = plain_addr(N, B);
+    // padded layouts: a_stride = elements between successive a, n_stride between successive n
+    PMX_REQUIRE(a_stride == 0 || a_stride >= N * B, PMX_EINVAL, "a_stride smaller than a dense (N, B) block");
+    PMX_REQUIRE(n_stride == 0 || n_stride >= B, PMX_EINVAL, "n_stride smaller than B");
+    PMX_REQUIRE(n_stride == 0 || n_stride == B || A == 1, PMX_EINVAL, "a padded line stride needs A == 1");
+    if (a_stride) g.in.sa = g.out.sa = a_stride;
+    if (n_stride) g.in.sn = g.out.sn = n_stride;
     bool apply = t != nullptr;
     if (apply) {
         PMX_REQUIRE(A == 1 && n1 * n2 == B && B < (1ll << 31), PMX_EINVAL,
@@ -649,6 +674,7 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     while ((1ll << split.sh) < nsplit) split.sh++;
     split.mask = (int32_t)(nsplit - 1);
     split.sa = nsplit * B;
+    split.sn = B;
     split.shi = A * nsplit * B;
     g.in = inverse ? split : plain_addr(N, B);
     g.out = inverse ? plain_addr(N, B) : split;

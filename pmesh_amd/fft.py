@@ -148,6 +148,22 @@ class Partition(object):
             oshape_mem[-1] = pitch_c
         self.o_strides = _c_strides(oshape_mem)
         self.o_alloc = int(numpy.prod(oshape_mem, dtype='i8'))
+        # The axis-0 pass of the transform walks lines one plane apart.  A plane of N1 * pitch_c
+        # elements that is a multiple of 8 KiB (2^16 x 33 bytes at 512^3) puts all lines of a
+        # column on the same few HBM channels (562 us instead of 470 us per pass at 512^3,
+        # scripts/stride_probe.py): one extra 128-byte line per plane breaks the pattern.
+        # Only where the LDS row/column kernels (which take the plane stride) run the transform.
+        self.plane_c = None
+        if P == 1 and nd == 3 and PLANE_PAD and _own_kernel_lengths(self.Nmesh, itemsize):
+            plane = int(self.Nmesh[1]) * pitch_c
+            if (plane * 2 * itemsize) % 8192 == 0:
+                plane += 128 // (2 * itemsize)
+                self.plane_c = plane
+                n0 = int(self.Nmesh[0])
+                self.i_strides = [2 * plane, 2 * pitch_c, 1]
+                self.i_alloc = n0 * 2 * plane
+                self.o_strides = [plane, pitch_c, 1]
+                self.o_alloc = n0 * plane
         # one buffer serves both views (in-place transforms)
         self.alloc_reals = max(self.i_alloc, 2 * self.o_alloc, 2)
         if P > 1:
@@ -155,6 +171,19 @@ class Partition(object):
             n0loc = int(self.local_i_shape[0])
             mid = n0loc * int(numpy.prod(Nc[1:], dtype='i8'))
             self.alloc_reals = max(self.alloc_reals, 2 * mid)
+
+
+#: pad the plane stride of the one-rank 3-d layout (see Partition); False: dense planes
+PLANE_PAD = True
+
+
+def _own_kernel_lengths(Nmesh, itemsize):
+    """True if csrc/pmx_colfft.hip runs every stage of a 3-d transform of this mesh (the
+    arithmetic of pmx_rowfft_supported / pmx_colfft_supported, needed here without a backend)"""
+    n0, n1, n2 = [int(x) for x in Nmesh]
+    cmax = 1024 if itemsize == 8 else 512
+    pow2 = all(n & (n - 1) == 0 for n in (n0, n1, n2))
+    return pow2 and 64 <= n0 <= cmax and 64 <= n1 <= cmax and 128 <= n2 <= 1024 and n1 % 16 == 0
 
 
 def _pencil_init(self, np_, itemsize):
@@ -409,30 +438,38 @@ class Plan(object):
         N2c = p.pitch_c                       # row pitch in complex elements (>= N2/2+1)
         norm = 1.0 / float(N0) / float(N1) / float(N2)
         rows = N0 * N1
+        plane = p.plane_c                      # padded plane stride (complex elements) or None
+        rpp, ppitch, sa, sn = (N1, plane, plane, plane) if plane else (0, 0, 0, 0)
+        if plane and not inplace:
+            # the padded layout is only walked by the in-place kernels: transform a copy
+            n = p.i_alloc if self.forward else 2 * p.o_alloc
+            bufout.storage[:n].copy_(bufin.storage[:n])
+            bufin = bufout
+            inplace = True
         own_rows = inplace and be.rowfft_supported(N2, self.elsize)
         if self.forward:
             if own_rows:
-                be.rowfft(self.elsize, False, bufin.storage, rows, N2, N2c)
+                be.rowfft(self.elsize, False, bufin.storage, rows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
             else:
                 def make():
                     return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, [N2], [1], 2 * N2c, [1], N2c,
                                          rows, 1.0, inplace)
                 be.fft_execute(self._native(('z', inplace), make), bufin.storage, bufout.storage)
             out = bufout.storage
-            be.colfft(self.elsize, False, out, N0, N1, N2c)
-            be.colfft(self.elsize, False, out, 1, N0, N1 * N2c, scale=norm)
+            be.colfft(self.elsize, False, out, N0, N1, N2c, a_stride=sa)
+            be.colfft(self.elsize, False, out, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
         else:
             # in place on the complex data (c2r(out=...) made `bufin` a copy when needed)
             src = bufin.storage
             if transfer is not None:
                 t, start, nmesh, boxsize = transfer
                 be.colfft(self.elsize, True, src, 1, N0, N1 * N2c, transfer=t, n1=N1, n2=N2c,
-                          start=start, nmesh=nmesh, boxsize=boxsize)
+                          start=start, nmesh=nmesh, boxsize=boxsize, n_stride=sn)
             else:
-                be.colfft(self.elsize, True, src, 1, N0, N1 * N2c)
-            be.colfft(self.elsize, True, src, N0, N1, N2c)
+                be.colfft(self.elsize, True, src, 1, N0, N1 * N2c, n_stride=sn)
+            be.colfft(self.elsize, True, src, N0, N1, N2c, a_stride=sa)
             if own_rows:
-                be.rowfft(self.elsize, True, src, rows, N2, N2c)
+                be.rowfft(self.elsize, True, src, rows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
             else:
                 def make():
                     return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, [N2], [1], N2c, [1], 2 * N2c,

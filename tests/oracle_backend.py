@@ -110,9 +110,13 @@ class OracleBackend(object):
         return 64 <= n <= 1024 and (n & (n - 1)) == 0
 
     def colfft(self, elsize, inverse, data, A, N, B, scale=1.0, transfer=None, n1=1, n2=1,
-               start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
+               start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0), a_stride=0, n_stride=0):
         cdt = 'c8' if elsize == 4 else 'c16'
-        arr = data.detach().numpy().reshape(-1).view(cdt)[:A * N * B].reshape(A, N, B)
+        flat = data.detach().numpy().reshape(-1).view(cdt)
+        sa = a_stride or N * B
+        sn = n_stride or B
+        arr = numpy.lib.stride_tricks.as_strided(flat, (A, N, B), (sa * flat.itemsize, sn * flat.itemsize,
+                                                                   flat.itemsize))
         x = arr.astype('c16')
         if transfer is not None:
             blk = numpy.ascontiguousarray(x.reshape(N, n1, n2))
@@ -137,9 +141,15 @@ class OracleBackend(object):
         n = int(n)
         return 128 <= n <= 1024 and (n & (n - 1)) == 0
 
-    def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0):
+    def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0, rows_per_plane=0, plane_pitch=0):
         rdt, cdt = ('f4', 'c8') if elsize == 4 else ('f8', 'c16')
         flat = data.detach().numpy().reshape(-1)
+        if rows_per_plane:
+            # planes of rows_per_plane rows, plane_pitch complex elements apart
+            for a in range(nrows // rows_per_plane):
+                sub = data.reshape(-1)[2 * a * plane_pitch:]
+                self.rowfft(elsize, inverse, sub, rows_per_plane, n, pitch, scale=scale)
+            return
         real = flat.view(rdt)[:nrows * 2 * pitch].reshape(nrows, 2 * pitch)
         cplx = flat.view(cdt)[:nrows * pitch].reshape(nrows, pitch)
         if inverse:

@@ -55,6 +55,24 @@ def test_rowfft_lengths(be, elsize, tol, n):
 
 
 @pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
+def test_rowfft_c2r_ignores_imag_of_dc_and_nyquist(be, elsize, tol):
+    """c2r of rows whose DC / Nyquist modes carry an imaginary part (a spectrum that is not
+    exactly Hermitian, e.g. after a gradient transfer on the Nyquist planes): FFTW's c2r behind
+    PFFT and numpy.fft.irfft ignore those imaginary parts; so must this kernel."""
+    rdt, cdt = ('f8', 'c16') if elsize == 8 else ('f4', 'c8')
+    n, nrows, pitch = 256, 11, 256 // 2 + 8
+    rs = numpy.random.RandomState(4)
+    X = (rs.normal(size=(nrows, n // 2 + 1)) + 1j * rs.normal(size=(nrows, n // 2 + 1))).astype(cdt)
+    buf = numpy.zeros((nrows, pitch), dtype=cdt)
+    buf[:, :n // 2 + 1] = X
+    t = torch.view_as_real(torch.from_numpy(buf.copy())).reshape(-1).to(be.device)
+    be.rowfft(elsize, True, t, nrows, n, pitch)
+    got = t.cpu().numpy().view(rdt).reshape(nrows, 2 * pitch)[:, :n]
+    want = numpy.fft.irfft(X.astype('c16'), n=n, axis=1) * n
+    assert rel(got, want) < 2 * tol * numpy.log2(n)
+
+
+@pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
 @pytest.mark.parametrize('N,nsplit', [(64, 8), (128, 64), (256, 1), (512, 64), (64, 64)])
 def test_colfft_split(be, elsize, tol, N, nsplit):
     """the axis-1 pass fused with the slab pack (forward) / unpack (inverse): the split layout

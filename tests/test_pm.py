@@ -309,6 +309,69 @@ def test_fft_column_path_vs_numpy(be, dtype, tol, Nmesh):
     assert rel_l2(res['auto'], res['never']) < 2 * tol
 
 
+@pytest.mark.parametrize('Nmesh', [[8, 6, 10], [16, 16, 16], [64, 64, 40], [64, 64, 128], [12, 10]])
+def test_c2r_of_a_non_hermitian_spectrum(be, Nmesh):
+    """c2r == irfftn * prod(N) also for spectra that are not exactly Hermitian (what
+    i k_d / k^2 leaves on the Nyquist planes): like FFTW's c2r behind PFFT, numpy ignores the
+    imaginary parts of the self-conjugate modes of the last axis; rocFFT and the LDS kernels
+    must agree with that, in place and out of place."""
+    pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, dtype='f8')
+    rs = numpy.random.RandomState(12)
+    ck = pm.create(type='complex')
+    shape = tuple(ck.shape)
+    val = rs.normal(size=shape) + 1j * rs.normal(size=shape)
+    ck[...] = val
+    want = numpy.fft.irfftn(val, s=Nmesh, axes=list(range(len(Nmesh)))) * numpy.prod(Nmesh)
+    assert rel_l2(ck.c2r(), want) < 1e-13
+    assert rel_l2(ck.c2r(out=Ellipsis), want) < 1e-13
+
+
+@pytest.mark.parametrize('dtype,tol', [('f8', 1e-12), ('f4', 2e-5)])
+def test_cycle_on_the_padded_plane_layout(be, oracle, dtype, tol):
+    """One rank, 3-d, lengths of the LDS FFT kernels: complex rows are padded to 128 bytes and
+    the plane stride by one more line (fft.Partition).  Every consumer must be stride
+    agnostic: paint, r2c, apply (stand-alone and fused), c2r, readout, reductions — the whole
+    cycle against the oracle, in place and out of place, and the same numbers as the dense
+    layout."""
+    from pmesh_amd import fft as _fft
+    from oracle import oracle as O
+    Nmesh, L = [64, 64, 128], 10.0
+    rs = numpy.random.RandomState(3)
+    pos = rs.uniform(0, L, size=(4000, 3))
+    res = {}
+    for pad in (True, False):
+        _fft.PLANE_PAD = pad
+        try:
+            pm = ParticleMesh(BoxSize=L, Nmesh=Nmesh, dtype=dtype, resampler='tsc')
+            part = pm.plans['forwardT'].partition
+            assert (part.plane_c is not None) == pad
+            if pad:
+                assert part.plane_c > Nmesh[1] * part.pitch_c and part.o_strides[0] == part.plane_c
+            rho = pm.paint(pos)
+            assert abs(rho.csum() - len(pos)) < 1e-4 * len(pos)
+            ck = rho.r2c()                                   # out of place
+            ref = numpy.fft.rfftn(numpy.asarray(rho).astype('f8')) / numpy.prod(Nmesh)
+            assert rel_l2(ck, ref) < tol
+            T = Transfer.dx1(1)
+            a = numpy.asarray(ck.apply(T).c2r())             # stand-alone transfer kernel
+            b = numpy.asarray(ck.c2r(transfer=T))            # fused
+            assert rel_l2(b, a) < 10 * tol
+            f = rho.r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=T).readout(pos)   # all in place
+            res[pad] = (numpy.asarray(ck), a, numpy.asarray(f))
+        finally:
+            _fft.PLANE_PAD = True
+    t = O.make_transfer(laplace_pow=-1, grad_dir=1, grad_kind=0)
+    aff = O.Affine(3, scale=[n / L for n in Nmesh], period=Nmesh)
+    real = numpy.zeros(Nmesh)
+    O.Window('tunedtsc').paint(real, pos, transform=aff)
+    ck = O.apply_transfer(t, O.r2c(real), (0, 0, 0), Nmesh, (L, L, L))
+    want = O.Window('tunedtsc').readout(O.c2r(ck, Nmesh), pos, transform=aff)
+    for pad in (True, False):
+        assert rel_l2(res[pad][2], want) < 50 * tol
+    for x, y in zip(res[True], res[False]):
+        assert rel_l2(x, y) < 10 * tol
+
+
 @pytest.mark.parametrize('dtype,tol', [('f8', 1e-13), ('f4', 5e-6)])
 def test_c2r_with_fused_transfer(be, dtype, tol):
     """c2r(transfer=T) == apply(T).c2r(): fused into the first column pass where possible,
