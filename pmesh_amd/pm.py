@@ -1134,3 +1134,25 @@ def _smoke_cycle(O):
     real, ck, back, out = O.pm_cycle(N, L, pos_h, kind='tunedcic', transfer=t)
     err = abs(f.cpu().numpy() - out).max() / max(abs(out).max(), 1e-300)
     assert err < 1e-11, err
+    # the production form of the cycle at the smallest mesh the LDS FFT kernels take: tile-binned
+    # paint/readout, row + column FFT kernels on the padded layout, transfer fused into c2r
+    from . import window as _window
+    Nmesh, L = [64, 64, 128], 500.0
+    pm = ParticleMesh(Nmesh, BoxSize=L, dtype='f8', resampler='tsc')
+    pos_h = numpy.random.RandomState(7).uniform(0, L, size=(200000, 3))
+    pos = torch.from_numpy(pos_h).to(backend.get().device)
+    old = _window.BINNED
+    _window.BINNED = 'always'
+    try:
+        f = pm.paint(pos).r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=Transfer.dx1(1)).readout(pos)
+        assert any(e[3] for e in _window.bin_cache().entries), 'the tile-binned kernels did not run'
+    finally:
+        _window.BINNED = old
+    t = O.make_transfer(laplace_pow=-1, grad_dir=1, grad_kind=0)
+    aff = O.Affine(3, scale=[n / L for n in Nmesh], period=Nmesh)
+    real = numpy.zeros(Nmesh)
+    O.Window('tunedtsc').paint(real, pos_h, transform=aff)
+    ck = O.apply_transfer(t, O.r2c(real), (0, 0, 0), Nmesh, (L, L, L))
+    want = O.Window('tunedtsc').readout(O.c2r(ck, Nmesh), pos_h, transform=aff)
+    err = abs(f.cpu().numpy() - want).max() / max(abs(want).max(), 1e-300)
+    assert err < 1e-11, err
