@@ -406,3 +406,57 @@ def pm_cycle(nmesh, boxsize, pos, kind='tunedcic', transfer=None, gradient=None,
     back = c2r(ck.astype('c16'), shape).astype(dtype)
     out = W.readout(back, pos, transform=aff, diffdir=gradient)
     return real, ck, back, out
+
+
+# ---------------------------------------------------------------- white noise
+
+def whitenoise(shape, start, nmesh, seed, unitary=False, dtype='c16', out=None):
+    """pmesh.whitenoise.generate (3-d) by the oracle port: the local block `shape` at `start`
+    of the half spectrum of an `nmesh` mesh."""
+    value = numpy.zeros(shape, dtype=dtype) if out is None else out
+    assert value.ndim == 3 and value.dtype.kind == 'c'
+    L, prefix = lib('oracle')
+    fn = getattr(L, prefix + 'whitenoise')
+    _check(fn(int(seed) & 0xFFFFFFFF, int(bool(unitary)), _abi.i64arr(nmesh, 3), _abi.i64arr(start, 3),
+              _abi.i64arr(value.shape, 3), _abi.i64arr(value.strides, 3), value.dtype.itemsize,
+              value.ctypes.data_as(C.c_void_p), None), 'whitenoise')
+    return value
+
+
+class _RefGenerator(C.Structure):
+    """struct PMeshWhiteNoiseGenerator of pmesh/_whitenoise_imp.h:1-15"""
+    _fields_ = [('ndim', C.c_int), ('seed', C.c_uint), ('unitary', C.c_uint),
+                ('Nmesh', C.c_ssize_t * 32), ('start', C.c_ssize_t * 32),
+                ('canvas', C.c_void_p), ('canvas_dtype_elsize', C.c_int),
+                ('size', C.c_ssize_t * 32), ('strides', C.c_ssize_t * 32),
+                ('seedtable', (C.c_void_p * 2) * 2)]
+
+
+def have_whitenoise_ref():
+    return os.path.exists(os.path.join(_HERE, '_ref', 'libwhitenoise_ref.so'))
+
+
+_wn_ref = None
+
+
+def whitenoise_ref(shape, start, nmesh, seed, unitary=False, dtype='c16'):
+    """the same through the reference's own compiled C (oracle/_ref/libwhitenoise_ref.so =
+    pmesh/_whitenoise_imp.c + pmesh/gsl), driven as pmesh/_whitenoise.pyx:25-45 does"""
+    global _wn_ref
+    if _wn_ref is None:
+        _wn_ref = C.CDLL(os.path.join(_HERE, '_ref', 'libwhitenoise_ref.so'))
+    value = numpy.zeros(shape, dtype=dtype)
+    g = _RefGenerator()
+    g.canvas = value.ctypes.data
+    g.canvas_dtype_elsize = value.dtype.itemsize
+    g.ndim = 3
+    for d in range(3):
+        g.size[d] = value.shape[d]
+        g.start[d] = int(start[d])
+        g.strides[d] = value.strides[d]
+        g.Nmesh[d] = int(nmesh[d])
+    g.unitary = int(bool(unitary))
+    g.seed = int(seed) & 0xFFFFFFFF
+    _wn_ref.pmesh_whitenoise_generator_init(C.byref(g))
+    _wn_ref.pmesh_whitenoise_generator_fill(C.byref(g))
+    return value

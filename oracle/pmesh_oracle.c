@@ -793,3 +793,179 @@ int pmo_synth_clustered(const pmx_vec *pos, int64_t nlat, double boxsize, const 
     }
     return PMX_OK;
 }
+
+/* ------------------------------------------------------------ white noise */
+
+/* Gadget / N-GenIC compatible white noise in Fourier space
+ * (pmesh/_whitenoise_generics.h:29-238, _whitenoise_imp.c:21-105, pm.py:1656-1696).
+ *
+ * Random numbers: Luescher's double-precision RANLUX ("ranlxd", luxury level 1: 202
+ * subtract-with-borrow steps per 12 delivered numbers; M. Luescher, Comput. Phys. Commun. 79
+ * (1994) 100, and the v2 double-precision variant), seeded as GSL's gsl_rng_ranlxd1 does
+ * (pmesh/gsl/ranlxd.c:191-235): 31 seed bits feed a lagged-Fibonacci bit generator
+ * (lags 31, 13) that fills twelve 48-bit fractions.  State: x[0..11] in (2^-48)Z, a borrow,
+ * the ring position `ir` (the oldest entry, next to be replaced; the short lag is 7 slots
+ * ahead).  One step: y = x[ir+7] - x[ir] - borrow; y < 0 -> y += 1, borrow = 2^-48.  A draw
+ * advances ir and returns x[ir]; when ir comes back to where the last refill ended, 202 steps
+ * are made first (ranlxd.c:63-171: its three loops are exactly 202 such steps). */
+typedef struct {
+    double x[12];
+    double borrow;
+    int ir, ir_refill;
+} rlx_t;
+
+static void rlx_seed(rlx_t *s, unsigned long seed)
+{
+    const double ulp48 = 1.0 / 281474976710656.0;
+    int bits[31];
+    if (seed == 0) seed = 1;
+    int v = (int)(seed & 0xFFFFFFFFUL);          /* an int in the reference: bit 31 makes it negative */
+    for (int k = 0; k < 31; k++) { bits[k] = v % 2; v /= 2; }
+    int a = 0, b = 18;
+    for (int k = 0; k < 12; k++) {
+        double acc = 0;
+        for (int l = 0; l < 48; l++) {
+            double y = (double)((bits[a] + 1) % 2);
+            acc += acc + y;
+            bits[a] = (bits[a] + bits[b]) % 2;
+            a = (a + 1) % 31;
+            b = (b + 1) % 31;
+        }
+        s->x[k] = ulp48 * acc;
+    }
+    s->borrow = 0;
+    s->ir = 11;
+    s->ir_refill = 0;
+}
+
+static double rlx_uniform(rlx_t *s)
+{
+    const double ulp48 = 1.0 / 281474976710656.0;
+    s->ir = (s->ir + 1) % 12;
+    if (s->ir == s->ir_refill) {
+        int ir = s->ir;
+        for (int k = 0; k < 202; k++) {
+            double y = s->x[(ir + 7) % 12] - s->x[ir];
+            y = y - s->borrow;
+            if (y < 0) { s->borrow = ulp48; y += 1; } else s->borrow = 0;
+            s->x[ir] = y;
+            ir = (ir + 1) % 12;
+        }
+        s->ir = ir;
+        s->ir_refill = ir;
+    }
+    return s->x[s->ir];
+}
+
+/* one (phase, amplitude) draw: _whitenoise_imp.c:21-27 */
+static void wn_sample(rlx_t *s, double *ampl, double *phase)
+{
+    *phase = rlx_uniform(s) * 2 * M_PI;
+    do *ampl = rlx_uniform(s); while (*ampl == 0);
+}
+
+typedef struct {
+    int64_t nmesh[3], start[3], size[3];
+    uint32_t *table[2][2];      /* seeds of column (i, j) and of its mirror images */
+} wn_seeds;
+
+/* _whitenoise_imp.c:30-53: the next number of the master stream seeds column (i, j) and its
+ * conjugate partners (N0-i, j), (i, N1-j), (N0-i, N1-j); each goes to the table of the
+ * quadrant pairing it was reached through, if that column is held locally */
+static void wn_assign(wn_seeds *w, int i, int j, rlx_t *master)
+{
+    unsigned int seed = 0x7fffffff * rlx_uniform(master);
+    int ii[2] = {i, (int)((w->nmesh[0] - i) % w->nmesh[0])};
+    int jj[2] = {j, (int)((w->nmesh[1] - j) % w->nmesh[1])};
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) {
+            int64_t li = ii[a] - w->start[0], lj = jj[b] - w->start[1];
+            if (li >= 0 && li < w->size[0] && lj >= 0 && lj < w->size[1])
+                w->table[a][b][li * w->size[1] + lj] = seed;
+        }
+}
+
+int pmo_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nmesh, const int64_t *start,
+                   const int64_t *size, const int64_t *strides, int32_t elsize, void *canvas, void *stream)
+{
+    (void)stream;
+    if (elsize != 8 && elsize != 16) return PMX_EINVAL;
+    wn_seeds w;
+    for (int d = 0; d < 3; d++) { w.nmesh[d] = nmesh[d]; w.start[d] = start[d]; w.size[d] = size[d]; }
+    size_t ncol = (size_t)(size[0] * size[1]);
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) {
+            w.table[a][b] = (uint32_t *)calloc(ncol + 1, sizeof(uint32_t));
+            if (!w.table[a][b]) return PMX_ENOMEM;
+        }
+    const int N0 = (int)nmesh[0], N1 = (int)nmesh[1], N2 = (int)nmesh[2];
+    /* the master stream walks rings of growing index i over the four corners of the (i, j)
+     * plane (_whitenoise_generics.h:73-90; N-GenIC's order, which makes the large scales of a
+     * finer mesh equal those of a coarser one).  The mixed use of N0 / N1 is the reference's. */
+    rlx_t master;
+    rlx_seed(&master, seed);
+    for (int i = 0; i < N0 / 2; i++) {
+        for (int j = 0; j < i; j++) wn_assign(&w, i, j, &master);
+        for (int j = 0; j < i + 1; j++) wn_assign(&w, j, i, &master);
+        for (int j = 0; j < i; j++) wn_assign(&w, N0 - 1 - i, j, &master);
+        for (int j = 0; j < i + 1; j++) wn_assign(&w, N1 - 1 - j, i, &master);
+        for (int j = 0; j < i; j++) wn_assign(&w, i, N1 - 1 - j, &master);
+        for (int j = 0; j < i + 1; j++) wn_assign(&w, j, N0 - 1 - i, &master);
+        for (int j = 0; j < i; j++) wn_assign(&w, N0 - 1 - i, N1 - 1 - j, &master);
+        for (int j = 0; j < i + 1; j++) wn_assign(&w, N1 - 1 - j, N0 - 1 - i, &master);
+    }
+    /* half spectrum requested (no local mode with k2 > N2/2): one pass, sign +1; otherwise
+     * the negative half first, then the positive one (which then owns the Nyquist plane) */
+    int full = 0;
+    for (int64_t k = N2 / 2 + 1; k < N2; k++)
+        if (k - start[2] >= 0 && k - start[2] < size[2]) { full = 1; break; }
+    const int signs[2] = {full ? -1 : 1, full ? 1 : 0};
+
+    for (int64_t i = start[0]; i < start[0] + size[0]; i++) {
+        int64_t ci = (N0 - i) % N0;
+        for (int64_t j = start[1]; j < start[1] + size[1]; j++) {
+            int64_t cj = (N1 - j) % N1;
+            /* columns in the "upper" half take the k2 = 0 and k2 = N2/2 planes from the
+             * generator of their mirror column and conjugate (generics.h:121-131) */
+            int mirror = (ci == i && cj < j) || (ci < i && cj != j) || (ci < i && cj == j);
+            int64_t col = (i - start[0]) * size[1] + (j - start[1]);
+            for (int is = 0; is < 2 && signs[is] != 0; is++) {
+                int sign = signs[is];
+                rlx_t lower, self;
+                rlx_seed(&lower, w.table[mirror][mirror][col]);
+                rlx_seed(&self, sign == 1 ? w.table[0][0][col] : w.table[1][1][col]);
+                for (int64_t k = 0; k <= N2 / 2; k++) {
+                    int use_conj = mirror && (k == 0 || k == N2 / 2);
+                    double ampl, phase;
+                    if (use_conj) { wn_sample(&self, &ampl, &phase); wn_sample(&lower, &ampl, &phase); }
+                    else { wn_sample(&lower, &ampl, &phase); wn_sample(&self, &ampl, &phase); }
+                    int64_t k2 = sign == -1 ? N2 - k : k;
+                    /* generics.h:158-166 tests the UNREFLECTED k for membership, then writes at the
+                     * reflected index if that is inside the block (generics.h:11-27) */
+                    if (!(k - start[2] >= 0 && k - start[2] < size[2])) continue;
+                    ampl = unitary ? 1.0 : sqrt(-log(ampl));
+                    /* two adjacent calls, as in the reference: gcc pairs them into one sincos(),
+                     * whose last bit can differ from separate cos() / sin() calls */
+                    double re = ampl * cos(phase);
+                    double im = ampl * sin(phase);
+                    if (elsize == 8) { re = (float)re; im = (float)im; }
+                    if (sign == -1) im = -im;
+                    if (use_conj) im *= -1;
+                    if ((N0 - i) % N0 == i && (N1 - j) % N1 == j && (N2 - k2) % N2 == k2) {
+                        im = 0;
+                        if (unitary) re = 1;
+                    }
+                    if (i == 0 && j == 0 && k2 == 0) re = im = 0;
+                    int64_t r2 = k2 - start[2];
+                    if (r2 < 0 || r2 >= size[2]) continue;
+                    char *p = (char *)canvas + (i - start[0]) * strides[0] + (j - start[1]) * strides[1] + r2 * strides[2];
+                    if (elsize == 16) { ((double *)p)[0] = re; ((double *)p)[1] = im; }
+                    else { ((float *)p)[0] = (float)re; ((float *)p)[1] = (float)im; }
+                }
+            }
+        }
+    }
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) free(w.table[a][b]);
+    return PMX_OK;
+}

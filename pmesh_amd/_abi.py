@@ -74,6 +74,7 @@ PROTOTYPES = {
     'scatter_add': (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i64, _vp, _i64, _vp]),
     'apply_transfer': (C.c_int, [_P(Transfer), _i32, _i32, _vp, _P(_i64), _vp, _P(_i64),
                                  _P(_i64), _P(_i64), _P(_i64), _P(_f64), _vp]),
+    'whitenoise': (C.c_int, [C.c_uint32, _i32, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _i32, _vp, _vp]),
     'synth_uniform': (C.c_int, [_P(Vec), _i64, _f64, C.c_uint64, _i64, _i64, _vp]),
     'synth_clustered': (C.c_int, [_P(Vec), _i64, _f64, _P(_f64), _i32, _f64, _i64, _i64, _vp]),
 }

@@ -941,6 +941,37 @@ class ParticleMesh(object):
         grid = torch.meshgrid(*axes, indexing='ij')
         return torch.stack([g.reshape(-1) for g in grid], dim=-1)
 
+    def generate_whitenoise(self, seed, unitary=False, mean=0, type=None, mode=None, base=None):
+        """ Generate white noise to the field with the given seed (pm.py:1656-1696).
+
+            The scheme is compatible with Gadget / N-GenIC when the field is three-dimensional
+            (csrc/pmx_whitenoise.hip): the same seed gives the same modes whatever the domain
+            decomposition, and the same large scales whatever the mesh size.
+
+            seed : int; mean : the mean of the field (the k = 0 mode); unitary : True for a
+            unitary white noise where the amplitude is fixed to 1 and only the phase is random;
+            type : 'complex' (default), 'real', 'transposedcomplex', 'untransposedcomplex'.
+        """
+        from .whitenoise import generate
+        if mode is not None:
+            warnings.warn("mode argument is deprecated, use type", DeprecationWarning, stacklevel=2)
+            type = mode
+        if type is None:
+            type = TransposedComplexField
+        type = _typestr_to_type(type)
+        if type is RealField:
+            # the reference goes through the untransposed layout (pm.py:1679-1680); the modes do
+            # not depend on the layout, and the transposed one is the one built for P > 1
+            complex_type = UntransposedComplexField if self.comm.size == 1 else TransposedComplexField
+        else:
+            complex_type = type
+        complex = self.create(type=complex_type, base=base)
+        generate(complex.value, complex.start, complex.Nmesh, seed, bool(unitary))
+        # the mean: the k = 0 mode, held by the rank whose block starts at the origin
+        if all(int(s) == 0 for s in complex.start) and complex.value.numel():
+            complex.value[(0,) * self.ndim] = mean
+        return complex.cast(type=type, out=None if type is RealField else complex)
+
     def generate_uniform_particle_grid(self, shift=None, dtype=None, return_id=False):
         """
             uniform grid of particles, one per grid point, in BoxSize coordinate

@@ -16,7 +16,7 @@ def pytest_configure(config):
 def golden():
     import numpy
     d = os.path.join(ROOT, 'tests', 'golden')
-    return {name: numpy.load(os.path.join(d, name + '.npz')) for name in ('window', 'decompose', 'cycle16')}
+    return {name: numpy.load(os.path.join(d, name + '.npz')) for name in ('window', 'decompose', 'cycle16', 'whitenoise')}
 
 
 @pytest.fixture(scope='session')

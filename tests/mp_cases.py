@@ -223,6 +223,29 @@ def case_fused_transfer_slab(be, comm):
         assert_allclose(got2, want, rtol=0, atol=1e-12 * scale)
 
 
+def case_whitenoise(be, comm):
+    """generate_whitenoise does not depend on the decomposition (slab and pencil blocks gathered
+    == the one-block oracle field), type='real' is its c2r, the mean lands on the k = 0 mode"""
+    from pmesh_amd.pm import ParticleMesh
+    from oracle import oracle as O
+    Nmesh = [12, 16, 10]
+    want = O.whitenoise((12, 16, 6), (0, 0, 0), Nmesh, 4242)
+    nps = [[comm.size]]
+    if comm.size == 4:
+        nps.append([2, 2])
+    for np_ in nps:
+        pm = ParticleMesh(BoxSize=3.0, Nmesh=Nmesh, comm=comm, dtype='f8', np=np_)
+        c = pm.generate_whitenoise(4242, mean=2.5)
+        full = gather_field(comm, c, (12, 16, 6))
+        ref = want.copy()
+        ref[0, 0, 0] = 2.5
+        assert_allclose(full, ref, rtol=0, atol=1e-14)
+        r = pm.generate_whitenoise(4242, type='real', mean=2.5)
+        rfull = gather_field(comm, r, tuple(Nmesh))
+        assert_allclose(rfull, numpy.fft.irfftn(ref, s=Nmesh, axes=(0, 1, 2)) * numpy.prod(Nmesh), rtol=0, atol=1e-11)
+        assert abs(r.cmean() - 2.5) < 1e-12
+
+
 def case_cycle(be, comm):
     """the whole PM cycle on P ranks == the serial oracle cycle"""
     from pmesh_amd.pm import ParticleMesh
@@ -298,7 +321,7 @@ def case_pencil(be, comm):
 
 
 CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
-         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_cycle]
+         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_whitenoise, case_cycle]
 
 
 def main():

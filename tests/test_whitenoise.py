@@ -1,0 +1,173 @@
+"""White noise (pmesh/whitenoise.py, _whitenoise_imp.c; ParticleMesh.generate_whitenoise,
+pm.py:1656-1696): the reference's own tests (pmesh/tests/test_whitenoise.py, test_pm.py:634-659)
+restated, plus parity against the golden vectors generated from the reference itself
+(tests/golden/make_golden_whitenoise.py) and, in this container, against the reference's C
+compiled from where it lies (oracle/_ref/libwhitenoise_ref.so).
+
+The random streams (RANLUX) are exact integer arithmetic: every implementation must agree on
+them bit for bit.  The amplitudes go through log / sqrt / sin / cos: the C oracle (same libm as
+the reference build) reproduces the reference exactly; the device library is held to 4 ulp.
+"""
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_array_equal, assert_allclose
+
+from pmesh_amd.pm import ParticleMesh, ComplexField
+from pmesh_amd.whitenoise import generate
+
+
+def cases(golden):
+    g = golden['whitenoise']
+    for n in range(int(g['ncases'])):
+        yield (tuple(int(x) for x in g['%d/nmesh' % n]), tuple(int(x) for x in g['%d/start' % n]),
+               int(g['%d/seed' % n]), bool(g['%d/unitary' % n]), g['%d/value' % n])
+
+
+# ---- the oracle is pinned: golden (reference python API) and _ref (reference C) -------------
+
+def test_oracle_equals_golden(oracle, golden):
+    for nmesh, start, seed, unitary, value in cases(golden):
+        got = oracle.whitenoise(value.shape, start, nmesh, seed, unitary, value.dtype)
+        assert_array_equal(got, value)
+
+
+def test_oracle_equals_compiled_reference(oracle):
+    if not oracle.have_whitenoise_ref():
+        pytest.skip('oracle/_ref/libwhitenoise_ref.so not built (no reference tree here)')
+    rs = numpy.random.RandomState(0)
+    for t in range(25):
+        nm = tuple(int(x) for x in rs.choice([4, 6, 8, 10, 12, 16], size=3))
+        full = rs.rand() < 0.3                      # the oracle also restates the full-spectrum form
+        n2 = nm[2] if full else nm[2] // 2 + 1
+        st = tuple(int(rs.randint(0, n)) for n in (nm[0], nm[1], n2))
+        sh = tuple(int(rs.randint(1, n - s + 1)) for n, s in zip((nm[0], nm[1], n2), st))
+        seed = int(rs.randint(0, 2 ** 32, dtype='u8'))
+        un = bool(rs.rand() < 0.5)
+        dt = 'c16' if rs.rand() < 0.6 else 'c8'
+        assert_array_equal(oracle.whitenoise(sh, st, nm, seed, un, dt), oracle.whitenoise_ref(sh, st, nm, seed, un, dt))
+
+
+def test_3d_genic(oracle):                      # pmesh/tests/test_whitenoise.py:27-38
+    value = oracle.whitenoise((4, 4, 3), 0 * numpy.ones(3, 'i8'), (4, 4, 4), 5463)
+    assert_allclose(value[0, 1, 0], (-0.040000000000000001 - 0.029999999999999999j), atol=0.02)
+    assert_allclose(value[1, 0, 0], (0.35999999999999999 - 0.78000000000000003j), atol=0.02)
+    assert_allclose(value[1, 1, 0], (-0.42999999999999999 + 0.33000000000000002j), atol=0.02)
+    assert_allclose(value[1, 1, 1], (-1.6499999999999999 - 0.64000000000000001j), atol=0.02)
+
+
+# ---- the library under test (oracle double on CPU, HIP on the GPU) ---------------------------
+
+def ulp_close(got, want):
+    tol = 4 * (numpy.finfo('f8').eps if want.dtype == numpy.complex128 else numpy.finfo('f4').eps)
+    assert_allclose(got.real, want.real, rtol=0, atol=tol * max(1.0, abs(want).max()))
+    assert_allclose(got.imag, want.imag, rtol=0, atol=tol * max(1.0, abs(want).max()))
+
+
+def test_generate_equals_golden(be, golden):
+    for nmesh, start, seed, unitary, value in cases(golden):
+        t = torch.zeros(value.shape, dtype=torch.complex128 if value.dtype == numpy.complex128 else torch.complex64,
+                        device=be.device)
+        generate(t, start, nmesh, seed, unitary)
+        got = t.cpu().numpy()
+        ulp_close(got, value)
+        # the structure is exact: zeros (mean, imaginary part of self-conjugate modes) and, for
+        # unitary fields, the real self-conjugate modes
+        assert_array_equal(got == 0, value == 0)
+        assert_array_equal(got.imag == 0, value.imag == 0)
+
+
+def test_generate_strided_and_host_arrays(be, oracle):
+    nmesh, start, shape = (16, 16, 16), (2, 0, 1), (9, 16, 7)
+    want = oracle.whitenoise(shape, start, nmesh, 99)
+    # a padded (strided) device block, as the field views are
+    buf = torch.zeros((9, 16, 12), dtype=torch.complex128, device=be.device)
+    view = buf[:, :, 2:9]
+    generate(view, start, nmesh, 99, False)
+    ulp_close(view.cpu().numpy(), want)
+    assert float(buf[:, :, :2].abs().max()) == 0 and float(buf[:, :, 9:].abs().max()) == 0
+    # numpy in, numpy out
+    host = numpy.zeros(shape, dtype='c16')
+    generate(host, start, nmesh, 99, False)
+    ulp_close(host, want)
+
+
+def test_generate_3d(be):                       # pmesh/tests/test_whitenoise.py:6-25
+    Nmesh = 64 if be.name != 'hip' else 128
+    value = torch.zeros((Nmesh, Nmesh, Nmesh // 2 + 1), dtype=torch.complex128, device=be.device)
+    generate(value, 0, (Nmesh, Nmesh, Nmesh), 1, unitary=False)
+    v = value.cpu().numpy()
+    assert_allclose(v.real.std(), 0.5 ** 0.5, rtol=1e-2)
+    assert_allclose(v.imag.std(), 0.5 ** 0.5, rtol=1e-2)
+    piece = torch.zeros((32, 4, 4), dtype=torch.complex128, device=be.device)
+    offset = [2, 2, 2]
+    generate(piece, offset, (Nmesh, Nmesh, Nmesh), 1, unitary=False)
+    truth = v[offset[0]:offset[0] + 32, offset[1]:offset[1] + 4, offset[2]:offset[2] + 4]
+    assert_array_equal(piece.cpu().numpy(), truth)
+
+
+def test_generate_3d_hermitian(be):             # pmesh/tests/test_whitenoise.py:40-63
+    Nmesh = 4
+    value = numpy.zeros((Nmesh, Nmesh, Nmesh // 2 + 1), dtype='complex128')
+    generate(value, 0, (Nmesh, Nmesh, Nmesh), 5463, unitary=False)
+    h = numpy.fft.rfftn(numpy.fft.irfftn(value.copy(), s=(Nmesh,) * 3, axes=(0, 1, 2)))
+    assert_array_equal(value[1, 1, 0], (value[Nmesh - 1, Nmesh - 1, 0]).conjugate())
+    assert_array_equal(value[1, 1, Nmesh // 2], (value[Nmesh - 1, Nmesh - 1, Nmesh // 2]).conjugate())
+    assert_allclose(h, value, rtol=1e-5, atol=1e-9)
+
+
+def test_full_spectrum_form_is_refused(be):
+    value = torch.zeros((8, 8, 8), dtype=torch.complex128, device=be.device)
+    if be.name == 'hip':
+        with pytest.raises(Exception):
+            generate(value, 0, (8, 8, 8), 1, unitary=False)
+    else:
+        generate(value, 0, (8, 8, 8), 1, unitary=False)      # the oracle restates it
+        v = value.numpy()
+        assert_allclose(numpy.fft.ifftn(v).imag, 0, atol=1e-12)
+
+
+# ---- ParticleMesh.generate_whitenoise ----------------------------------------------------------
+
+def test_whitenoise_preserves_the_large_scales(be):   # test_pm.py:634-649
+    pm1 = ParticleMesh(BoxSize=8.0, Nmesh=[16, 16, 16], dtype='f8')
+    pm2 = ParticleMesh(BoxSize=8.0, Nmesh=[32, 32, 32], dtype='f8')
+    c1 = numpy.asarray(pm1.generate_whitenoise(seed=8, unitary=True))
+    c2 = numpy.asarray(pm2.generate_whitenoise(seed=8, unitary=True))
+    # modes |k_d| < 4 of both meshes (what resampling both down to 8^3 compares), Nyquist excluded
+    lo1 = numpy.r_[0:4, 13:16]
+    lo2 = numpy.r_[0:4, 29:32]
+    a = c1[numpy.ix_(lo1, lo1, numpy.arange(4))]
+    b = c2[numpy.ix_(lo2, lo2, numpy.arange(4))]
+    if be.name == 'hip':
+        assert_allclose(a, b, rtol=0, atol=1e-15)
+    else:
+        assert_array_equal(a, b)
+
+
+def test_whitenoise_mean(be):                   # test_pm.py:651-659
+    pm0 = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='f8')
+    complex1 = pm0.generate_whitenoise(seed=8, unitary=True, mean=1.0)
+    assert_allclose(complex1.c2r().cmean(), 1.0)
+    assert_allclose(complex(numpy.asarray(pm0.generate_whitenoise(seed=8))[0, 0, 0]), 0.0)
+
+
+def test_whitenoise_real_and_complex(be):       # test_pm.py:55-80
+    for Nmesh in ([8, 8, 8], [8, 8], [64, 64, 128]):
+        pm = ParticleMesh(BoxSize=8.0, Nmesh=Nmesh, dtype='f8')
+        real = pm.generate_whitenoise(seed=123, type='real')
+        cplx = pm.generate_whitenoise(seed=123, type='complex')
+        assert isinstance(cplx, ComplexField)
+        assert_allclose(numpy.asarray(real), numpy.asarray(cplx.c2r()), rtol=0, atol=1e-12 * numpy.prod(Nmesh) ** 0.5)
+        f1 = pm.generate_whitenoise(seed=123, type='untransposedcomplex')
+        assert_array_equal(numpy.asarray(f1), numpy.asarray(cplx))
+        # a field with unit variance per mode: c2r gives N^3 real numbers of variance ~ N^3
+        assert abs(numpy.asarray(real).std() / numpy.prod(Nmesh) ** 0.5 - 1) < 0.2
+
+
+def test_whitenoise_f4(be, oracle):
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[16, 16, 16], dtype='f4')
+    c = pm.generate_whitenoise(seed=5)
+    assert numpy.asarray(c).dtype == numpy.complex64
+    want = oracle.whitenoise((16, 16, 9), (0, 0, 0), (16, 16, 16), 5, False, 'c8')
+    ulp_close(numpy.asarray(c), want)
