@@ -290,7 +290,195 @@ class Field(NDArrayLike):
             ret = value[tuple(int(i) for i in localindex)].item()
         else:
             ret = 0
-        return self.pm.comm.allreduce(ret)
+        # every rank must bring the same kind of number to the collective
+        return self.pm.comm.allreduce(complex(ret) if value.is_complex() else float(ret))
+
+    def csetitem(self, index, y):
+        """ set a value at an absolute index collectively; maintains Hermitian conjugation
+            (pm.py:298-345).  Returns the value that was actually set. """
+        index = numpy.array(index, copy=True)
+        value, localindex = self._ctol(index)
+        if isinstance(self, BaseComplexField):
+            dualindex = numpy.negative(index)
+            if len(dualindex) == self.ndim + 1:
+                dualindex[-1] *= -1
+            dualindex[:self.ndim] += self.Nmesh
+            dualindex[:self.ndim] %= self.Nmesh
+            unused, duallocalindex = self._ctol(dualindex)
+        else:
+            duallocalindex = None          # real field, no dual
+        dualy = y
+        if localindex is None:
+            y = 0
+        if duallocalindex is None:
+            dualy = 0
+        if len(index) == self.ndim + 1 and index[-1] == 1:
+            dualy = -dualy
+            if localindex is not None and duallocalindex is not None and localindex == duallocalindex:
+                y = 0                      # self dual and imag
+                dualy = 0
+        elif len(index) == self.ndim:
+            dualy = numpy.conjugate(dualy)
+            if localindex is not None and duallocalindex is not None and localindex == duallocalindex:
+                dualy = dualy.real         # self conjugate
+                y = y.real
+        if localindex is not None:
+            value[tuple(int(i) for i in localindex)] = y
+        if duallocalindex is not None:
+            value[tuple(int(i) for i in duallocalindex)] = dualy
+        r = self.pm.comm.allreduce(complex(y) if value.is_complex() else float(numpy.real(y)))
+        if isinstance(r, complex) and r.imag == 0 and not isinstance(y, complex):
+            r = r.real
+        return r
+
+    # ---- C-order redistribution (pm.py:384-448; the reference uses mpsort) --------------
+    def _cindex(self):
+        """ position of every local element in the C-ordered global array (int64 tensor) """
+        dev = self.value.device
+        g = torch.zeros([int(n) for n in self.shape], dtype=torch.int64, device=dev)
+        for d in range(self.ndim):
+            idx = torch.arange(int(self.start[d]), int(self.start[d]) + int(self.shape[d]), device=dev)
+            g = g * int(self.cshape[d]) + idx.reshape([-1 if dd == d else 1 for dd in range(self.ndim)])
+        return g
+
+    def sort(self, out=None):
+        warnings.warn("Use ravel instead of sort", DeprecationWarning, stacklevel=2)
+        return self.ravel(out)
+
+    def unsort(self, flatiter):
+        warnings.warn("Use pm.unravel instead of unsort", DeprecationWarning, stacklevel=2)
+        return self.unravel(flatiter)
+
+    def ravel(self, out=None):
+        """ Ravel the field to 'C'-order, partitioned by ranks: rank r receives the next
+            `self.size` items of the global C-ordered sequence (pm.py:389-424).
+
+            out : None (a new 1-d device tensor is returned), Ellipsis (in place: the local
+            buffer is overwritten), a device tensor, or a numpy array / flatiter (filled on
+            the host).  Returns what was filled. """
+        n = int(self.size)
+        if self.pm.comm.size > 1:
+            offs = _flat_offsets(self.pm.comm, n)
+            res = torch.empty(n, dtype=self.value.dtype, device=self.value.device)
+            _cpush(self.pm.comm, self.value.reshape(-1), self._cindex().reshape(-1), res, offs)
+        else:
+            res = self.value.reshape(-1)          # a single rank is already in C order
+        if out is None:
+            return res.clone() if self.pm.comm.size == 1 else res
+        if is_inplace(out):
+            self.value[...] = res.reshape(self.value.shape)
+            return self.value
+        if is_tensor(out):
+            out.reshape(-1).copy_(res)
+            return out
+        flat = out if isinstance(out, numpy.flatiter) else out.flat
+        assert len(flat) == n
+        flat[...] = res.cpu().numpy()
+        return flat
+
+    def unravel(self, flatiter):
+        """ Fill the field from C-ordered values partitioned over the ranks in any way
+            (pm.py:426-448): `flatiter` is this rank's consecutive piece (numpy array, flatiter or
+            device tensor); the pieces of all ranks, in rank order, are the global array. """
+        if is_tensor(flatiter):
+            flat = flatiter.reshape(-1)
+        else:
+            if not isinstance(flatiter, numpy.flatiter):
+                flatiter = numpy.asarray(flatiter).flat
+            a = numpy.array(flatiter, copy=True)
+            a.setflags(write=True)
+            flat = torch.from_numpy(a).to(self.value.device)
+        if flat.dtype != self.value.dtype:
+            flat = flat.to(self.value.dtype)
+        comm = self.pm.comm
+        assert comm.allreduce(int(flat.numel())) == self.csize
+        if comm.size > 1:
+            offs = _flat_offsets(comm, int(flat.numel()))
+            vals = _ctake(comm, flat, offs, self._cindex().reshape(-1))
+            self.value[...] = vals.reshape(self.value.shape)
+        else:
+            self.value[...] = flat.reshape(self.value.shape)
+
+    def resample(self, out):
+        """ Resample the Field by filling 0 or truncating modes.  Convert from and between
+            Real/Complex automatically (pm.py:479-547).
+
+            out : Field of another ParticleMesh (RealField or a complex field). """
+        assert isinstance(out, Field)
+        if all(out.Nmesh == self.Nmesh):
+            # no resampling needed, just the Fourier transforms (the reference then still runs
+            # the mode loop below, which removes the Nyquist planes; kept)
+            self.cast(type=_gettype(out), out=out)
+        src = self.cast(type=TransposedComplexField)
+        complex = out.pm.create(type=TransposedComplexField, base=out._base, value=0)
+        tmp = src.ravel()
+        dev = tmp.device
+        # indtable stores the index in the source for the mode in the destination
+        indtable = [reindex(int(src.Nmesh[d]), int(out.Nmesh[d])) for d in range(src.ndim)]
+        ind = build_index([t[numpy.r_[sl]] for t, sl in zip(indtable, complex.slices)], src.cshape)
+        ind = torch.from_numpy(ind).to(dev)
+        mask = ind >= 0
+        argind = ind[mask]
+        if src.pm.comm.size > 1:
+            data = _ctake(src.pm.comm, tmp, _flat_offsets(src.pm.comm, int(tmp.numel())), argind)
+        else:
+            data = tmp[argind]
+        complex.value[mask] = data.to(complex.value.dtype)
+        # ensure the down sample is real; remove the Nyquist planes of the output and of the input
+        ii = [torch.arange(int(st), int(st) + int(n), device=dev).reshape([-1 if dd == d else 1 for dd in range(src.ndim)])
+              for d, (st, n) in enumerate(zip(complex.start, complex.shape))]
+        selfconj = functools.reduce(operator.and_, [(int(n) - i) % int(n) == i for i, n in zip(ii, complex.Nmesh)])
+        selfconj = selfconj.expand(complex.value.shape)
+        complex.value.imag[selfconj] = 0
+        for Nm in (complex.Nmesh, src.Nmesh):
+            nyq = functools.reduce(operator.or_, [i == int(n) // 2 for i, n in zip(ii, Nm)])
+            complex.value[nyq.expand(complex.value.shape)] = 0
+        if isinstance(out, RealField):
+            complex.c2r(out)
+        elif complex._base is not out._base or _gettype(out) is not TransposedComplexField:
+            complex.cast(type=_gettype(out), out=out)
+        return out
+
+    def preview(self, Nmesh=None, axes=None, resampler=None, method=None):
+        """ gathers the mesh into a numpy array (with reduced resolution), projected onto
+            `axes`, broadcast to all ranks (pm.py:549-615).
+
+            Nmesh : desired Nmesh of the result or None; axes : axes to preserve;
+            method : "upsample" | "downsample" | None (by the direction of the change). """
+        if axes is None:
+            axes = range(self.ndim)
+        if not hasattr(axes, '__iter__'):
+            axes = (axes,)
+        else:
+            axes = list(axes)
+        if isinstance(self, BaseComplexField):
+            self = self.c2r()
+        if Nmesh is not None:
+            Nmesh = numpy.ones(self.ndim, dtype='intp') * numpy.asarray(Nmesh)
+            if all(Nmesh == self.Nmesh):
+                Nmesh = None
+        if Nmesh is not None:
+            pm = self.pm.reshape(Nmesh)
+            if method is None:
+                method = 'downsample' if any(Nmesh < self.Nmesh) else 'upsample'
+            if method == 'downsample':
+                out = pm.downsample(self, resampler=resampler, keep_mean=True)
+            elif method == 'upsample':
+                out = pm.upsample(self, resampler=resampler, keep_mean=True)
+            else:
+                raise ValueError("method can only be downsample or upsample")
+        else:
+            out = self
+        result = numpy.zeros([out.cshape[i] for i in axes], dtype=out.dtype)
+        local_slice = tuple([out.slices[i] for i in axes])
+        value = out.value
+        if len(axes) != self.ndim:
+            removeaxes = [d for d in range(self.ndim) if d not in axes]
+            value = value.permute(list(axes) + removeaxes).sum(dim=tuple(range(len(axes), self.ndim)))
+        else:
+            value = value.permute(list(axes))
+        result[local_slice] += value.cpu().numpy()
+        return numpy.asarray(self.pm.comm.allreduce(result))
 
     def cast(self, type=None, out=None):
         """ cast the field object to the given type, maintaining the meaning of the field
@@ -714,6 +902,82 @@ def _ghosts_only(layout, resampler, transform, hsml):
     return bool(numpy.all(smoothing >= 0.5 * resampler.support))
 
 
+def build_index(indices, fullshape):
+    """ Build a linear index array based on indices on an array of fullshape, similar to
+        numpy.ravel_multi_index; an index of -1 on any axis gives -1 (pm.py:1091-1126). """
+    localshape = [len(i) for i in indices]
+    ndim = len(localshape)
+    ind = numpy.zeros(localshape, dtype='i8')
+    mask = numpy.zeros(localshape, dtype='?')
+    for d in range(ndim):
+        i = numpy.asarray(indices[d]).reshape([-1 if dd == d else 1 for dd in range(ndim)])
+        ind[...] *= int(fullshape[d])
+        ind[...] += i
+        mask |= i == -1
+    ind[mask] = -1
+    return ind
+
+
+def reindex(Nsrc, Ndest):
+    """ the index in the frequency array of Nsrc for the corresponding k of Ndest; -1 for
+        those of Ndest that do not exist in Nsrc (pm.py:1128-1144):
+        reindex(8, 4) -> [0, 1, 2, 7];  reindex(4, 8) -> [0, 1, 2, -1, -1, -1, -1, 3] """
+    r = numpy.arange(Ndest)
+    r[Ndest // 2 + 1:] = numpy.arange(Nsrc - Ndest // 2 + 1, Nsrc, 1)
+    r[Nsrc // 2 + 1: Ndest - Nsrc // 2 + 1] = -1
+    return r
+
+
+# ---- global C-order gather / scatter over the ranks (what the reference uses mpsort for) ----
+def _flat_offsets(comm, n):
+    """ offsets of the ranks' consecutive pieces of a global flat array """
+    sizes = comm.allgather(int(n))
+    return numpy.concatenate([[0], numpy.cumsum(sizes)]).astype('i8')
+
+
+def _as_rows(t):
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+def _route(comm, dest, payloads):
+    """ send row k of every payload to rank dest[k]; returns the received payloads and what is
+        needed to send answers back in the original order """
+    order = torch.argsort(dest, stable=True)
+    counts = torch.bincount(dest, minlength=comm.size).cpu().numpy().astype('i8')
+    recvcounts = numpy.asarray(comm.alltoall_counts(counts)).astype('i8')
+    nrecv = int(recvcounts.sum())
+    got = []
+    for p in payloads:
+        rows = _as_rows(p[order].contiguous())
+        r = torch.empty((nrecv,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        comm.alltoallv(rows, counts, r, recvcounts)
+        got.append(torch.view_as_complex(r) if p.is_complex() else r)
+    return got, order, counts, recvcounts
+
+
+def _cpush(comm, values, gidx, out, offs):
+    """ out[g - offs[rank]] = v on the rank whose piece [offs[r], offs[r+1]) contains g """
+    edges = torch.as_tensor(offs[1:], device=gidx.device)
+    dest = torch.bucketize(gidx, edges, right=True)
+    (g, v), _, _, _ = _route(comm, dest, [gidx, values])
+    out[g - int(offs[comm.rank])] = v
+
+
+def _ctake(comm, flat, offs, gidx):
+    """ the values at global positions gidx of the flat array whose pieces the ranks hold """
+    edges = torch.as_tensor(offs[1:], device=gidx.device)
+    dest = torch.bucketize(gidx, edges, right=True)
+    (g,), order, counts, recvcounts = _route(comm, dest, [gidx])
+    ans = _as_rows(flat[g - int(offs[comm.rank])].contiguous())
+    back = torch.empty((int(gidx.numel()),) + tuple(ans.shape[1:]), dtype=ans.dtype, device=ans.device)
+    comm.alltoallv(ans, recvcounts, back, counts)
+    if flat.is_complex():
+        back = torch.view_as_complex(back)
+    res = torch.empty_like(back)
+    res[order] = back
+    return res
+
+
 def exchange(layout, value):
     """ pm.py:1146-1157: scalars are not exchanged """
     if value is None:
@@ -940,6 +1204,12 @@ class ParticleMesh(object):
                 for n, s in zip(partition.local_i_shape, partition.local_i_start)]
         grid = torch.meshgrid(*axes, indexing='ij')
         return torch.stack([g.reshape(-1) for g in grid], dim=-1)
+
+    def unravel(self, type, flatiter):
+        """ Unravel c-ordered field values into a new field of `type` (pm.py:1636-1654). """
+        r = self.create(type=type)
+        r.unravel(flatiter)
+        return r
 
     def generate_whitenoise(self, seed, unitary=False, mean=0, type=None, mode=None, base=None):
         """ Generate white noise to the field with the given seed (pm.py:1656-1696).

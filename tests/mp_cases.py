@@ -246,6 +246,64 @@ def case_whitenoise(be, comm):
         assert abs(r.cmean() - 2.5) < 1e-12
 
 
+def case_ravel_resample_preview(be, comm):
+    """the C-order redistribution (ravel/unravel), Fourier resampling, collective item access and
+    preview on several ranks (test_pm.py:394-454, 553-630, 780-814)"""
+    from pmesh_amd.pm import ParticleMesh, RealField, ComplexField
+    # ravel / unravel: slab blocks of a 3-d mesh (the transposed complex layout really moves data)
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 6, 4], comm=comm, dtype='f8', np=[comm.size])
+    real = RealField(pm)
+    truth = numpy.arange(8 * 6 * 4, dtype='f8')
+    real[...] = truth.reshape(8, 6, 4)[real.slices]
+    unsorted = numpy.asarray(real).copy()
+    flat = real.ravel()
+    assert len(flat) == real.size
+    assert_array_equal(numpy.concatenate(comm.allgather(flat.cpu().numpy())), truth)
+    real[...] = 0
+    real.unravel(flat)
+    assert_array_equal(numpy.asarray(real), unsorted)
+    cplx = ComplexField(pm)
+    ctruth = numpy.arange(8 * 6 * 3) * (1 + 2j)
+    cplx[...] = ctruth.reshape(8, 6, 3)[cplx.slices]
+    cflat = cplx.ravel()
+    assert_array_equal(numpy.concatenate(comm.allgather(cflat.cpu().numpy())), ctruth)
+    # unravel from an arbitrary partition of the flat array: everything on the last rank
+    piece = ctruth if comm.rank == comm.size - 1 else ctruth[:0]
+    again = pm.unravel(ComplexField, piece)
+    assert_array_equal(numpy.asarray(again), numpy.asarray(cplx))
+    # Fourier down-sampling == the one-rank result
+    pm1 = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], comm=comm, dtype='f8', np=[comm.size])
+    pm2 = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4, 4], comm=comm, dtype='f8', np=[comm.size])
+    data = numpy.random.RandomState(3333).normal(size=(8, 8, 8))
+    c1 = pm1.create('real', value=data[pm1.create('real').slices]).r2c()
+    down = ComplexField(pm2)
+    c1.resample(down)
+    full = numpy.fft.rfftn(data) / 8 ** 3
+    pick = numpy.r_[0:3, 7]                       # modes 0, 1, 2(-> Nyquist, removed), -1
+    want = full[numpy.ix_(pick, pick, numpy.arange(3))].copy()
+    want[2, :, :] = 0
+    want[:, 2, :] = 0
+    want[:, :, 2] = 0
+    got = gather_field(comm, down, (4, 4, 3))
+    assert_allclose(got, want, rtol=0, atol=1e-14)
+    rdown = RealField(pm2)
+    c1.resample(rdown)
+    assert_allclose(gather_field(comm, rdown.r2c(), (4, 4, 3)), want, rtol=0, atol=1e-14)
+    # collective item access
+    v = down.cgetitem((1, 3, 1))
+    assert abs(v - want[1, 3, 1]) < 1e-14
+    z = ComplexField(pm2)
+    z[...] = 0
+    assert z.csetitem((1, 0, 0), 100 + 10j) == 100 + 10j
+    assert abs(z.cgetitem((3, 0, 0)) - (100 - 10j)) == 0          # the Hermitian partner was set too
+    # preview: the gathered field, and projections of it
+    r = pm2.create('real', value=numpy.arange(64.).reshape(4, 4, 4)[pm2.create('real').slices])
+    prev = r.preview(axes=(0, 1, 2))
+    assert_array_equal(prev, numpy.arange(64.).reshape(4, 4, 4))
+    assert_allclose(r.preview(axes=(2, 0)), prev.sum(axis=1).T)
+    assert r.preview(Nmesh=2).shape == (2, 2, 2)
+
+
 def case_cycle(be, comm):
     """the whole PM cycle on P ranks == the serial oracle cycle"""
     from pmesh_amd.pm import ParticleMesh
@@ -321,7 +379,7 @@ def case_pencil(be, comm):
 
 
 CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
-         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_whitenoise, case_cycle]
+         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_cycle]
 
 
 def main():

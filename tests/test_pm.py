@@ -421,3 +421,153 @@ def test_transpose(be):                       # test_pm.py:754-776
     assert_allclose(numpy.asarray(comp1t), numpy.asarray(comp1).transpose(1, 2, 0))
     comp1ttt = comp1t.ctranspose([1, 2, 0]).ctranspose([1, 2, 0])
     assert_allclose(numpy.asarray(comp1ttt), numpy.asarray(comp1))
+
+
+# ---- C-order redistribution, Fourier resampling, collective item access, preview ----------
+
+def test_sort(be):                            # test_pm.py:394-412
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 6], dtype='f8')
+    real = RealField(pm)
+    truth = numpy.arange(8 * 6)
+    real[...] = truth.reshape(8, 6)[real.slices]
+    unsorted = real.copy()
+    with pytest.warns(DeprecationWarning):
+        real.sort(out=Ellipsis)
+    assert_array_equal(numpy.asarray(real).ravel(), truth)
+    real.unravel(numpy.asarray(real))
+    assert_array_equal(numpy.asarray(real), numpy.asarray(unsorted))
+    cplx = ComplexField(pm)
+    truth = numpy.arange(8 * 4)
+    cplx[...] = truth.reshape(8, 4)[cplx.slices]
+    cplx.ravel(out=Ellipsis)
+    assert_array_equal(numpy.asarray(cplx).ravel(), truth)
+    # ravel into a host array / a new device tensor; pm.unravel builds a field
+    host = numpy.empty(8 * 4, dtype='c16')
+    cplx.ravel(out=host)
+    assert_array_equal(host, truth)
+    flat = cplx.ravel()
+    assert_array_equal(flat.cpu().numpy(), truth)
+    again = pm.unravel(ComplexField, flat)
+    assert_array_equal(numpy.asarray(again), numpy.asarray(cplx))
+
+
+def _fill_by_csetitem(field, truth, zero=lambda ind: False, remap=lambda ind: ind):
+    for ind in numpy.ndindex(*field.cshape):
+        field.csetitem(ind, 0 if zero(ind) else truth[remap(ind)])
+
+
+def test_fdownsample(be):                     # test_pm.py:416-454
+    pm1 = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    pm2 = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f8')
+    numpy.random.seed(3333)
+    truth = numpy.fft.rfftn(numpy.random.normal(size=(8, 8)))
+    complex1 = ComplexField(pm1)
+    _fill_by_csetitem(complex1, truth)
+    assert_almost_equal(numpy.asarray(complex1), numpy.asarray(complex1.c2r().r2c()))
+    complex2 = ComplexField(pm2)
+    _fill_by_csetitem(complex2, truth, zero=lambda ind: any(i == 2 for i in ind),
+                      remap=lambda ind: tuple([i if i <= 2 else 8 - (4 - i) for i in ind]))
+    tmpr = RealField(pm2)
+    tmp = ComplexField(pm2)
+    complex1.resample(tmp)
+    assert_almost_equal(numpy.asarray(complex2), numpy.asarray(tmp), decimal=5)
+    complex1.c2r().resample(tmp)
+    assert_almost_equal(numpy.asarray(complex2), numpy.asarray(tmp), decimal=5)
+    complex1.resample(tmpr)
+    assert_almost_equal(numpy.asarray(tmpr.r2c()), numpy.asarray(tmp))
+    complex1.c2r().resample(tmpr)
+    assert_almost_equal(numpy.asarray(tmpr.r2c()), numpy.asarray(tmp))
+
+
+def test_fupsample(be):                       # test_pm.py:493-537
+    pm1 = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    pm2 = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f8')
+    numpy.random.seed(3333)
+    truth = numpy.fft.rfftn(numpy.random.normal(size=(8, 8)))
+    complex1 = ComplexField(pm1)
+    _fill_by_csetitem(complex1, truth, zero=lambda ind: any(i == 4 for i in ind) or any(2 <= i < 7 for i in ind))
+    assert_almost_equal(numpy.asarray(complex1), numpy.asarray(complex1.c2r().r2c()))
+    complex2 = ComplexField(pm2)
+    _fill_by_csetitem(complex2, truth, zero=lambda ind: any(i == 2 for i in ind),
+                      remap=lambda ind: tuple([i if i <= 2 else 8 - (4 - i) for i in ind]))
+    tmpr = RealField(pm1)
+    tmp = ComplexField(pm1)
+    complex2.resample(tmp)
+    assert_almost_equal(numpy.asarray(complex1), numpy.asarray(tmp), decimal=5)
+    complex2.c2r().resample(tmp)
+    assert_almost_equal(numpy.asarray(complex1), numpy.asarray(tmp), decimal=5)
+    complex2.resample(tmpr)
+    assert_almost_equal(numpy.asarray(tmpr.r2c()), numpy.asarray(tmp))
+    complex2.c2r().resample(tmpr)
+    assert_almost_equal(numpy.asarray(tmpr.r2c()), numpy.asarray(tmp))
+
+
+def test_resample_3d_keeps_the_large_scales(be):
+    """resampling white noise of a finer mesh down equals the white noise of the coarser mesh on
+    the modes both have (the generator is scale invariant), Nyquist planes removed"""
+    pm1 = ParticleMesh(BoxSize=8.0, Nmesh=[16, 16, 16], dtype='f8')
+    pm0 = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='f8')
+    c1 = pm1.generate_whitenoise(seed=8, unitary=True)
+    down = ComplexField(pm0)
+    c1.resample(down)
+    c0 = numpy.asarray(pm0.generate_whitenoise(seed=8, unitary=True)).copy()
+    c0[4, :, :] = 0
+    c0[:, 4, :] = 0
+    c0[:, :, 4] = 0
+    assert_allclose(numpy.asarray(down), c0, rtol=0, atol=1e-14)
+
+
+def test_ctol_cgetitem_csetitem(be):          # test_pm.py:553-630
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f8')
+    value, local = ComplexField(pm)._ctol((3, 3))
+    assert local is None
+    for i in numpy.ndindex((4, 4)):
+        real = RealField(pm)
+        real[...] = 0
+        v2 = real.csetitem(i, 100.)
+        assert v2 == 100. and real.cgetitem(i) == v2
+    once = {(0, 0), (0, 2), (2, 0), (2, 2)}           # self-conjugate modes keep the real part only
+    twice = {(1, 0), (3, 0), (3, 2), (1, 2)}          # modes whose conjugate is stored too
+    for i in numpy.ndindex((4, 3)):
+        cplx = ComplexField(pm)
+        cplx[...] = 0
+        v2 = cplx.csetitem(i, 100. + 10j)
+        cplx.c2r(out=Ellipsis).r2c(out=Ellipsis)
+        v1 = cplx.cgetitem(i)
+        total = complex(numpy.asarray(cplx).sum())
+        if i in once:
+            assert v2 == 100. and abs(total - 100.) < 1e-12
+        elif i in twice:
+            assert v2 == 100 + 10j and abs(total - 200.) < 1e-12
+        else:
+            assert v2 == 100. + 10j and abs(total - (100. + 10j)) < 1e-12
+        assert abs(v1 - v2) < 1e-12
+    for i in numpy.ndindex((4, 3, 2)):
+        cplx = ComplexField(pm)
+        cplx[...] = 0
+        v2 = cplx.csetitem(i, 100.)
+        cplx.c2r(out=Ellipsis).r2c(out=Ellipsis)
+        v1 = cplx.cgetitem(i)
+        if i[:2] in once and i[2] == 1:
+            assert v2 == 0.
+        else:
+            assert v2 == 100.
+        assert abs(v1 - v2) < 1e-12
+
+
+def test_preview(be):                         # test_pm.py:780-814
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4, 4], dtype='f8')
+    comp1 = pm.generate_whitenoise(1234, type='real')
+    preview = comp1.preview(axes=(0, 1, 2))
+    preview = comp1.preview(Nmesh=4, axes=(0, 1, 2))
+    for ind1 in numpy.ndindex(*(list(comp1.cshape))):
+        assert_allclose(preview[ind1], comp1.cgetitem(ind1))
+    assert_allclose(comp1.preview(Nmesh=4, axes=(0, 1)), preview.sum(axis=2))
+    assert_allclose(comp1.preview(Nmesh=4, axes=(1, 2)), preview.sum(axis=0))
+    assert_allclose(comp1.preview(Nmesh=4, axes=(0, 2)), preview.sum(axis=1))
+    assert_allclose(comp1.preview(Nmesh=4, axes=(2, 0)), preview.sum(axis=1).T)
+    assert_allclose(comp1.preview(Nmesh=4, axes=(0,)), preview.sum(axis=(1, 2)))
+    p8 = comp1.preview(Nmesh=8, axes=(0,))
+    assert p8.shape == (8,)
+    p2 = comp1.preview(Nmesh=2)
+    assert p2.shape == (2, 2, 2) and abs(p2.mean() - preview.mean()) < 1e-12
