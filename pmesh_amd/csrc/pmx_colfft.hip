@@ -232,13 +232,19 @@ template <> struct Radices<9>  { static constexpr int n = 3; static constexpr in
 template <> struct Radices<10> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
 template <> struct Radices<11> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
 
+// lines of a column per thread: 8 for double; 16 for float, whose 8-byte elements would
+// otherwise keep only half the bytes in flight per thread (measured 3.1 vs 4.6 TB/s per pass)
+template <typename T> struct Rpt { static constexpr int value = 8; };
+template <> struct Rpt<float> { static constexpr int value = 16; };
+
 template <typename T, int LOGN, bool INV, bool APPLY, int RB>
-__global__ void __launch_bounds__((1 << LOGN) / 8 * (RB / (int)sizeof(cpx<T>)))
+__global__ void __launch_bounds__((1 << LOGN) / Rpt<T>::value * (RB / (int)sizeof(cpx<T>)))
 colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 {
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);    // columns per tile: RB-byte row segments
-    constexpr int TPC = N / 8;                     // threads per column
+    constexpr int RPT = Rpt<T>::value;             // lines per thread
+    constexpr int TPC = N / RPT;                   // threads per column
     constexpr int NT = TPC * W;                    // threads per workgroup
     extern __shared__ __align__(16) unsigned char smem[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
@@ -257,16 +263,16 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         ColK ck = {0, 0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         __syncthreads();
-        // load: 8 rows per thread, all loads issued before the first LDS store
-        cpx<T> ld[8];
+        // load: RPT rows per thread, all loads issued before the first LDS store
+        cpx<T> ld[RPT];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < RPT; u++) {
             int n = tj + u * TPC;
             ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + col]
                           : cpx<T>{0, 0};
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < RPT; u++) {
             int n = tj + u * TPC;
             cpx<T> v = ld[u];
             if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
@@ -296,7 +302,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         // store
         const T sc = (T)g.scale;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < RPT; u++) {
             int n = tj + u * TPC;
             if (colok) {
                 cpx<T> v = buf[lds_index<T, RB>(n, col)];
@@ -469,7 +475,7 @@ static int launch_colfft(const ColGeom &g, const void *src, void *dst, const voi
 {
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);
-    constexpr int NT = N / 8 * W;
+    constexpr int NT = N / Rpt<T>::value * W;
     size_t lds = (size_t)(N * W + N) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
@@ -593,7 +599,7 @@ static ColAddr plain_addr(int64_t N, int64_t B)
 extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
-    if (n < 64 || n > (elsize == 8 ? 1024 : 512) || (n & (n - 1))) return PMX_EUNSUPPORTED;
+    if (n < 64 || n > 1024 || (n & (n - 1))) return PMX_EUNSUPPORTED;
     return PMX_OK;
 }
 
@@ -643,8 +649,7 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     rc = get_twiddles((int)N, elsize, &tw, st);
     if (rc) return rc;
     if (elsize == 8) return dispatch_logn<double>(g, data, data, tw, inverse != 0, apply, st);
-    // float: 16 columns x 8 B = 128-byte rows; 1024 threads at N = 512, so N <= 512 only
-    PMX_REQUIRE(N <= 512, PMX_EUNSUPPORTED, "single precision column FFT is built up to length 512");
+    // float: 16 columns x 8 B = 128-byte rows, 16 lines per thread: 1024 threads at N = 1024
     return dispatch_logn<float>(g, data, data, tw, inverse != 0, apply, st);
 }
 
@@ -683,6 +688,5 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     rc = get_twiddles((int)N, elsize, &tw, st);
     if (rc) return rc;
     if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, false, st);
-    PMX_REQUIRE(N <= 512, PMX_EUNSUPPORTED, "single precision column FFT is built up to length 512");
     return dispatch_logn<float>(g, src, dst, tw, inverse != 0, false, st);
 }

@@ -181,7 +181,7 @@ def _own_kernel_lengths(Nmesh, itemsize):
     """True if csrc/pmx_colfft.hip runs every stage of a 3-d transform of this mesh (the
     arithmetic of pmx_rowfft_supported / pmx_colfft_supported, needed here without a backend)"""
     n0, n1, n2 = [int(x) for x in Nmesh]
-    cmax = 1024 if itemsize == 8 else 512
+    cmax = 1024
     pow2 = all(n & (n - 1) == 0 for n in (n0, n1, n2))
     return pow2 and 64 <= n0 <= cmax and 64 <= n1 <= cmax and 128 <= n2 <= 1024 and n1 % 16 == 0
 
