@@ -220,7 +220,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl')
 
-    from pmesh_amd import backend, _abi
+    from pmesh_amd import backend
     from pmesh_amd._arrays import vec
     from pmesh_amd.comm import default_comm
     from pmesh_amd.pm import ParticleMesh

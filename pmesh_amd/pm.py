@@ -22,12 +22,11 @@ import operator
 import warnings
 from collections import OrderedDict
 
-import ctypes as C
 import numpy
 import torch
 from numpy.lib.mixins import NDArrayOperatorsMixin as NDArrayLike
 
-from . import _abi, backend, domain
+from . import backend, domain
 from . import fft as _fft
 from ._arrays import to_device, is_tensor, torch_dtype, numpy_dtype
 from .comm import default_comm

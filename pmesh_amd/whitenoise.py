@@ -6,7 +6,6 @@ decomposition, large scales invariant under a change of the mesh size, Hermitian
 1-d / 2-d: the reference's own numpy definition (a normal field through fftn; "only used for
 testing", whitenoise.py:24-41) evaluated on the host and copied into the block.
 """
-import ctypes as C
 
 import numpy
 import torch
