@@ -18,7 +18,6 @@ with array operators), so it can be passed anywhere the reference takes a
 filter, and the two evaluations are tested against each other.
 """
 import ctypes as C
-import math
 
 import numpy
 import torch
