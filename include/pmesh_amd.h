@@ -222,9 +222,11 @@ int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N
  * brackets PFFT's global transpose (what pmx_slab_pack does, for equal power-of-two ranges):
  * inverse = 0: src plain (A, N, B) -> dst "split": block r = lines [r*nsplit, (r+1)*nsplit)
  * as one contiguous (A, nsplit, B) array, i.e. the all-to-all send buffer; inverse = 1: src
- * split (the receive buffer) -> dst plain.  Out of place; unnormalised, times `scale`. */
+ * split (the receive buffer) -> dst plain.  Out of place; unnormalised, times `scale`.
+ * plain_pitch: elements per line of the plain side (>= B; 0 = B): the slab layout keeps its
+ * real-side rows on 128-byte boundaries while the wire format stays dense. */
 int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N,
-                     int64_t B, int64_t nsplit, double scale, void *stream);
+                     int64_t B, int64_t nsplit, double scale, int64_t plain_pitch, void *stream);
 
 /* Real <-> half-complex transform along the contiguous axis, in place, with the rows
  * resident in LDS (csrc/pmx_colfft.hip): `nrows` rows of n reals (n a power of two in

@@ -98,7 +98,7 @@ DEVICE_ONLY = {
     'colfft_supported': (C.c_int, [_i64, _i32]),
     'colfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
                          _P(_i64), _P(_f64), _i64, _i64, _vp]),
-    'colfft_split': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _vp]),
+    'colfft_split': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _i64, _vp]),
     'rowfft_supported': (C.c_int, [_i64, _i32]),
     'rowfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp]),
     'slab_pack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),

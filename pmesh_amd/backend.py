@@ -101,10 +101,11 @@ class HipBackend(object):
                   _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3),
                   int(a_stride), int(n_stride), self.stream())
 
-    def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0):
-        """column FFT fused with the slab pack (forward: plain -> split) / unpack (inverse)"""
+    def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0, plain_pitch=0):
+        """column FFT fused with the slab pack (forward: plain -> split) / unpack (inverse);
+        plain_pitch: elements per line of the plain side (0 = B)"""
         self.call('colfft_split', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), A, N, B,
-                  int(nsplit), float(scale), self.stream())
+                  int(nsplit), float(scale), int(plain_pitch), self.stream())
 
     def rowfft_supported(self, n, elsize):
         return self.lib.pmx_rowfft_supported(int(n), int(elsize)) == 0

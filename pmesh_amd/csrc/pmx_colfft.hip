@@ -661,7 +661,8 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
 //   inverse = 1: src is that split layout (the receive buffer), dst the plain (A, N, B) array.
 // src and dst must not overlap.
 extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A,
-                                int64_t N, int64_t B, int64_t nsplit, double scale, void *stream)
+                                int64_t N, int64_t B, int64_t nsplit, double scale, int64_t plain_pitch,
+                                void *stream)
 {
     int rc = pmx_colfft_supported(N, elsize);
     if (rc) { set_error("pmx_colfft_split: unsupported length %lld", (long long)N); return rc; }
@@ -681,8 +682,12 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     split.sa = nsplit * B;
     split.sn = B;
     split.shi = A * nsplit * B;
-    g.in = inverse ? split : plain_addr(N, B);
-    g.out = inverse ? plain_addr(N, B) : split;
+    // the plain side may have padded lines (plain_pitch >= B elements per line, e.g. rows
+    // rounded up to 128 bytes); the split side is always dense
+    PMX_REQUIRE(plain_pitch == 0 || plain_pitch >= B, PMX_EINVAL, "plain_pitch smaller than B");
+    ColAddr plain = plain_addr(N, plain_pitch ? plain_pitch : B);
+    g.in = inverse ? split : plain;
+    g.out = inverse ? plain : split;
     hipStream_t st = (hipStream_t)stream;
     void *tw = nullptr;
     rc = get_twiddles((int)N, elsize, &tw, st);

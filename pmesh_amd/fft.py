@@ -164,12 +164,28 @@ class Partition(object):
                 self.i_alloc = n0 * 2 * plane
                 self.o_strides = [plane, pitch_c, 1]
                 self.o_alloc = n0 * plane
+        # Several ranks, slab, lengths of the LDS kernels, equal power-of-two ranges of axis 1 (the
+        # case where the pack / unpack ride on the column pass, Plan._execute_slab): the REAL side
+        # keeps its rows on 128-byte boundaries (pitch_i complex per row; 257 -> 264 at 512^3:
+        # row and axis-1 passes 57 -> 50 and 75 -> 58 us per rank at P = 8, scripts/pitch_probe.py)
+        # while the transposed complex side and the wire format stay dense.
+        self.pitch_i = pitch_c
+        if (P > 1 and nd == 3 and transposed and PLANE_PAD and _own_kernel_lengths(self.Nmesh, itemsize)):
+            n1 = int(self.Nmesh[1])
+            n1loc = n1 // P
+            if n1loc * P == n1 and n1loc >= 1 and n1loc & (n1loc - 1) == 0:
+                q = 128 // (2 * itemsize)
+                self.pitch_i = -(-int(Nc[-1]) // q) * q
+                padded = list(self.local_i_shape)
+                padded[-1] = 2 * self.pitch_i
+                self.i_strides = _c_strides(padded)
+                self.i_alloc = int(numpy.prod(padded, dtype='i8'))
         # one buffer serves both views (in-place transforms)
         self.alloc_reals = max(self.i_alloc, 2 * self.o_alloc, 2)
         if P > 1:
             # the slab transpose needs the full local plane set on both sides
             n0loc = int(self.local_i_shape[0])
-            mid = n0loc * int(numpy.prod(Nc[1:], dtype='i8'))
+            mid = n0loc * int(numpy.prod(Nc[1:-1], dtype='i8')) * max(int(Nc[-1]), self.pitch_i)
             self.alloc_reals = max(self.alloc_reals, 2 * mid)
 
 
@@ -500,7 +516,7 @@ class Plan(object):
         cdt = torch.complex64 if self.elsize == 4 else torch.complex128
         norm = 1.0 / float(numpy.prod(p.Nmesh, dtype='f8'))
         rdt = bufin.storage.dtype
-        need = max(2 * n0loc * N1c * n2, 2 * n1loc * N0 * n2, 2)
+        need = max(2 * n0loc * N1c * max(n2, int(getattr(p, 'pitch_i', 0))), 2 * n1loc * N0 * n2, 2)
         if self._work is None or self._work[0].numel() < need or self._work[0].dtype != rdt:
             self._work = [torch.empty(need, dtype=rdt, device=bufin.storage.device) for _ in range(3)]
         W0, W1, W2 = self._work
@@ -523,19 +539,22 @@ class Plan(object):
             N1, N2 = int(p.Nmesh[1]), int(p.Nmesh[2])
             N2c = n2
             nb = n1loc * N2c
+            pi = int(getattr(p, 'pitch_i', N2c))                # complex elements per real-side row
             if self.forward:
                 X = bufin.storage
                 if not same:
-                    nreal = n0loc * N1 * 2 * N2c
+                    nreal = n0loc * N1 * 2 * pi
                     W0[:nreal].copy_(bufin.storage[:nreal])     # r2c preserves its input
                     X = W0
                 # equal power-of-two ranges of axis 1: the pack rides on the column pass
                 fuse_pack = (hasattr(be, 'colfft_split') and n1loc * P == N1 and
                              n1loc & (n1loc - 1) == 0 and all(e1[r + 1] - e1[r] == n1loc for r in range(P)))
+                assert fuse_pack or pi == N2c               # padded rows only with the fused pack
                 if n0loc:
-                    be.rowfft(self.elsize, False, X, n0loc * N1, N2, N2c)
+                    be.rowfft(self.elsize, False, X, n0loc * N1, N2, pi)
                     if fuse_pack:
-                        be.colfft_split(self.elsize, False, X, W1, n0loc, N1, N2c, n1loc, scale=norm)
+                        be.colfft_split(self.elsize, False, X, W1, n0loc, N1, N2c, n1loc, scale=norm,
+                                        plain_pitch=pi)
                     else:
                         be.colfft(self.elsize, False, X, n0loc, N1, N2c, scale=norm)
                 if not (fuse_pack and n0loc):
@@ -561,9 +580,10 @@ class Plan(object):
                 Y = bufout.storage
                 fuse_pack = (hasattr(be, 'colfft_split') and n1loc * P == N1 and
                              n1loc & (n1loc - 1) == 0 and all(e1[r + 1] - e1[r] == n1loc for r in range(P)))
+                assert fuse_pack or pi == N2c
                 if fuse_pack and n0loc:
-                    be.colfft_split(self.elsize, True, W1, Y, n0loc, N1, N2c, n1loc)
-                    be.rowfft(self.elsize, True, Y, n0loc * N1, N2, N2c)
+                    be.colfft_split(self.elsize, True, W1, Y, n0loc, N1, N2c, n1loc, plain_pitch=pi)
+                    be.rowfft(self.elsize, True, Y, n0loc * N1, N2, pi)
                 else:
                     be.slab_pack(W1, Y, n0loc, N1c, n2, e1, elb, inverse=True)
                     if n0loc:

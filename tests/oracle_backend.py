@@ -125,17 +125,19 @@ class OracleBackend(object):
         y = numpy.fft.ifft(x, axis=1) * N if inverse else numpy.fft.fft(x, axis=1)
         arr[...] = y * scale
 
-    def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0):
+    def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0, plain_pitch=0):
         cdt = 'c8' if elsize == 4 else 'c16'
-        s = src.detach().numpy().reshape(-1).view(cdt)[:A * N * B]
-        d = dst.detach().numpy().reshape(-1).view(cdt)[:A * N * B]
+        pp = plain_pitch or B
+        plain_t, split_t = (dst, src) if inverse else (src, dst)
+        plain = plain_t.detach().numpy().reshape(-1).view(cdt)[:A * N * pp].reshape(A, N, pp)[:, :, :B]
+        split = split_t.detach().numpy().reshape(-1).view(cdt)[:A * N * B]
         R = N // nsplit
         if inverse:
-            x = s.reshape(R, A, nsplit, B).transpose(1, 0, 2, 3).reshape(A, N, B).astype('c16')
-            d.reshape(A, N, B)[...] = numpy.fft.ifft(x, axis=1) * N * scale
+            x = split.reshape(R, A, nsplit, B).transpose(1, 0, 2, 3).reshape(A, N, B).astype('c16')
+            plain[...] = numpy.fft.ifft(x, axis=1) * N * scale
         else:
-            y = numpy.fft.fft(s.reshape(A, N, B).astype('c16'), axis=1) * scale
-            d.reshape(R, A, nsplit, B)[...] = y.reshape(A, R, nsplit, B).transpose(1, 0, 2, 3)
+            y = numpy.fft.fft(plain.astype('c16'), axis=1) * scale
+            split.reshape(R, A, nsplit, B)[...] = y.reshape(A, R, nsplit, B).transpose(1, 0, 2, 3)
 
     def rowfft_supported(self, n, elsize):
         n = int(n)
