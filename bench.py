@@ -57,7 +57,9 @@ def parse():
     ap.add_argument('--particles', type=int, default=None, help='lattice size per side (default: mesh)')
     ap.add_argument('--window', default='cic', choices=['nnb', 'cic', 'tsc', 'pcs'])
     ap.add_argument('--dtype', default='f8', choices=['f4', 'f8'])
-    ap.add_argument('--data', default='uniform', choices=['uniform', 'clustered'])
+    ap.add_argument('--data', default='uniform', choices=['uniform', 'clustered', 'shuffled'],
+                    help="uniform / clustered: SURVEY.md 8d, in lattice order; shuffled: the uniform set in "
+                         "random order (diagnostic: no spatial coherence between neighbouring rows)")
     ap.add_argument('--gradient', type=int, default=None, help='gradient readout direction')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-mesh', type=int, default=256)
@@ -241,8 +243,12 @@ def main():
     # ---- synthetic particles, generated in HBM ---------------------------------
     pos = torch.empty((nloc, 3), dtype=tdt, device=be.device)
     pv = vec(pos)
-    if args.data == 'uniform':
+    if args.data in ('uniform', 'shuffled'):
         be.call('synth_uniform', C.byref(pv), Np_side, L, 42, g0, nloc, be.stream())
+        if args.data == 'shuffled':
+            gen = torch.Generator(device=be.device)
+            gen.manual_seed(1234 + rank)
+            pos = pos[torch.randperm(nloc, device=be.device, generator=gen)].contiguous()
     else:
         modes = zeldovich_modes(numpy, Np_side, L)
         be.call('synth_clustered', C.byref(pv), Np_side, L,
@@ -361,7 +367,8 @@ def main():
             'config': {'workload': '%d^3 mesh, %d^3 %s particles (lattice + %s), %s window, %s, '
                                    'paint->r2c->apply(i kx/k^2)->c2r->readout%s'
                                    % (N, Np_side, args.data,
-                                      'hashed jitter' if args.data == 'uniform' else "Zel'dovich plane waves",
+                                      {'uniform': 'hashed jitter', 'shuffled': 'hashed jitter, rows in random order'}.get(
+                                          args.data, "Zel'dovich plane waves"),
                                       args.window.upper(), 'fp64' if args.dtype == 'f8' else 'fp32',
                                       '' if args.gradient is None else ' (gradient %d)' % args.gradient),
                        'decomposition': ('single GPU' if world == 1 else
