@@ -170,7 +170,7 @@ class Partition(object):
         # row and axis-1 passes 57 -> 50 and 75 -> 58 us per rank at P = 8, scripts/pitch_probe.py)
         # while the transposed complex side and the wire format stay dense.
         self.pitch_i = pitch_c
-        if (P > 1 and nd == 3 and transposed and PLANE_PAD and _own_kernel_lengths(self.Nmesh, itemsize)):
+        if (P > 1 and nd == 3 and PLANE_PAD and _own_kernel_lengths(self.Nmesh, itemsize)):
             n1 = int(self.Nmesh[1])
             n1loc = n1 // P
             if n1loc * P == n1 and n1loc >= 1 and n1loc & (n1loc - 1) == 0:
@@ -276,6 +276,12 @@ class LocalBuffer(object):
         return self.storage
 
 
+class _Storage(object):
+    """a bare work buffer with the one attribute Plan.execute reads from a LocalBuffer"""
+    def __init__(self, storage):
+        self.storage = storage
+
+
 class Plan(object):
     """pfft.Plan(...).execute(bufin, bufout) for one direction."""
 
@@ -286,6 +292,7 @@ class Plan(object):
         self.elsize = numpy.dtype(dtype).itemsize
         self._plans = {}
         self._work = None
+        self.sibling = None       # untransposed plans: the plan of the transposed partition
 
     # lazily created native plans (rocFFT kernels are built on first use)
     def _native(self, key, maker):
@@ -498,8 +505,7 @@ class Plan(object):
         p = self.partition
         comm = p.procmesh.comm
         if not p.transposed:
-            raise NotImplementedError('untransposed complex fields on more than one rank are not '
-                                      'built yet (they need a second global transpose)')
+            return self._execute_slab_untransposed(bufin, bufout)
         nd = p.ndim
         P = p.nproc
         N0 = int(p.Nmesh[0])
@@ -649,6 +655,61 @@ class Plan(object):
                     shape = [n0loc] + inner_real
                     dst = torch.as_strided(bufout.storage, shape, [plane_r] + list(inner_strides_r))
                     dst.copy_(W1[:int(numpy.prod(shape, dtype='i8'))].view(shape))
+
+    def _execute_slab_untransposed(self, bufin, bufout, mode=None):
+        """The untransposed complex layout (n0_local, N1, N2c) on several ranks: the transposed
+        transform (self.sibling, the plan of the transposed partition) plus the second global
+        transpose that PFFT makes when PFFT_TRANSPOSED_OUT is not asked for."""
+        be = backend.get()
+        p = self.partition
+        t = self.sibling
+        if t is None:
+            raise NotImplementedError('untransposed plan without its transposed sibling')
+        pt = t.partition
+        comm = p.procmesh.comm
+        P = p.nproc
+        N0 = int(p.Nmesh[0])
+        n0loc = int(p.local_i_shape[0])
+        N1c = int(pt.cshape_o[1])
+        n1loc = int(pt.local_o_shape[1])
+        n2 = 1
+        for x in pt.cshape_o[2:]:
+            n2 *= int(x)
+        e0 = [int(x) for x in pt.i_edges[0]]
+        e1 = [int(x) for x in pt.o_edges[1]]
+        elb = 2 * self.elsize
+        rdt = bufin.storage.dtype
+        dev = bufin.storage.device
+        need = max(int(pt.alloc_reals), 2 * n0loc * N1c * n2, 2)
+        if self._work is None or self._work[0].numel() < need or self._work[0].dtype != rdt:
+            self._work = [torch.empty(need, dtype=rdt, device=dev) for _ in range(2)]
+        TB, W = self._work
+        tb = _Storage(TB)
+        # blocks of the transposed array by row range (contiguous) <-> blocks by axis-1 range
+        rows_splits = [2 * (e0[s + 1] - e0[s]) * n1loc * n2 for s in range(P)]
+        col_splits = [2 * n0loc * (e1[r + 1] - e1[r]) * n2 for r in range(P)]
+        if mode == 'T->U':            # cast of a transposed complex field (bufin) to the untransposed layout
+            comm.alltoall(bufin.storage[:sum(rows_splits)], W[:sum(col_splits)], rows_splits, col_splits)
+            be.slab_pack(W, bufout.storage, n0loc, N1c, n2, e1, elb, inverse=True)
+        elif mode == 'U->T':
+            be.slab_pack(bufin.storage, W, n0loc, N1c, n2, e1, elb)
+            comm.alltoall(W[:sum(col_splits)], bufout.storage[:sum(rows_splits)], col_splits, rows_splits)
+        elif self.forward:
+            t.execute(bufin, tb)                                        # -> (N0, n1loc, n2) in TB
+            comm.alltoall(TB[:sum(rows_splits)], W[:sum(col_splits)], rows_splits, col_splits)
+            be.slab_pack(W, bufout.storage, n0loc, N1c, n2, e1, elb, inverse=True)
+        else:
+            be.slab_pack(bufin.storage, W, n0loc, N1c, n2, e1, elb)
+            comm.alltoall(W[:sum(col_splits)], TB[:sum(rows_splits)], col_splits, rows_splits)
+            t.execute(tb, bufout)
+
+    def retranspose(self, bufin, bufout, to_untransposed):
+        """(N0, n1_local, N2c) <-> (n0_local, N1, N2c): the layout change between the transposed
+        and the untransposed complex field of a slab decomposition (Field.cast); out of place"""
+        p = self.partition
+        if p.nproc == 1 or getattr(p, 'pencil', False) or p.transposed:
+            raise NotImplementedError('retranspose is a method of untransposed slab plans')
+        self._execute_slab_untransposed(bufin, bufout, mode='T->U' if to_untransposed else 'U->T')
 
     def destroy(self):
         try:

@@ -504,8 +504,14 @@ class Field(NDArrayLike):
             if self.pm.comm.size == 1:
                 out.value[...] = self.value
                 return out
-            raise NotImplementedError('casting between transposed and untransposed complex '
-                                      'fields on several ranks needs a global transpose')
+            if len(self.pm.np) != 1:
+                raise NotImplementedError('casting between transposed and untransposed complex '
+                                          'fields on a pencil decomposition')
+            if out._base in self._base:
+                raise ValueError('the layouts differ: this cast cannot be done in place')
+            to_u = isinstance(out, UntransposedComplexField)
+            self.pm.plans['forwardU'].retranspose(self._base, out._base, to_u)
+            return out
         raise TypeError('unsupported cast')
 
     def apply(self, func, kind, out):
@@ -1097,6 +1103,10 @@ class ParticleMesh(object):
             plans['ipforward' + T] = _fft.Plan(part, True, dtype, inplace=True)
             plans['ipbackward' + T] = _fft.Plan(part, False, dtype, inplace=True)
 
+        for k in ('forward', 'backward'):
+            # out of place in both cases: the transposed plan works into / out of a scratch buffer
+            plans[k + 'U'].sibling = plans[k + 'T']
+            plans['ip' + k + 'U'].sibling = plans[k + 'T']
         # use the transposed partition for configuration space edges (pm.py:1443-1461);
         # here rank r owns block r in C order, so DomainAssign is the identity ramp
         partition = plans['partitionT']
@@ -1230,8 +1240,8 @@ class ParticleMesh(object):
         type = _typestr_to_type(type)
         if type is RealField:
             # the reference goes through the untransposed layout (pm.py:1679-1680); the modes do
-            # not depend on the layout, and the transposed one is the one built for P > 1
-            complex_type = UntransposedComplexField if self.comm.size == 1 else TransposedComplexField
+            # not depend on the layout, and pencils only have the transposed one
+            complex_type = UntransposedComplexField if len(self.np) <= 1 else TransposedComplexField
         else:
             complex_type = type
         complex = self.create(type=complex_type, base=base)

@@ -307,6 +307,46 @@ def case_ravel_resample_preview(be, comm):
     assert r.preview(Nmesh=2).shape == (2, 2, 2)
 
 
+def case_untransposed(be, comm):
+    """the untransposed complex layout (n0_local, N1, N2c) on several ranks (test_pm.py:128-165):
+    r2c / c2r through it, casts between the two layouts, white noise in both"""
+    from pmesh_amd.pm import ParticleMesh, UntransposedComplexField, TransposedComplexField
+    for Nmesh, dtype, tol in (([8, 12, 10], 'f8', 1e-13), ([9, 7], 'f8', 1e-13), ([64, 64, 128], 'f8', 1e-13),
+                              ([16, 8, 8], 'f4', 5e-6)):
+        pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, comm=comm, dtype=dtype, np=[comm.size])
+        data = numpy.random.RandomState(29).normal(size=Nmesh).astype(dtype)
+        real = pm.create('real', value=data[pm.create('real').slices])
+        Nc = list(Nmesh[:-1]) + [Nmesh[-1] // 2 + 1]
+        ref = numpy.fft.rfftn(data.astype('f8')) / numpy.prod(Nmesh)
+        cu = real.r2c(out=UntransposedComplexField(pm))
+        assert isinstance(cu, UntransposedComplexField)
+        assert tuple(cu.start[1:]) == (0,) * (len(Nmesh) - 1)            # axis 0 is the distributed one
+        full = gather_field(comm, cu, Nc)
+        assert numpy.sqrt((abs(full - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < tol, Nmesh
+        assert_array_equal(numpy.asarray(real), data[real.slices])       # input preserved
+        back = cu.c2r()
+        assert numpy.sqrt(((numpy.asarray(back) - data[back.slices]) ** 2).sum() /
+                          max((data[back.slices] ** 2).sum(), 1e-300)) < 4 * tol
+        # the two layouts hold the same modes: casts both ways
+        ct = real.r2c()
+        as_u = ct.cast(type='untransposedcomplex')
+        assert_array_equal(gather_field(comm, as_u, Nc), gather_field(comm, ct, Nc))
+        as_t = cu.cast(type='transposedcomplex')
+        assert_array_equal(numpy.asarray(as_t), numpy.asarray(as_u.cast(type=TransposedComplexField)))
+        assert numpy.sqrt((abs(gather_field(comm, as_t, Nc) - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < tol
+        # in place
+        cu2 = real.r2c(out=UntransposedComplexField(pm, base=real._base))
+        assert numpy.sqrt((abs(gather_field(comm, cu2, Nc) - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < tol
+        back2 = cu2.c2r(out=Ellipsis)
+        assert numpy.sqrt(((numpy.asarray(back2) - data[back2.slices]) ** 2).sum() /
+                          max((data[back2.slices] ** 2).sum(), 1e-300)) < 4 * tol
+    # white noise does not depend on the layout (test_pm.py:145-165)
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], comm=comm, dtype='f4', np=[comm.size])
+    f1 = pm.generate_whitenoise(seed=3333, type='untransposedcomplex')
+    f2 = pm.generate_whitenoise(seed=3333, type='transposedcomplex')
+    assert_array_equal(gather_field(comm, f1, (8, 8, 5)), gather_field(comm, f2, (8, 8, 5)))
+
+
 def case_cycle(be, comm):
     """the whole PM cycle on P ranks == the serial oracle cycle"""
     from pmesh_amd.pm import ParticleMesh
@@ -382,7 +422,7 @@ def case_pencil(be, comm):
 
 
 CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
-         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_cycle]
+         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_cycle]
 
 
 def main():
