@@ -19,6 +19,8 @@
 namespace pmx {
 
 constexpr int DBLOCK = 256;
+constexpr int DSUB = 8;                       // sub-batches of DBLOCK particles per chunk
+constexpr int DCHUNK = DBLOCK * DSUB;         // particles per chunk of the stable multi-split
 
 struct GridD {
     int32_t ndim, periodic, nranks;
@@ -41,6 +43,21 @@ __device__ inline double np_remainder(double a, double b)
     return mod;
 }
 
+// The same value without the (slow, software) fmod for arguments within one period of
+// [0, b): fmod(a, b) is a itself for |a| < b and a - b, exactly (Sterbenz), for b <= a < 2b.
+__device__ inline double np_remainder_near(double a, double b)
+{
+    if (b > 0) {
+        if (a >= 0) {
+            if (a < b) return a + 0.0;            // -0.0 -> +0.0 as copysign(0, b) does
+            if (a < b + b) return a - b;
+        } else if (a >= -b) {
+            return a == -b ? 0.0 : a + b;         // fmod = a (negative): one rounding in a + b
+        }
+    }
+    return np_remainder(a, b);
+}
+
 // numpy.digitize(x, bins, right=False) == searchsorted(bins, x, 'right')
 __device__ inline int np_digitize(double x, const double *bins, int n)
 {
@@ -55,6 +72,13 @@ __device__ inline int np_digitize(double x, const double *bins, int n)
 
 __device__ inline int py_mod(int a, int n)
 {
+    // arguments are within a period or two of [0, n) almost always: no integer division then
+    if (a >= 0) {
+        if (a < n) return a;
+        if (a < n + n) return a - n;
+    } else if (a >= -n) {
+        return a + n;
+    }
     int r = a % n;
     return r < 0 ? r + n : r;
 }
@@ -65,11 +89,20 @@ __device__ inline void classify_axis(const GridD &g, int j, double x, double s, 
     const double *edges = g.edges[j];
     int ne = g.shape[j] + 1;
     int l, r;
+    if (g.periodic && g.shape[j] == 1) {
+        // an axis that is not split (two of three on a slab decomposition): every position,
+        // finite or not, resolves to the one domain whatever the smoothing — the general branch
+        // gives (0, 1) for values inside the period and (1, 2) otherwise, both of which wrap to
+        // domain 0 with a patch of one
+        *sil = 0;
+        *sir = 1;
+        return;
+    }
     if (g.periodic) {
         double box = edges[ne - 1];
-        double c = np_remainder(x, box);
-        l = np_digitize(np_remainder(c - s, box), edges, ne);
-        r = np_digitize(np_remainder(c + s, box), edges, ne);
+        double c = np_remainder_near(x, box);
+        l = np_digitize(np_remainder_near(c - s, box), edges, ne);
+        r = np_digitize(np_remainder_near(c + s, box), edges, ne);
         int p = np_digitize(c, edges, ne);
         l = p - py_mod(p - l, g.shape[j]) - 1;
         r = p + py_mod(r - p, g.shape[j]);
@@ -97,6 +130,17 @@ __device__ inline uint64_t particle_targets(const GridD &g, const int *sil, cons
         p[j] = sil[j];
     }
     uint64_t mask = 0;
+    if (patch == 1) {
+        // the common case: the particle and its smoothing region lie in one domain
+        int64_t target = 0;
+        for (int j = 0; j < nd; j++) {
+            int t = p[j];
+            if (g.periodic) t = py_mod(t, g.shape[j]);
+            target += (int64_t)t * strides[j];
+        }
+        target = g.assign[target];
+        return g.degenerate[target] ? 0 : (uint64_t)1 << target;
+    }
     for (int64_t q = 0; q < patch; q++) {
         int64_t target = 0;
         for (int j = 0; j < nd; j++) {
@@ -120,35 +164,72 @@ struct F3 { double v[PMX_MAXDIM]; };
 
 __global__ void __launch_bounds__(DBLOCK) classify_kernel(GridD g, DVec pos, F3 scale, F3 smoothing,
                                                           int64_t n, uint64_t *masks,
-                                                          unsigned long long *counts)
+                                                          unsigned long long *counts, int64_t nchunks,
+                                                          int64_t *chunk_counts)
 {
-    __shared__ unsigned int lcount[PMX_MAXRANKS];
-    if (threadIdx.x < PMX_MAXRANKS) lcount[threadIdx.x] = 0;
-    __syncthreads();
-    for (int64_t base = blockIdx.x * (int64_t)DBLOCK; base < n; base += (int64_t)gridDim.x * DBLOCK) {
-        int64_t i = base + threadIdx.x;
-        uint64_t m = 0;
-        if (i < n) {
-            int sil[PMX_MAXDIM], sir[PMX_MAXDIM];
-            for (int j = 0; j < g.ndim; j++) {
-                // transform0 (pm.py:1788-1790): scale * x in double
-                double x = scale.v[j] * pos.get(i, j);
-                classify_axis(g, j, x, smoothing.v[j], &sil[j], &sir[j]);
-            }
-            m = particle_targets(g, sil, sir);
-            masks[i] = m;
+    // a block walks whole chunks of DCHUNK consecutive particles: the per-chunk, per-rank
+    // counts that the fill pass needs fall out of the classification (no second pass over the masks)
+    __shared__ unsigned int lcount[PMX_MAXRANKS];      // this chunk
+    __shared__ unsigned int tcount[PMX_MAXRANKS];      // all chunks of this block
+    // the grid description is read through dependent loads (binary searches, the domain -> rank
+    // table): keep it in LDS when it is small (it always is for the ParticleMesh domains)
+    constexpr int MAXE = 80, MAXCELLS = 256;
+    __shared__ double s_edges[PMX_MAXDIM][MAXE];
+    __shared__ int32_t s_assign[MAXCELLS];
+    __shared__ int16_t s_degenerate[PMX_MAXRANKS];
+    {
+        int cells = 1;
+        bool fits = true;
+        for (int j = 0; j < g.ndim; j++) {
+            cells *= g.shape[j];
+            fits = fits && g.shape[j] + 1 <= MAXE;
         }
-        for (int r = 0; r < g.nranks; r++) {
-            unsigned long long b = __ballot((m >> r) & 1);
-            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&lcount[r], (unsigned)__popcll(b));
+        fits = fits && cells <= MAXCELLS;
+        if (fits) {
+            for (int j = 0; j < g.ndim; j++)
+                for (int q = threadIdx.x; q <= g.shape[j]; q += DBLOCK) s_edges[j][q] = g.edges[j][q];
+            for (int q = threadIdx.x; q < cells; q += DBLOCK) s_assign[q] = g.assign[q];
+            for (int q = threadIdx.x; q < g.nranks; q += DBLOCK) s_degenerate[q] = g.degenerate[q];
+            for (int j = 0; j < g.ndim; j++) g.edges[j] = s_edges[j];
+            g.assign = s_assign;
+            g.degenerate = s_degenerate;
         }
     }
-    __syncthreads();
-    if (threadIdx.x < g.nranks && lcount[threadIdx.x])
-        atomicAdd(&counts[threadIdx.x], (unsigned long long)lcount[threadIdx.x]);
+    if (threadIdx.x < PMX_MAXRANKS) tcount[threadIdx.x] = 0;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x < PMX_MAXRANKS) lcount[threadIdx.x] = 0;
+        __syncthreads();
+        for (int k = 0; k < DSUB; k++) {
+            int64_t i = chunk * DCHUNK + k * DBLOCK + threadIdx.x;
+            uint64_t m = 0;
+            if (i < n) {
+                int sil[PMX_MAXDIM], sir[PMX_MAXDIM];
+                for (int j = 0; j < g.ndim; j++) {
+                    // transform0 (pm.py:1788-1790): scale * x in double
+                    double x = scale.v[j] * pos.get(i, j);
+                    classify_axis(g, j, x, smoothing.v[j], &sil[j], &sir[j]);
+                }
+                m = particle_targets(g, sil, sir);
+                masks[i] = m;
+            }
+            for (int r = 0; r < g.nranks; r++) {
+                unsigned long long b = __ballot((m >> r) & 1);
+                if ((threadIdx.x & 63) == 0 && b) atomicAdd(&lcount[r], (unsigned)__popcll(b));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < g.nranks) {
+            chunk_counts[(int64_t)threadIdx.x * nchunks + chunk] = lcount[threadIdx.x];
+            tcount[threadIdx.x] += lcount[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < g.nranks && tcount[threadIdx.x])
+        atomicAdd(&counts[threadIdx.x], (unsigned long long)tcount[threadIdx.x]);
 }
 
-// per-chunk (DBLOCK particles), per-rank counts
+// per-chunk (DCHUNK particles), per-rank counts from the masks alone (when the classification
+// was not run by this library instance just before, see pmx_decompose_fill)
 __global__ void __launch_bounds__(DBLOCK) chunk_count_kernel(const uint64_t *masks, int64_t n,
                                                              int nranks, int64_t nchunks,
                                                              int64_t *chunk_counts)
@@ -157,11 +238,13 @@ __global__ void __launch_bounds__(DBLOCK) chunk_count_kernel(const uint64_t *mas
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (threadIdx.x < PMX_MAXRANKS) lcount[threadIdx.x] = 0;
         __syncthreads();
-        int64_t i = chunk * DBLOCK + threadIdx.x;
-        uint64_t m = i < n ? masks[i] : 0;
-        for (int r = 0; r < nranks; r++) {
-            unsigned long long b = __ballot((m >> r) & 1);
-            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&lcount[r], (unsigned)__popcll(b));
+        for (int k = 0; k < DSUB; k++) {
+            int64_t i = chunk * DCHUNK + k * DBLOCK + threadIdx.x;
+            uint64_t m = i < n ? masks[i] : 0;
+            for (int r = 0; r < nranks; r++) {
+                unsigned long long b = __ballot((m >> r) & 1);
+                if ((threadIdx.x & 63) == 0 && b) atomicAdd(&lcount[r], (unsigned)__popcll(b));
+            }
         }
         __syncthreads();
         if (threadIdx.x < nranks) chunk_counts[(int64_t)threadIdx.x * nchunks + chunk] = lcount[threadIdx.x];
@@ -170,22 +253,23 @@ __global__ void __launch_bounds__(DBLOCK) chunk_count_kernel(const uint64_t *mas
 }
 
 // exclusive scan along chunks for each rank, seeded with the rank's offset.
-// One block per rank; sequential over tiles of DBLOCK chunks.
-__global__ void __launch_bounds__(DBLOCK) chunk_scan_kernel(int64_t *chunk_counts, int64_t nchunks,
-                                                            const int64_t *offsets)
+// One block of 1024 threads per rank; sequential over tiles of 1024 chunks.
+constexpr int DSCAN = 1024;
+__global__ void __launch_bounds__(DSCAN) chunk_scan_kernel(int64_t *chunk_counts, int64_t nchunks,
+                                                           const int64_t *offsets)
 {
-    __shared__ int64_t sh[DBLOCK];
+    __shared__ int64_t sh[DSCAN];
     __shared__ int64_t carry;
     int r = blockIdx.x;
     int64_t *row = chunk_counts + (int64_t)r * nchunks;
     if (threadIdx.x == 0) carry = offsets[r];
     __syncthreads();
-    for (int64_t base = 0; base < nchunks; base += DBLOCK) {
+    for (int64_t base = 0; base < nchunks; base += DSCAN) {
         int64_t i = base + threadIdx.x;
         int64_t v = i < nchunks ? row[i] : 0;
         sh[threadIdx.x] = v;
         __syncthreads();
-        for (int off = 1; off < DBLOCK; off <<= 1) {
+        for (int off = 1; off < DSCAN; off <<= 1) {
             int64_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
             __syncthreads();
             sh[threadIdx.x] += t;
@@ -194,7 +278,7 @@ __global__ void __launch_bounds__(DBLOCK) chunk_scan_kernel(int64_t *chunk_count
         int64_t incl = sh[threadIdx.x];
         if (i < nchunks) row[i] = carry + incl - v;
         __syncthreads();
-        if (threadIdx.x == DBLOCK - 1) carry += incl;
+        if (threadIdx.x == DSCAN - 1) carry += incl;
         __syncthreads();
     }
 }
@@ -205,21 +289,33 @@ __global__ void __launch_bounds__(DBLOCK) fill_kernel(const uint64_t *masks, int
                                                       IDX *indices)
 {
     __shared__ unsigned int wcount[DBLOCK / 64];
+    __shared__ int64_t rbase[PMX_MAXRANKS];            // next free slot per rank within this chunk
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        int64_t i = chunk * DBLOCK + threadIdx.x;
-        uint64_t m = i < n ? masks[i] : 0;
-        for (int r = 0; r < nranks; r++) {
-            bool hit = (m >> r) & 1;
-            unsigned long long b = __ballot(hit);
-            if (lane == 0) wcount[wave] = (unsigned)__popcll(b);
-            __syncthreads();
-            if (hit) {
-                unsigned before = __popcll(b & (((unsigned long long)1 << lane) - 1));
-                for (int w = 0; w < wave; w++) before += wcount[w];
-                indices[chunk_base[(int64_t)r * nchunks + chunk] + before] = (IDX)i;
+        __syncthreads();
+        if (threadIdx.x < nranks) rbase[threadIdx.x] = chunk_base[(int64_t)threadIdx.x * nchunks + chunk];
+        __syncthreads();
+        for (int k = 0; k < DSUB; k++) {
+            int64_t i = chunk * DCHUNK + k * DBLOCK + threadIdx.x;
+            uint64_t m = i < n ? masks[i] : 0;
+            for (int r = 0; r < nranks; r++) {
+                bool hit = (m >> r) & 1;
+                unsigned long long b = __ballot(hit);
+                if (lane == 0) wcount[wave] = (unsigned)__popcll(b);
+                __syncthreads();
+                if (hit) {
+                    unsigned before = __popcll(b & (((unsigned long long)1 << lane) - 1));
+                    for (int w = 0; w < wave; w++) before += wcount[w];
+                    indices[rbase[r] + before] = (IDX)i;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned tot = 0;
+                    for (int w = 0; w < DBLOCK / 64; w++) tot += wcount[w];
+                    rbase[r] += tot;
+                }
+                __syncthreads();      // wcount / rbase are rewritten by the next round
             }
-            __syncthreads();
         }
     }
 }
@@ -269,6 +365,11 @@ struct Scratch {
     }
 };
 static thread_local Scratch g_scratch;
+// what the chunk table in g_scratch describes: pmx_decompose_count leaves the per-chunk
+// counts of its classification there and pmx_decompose_fill picks them up if it is called
+// next, on the same thread, for the same masks (what domain.py does); anything else recounts
+struct ChunkTag { const void *masks = nullptr; int64_t npart = -1; int nranks = 0; };
+static thread_local ChunkTag g_chunk_tag;
 
 }  // namespace pmx
 
@@ -300,9 +401,17 @@ extern "C" int pmx_decompose_count(const pmx_grid *g, const pmx_vec *pos, const 
     }
     gd.assign = g->assign;
     gd.degenerate = g->degenerate;
-    classify_kernel<<<grid_for(npart, DBLOCK, 256 * 8), DBLOCK, 0, st>>>(
-        gd, dvec(pos), sc, sm, npart, masks, (unsigned long long *)counts);
+    int64_t nchunks = (npart + DCHUNK - 1) / DCHUNK;
+    g_chunk_tag = ChunkTag();
+    int rc = g_scratch.ensure(sizeof(int64_t) * nchunks * g->nranks);
+    if (rc) return rc;
+    unsigned grid = (unsigned)(nchunks < 256 * 16 ? nchunks : 256 * 16);
+    classify_kernel<<<grid, DBLOCK, 0, st>>>(gd, dvec(pos), sc, sm, npart, masks, (unsigned long long *)counts,
+                                             nchunks, (int64_t *)g_scratch.ptr);
     PMX_HIP_CHECK(hipGetLastError());
+    g_chunk_tag.masks = masks;
+    g_chunk_tag.npart = npart;
+    g_chunk_tag.nranks = g->nranks;
     return PMX_OK;
 }
 
@@ -314,13 +423,15 @@ extern "C" int pmx_decompose_fill(int32_t nranks, const uint64_t *masks, int64_t
     PMX_REQUIRE(index_elsize == 4 || index_elsize == 8, PMX_EINVAL, "index_elsize must be 4 or 8");
     if (npart == 0) return PMX_OK;
     hipStream_t st = (hipStream_t)stream;
-    int64_t nchunks = (npart + DBLOCK - 1) / DBLOCK;
-    int rc = g_scratch.ensure(sizeof(int64_t) * nchunks * nranks);
+    int64_t nchunks = (npart + DCHUNK - 1) / DCHUNK;
+    const bool have = g_chunk_tag.masks == masks && g_chunk_tag.npart == npart && g_chunk_tag.nranks == nranks;
+    int rc = have ? PMX_OK : g_scratch.ensure(sizeof(int64_t) * nchunks * nranks);
     if (rc) return rc;
     int64_t *cc = (int64_t *)g_scratch.ptr;
-    unsigned grid = grid_for(nchunks * DBLOCK, DBLOCK);
-    chunk_count_kernel<<<grid, DBLOCK, 0, st>>>(masks, npart, nranks, nchunks, cc);
-    chunk_scan_kernel<<<nranks, DBLOCK, 0, st>>>(cc, nchunks, offsets);
+    unsigned grid = (unsigned)(nchunks < 256 * 16 ? nchunks : 256 * 16);
+    if (!have) chunk_count_kernel<<<grid, DBLOCK, 0, st>>>(masks, npart, nranks, nchunks, cc);
+    g_chunk_tag = ChunkTag();                 // the scan turns the counts into offsets, in place
+    chunk_scan_kernel<<<nranks, DSCAN, 0, st>>>(cc, nchunks, offsets);
     if (index_elsize == 8)
         fill_kernel<int64_t><<<grid, DBLOCK, 0, st>>>(masks, npart, nranks, nchunks, cc, (int64_t *)indices);
     else
