@@ -232,18 +232,24 @@ template <> struct Radices<9>  { static constexpr int n = 3; static constexpr in
 template <> struct Radices<10> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
 template <> struct Radices<11> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
 
+#ifndef PMX_RPT_D1024
+#define PMX_RPT_D1024 16
+#endif
 // lines of a column per thread: 8 for double; 16 for float, whose 8-byte elements would
 // otherwise keep only half the bytes in flight per thread (measured 3.1 vs 4.6 TB/s per pass)
-template <typename T> struct Rpt { static constexpr int value = 8; };
-template <> struct Rpt<float> { static constexpr int value = 16; };
+template <typename T, int LOGN> struct Rpt { static constexpr int value = 8; };
+template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = 16; };
+// N = 1024 in double: the tile takes 147 KB of LDS, one workgroup per CU; 512 threads with 16
+// lines each keep twice the loads in flight per workgroup
+template <> struct Rpt<double, 10> { static constexpr int value = PMX_RPT_D1024; };
 
 template <typename T, int LOGN, bool INV, bool APPLY, int RB>
-__global__ void __launch_bounds__((1 << LOGN) / Rpt<T>::value * (RB / (int)sizeof(cpx<T>)))
+__global__ void __launch_bounds__(((1 << LOGN) / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))))
 colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 {
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);    // columns per tile: RB-byte row segments
-    constexpr int RPT = Rpt<T>::value;             // lines per thread
+    constexpr int RPT = Rpt<T, LOGN>::value;       // lines per thread
     constexpr int TPC = N / RPT;                   // threads per column
     constexpr int NT = TPC * W;                    // threads per workgroup
     extern __shared__ __align__(16) unsigned char smem[];
@@ -475,7 +481,7 @@ static int launch_colfft(const ColGeom &g, const void *src, void *dst, const voi
 {
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);
-    constexpr int NT = N / Rpt<T>::value * W;
+    constexpr int NT = N / Rpt<T, LOGN>::value * W;
     size_t lds = (size_t)(N * W + N) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
