@@ -228,6 +228,17 @@ int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N
 int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N,
                      int64_t B, int64_t nsplit, double scale, int64_t plain_pitch, void *stream);
 
+/* The axis-0 pass on one chunk [coff, coff + cw) of the last axis of the (N, n1, pitch) block
+ * `full` (pipelined slab transposes: the all-to-all of one chunk overlaps the passes of its
+ * neighbours; PFFT has no such overlap).  `chunk` is the dense (N, n1, cw) buffer the
+ * all-to-all delivers or takes.  to_full = 1: transform `chunk`, scatter into `full`;
+ * to_full = 0: gather the chunk's columns from `full` (optionally times the transfer function,
+ * as in pmx_colfft; start[] = global start of `full`), transform, write `chunk`. */
+int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, void *full, int64_t N, int64_t n1,
+                     int64_t cw, int64_t pitch, int64_t coff, int32_t to_full, double scale,
+                     const pmx_transfer *transfer, const int64_t *start, const int64_t *nmesh,
+                     const double *boxsize, void *stream);
+
 /* Real <-> half-complex transform along the contiguous axis, in place, with the rows
  * resident in LDS (csrc/pmx_colfft.hip): `nrows` rows of n reals (n a power of two in
  * 128..1024) at a pitch of `pitch` complex elements <-> n/2+1 modes.  inverse = 0: r2c,

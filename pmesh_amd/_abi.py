@@ -99,6 +99,8 @@ DEVICE_ONLY = {
     'colfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
                          _P(_i64), _P(_f64), _i64, _i64, _vp]),
     'colfft_split': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _i64, _vp]),
+    'colfft_chunk': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f64, _P(Transfer),
+                               _P(_i64), _P(_i64), _P(_f64), _vp]),
     'rowfft_supported': (C.c_int, [_i64, _i32]),
     'rowfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp]),
     'slab_pack': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _P(_i64), _i32, _i32, _vp]),

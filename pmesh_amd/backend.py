@@ -107,6 +107,15 @@ class HipBackend(object):
         self.call('colfft_split', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), A, N, B,
                   int(nsplit), float(scale), int(plain_pitch), self.stream())
 
+    def colfft_chunk(self, elsize, inverse, chunk, full, N, n1, cw, pitch, coff, to_full, scale=1.0,
+                     transfer=None, start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
+        """axis-0 pass on the columns [coff, coff+cw) of the (N, n1, pitch) block `full`, through the
+        dense (N, n1, cw) buffer `chunk` (pipelined slab transposes)"""
+        self.call('colfft_chunk', elsize, int(bool(inverse)), chunk.data_ptr(), full.data_ptr(), N, n1, cw,
+                  pitch, coff, int(bool(to_full)), float(scale),
+                  C.byref(transfer) if transfer is not None else None,
+                  _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3), self.stream())
+
     def rowfft_supported(self, n, elsize):
         return self.lib.pmx_rowfft_supported(int(n), int(elsize)) == 0
 

@@ -20,6 +20,12 @@ import numpy
 import torch
 
 
+class _Done(object):
+    """handle of an exchange that has already happened"""
+    def wait(self):
+        return True
+
+
 class SelfComm(object):
     """The single-process communicator (size 1): every collective is the identity."""
     rank = 0
@@ -43,8 +49,9 @@ class SelfComm(object):
     def alltoallv(self, send, sendcounts, recv, recvcounts):
         recv.copy_(send)
 
-    def alltoall(self, send, recv):
+    def alltoall(self, send, recv, send_splits=None, recv_splits=None, async_op=False):
         recv.copy_(send)
+        return _Done() if async_op else None
 
     def subgroups(self, rank_lists):
         return [self for _ in rank_lists]
@@ -116,12 +123,16 @@ class TorchComm(object):
                                      input_split_sizes=[int(c) for c in sendcounts],
                                      group=self.group)
 
-    def alltoall(self, send, recv, send_splits=None, recv_splits=None):
+    def alltoall(self, send, recv, send_splits=None, recv_splits=None, async_op=False):
+        """async_op: returns a handle whose wait() orders the *current stream* (RCCL) / the host
+        (gloo) after the exchange; the buffers must stay untouched until then"""
         if send_splits is None:
-            self._dist.all_to_all_single(recv, send, group=self.group)
+            w = self._dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
         else:
-            self._dist.all_to_all_single(recv, send, output_split_sizes=list(recv_splits),
-                                         input_split_sizes=list(send_splits), group=self.group)
+            w = self._dist.all_to_all_single(recv, send, output_split_sizes=list(recv_splits),
+                                             input_split_sizes=list(send_splits), group=self.group,
+                                             async_op=async_op)
+        return w if async_op else None
 
 
 def _torch_subgroups(self, rank_lists):

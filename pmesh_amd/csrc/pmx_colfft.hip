@@ -101,10 +101,22 @@ template <typename T, bool INV, int R> __device__ __forceinline__ void fftR(cpx<
 // complex layout pads its plane stride, see fft.py).  The "split" layout of the slab transpose
 // cuts axis N into N/nl ranges of nl = 1 << sh lines, one contiguous (A, nl, B) block per
 // range (= per destination rank): sa = nl*B, shi = A*nl*B, mask = nl-1.
+// Column remap (cw > 0): column b of the batch is column (b / cw) * cpitch + b % cw of the
+// array — the B = n1 * cw columns of a chunk [coff, coff + cw) of the last axis of an
+// (N, n1, cpitch) array (coff is folded into the base pointer).  This is how the chunks of a
+// pipelined slab transpose are gathered from / scattered into the standard layout.
 struct ColAddr {
     int64_t sa, shi, sn;   // sn: stride between successive lines n (B when dense)
+    int64_t cw, cpitch;
     int32_t sh, mask;
 };
+
+__device__ __forceinline__ int64_t col_offset(const ColAddr &a, int64_t b)
+{
+    if (a.cw <= 0) return b;
+    int64_t q = b / a.cw;
+    return q * a.cpitch + (b - q * a.cw);
+}
 
 struct ColGeom {
     int64_t A, B;          // outer and inner batch extents
@@ -263,9 +275,9 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     const int col = tid % W, tj = tid / W;   // W consecutive lanes = one 128-byte row segment
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
-        const cpx<T> *ibase = src + a * g.in.sa + b0;
-        cpx<T> *obase = dst + a * g.out.sa + b0;
         const bool colok = b0 + col < g.B;
+        const cpx<T> *ibase = src + a * g.in.sa + (colok ? col_offset(g.in, b0 + col) : 0);
+        cpx<T> *obase = dst + a * g.out.sa + (colok ? col_offset(g.out, b0 + col) : 0);
         ColK ck = {0, 0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         __syncthreads();
@@ -274,7 +286,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
             int n = tj + u * TPC;
-            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + col]
+            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn]
                           : cpx<T>{0, 0};
         }
 #pragma unroll
@@ -314,7 +326,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
                 cpx<T> v = buf[lds_index<T, RB>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
-                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn + col] = v;
+                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn] = v;
             }
         }
     }
@@ -597,7 +609,7 @@ extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t n
 static ColAddr plain_addr(int64_t N, int64_t B)
 {
     ColAddr a;
-    a.sa = N * B; a.shi = 0; a.sn = B; a.sh = 31; a.mask = 0x7fffffff;
+    a.sa = N * B; a.shi = 0; a.sn = B; a.sh = 31; a.mask = 0x7fffffff; a.cw = 0; a.cpitch = 0;
     return a;
 }
 
@@ -687,6 +699,7 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     split.mask = (int32_t)(nsplit - 1);
     split.sa = nsplit * B;
     split.sn = B;
+    split.cw = 0; split.cpitch = 0;
     split.shi = A * nsplit * B;
     // the plain side may have padded lines (plain_pitch >= B elements per line, e.g. rows
     // rounded up to 128 bytes); the split side is always dense
@@ -700,4 +713,61 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     if (rc) return rc;
     if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, false, st);
     return dispatch_logn<float>(g, src, dst, tw, inverse != 0, false, st);
+}
+
+// The axis-0 pass of a slab transform on ONE chunk of the last axis (pipelined transposes: the
+// all-to-all of chunk c overlaps the passes of chunks c-1 and c+1).  `full` is the standard
+// (N, n1, pitch) block of the transposed complex field; the chunk is its columns
+// [coff, coff + cw) of every n1 row, and `chunk` is the dense (N, n1, cw) buffer that the
+// all-to-all delivers (r2c: what the ranks sent, row-major by source = line index) or takes.
+//   to_full = 1: FFT along N of `chunk`, result scattered into `full` (r2c, last stage);
+//   to_full = 0: FFT along N of the chunk's columns gathered from `full`, result dense in
+//                `chunk` (c2r, first stage; t != NULL multiplies by the transfer function first,
+//                see pmx_colfft; start[] is the global start of the full block).
+extern "C" int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, void *full, int64_t N,
+                                int64_t n1, int64_t cw, int64_t pitch, int64_t coff, int32_t to_full,
+                                double scale, const pmx_transfer *t, const int64_t *start,
+                                const int64_t *nmesh, const double *boxsize, void *stream)
+{
+    int rc = pmx_colfft_supported(N, elsize);
+    if (rc) { set_error("pmx_colfft_chunk: unsupported length %lld", (long long)N); return rc; }
+    PMX_REQUIRE(chunk != nullptr && full != nullptr && chunk != full, PMX_EINVAL, "bad buffers");
+    PMX_REQUIRE(n1 >= 0 && cw >= 0 && coff >= 0 && coff + cw <= pitch, PMX_EINVAL, "bad chunk geometry");
+    if (n1 == 0 || cw == 0) return PMX_OK;
+    const int64_t B = n1 * cw;
+    ColGeom g;
+    g.A = 1; g.B = B; g.N = (int32_t)N; g.scale = scale;
+    g.logN = 0;
+    while ((1ll << g.logN) < N) g.logN++;
+    g.n1 = 1; g.n2 = 1;
+    ColAddr dense = plain_addr(N, B);
+    ColAddr mapped = plain_addr(N, n1 * pitch);
+    mapped.cw = cw;
+    mapped.cpitch = pitch;
+    g.in = to_full ? dense : mapped;
+    g.out = to_full ? mapped : dense;
+    bool apply = t != nullptr;
+    if (apply) {
+        PMX_REQUIRE(!to_full && B < (1ll << 31), PMX_EINVAL, "the fused transfer belongs to the gathering pass");
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
+                    t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
+                    PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
+        g.t = *t;
+        g.n1 = (int32_t)n1; g.n2 = (int32_t)cw;        // column b = (i1, i2 - coff)
+        for (int d = 0; d < 3; d++) {
+            g.start[d] = start[d] + (d == 2 ? coff : 0);
+            g.nmesh[d] = nmesh[d];
+            g.dw[d] = 2 * M_PI / nmesh[d];
+            g.nl[d] = nmesh[d] / boxsize[d];
+        }
+    }
+    size_t es = 2 * (size_t)elsize;
+    const void *src = to_full ? chunk : (const void *)((const char *)full + coff * es);
+    void *dst = to_full ? (void *)((char *)full + coff * es) : chunk;
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)N, elsize, &tw, st);
+    if (rc) return rc;
+    if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, apply, st);
+    return dispatch_logn<float>(g, src, dst, tw, inverse != 0, apply, st);
 }

@@ -189,6 +189,10 @@ class Partition(object):
             self.alloc_reals = max(self.alloc_reals, 2 * mid)
 
 
+#: number of chunks of the last axis the slab transposes are pipelined over (the all-to-all of
+#: a chunk runs under the column passes of its neighbours); 1: one exchange per transform
+OVERLAP_CHUNKS = 2
+
 #: pad the plane stride of the one-rank 3-d layout (see Partition); False: dense planes
 PLANE_PAD = True
 
@@ -546,6 +550,10 @@ class Plan(object):
             N2c = n2
             nb = n1loc * N2c
             pi = int(getattr(p, 'pitch_i', N2c))                # complex elements per real-side row
+            chunks = self._chunks(be, p, P, N0, N1, N2c, n0loc, n1loc, e0, e1)
+            if chunks:
+                return self._execute_slab_pipelined(be, comm, bufin, bufout, transfer, chunks, same,
+                                                    N0, N1, N2, N2c, n0loc, n1loc, pi, norm, W0, W1, W2)
             if self.forward:
                 X = bufin.storage
                 if not same:
@@ -655,6 +663,71 @@ class Plan(object):
                     shape = [n0loc] + inner_real
                     dst = torch.as_strided(bufout.storage, shape, [plane_r] + list(inner_strides_r))
                     dst.copy_(W1[:int(numpy.prod(shape, dtype='i8'))].view(shape))
+
+    def _chunks(self, be, p, P, N0, N1, N2c, n0loc, n1loc, e0, e1):
+        """[(first column, width)] of the last axis if the transposes can be pipelined: equal
+        power-of-two blocks on both sides and enough columns; widths are multiples of 8 columns
+        (128-byte lines of complex128) except for the last chunk"""
+        C = int(OVERLAP_CHUNKS)
+        if C < 2 or not hasattr(be, 'colfft_chunk') or N2c < 64:
+            return None
+        if n1loc * P != N1 or n1loc & (n1loc - 1) or n0loc * P != N0 or n0loc == 0:
+            return None
+        if any(e1[r + 1] - e1[r] != n1loc for r in range(P)) or any(e0[r + 1] - e0[r] != n0loc for r in range(P)):
+            return None
+        w = -(-N2c // C)
+        w = -(-w // 8) * 8
+        out, b0 = [], 0
+        while b0 < N2c:
+            cw = min(w, N2c - b0)
+            out.append((b0, cw))
+            b0 += cw
+        return out if len(out) > 1 else None
+
+    def _execute_slab_pipelined(self, be, comm, bufin, bufout, transfer, chunks, same,
+                                N0, N1, N2, N2c, n0loc, n1loc, pi, norm, W0, W1, W2):
+        """The slab transform with its global transpose cut into chunks of the last axis: every
+        stage but the row transform works chunk by chunk, so the all-to-all of chunk c (on RCCL's
+        stream) runs under the column pass of chunk c+1 before it and of chunk c-1 after it.
+        The fused pack / unpack and the axis-0 pass address their chunk inside the standard
+        layouts (pmx_colfft_split with an offset base, pmx_colfft_chunk), nothing is copied."""
+        es = self.elsize
+        offs, o = [], 0
+        for b0, cw in chunks:
+            offs.append(o)
+            o += 2 * n0loc * N1 * cw                  # reals of a chunk (= 2 * N0 * n1loc * cw)
+        works = []
+        if self.forward:
+            X = bufin.storage
+            if not same:
+                nreal = n0loc * N1 * 2 * pi
+                W0[:nreal].copy_(bufin.storage[:nreal])     # r2c preserves its input
+                X = W0
+            be.rowfft(es, False, X, n0loc * N1, N2, pi)
+            for (b0, cw), o in zip(chunks, offs):
+                n = 2 * n0loc * N1 * cw
+                be.colfft_split(es, False, X[2 * b0:], W1[o:o + n], n0loc, N1, cw, n1loc, scale=norm, plain_pitch=pi)
+                works.append(comm.alltoall(W1[o:o + n], W2[o:o + n], async_op=True))
+            out = bufout.storage
+            for (b0, cw), o, w in zip(chunks, offs, works):
+                w.wait()
+                be.colfft_chunk(es, False, W2[o:], out, N0, n1loc, cw, N2c, b0, True)
+        else:
+            S = bufin.storage                              # read only: c2r preserves its input
+            t = transfer
+            for (b0, cw), o in zip(chunks, offs):
+                n = 2 * N0 * n1loc * cw
+                if t is not None:
+                    be.colfft_chunk(es, True, W2[o:], S, N0, n1loc, cw, N2c, b0, False, transfer=t[0],
+                                    start=t[1], nmesh=t[2], boxsize=t[3])
+                else:
+                    be.colfft_chunk(es, True, W2[o:], S, N0, n1loc, cw, N2c, b0, False)
+                works.append(comm.alltoall(W2[o:o + n], W1[o:o + n], async_op=True))
+            Y = bufout.storage
+            for (b0, cw), o, w in zip(chunks, offs, works):
+                w.wait()
+                be.colfft_split(es, True, W1[o:], Y[2 * b0:], n0loc, N1, cw, n1loc, plain_pitch=pi)
+            be.rowfft(es, True, Y, n0loc * N1, N2, pi)
 
     def _execute_slab_untransposed(self, bufin, bufout, mode=None):
         """The untransposed complex layout (n0_local, N1, N2c) on several ranks: the transposed

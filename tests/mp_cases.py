@@ -205,6 +205,43 @@ def case_slab_fft(be, comm):
                                numpy.arange(ck.slices[d].start, ck.slices[d].stop))
 
 
+def case_pipelined_equals_single_exchange(be, comm):
+    """the slab transform with its transposes pipelined over chunks of the last axis
+    (fft.OVERLAP_CHUNKS) gives the same numbers as one exchange per transform"""
+    from pmesh_amd import fft as _fft
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    if comm.size not in (2, 4, 8):
+        return
+    Nmesh = [64, 64, 128]
+    data = numpy.random.RandomState(31).normal(size=Nmesh)
+    res = {}
+    for chunks in (3, 2, 1):
+        comm.Barrier()
+        _fft.OVERLAP_CHUNKS = chunks
+        comm.Barrier()
+        try:
+            pm = ParticleMesh(BoxSize=[3.0, 2.0, 5.0], Nmesh=Nmesh, comm=comm, dtype='f8', np=[comm.size])
+            plan = pm.plans['forwardT']
+            p = plan.partition
+            got = plan._chunks(be, p, comm.size, 64, 64, 65, 64 // comm.size, 64 // comm.size,
+                               [int(x) for x in p.i_edges[0]], [int(x) for x in p.o_edges[1]])
+            assert (got is None) == (chunks == 1), (chunks, got)
+            if got:
+                assert sum(w for _, w in got) == 65 and all(b % 8 == 0 for b, _ in got)
+            real = pm.create('real', value=data[pm.create('real').slices])
+            ck = real.r2c()
+            back = ck.c2r(transfer=Transfer.dx1(2))
+            ip = real.copy().r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=Transfer.dx1(2))
+            res[chunks] = [numpy.asarray(x.value.cpu()) for x in (ck, back, ip)]
+        finally:
+            comm.Barrier()
+            _fft.OVERLAP_CHUNKS = 2
+    for chunks in (3, 2):
+        for a, b in zip(res[chunks], res[1]):
+            assert_allclose(a, b, rtol=0, atol=1e-13 * max(1.0, abs(b).max()))
+
+
 def case_fused_transfer_slab(be, comm):
     """c2r(transfer=T) on a slab decomposition (T folded into the first column pass of the
     inverse transform) == apply(T).c2r(), and leaves the complex field untouched out of place"""
@@ -422,7 +459,7 @@ def case_pencil(be, comm):
 
 
 CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
-         case_ghosts_only_equals_literal, case_slab_fft, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_cycle]
+         case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_cycle]
 
 
 def main():

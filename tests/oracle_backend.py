@@ -129,7 +129,9 @@ class OracleBackend(object):
         cdt = 'c8' if elsize == 4 else 'c16'
         pp = plain_pitch or B
         plain_t, split_t = (dst, src) if inverse else (src, dst)
-        plain = plain_t.detach().numpy().reshape(-1).view(cdt)[:A * N * pp].reshape(A, N, pp)[:, :, :B]
+        pflat = plain_t.detach().numpy().reshape(-1).view(cdt)      # may start at a column offset
+        isz = pflat.itemsize
+        plain = numpy.lib.stride_tricks.as_strided(pflat, (A, N, B), (N * pp * isz, pp * isz, isz))
         split = split_t.detach().numpy().reshape(-1).view(cdt)[:A * N * B]
         R = N // nsplit
         if inverse:
@@ -138,6 +140,21 @@ class OracleBackend(object):
         else:
             y = numpy.fft.fft(plain.astype('c16'), axis=1) * scale
             split.reshape(R, A, nsplit, B)[...] = y.reshape(A, R, nsplit, B).transpose(1, 0, 2, 3)
+
+    def colfft_chunk(self, elsize, inverse, chunk, full, N, n1, cw, pitch, coff, to_full, scale=1.0,
+                     transfer=None, start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
+        cdt = 'c8' if elsize == 4 else 'c16'
+        ch = chunk.detach().numpy().reshape(-1).view(cdt)[:N * n1 * cw].reshape(N, n1, cw)
+        fu = full.detach().numpy().reshape(-1).view(cdt)[:N * n1 * pitch].reshape(N, n1, pitch)[:, :, coff:coff + cw]
+        x = (ch if to_full else fu).astype('c16')
+        if transfer is not None:
+            st = (start[0], start[1], start[2] + coff)
+            x = O.apply_transfer(transfer, numpy.ascontiguousarray(x), st, nmesh, boxsize)
+        y = (numpy.fft.ifft(x, axis=0) * N if inverse else numpy.fft.fft(x, axis=0)) * scale
+        if to_full:
+            fu[...] = y
+        else:
+            ch[...] = y
 
     def rowfft_supported(self, n, elsize):
         n = int(n)

@@ -119,3 +119,46 @@ def test_colfft_fused_transfer(be, oracle):
         be.colfft(8, True, d, 1, N0, n1 * n2, transfer=t, n1=n1, n2=n2, start=start, nmesh=nmesh, boxsize=box)
         got = d.cpu().numpy().view('c16').reshape(N0, n1, n2)
         assert rel(got, want) < 1e-14
+
+
+@pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
+def test_colfft_chunk(be, oracle, elsize, tol):
+    """the axis-0 pass on a chunk [coff, coff+cw) of the last axis of an (N, n1, pitch) block,
+    through the dense chunk buffer of a pipelined transpose: scatter (r2c side), gather (c2r
+    side), gather with the fused transfer; everything outside the chunk stays untouched"""
+    cdt = 'c16' if elsize == 8 else 'c8'
+    tdt = torch.complex128 if elsize == 8 else torch.complex64
+    N, n1, pitch = 64, 5, 21
+    nmesh, box, start = (N, 10, 40), (30.0, 20.0, 50.0), (0, 5, 0)
+    rs = numpy.random.RandomState(9)
+    full_h = (rs.normal(size=(N, n1, pitch)) + 1j * rs.normal(size=(N, n1, pitch))).astype(cdt)
+    for coff, cw in ((0, 8), (8, 13), (3, 7), (0, 21)):
+        chunk_h = (rs.normal(size=(N, n1, cw)) + 1j * rs.normal(size=(N, n1, cw))).astype(cdt)
+        # to_full: FFT of the chunk lands in the columns of the block
+        full = torch.from_numpy(full_h.copy()).to(be.device)
+        chunk = torch.from_numpy(chunk_h.copy()).to(be.device)
+        be.colfft_chunk(elsize, False, torch.view_as_real(chunk).reshape(-1), torch.view_as_real(full).reshape(-1),
+                        N, n1, cw, pitch, coff, True, scale=0.5)
+        got = full.cpu().numpy()
+        want = full_h.copy()
+        want[:, :, coff:coff + cw] = numpy.fft.fft(chunk_h.astype('c16'), axis=0) * 0.5
+        assert rel(got[:, :, coff:coff + cw], want[:, :, coff:coff + cw]) < tol * 6
+        mask = numpy.ones(pitch, bool)
+        mask[coff:coff + cw] = False
+        assert numpy.array_equal(got[:, :, mask], full_h[:, :, mask])
+        assert numpy.array_equal(chunk.cpu().numpy(), chunk_h)
+        # gather: inverse FFT of the block's columns into the chunk buffer, block untouched
+        full = torch.from_numpy(full_h.copy()).to(be.device)
+        chunk = torch.zeros((N, n1, cw), dtype=tdt, device=be.device)
+        be.colfft_chunk(elsize, True, torch.view_as_real(chunk).reshape(-1), torch.view_as_real(full).reshape(-1),
+                        N, n1, cw, pitch, coff, False)
+        want = numpy.fft.ifft(full_h[:, :, coff:coff + cw].astype('c16'), axis=0) * N
+        assert rel(chunk.cpu().numpy(), want) < tol * 6
+        assert numpy.array_equal(full.cpu().numpy(), full_h)
+        # gather with the transfer function of the block's global coordinates
+        t = oracle.make_transfer(laplace_pow=-1, grad_dir=2)
+        be.colfft_chunk(elsize, True, torch.view_as_real(chunk).reshape(-1), torch.view_as_real(full).reshape(-1),
+                        N, n1, cw, pitch, coff, False, transfer=t, start=start, nmesh=nmesh, boxsize=box)
+        tk = oracle.apply_transfer(t, full_h.astype('c16'), start, nmesh, box)
+        want = numpy.fft.ifft(tk[:, :, coff:coff + cw], axis=0) * N
+        assert rel(chunk.cpu().numpy(), want) < tol * 6

@@ -62,7 +62,13 @@ class ThreadComm(object):
     def alltoallv(self, send, sendcounts, recv, recvcounts):
         self.alltoall(send, recv, [int(c) for c in sendcounts], [int(c) for c in recvcounts], rows=True)
 
-    def alltoall(self, send, recv, send_splits=None, recv_splits=None, rows=False):
+    def alltoall(self, send, recv, send_splits=None, recv_splits=None, rows=False, async_op=False):
+        self._alltoall(send, recv, send_splits, recv_splits, rows)
+        if async_op:
+            from pmesh_amd.comm import _Done
+            return _Done()
+
+    def _alltoall(self, send, recv, send_splits=None, recv_splits=None, rows=False):
         if send_splits is None:
             n = send.shape[0] // self.size
             send_splits = [n] * self.size
