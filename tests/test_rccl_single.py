@@ -36,6 +36,15 @@ b = torch.empty_like(a)
 comm.alltoallv(a, [4], b, [4]); assert torch.equal(a, b)
 c = torch.empty(12, dtype=torch.float64, device=dev)
 comm.alltoall(a.reshape(-1), c, [12], [12]); assert torch.equal(a.reshape(-1), c)
+# the pipelined transposes: several asynchronous exchanges of slices of persistent buffers in
+# flight while kernels run on the current stream; wait() orders the stream after each
+W1 = torch.arange(4096, dtype=torch.float64, device=dev)
+W2 = torch.zeros_like(W1)
+works = [comm.alltoall(W1[o:o + 1024], W2[o:o + 1024], async_op=True) for o in (0, 1024, 2048)]
+busy = (W1 * 2.0).sum()
+for w in works:
+    w.wait()
+assert torch.equal(W2[:3072], W1[:3072]) and float(W2[3072:].abs().max()) == 0 and float(busy) == 4095 * 4096
 comm.Barrier()
 subs = comm.subgroups([[0], [0]])
 assert subs[0].size == 1 and subs[1].size == 1
