@@ -18,6 +18,9 @@ PFFT = serial FFTW per rank + MPI all-to-all transposes.  Here
 Partitions are block distributions with block = ceil(N / P) (FFTW-MPI / PFFT
 default): rank r owns [r*block, min((r+1)*block, N)).
 """
+import os
+import warnings
+
 import numpy
 import torch
 
@@ -191,7 +194,29 @@ class Partition(object):
 
 #: number of chunks of the last axis the slab transposes are pipelined over (the all-to-all of
 #: a chunk runs under the column passes of its neighbours); 1: one exchange per transform
-OVERLAP_CHUNKS = 2
+OVERLAP_CHUNKS = int(os.environ.get('PMESH_AMD_OVERLAP_CHUNKS', '2'))
+
+
+def _async_exchange_works(comm):
+    """one tiny asynchronous all-to-all per communicator, the first time a transform wants to
+    pipeline its transposes: a backend that cannot do it (raises) switches the pipeline off for
+    that communicator instead of failing the transform.  Collective: every rank calls it."""
+    ok = getattr(comm, '_pmx_async_ok', None)
+    if ok is None:
+        try:
+            dev = backend.get().device
+            a = torch.arange(comm.size, dtype=torch.float64, device=dev)
+            b = torch.empty_like(a)
+            comm.alltoall(a, b, async_op=True).wait()
+            ok = True
+        except Exception as ex:          # noqa
+            warnings.warn('asynchronous all-to-all is not available (%r): transposes are not pipelined' % (ex,))
+            ok = False
+        try:
+            comm._pmx_async_ok = ok
+        except Exception:
+            pass
+    return ok
 
 #: pad the plane stride of the one-rank 3-d layout (see Partition); False: dense planes
 PLANE_PAD = True
@@ -670,6 +695,8 @@ class Plan(object):
         (128-byte lines of complex128) except for the last chunk"""
         C = int(OVERLAP_CHUNKS)
         if C < 2 or not hasattr(be, 'colfft_chunk') or N2c < 64:
+            return None
+        if not _async_exchange_works(p.procmesh.comm):
             return None
         if n1loc * P != N1 or n1loc & (n1loc - 1) or n0loc * P != N0 or n0loc == 0:
             return None
