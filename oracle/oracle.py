@@ -350,7 +350,11 @@ def zeldovich_modes(nlat, boxsize, rms_cells=3.0, nmodes=16, seed=1234):
     directions, amplitudes ~ 1/|n| scaled to an rms displacement of
     `rms_cells` cells, phases — from numpy.random.RandomState(seed)."""
     rng = numpy.random.RandomState(seed)
-    n = rng.randint(-4, 5, size=(nmodes, 3)).astype('f8')
+    # wavenumbers up to nlat/16 per axis: with a 3-cell rms displacement the displacement gradient
+    # is ~1 (shell crossing, caustics: density contrast >> 10); |n| <= 4 alone would be a smooth,
+    # single-stream flow with a contrast of order one
+    nmax = max(4, int(nlat) // 16)
+    n = rng.randint(-nmax, nmax + 1, size=(nmodes, 3)).astype('f8')
     n[(n == 0).all(axis=1)] = [1, 0, 0]
     norm = numpy.sqrt((n ** 2).sum(axis=1))
     direc = n / norm[:, None]

@@ -253,12 +253,13 @@ def test_full_size_properties(hip, name, dtype):
     assert abs(lhs - rhs) <= (1e-10 if dtype == 'f8' else 1e-3) * abs(rhs)
 
 
-@pytest.mark.parametrize('N,name,dtype,gradient,tol', [
-    (256, 'cic', 'f8', None, 1e-11),       # BASELINE config 2 (measured 2.6e-15)
-    (512, 'cic', 'f8', None, 1e-11),       # the headline workload of bench.py (measured 3.9e-15)
-    (512, 'tsc', 'f4', 0, 2e-5),           # BASELINE config 3: TSC + gradient readout, fp32 (measured 1.3e-6)
+@pytest.mark.parametrize('N,name,dtype,gradient,tol,data', [
+    (256, 'cic', 'f8', None, 1e-11, 'uniform'),     # BASELINE config 2 (measured 2.6e-15)
+    (512, 'cic', 'f8', None, 1e-11, 'uniform'),     # the headline workload of bench.py (measured 3.9e-15)
+    (512, 'tsc', 'f4', 0, 2e-5, 'uniform'),         # BASELINE config 3: TSC + gradient readout, fp32 (1.3e-6)
+    (512, 'cic', 'f8', None, 1e-11, 'clustered'),   # the headline on the Zel'dovich-displaced set
 ])
-def test_baseline_cycle_equals_oracle(hip, oracle, N, name, dtype, gradient, tol):
+def test_baseline_cycle_equals_oracle(hip, oracle, N, name, dtype, gradient, tol, data):
     """BASELINE.json's single-GPU configurations at their FULL size — uniform particles (the
     bench's lattice + hashed jitter), one per cell — through the production form of the cycle
     (tile-binned paint/readout, LDS row/column FFT on the padded layout, transfer fused into
@@ -272,17 +273,27 @@ def test_baseline_cycle_equals_oracle(hip, oracle, N, name, dtype, gradient, tol
     tdt = torch.float64 if dtype == 'f8' else torch.float32
     pos = torch.empty((N ** 3, 3), dtype=tdt, device=hip.device)
     pv = vec(pos)
-    hip.call('synth_uniform', C.byref(pv), N, L, 42, 0, N ** 3, hip.stream())
+    if data == 'uniform':
+        hip.call('synth_uniform', C.byref(pv), N, L, 42, 0, N ** 3, hip.stream())
+    else:
+        modes = oracle.zeldovich_modes(N, L)                        # 3-cell rms displacement, 16 plane waves
+        hip.call('synth_clustered', C.byref(pv), N, L, modes.ctypes.data_as(C.POINTER(C.c_double)), len(modes),
+                 0.0, 0, N ** 3, hip.stream())
     pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype=dtype, resampler=name)
     rho = pm.paint(pos)
     assert_binned_ran()
+    peak = float(rho.value.max())                                   # before the in-place transforms
     f = rho.r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=Transfer.dx1(0)).readout(pos, gradient=gradient)
-    pos_h = oracle.synth_uniform(N, L, dtype=dtype)
-    assert numpy.array_equal(pos_h, pos.cpu().numpy())             # the same particles, bit for bit
+    pos_h = pos.cpu().numpy()
+    if data == 'uniform':
+        assert numpy.array_equal(pos_h, oracle.synth_uniform(N, L, dtype=dtype))   # bit for bit the oracle's set
+    else:
+        print('clustered set: densest cell holds %.1f particles (mean 1)' % peak)
+        assert peak > 10                                            # density contrast >> 1
     t = oracle.make_transfer(laplace_pow=-1, grad_dir=0, grad_kind=0)
     real, ck, back, want = oracle.pm_cycle(N, L, pos_h, kind='tuned' + name, transfer=t, gradient=gradient,
                                            dtype=dtype)
     got = f.cpu().numpy()
     err = abs(got - want).max() / abs(want).max()
-    print('full-size cycle N=%d %s %s: max |error| / max |value| = %.3e' % (N, name, dtype, err))
+    print('full-size cycle N=%d %s %s %s: max |error| / max |value| = %.3e' % (N, name, dtype, data, err))
     assert err <= tol
