@@ -294,39 +294,41 @@ class Field(NDArrayLike):
 
     def csetitem(self, index, y):
         """ set a value at an absolute index collectively; maintains Hermitian conjugation
-            (pm.py:298-345).  Returns the value that was actually set. """
+            (pm.py:298-345).  Returns the value that was actually set.
+
+            A complex field stores one of every conjugate pair (k, -k); setting mode k also sets
+            its partner -k (if this rank holds it) to conj(y).  A mode that is its own partner
+            keeps only the real part.  With a trailing 0 / 1 the index addresses the real /
+            imaginary component alone (the partner's imaginary part gets the opposite sign, and
+            the imaginary part of a self-conjugate mode cannot be set: 0 is returned). """
         index = numpy.array(index, copy=True)
-        value, localindex = self._ctol(index)
+        component = len(index) == self.ndim + 1            # (..., 0 | 1): one component
+        value, here = self._ctol(index)
+        there = None
         if isinstance(self, BaseComplexField):
-            dualindex = numpy.negative(index)
-            if len(dualindex) == self.ndim + 1:
-                dualindex[-1] *= -1
-            dualindex[:self.ndim] += self.Nmesh
-            dualindex[:self.ndim] %= self.Nmesh
-            unused, duallocalindex = self._ctol(dualindex)
-        else:
-            duallocalindex = None          # real field, no dual
-        dualy = y
-        if localindex is None:
-            y = 0
-        if duallocalindex is None:
-            dualy = 0
-        if len(index) == self.ndim + 1 and index[-1] == 1:
-            dualy = -dualy
-            if localindex is not None and duallocalindex is not None and localindex == duallocalindex:
-                y = 0                      # self dual and imag
-                dualy = 0
+            partner = index.copy()
+            partner[:self.ndim] = (self.Nmesh - index[:self.ndim]) % self.Nmesh
+            there = self._ctol(partner)[1]
+        mine = y if here is not None else 0
+        theirs = y if there is not None else 0
+        selfconj = here is not None and here == there
+        if component:
+            if index[-1] == 1:
+                theirs = -theirs
+                if selfconj:
+                    mine = theirs = 0
         elif len(index) == self.ndim:
-            dualy = numpy.conjugate(dualy)
-            if localindex is not None and duallocalindex is not None and localindex == duallocalindex:
-                dualy = dualy.real         # self conjugate
-                y = y.real
-        if localindex is not None:
-            value[tuple(int(i) for i in localindex)] = y
-        if duallocalindex is not None:
-            value[tuple(int(i) for i in duallocalindex)] = dualy
-        r = self.pm.comm.allreduce(complex(y) if value.is_complex() else float(numpy.real(y)))
-        if isinstance(r, complex) and r.imag == 0 and not isinstance(y, complex):
+            theirs = numpy.conjugate(theirs)
+            if selfconj:
+                mine = numpy.real(mine)
+                theirs = numpy.real(theirs)
+        if here is not None:
+            value[tuple(int(i) for i in here)] = mine
+        if there is not None:
+            value[tuple(int(i) for i in there)] = theirs
+        # every rank brings the same kind of number to the collective
+        r = self.pm.comm.allreduce(complex(mine) if value.is_complex() else float(numpy.real(mine)))
+        if isinstance(r, complex) and r.imag == 0 and not isinstance(mine, complex):
             r = r.real
         return r
 
@@ -995,20 +997,15 @@ def exchange(layout, value):
 
 
 def _typestr_to_type(typestr):
-    if not isinstance(typestr, type):
-        if typestr == 'real':
-            typestr = RealField
-        elif typestr == 'complex':
-            typestr = ComplexField
-        elif typestr == 'transposedcomplex':
-            typestr = TransposedComplexField
-        elif typestr == 'untransposedcomplex':
-            typestr = UntransposedComplexField
-        else:
-            raise ValueError('mode must be real or complex, or ')
-    if not issubclass(typestr, Field):
+    """ field class from its name or itself (pm.py:1159-1176): same names, same exceptions """
+    names = {'real': RealField, 'complex': ComplexField, 'transposedcomplex': TransposedComplexField,
+             'untransposedcomplex': UntransposedComplexField}
+    cls = typestr if isinstance(typestr, type) else names.get(typestr)
+    if cls is None:
+        raise ValueError('mode must be real or complex, or ')
+    if not issubclass(cls, Field):
         raise TypeError("mode must be a subclass of %s" % str(Field))
-    return typestr
+    return cls
 
 
 def _init_i_coords(partition, Nmesh, BoxSize, dtype, device):
