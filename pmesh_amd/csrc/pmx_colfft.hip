@@ -255,7 +255,10 @@ template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = 16; }
 // lines each keep twice the loads in flight per workgroup
 template <> struct Rpt<double, 10> { static constexpr int value = PMX_RPT_D1024; };
 
-template <typename T, int LOGN, bool INV, bool APPLY, int RB>
+// REMAP: the columns go through col_offset (chunks of a pipelined transpose).  A template
+// parameter because the per-lane column offsets cost the plain passes 34 VGPRs (156 instead of
+// 122 at N = 512: one workgroup per CU instead of two, 541 instead of 476 us per pass).
+template <typename T, int LOGN, bool INV, bool APPLY, int RB, bool REMAP>
 __global__ void __launch_bounds__(((1 << LOGN) / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))))
 colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 {
@@ -276,8 +279,10 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
         const bool colok = b0 + col < g.B;
-        const cpx<T> *ibase = src + a * g.in.sa + (colok ? col_offset(g.in, b0 + col) : 0);
-        cpx<T> *obase = dst + a * g.out.sa + (colok ? col_offset(g.out, b0 + col) : 0);
+        // plain: one base per tile, lanes add their column; REMAP: a base per lane
+        const cpx<T> *ibase = src + a * g.in.sa + (REMAP ? (colok ? col_offset(g.in, b0 + col) : 0) : b0);
+        cpx<T> *obase = dst + a * g.out.sa + (REMAP ? (colok ? col_offset(g.out, b0 + col) : 0) : b0);
+        const int lcol = REMAP ? 0 : col;
         ColK ck = {0, 0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         __syncthreads();
@@ -286,7 +291,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
             int n = tj + u * TPC;
-            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn]
+            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + lcol]
                           : cpx<T>{0, 0};
         }
 #pragma unroll
@@ -326,7 +331,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
                 cpx<T> v = buf[lds_index<T, RB>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
-                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn] = v;
+                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn + lcol] = v;
             }
         }
     }
@@ -487,9 +492,9 @@ static int get_twiddles(int N, int es, void **out, hipStream_t st)
     return PMX_OK;
 }
 
-template <typename T, int LOGN, int RB>
-static int launch_colfft(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
-                         hipStream_t st)
+template <typename T, int LOGN, int RB, bool RM>
+static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
+                            hipStream_t st)
 {
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);
@@ -499,7 +504,7 @@ static int launch_colfft(const ColGeom &g, const void *src, void *dst, const voi
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
-        auto k = colfft_kernel<T, LOGN, INV, AP, RB>;                                                          \
+        auto k = colfft_kernel<T, LOGN, INV, AP, RB, RM>;                                                      \
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         k<<<grid, NT, lds, st>>>(g, (const cpx<T> *)src, (cpx<T> *)dst, (const cpx<T> *)tw);                   \
     } while (0)
@@ -508,6 +513,14 @@ static int launch_colfft(const ColGeom &g, const void *src, void *dst, const voi
 #undef LAUNCH
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
+}
+
+template <typename T, int LOGN, int RB>
+static int launch_colfft(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
+                         hipStream_t st)
+{
+    if (g.in.cw > 0 || g.out.cw > 0) return launch_colfft_rm<T, LOGN, RB, true>(g, src, dst, tw, inverse, apply, st);
+    return launch_colfft_rm<T, LOGN, RB, false>(g, src, dst, tw, inverse, apply, st);
 }
 
 // (A 256-byte-row variant, RB = 256 with one workgroup per CU, was measured for the axis-0
