@@ -1,0 +1,67 @@
+"""Register / LDS budgets of the hot kernels, read from the compiler's resource remarks (hipcc
+cross-compiles gfx950 without a GPU).  The budgets are what the measured occupancy depends on:
+the plain column-FFT pass at N = 512 must stay within 128 VGPRs (two 512-thread workgroups per
+CU; at 156 VGPRs r2c went from 1.35 to 1.49 ms), the tile kernels must not spill, and the CIC
+tile region must leave room for four workgroups per CU."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'pmesh_amd', 'csrc')
+HIPCC = '/opt/rocm/bin/hipcc'
+
+
+def resources(source):
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math',
+           '-I' + os.path.join(ROOT, 'include'), '-c', os.path.join(CSRC, source), '-o', os.devnull,
+           '-Rpass-analysis=kernel-resource-usage']
+    out = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    table, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            table[name] = {}
+            continue
+        m = re.search(r'remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\d+)', line)
+        if m and name:
+            table[name][m.group(1).split(' ')[0]] = int(m.group(2))
+    return table
+
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+
+
+def test_column_fft_budgets():
+    t = resources('pmx_colfft.hip')
+    # colfft_kernel<T, LOGN, INV, APPLY, RB, REMAP>: plain passes (no transfer, no chunk remap)
+    plain = {k: v for k, v in t.items() if 'colfft_kernelId' in k and 'ELb0ELi128ELb0E' in k}
+    assert len(plain) >= 10
+    for k, v in plain.items():
+        assert v['ScratchSize'] == 0, k
+    n512 = [v for k, v in plain.items() if 'Li9E' in k]
+    assert len(n512) == 2 and all(v['VGPRs'] <= 128 for v in n512), n512
+    for k, v in t.items():
+        if 'rowfft_kernel' in k:
+            assert v['ScratchSize'] == 0 and v['VGPRs'] <= 128, (k, v)
+
+
+def test_tile_kernel_budgets():
+    t = resources('pmx_binned.hip')
+    tiles = {k: v for k, v in t.items() if 'paint_tile_kernel' in k or 'readout_tile_kernel' in k}
+    assert len(tiles) >= 16
+    for k, v in tiles.items():
+        assert v['ScratchSize'] == 0, k
+        assert v['VGPRs'] <= 128, (k, v)
+    # CIC (kind 5), double canvas: 40 KB regions -> four workgroups per CU
+    for k, v in tiles.items():
+        if 'ILi5Ed' in k:
+            assert v['LDS'] <= 40960 and v['Occupancy'] >= 4, (k, v)
+    for k, v in t.items():
+        if 'bin_count_kernel' in k:
+            assert v['ScratchSize'] == 0, k
