@@ -217,7 +217,8 @@ def main():
             raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`'
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ      # under torch.distributed.run
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl')
@@ -265,6 +266,9 @@ def main():
         from pmesh_amd import pm as _pm
         _pm.GHOSTS_ONLY = 'never'
     if world > 1 or args.exchange:
+        comm.Barrier()                         # RCCL builds its communicator on the first collective
+        layout = pm.decompose(pos)             # untimed first call (allocations, lazy initialisation)
+        comm.Barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         layout = pm.decompose(pos)
@@ -393,7 +397,7 @@ def main():
                 line['cpu_baseline'] = {'value': None, 'unit': 'particles/s', 'cores': 1,
                                         'kind': 'port', 'sample': 'failed: %r' % (ex,)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or launched:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
