@@ -65,6 +65,9 @@ def parse():
     ap.add_argument('--cpu-sample-mesh', type=int, default=256)
     ap.add_argument('--binned', type=int, default=-1, help='1/0 force the tile-binned kernels on/off')
     ap.add_argument('--colfft', type=int, default=1, help='0: all-rocFFT 3-d transforms; 1: LDS column FFT')
+    ap.add_argument('--tile-order', type=int, default=0,
+                    help='1: reorder the particle rows once with ParticleMesh.tile_order before the cycles '
+                         '(the remedy for --data shuffled); the reordering time is reported, not timed')
     ap.add_argument('--exchange', type=int, default=0,
                     help='1: route the particles through a decompose() layout even on one rank')
     ap.add_argument('--ghosts-only', type=int, default=1,
@@ -259,6 +262,14 @@ def main():
                       np=[world])
     transfer = Transfer.dx1(0)             # T(k) = i k_x / k^2
     rho = pm.create('real')
+    t_order = 0.0
+    if args.tile_order:
+        pm.tile_order(pos[:1024])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pos = pos[pm.tile_order(pos)].contiguous()
+        torch.cuda.synchronize()
+        t_order = time.perf_counter() - t0
 
     layout = None
     t_decompose = 0.0
@@ -382,6 +393,7 @@ def main():
                        'fft': 'rocFFT z + LDS column FFT' if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'decompose_ms': round(1e3 * t_decompose, 3),
+            'tile_order_ms': round(1e3 * t_order, 3),
             'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu) for s in
                                         ('paint', 'r2c', 'apply', 'c2r', 'readout')) * units /
                                     (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,

@@ -1272,6 +1272,43 @@ class ParticleMesh(object):
             id += isource[:, i]
         return source, id
 
+    def tile_order(self, pos, transform=None):
+        """ A permutation of the rows of `pos` that makes them spatially coherent (an extension;
+            the reference has no counterpart).
+
+            The tiled paint / readout kernels keep the caller's rows where they are and lean on
+            neighbouring rows being neighbouring particles — what a simulation that stores its
+            particles in ID (lattice) order has.  Rows in random order cost 3-4x (DESIGN.md,
+            "Sensitivity to the order of the particles").  Reordering the particle arrays ONCE,
+
+                o = pm.tile_order(pos);  pos = pos[o];  vel = vel[o];  ...
+
+            restores the coherent case for as long as particles stay near their neighbours (an
+            N-body run: many steps).  The key is the mesh tile (8 x 16 x 32 cells, C order) of the
+            particle's cell, then the cell inside the tile; ties keep their order.  Returns an
+            int64 device tensor. """
+        be = backend.get()
+        dpos, _ = to_device(pos, be.device, 'pos')
+        if transform is None:
+            transform = self.affine
+        nd = self.ndim
+        scale = torch.as_tensor(numpy.broadcast_to(numpy.asarray(transform.scale, dtype='f8'), (nd,)).copy(),
+                                device=be.device)
+        cell = torch.floor(dpos[:, :nd].to(torch.float64) * scale).to(torch.int64)
+        tile = (8, 16, 32)[-nd:] if nd <= 3 else (8,) * nd
+        key = torch.zeros(dpos.shape[0], dtype=torch.int64, device=be.device)
+        inner = torch.zeros_like(key)
+        for d in range(nd):
+            n = int(self.Nmesh[d])
+            c = torch.remainder(cell[:, d], n)
+            nt = -(-n // tile[d])
+            key = key * nt + torch.div(c, tile[d], rounding_mode='floor')
+            inner = inner * tile[d] + torch.remainder(c, tile[d])
+        cells_per_tile = 1
+        for t in tile:
+            cells_per_tile *= t
+        return torch.argsort(key * cells_per_tile + inner, stable=True)
+
     def decompose(self, pos, smoothing=None, transform=None):
         """
         Create a domain decompose layout for particles at given coordinates (pm.py:1754-1793).

@@ -571,3 +571,21 @@ def test_preview(be):                         # test_pm.py:780-814
     assert p8.shape == (8,)
     p2 = comp1.preview(Nmesh=2)
     assert p2.shape == (2, 2, 2) and abs(p2.mean() - preview.mean()) < 1e-12
+
+
+def test_tile_order(be):
+    """pm.tile_order: a permutation; rows that follow each other afterwards share a tile or
+    sit in neighbouring ones; painting the reordered rows gives the same field"""
+    pm = ParticleMesh(BoxSize=64.0, Nmesh=[32, 32, 64], dtype='f8')
+    rs = numpy.random.RandomState(2)
+    pos = rs.uniform(-10, 80, size=(5000, 3))
+    o = pm.tile_order(pos)
+    o = o.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(5000))
+    cell = numpy.floor(pos[o] * (pm.Nmesh / pm.BoxSize)).astype('i8') % pm.Nmesh
+    tile = cell // numpy.array([8, 16, 32])
+    tid = (tile[:, 0] * 2 + tile[:, 1]) * 2 + tile[:, 2]
+    assert (numpy.diff(tid) >= 0).all()                     # tile-major
+    a = numpy.asarray(pm.paint(pos))
+    b = numpy.asarray(pm.paint(pos[o]))
+    assert_allclose(a, b, rtol=0, atol=1e-12 * abs(a).max())
