@@ -56,7 +56,9 @@ typedef enum pmx_window_kind {
     PMX_TUNED_PCS = 7, /* PMESH_PAINTER_TUNED_PCS */
     /* table driven (generic path only; need pmx_window_set_table first) */
     PMX_LANCZOS2 = 8, PMX_LANCZOS3 = 9, PMX_LANCZOS4 = 10, PMX_LANCZOS5 = 11, PMX_LANCZOS6 = 12,
-    PMX_ACG2 = 13, PMX_ACG3 = 14, PMX_ACG4 = 15, PMX_ACG5 = 16, PMX_ACG6 = 17
+    PMX_ACG2 = 13, PMX_ACG3 = 14, PMX_ACG4 = 15, PMX_ACG5 = 16, PMX_ACG6 = 17,
+    /* scaling functions of orthonormal wavelets, tabulated on [0, support) (_window_wavelets.h) */
+    PMX_DB6 = 18, PMX_DB12 = 19, PMX_DB20 = 20, PMX_SYM6 = 21, PMX_SYM12 = 22, PMX_SYM20 = 23
 } pmx_window_kind;
 
 /* The geometric part of `struct PMeshPainter` (pmesh/_window_imp.h:48-62):

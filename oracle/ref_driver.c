@@ -45,6 +45,12 @@ static int ref_type(int kind)
     case PMX_ACG4: return PMESH_PAINTER_ACG4;
     case PMX_ACG5: return PMESH_PAINTER_ACG5;
     case PMX_ACG6: return PMESH_PAINTER_ACG6;
+    case PMX_DB6: return PMESH_PAINTER_DB6;
+    case PMX_DB12: return PMESH_PAINTER_DB12;
+    case PMX_DB20: return PMESH_PAINTER_DB20;
+    case PMX_SYM6: return PMESH_PAINTER_SYM6;
+    case PMX_SYM12: return PMESH_PAINTER_SYM12;
+    case PMX_SYM20: return PMESH_PAINTER_SYM20;
     }
     return kind - 100; /* kind >= 100: raw reference enum value (lanczos, acg, ...) */
 }

@@ -19,6 +19,7 @@ KINDS = {
     'tunednnb': 4, 'tunedcic': 5, 'tunedtsc': 6, 'tunedpcs': 7,
     'lanczos2': 8, 'lanczos3': 9, 'lanczos4': 10, 'lanczos5': 11, 'lanczos6': 12,
     'acg2': 13, 'acg3': 14, 'acg4': 15, 'acg5': 16, 'acg6': 17,
+    'db6': 18, 'db12': 19, 'db20': 20, 'sym6': 21, 'sym12': 22, 'sym20': 23,
 }
 TABLE_KINDS = [k for k, v in KINDS.items() if v >= 8]
 

@@ -138,11 +138,22 @@ struct TableD {
     const double *v;
     int n;
     double step;
+    double hsupport;    // wavelets: the table starts at -support/2 (not symmetric); else < 0
 };
 
 // `_<name>_kernel` of the generated headers (makelanczos.py:20-30): linear interpolation
 __device__ inline double table_kernel(const TableD &t, double x)
 {
+    if (t.hsupport >= 0) {
+        // makewavelets.py:26-35: one-sided table over [0, support), no symmetry
+        x += t.hsupport;
+        double f = x / t.step;
+        if (f < 0) return 0;
+        int i = (int)f;
+        f -= i;
+        if (i >= t.n - 1) return 0;
+        return t.v[i] * (1 - f) + t.v[i + 1] * f;
+    }
     x = fabs(x);
     double f = x / t.step;
     int i = (int)f;
@@ -155,6 +166,14 @@ __device__ inline double table_kernel(const TableD &t, double x)
 // `_<name>_diff` (makelanczos.py:31-46): slope of the table segment
 __device__ inline double table_diff(const TableD &t, double x)
 {
+    if (t.hsupport >= 0) {
+        // makewavelets.py:36-46 (the index truncates towards zero, as `int i = x / step` does)
+        x += t.hsupport;
+        int i = (int)(x / t.step);
+        if (i < 0) return 0;
+        if (i >= t.n - 1) return 0;
+        return (t.v[i + 1] - t.v[i]) / t.step;
+    }
     double factor;
     if (x >= 0) factor = 1;
     else { factor = -1; x = -x; }
@@ -376,13 +395,14 @@ static bool is_fast(const pmx_painter &p, const pmx_vec *hsml)
 
 // device tables of the table-driven kinds, per device
 struct TableSlot { double *v = nullptr; int n = 0; double step = 0; };
-static TableSlot g_tables[16][PMX_ACG6 + 1];
+static TableSlot g_tables[16][PMX_SYM20 + 1];
 static std::mutex g_tables_mutex;
 
 static int lookup_table(int kind, TableD *t)
 {
-    t->v = nullptr; t->n = 0; t->step = 0;
+    t->v = nullptr; t->n = 0; t->step = 0; t->hsupport = -1.0;
     if (kind < PMX_LANCZOS2) return PMX_OK;
+    if (kind >= PMX_DB6) t->hsupport = 0.5 * native_support(kind);
     int dev = 0;
     PMX_HIP_CHECK(hipGetDevice(&dev));
     PMX_REQUIRE(dev < 16, PMX_EUNSUPPORTED, "device index above 15");
@@ -399,7 +419,7 @@ using namespace pmx;
 
 extern "C" int pmx_window_set_table(int32_t kind, const double *values, int32_t n, double step)
 {
-    PMX_REQUIRE(kind >= PMX_LANCZOS2 && kind <= PMX_ACG6, PMX_EINVAL, "not a table-driven window kind");
+    PMX_REQUIRE(kind >= PMX_LANCZOS2 && kind <= PMX_SYM20, PMX_EINVAL, "not a table-driven window kind");
     PMX_REQUIRE(values != nullptr && n >= 2 && step > 0, PMX_EINVAL, "bad table");
     int dev = 0;
     PMX_HIP_CHECK(hipGetDevice(&dev));

@@ -19,6 +19,13 @@ __host__ __device__ inline int native_support(int kind)
     // table driven: lanczos n has support 2n, acg n has support n (_window_lanczos.h:2057, _window_acg.h:2057)
     if (kind >= PMX_LANCZOS2 && kind <= PMX_LANCZOS6) return 2 * (kind - PMX_LANCZOS2 + 2);
     if (kind >= PMX_ACG2 && kind <= PMX_ACG6) return kind - PMX_ACG2 + 2;
+    // wavelet scaling functions (_window_wavelets.h: _<name>_nativesupport)
+    switch (kind) {
+    case PMX_DB6: case PMX_SYM6: return 7;
+    case PMX_DB12: case PMX_SYM12: return 10;
+    case PMX_DB20: return 13;
+    case PMX_SYM20: return 12;
+    }
     return -1;
 }
 

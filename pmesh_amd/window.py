@@ -168,9 +168,9 @@ def _binned_ok(be, painter, pos, n, hs):
     return be.lib.pmx_binplan_supported(C.byref(painter), n) == 0
 
 
-# wavelet kinds of the reference registry (_window_wavelets.h, generated with PyWavelets):
-# not built.  lanczos / acg are table driven too and ARE built (pmesh_amd/_tables.py).
-_UNBUILT = ['db6', 'db12', 'db20', 'sym6', 'sym12', 'sym20']
+# every kind of the reference registry is built; the table-driven ones (lanczos, acg and the
+# wavelet scaling functions db / sym) regenerate their tables in pmesh_amd/_tables.py
+_UNBUILT = []
 _TABLES_SENT = set()
 
 
@@ -204,8 +204,7 @@ class ResampleWindow(object):
     def _require_built(self):
         if self._k is None:
             raise NotImplementedError(
-                "window kind %r (wavelet tables) is not built; use nnb/cic/tsc/pcs, "
-                "nearest/linear/quadratic/cubic, lanczos2-6 or acg2-6" % (self.kind,))
+                "window kind %r is not built" % (self.kind,))
         if self.kind in _abi.TABLE_KINDS:
             be = backend.get()
             key = (id(be), self._k)
@@ -450,6 +449,8 @@ windows = dict(
     LANCZOS6=ResampleWindow(kind="lanczos6"),
     ACG2=ResampleWindow(kind="acg2"), ACG3=ResampleWindow(kind="acg3"), ACG4=ResampleWindow(kind="acg4"),
     ACG5=ResampleWindow(kind="acg5"), ACG6=ResampleWindow(kind="acg6"),
+    DB6=ResampleWindow(kind="db6"), DB12=ResampleWindow(kind="db12"), DB20=ResampleWindow(kind="db20"),
+    SYM6=ResampleWindow(kind="sym6"), SYM12=ResampleWindow(kind="sym12"), SYM20=ResampleWindow(kind="sym20"),
     NEAREST=ResampleWindow(kind="nearest"),
     LINEAR=ResampleWindow(kind="linear"),
     NNB=ResampleWindow(kind="tunednnb"),

@@ -445,6 +445,8 @@ def test_tables_equal_reference(oracle):
         values, step, ns = _tables.table(kind)
         W = oracle.Window(_abi.KINDS[kind], which='ref')
         assert W.nativesupport == ns and W.support == ns
+        if kind in _tables.WAVELET_FILTERS:
+            continue                        # one-sided tables: test_wavelet_tables_equal_reference
         for x0 in (0.0, 0.123456789, 0.5, 0.987654321):
             n = ns + 4
             real = numpy.zeros(n)
@@ -464,7 +466,45 @@ def test_tables_equal_reference(oracle):
             assert_array_equal(real, want)
 
 
-@pytest.mark.parametrize('name', ['lanczos2', 'lanczos3', 'lanczos6', 'acg2', 'acg5'])
+def test_wavelet_tables_equal_reference(oracle):
+    """The scaling-function tables of db6/12/20 and sym6/12/20 (pmesh/_window_wavelets.h, made with
+    PyWavelets) regenerated from the filters' definition by pmesh_amd/_tables.py: the compiled
+    reference, swept with one particle, must give what the regenerated table interpolates to —
+    exactly for db6/12/20 and sym6/12; sym20 has 4 of 3076 entries off by 1e-8 (values on a
+    rounding boundary of the 8-decimal rendering), so 1e-8 there."""
+    if not oracle.have_ref():
+        pytest.skip('oracle/_ref not built')
+    from pmesh_amd import _tables, _abi
+    for kind in ('db6', 'db12', 'db20', 'sym6', 'sym12', 'sym20'):
+        values, step, ns = _tables.table(kind)
+        assert step == 1.0 / 256 and len(values) % 4 == 0
+        W = oracle.Window(_abi.KINDS[kind], which='ref')
+        assert W.nativesupport == ns
+        left = (ns - 1) // 2
+        shift = ns / 2.0 - ns // 2
+        worst = 0.0
+        for x0 in numpy.linspace(0.0, 1.0, 41)[:-1] + 1e-3:
+            n = ns + 6
+            real = numpy.zeros(n)
+            W.paint(real, [[n // 2 + x0]])
+            g = n // 2 + x0
+            ipos = int(numpy.floor(g + shift)) - left
+            want = numpy.zeros(n)
+            for i in range(ns):
+                x = (g - ipos) - i + 0.5 * ns          # _<name>_kernel: x += support / 2
+                f = x / step
+                if f < 0:
+                    continue
+                j = int(f)
+                if j >= len(values) - 1:
+                    continue
+                want[ipos + i] += values[j] * (1 - (f - j)) + values[j + 1] * (f - j)
+            worst = max(worst, abs(real - want).max())
+        assert worst == 0.0 if kind != 'sym20' else worst <= 1.0000001e-8, (kind, worst)
+        assert abs(sum(values) * step - 1.0) < 2e-3       # a scaling function integrates to one
+
+
+@pytest.mark.parametrize('name', ['lanczos2', 'lanczos3', 'lanczos6', 'acg2', 'acg5', 'db6', 'db20', 'sym12', 'sym20'])
 def test_table_windows_vs_compiled_reference(be, oracle, name):
     """paint / readout / gradients / hsml of the table-driven kinds == the reference's
     compiled kernels (oracle/_ref) on random particles."""
@@ -487,7 +527,15 @@ def test_table_windows_vs_compiled_reference(be, oracle, name):
             want = numpy.zeros(shape)
             W.paint(got, pos, mass=mass, hsml=h, diffdir=d, transform=aff)
             R.paint(want, pos, mass=mass, hsml=h, diffdir=d, transform=oaff)
+            r_got = W.readout(field, pos, hsml=h, diffdir=d, transform=aff)
+            r_want = R.readout(field, pos, hsml=h, diffdir=d, transform=oaff)
+            if name == 'sym20' and be.name == 'hip':
+                # 4 of the 3076 regenerated table entries differ by 1e-8 (test_wavelet_tables_equal_reference);
+                # the slope of a 1/256 table segment turns that into 2.6e-6 for the gradient
+                tol = 1e-7 if d is None else 1e-4
+                assert_allclose(got, want, rtol=0, atol=tol * max(1.0, abs(want).max()))
+                assert_allclose(r_got, r_want, rtol=0, atol=tol * max(1.0, abs(r_want).max()))
+                continue
             check_paint(be, got, want)
-            check_readout(be, W.readout(field, pos, hsml=h, diffdir=d, transform=aff),
-                          R.readout(field, pos, hsml=h, diffdir=d, transform=oaff))
+            check_readout(be, r_got, r_want)
     assert_array_equal(W.get_fwindow([0.0, 1.0]), [1.0, 1.0])      # "not implemented" -> 1
