@@ -280,14 +280,14 @@ int pmx_apply_transfer(const pmx_transfer *t, int32_t ndim, int32_t elsize, cons
 /* ---- white noise (the step before the cycle: initial conditions) -------------------------
  * pmesh.whitenoise.generate for 3-d meshes (pmesh/_whitenoise.pyx:25-45,
  * _whitenoise_imp.c:75-105, _whitenoise_generics.h:29-238; pm.py:1656-1696): fills the local
- * block [start, start+size) of the half-complex spectrum (size[2] <= nmesh[2]/2+1 modes from
- * start[2]) with the Gadget / N-GenIC compatible Gaussian (unitary = 0) or fixed-amplitude
+ * block [start, start+size) of the spectrum with the Gadget / N-GenIC compatible Gaussian (unitary = 0) or fixed-amplitude
  * (unitary = 1) Hermitian white noise of `seed`: every (i, j) column has its own RANLUX stream
  * seeded from a master stream walked in N-GenIC's ring order, so the result is independent
  * of the decomposition and the large scales do not change with the mesh size.
  * canvas: complex64 (elsize 8) or complex128 (elsize 16), byte strides.  The (i, j) seed table
  * is built on the host (a sequential stream of N0*N1 draws) and the columns are filled on the
- * device, one thread per column and generator.  The full-spectrum (c2c) form is not built. */
+ * device, one thread per column and generator.  A block that reaches beyond the Nyquist plane
+ * (start[2] + size[2] > nmesh[2]/2 + 1: complex-to-complex meshes) gets the full spectrum. */
 int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nmesh, const int64_t *start,
                    const int64_t *size, const int64_t *strides, int32_t elsize, void *canvas,
                    void *stream);

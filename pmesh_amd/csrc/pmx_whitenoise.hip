@@ -150,8 +150,12 @@ struct WnGeom {
 };
 
 // blockIdx.y = 0: the column's own stream; 1: the mirror stream (upper-half columns only)
+// sign = +1: the modes k2 = 0..N2/2; sign = -1 (full, uncompressed spectra only): the same draws
+// from the conjugate quadrant's stream, written at N2 - k2 with the opposite imaginary part
+// (_whitenoise_generics.h:133-147, 188-195).  The -1 pass is launched first so that the +1 pass
+// owns the Nyquist plane, as the reference's loop order does.
 __global__ void __launch_bounds__(WN_BLOCK) whitenoise_kernel(WnGeom g, const uint32_t *seed_own,
-                                                              const uint32_t *seed_mirror, char *canvas)
+                                                              const uint32_t *seed_mirror, char *canvas, int sign)
 {
     __shared__ double parked[12][WN_BLOCK];
     const int tid = threadIdx.x;
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(WN_BLOCK) whitenoise_kernel(WnGeom g, const ui
     if (which == 1 && !mirror) return;
 
     DevRlx rng;
-    rng.seed(which == 0 ? seed_own[col] : seed_mirror[col]);
+    rng.seed(which == 0 ? (sign > 0 ? seed_own[col] : seed_mirror[col]) : seed_mirror[col]);
     int have = 12;                                   // delivered numbers already consumed
     auto draw = [&]() -> double {
         if (have == 12) {
@@ -189,17 +193,22 @@ __global__ void __launch_bounds__(WN_BLOCK) whitenoise_kernel(WnGeom g, const ui
         const bool plane = k == 0 || k == N2 / 2;
         const bool use_conj = mirror && plane;
         if (which == 0 ? use_conj : !plane) continue;      // this mode belongs to the other stream
-        const int64_t r2 = k - g.start[2];
-        if (r2 < 0 || r2 >= g.size[2]) continue;
+        // the reference tests the UNREFLECTED k for membership, then writes at the reflected
+        // index if that is inside the block (_whitenoise_generics.h:158-166, 11-27)
+        if (k - g.start[2] < 0 || k - g.start[2] >= g.size[2]) continue;
         ampl = g.unitary ? 1.0 : sqrt(-log(ampl));
         double re = ampl * cos(phase), im = ampl * sin(phase);
         if (g.elsize == 8) { re = (double)(float)re; im = (double)(float)im; }
+        const int64_t k2 = sign < 0 ? N2 - k : k;
+        if (sign < 0) im = -im;
         if (use_conj) im = -im;
-        if (selfconj_ij && (N2 - k) % N2 == k) {
+        if (selfconj_ij && (N2 - k2) % N2 == k2) {
             im = 0;                                       // self-conjugate mode: real
             if (g.unitary) re = 1;
         }
-        if (i == 0 && j == 0 && k == 0) re = im = 0;      // the mean is set by the caller
+        if (i == 0 && j == 0 && k2 == 0) re = im = 0;     // the mean is set by the caller
+        const int64_t r2 = k2 - g.start[2];
+        if (r2 < 0 || r2 >= g.size[2]) continue;
         char *p = colbase + r2 * g.strides[2];
         if (g.elsize == 16) { ((double *)p)[0] = re; ((double *)p)[1] = im; }
         else { ((float *)p)[0] = (float)re; ((float *)p)[1] = (float)im; }
@@ -222,9 +231,10 @@ extern "C" int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nme
     }
     PMX_REQUIRE(start[0] + size[0] <= nmesh[0] && start[1] + size[1] <= nmesh[1], PMX_EINVAL,
                 "block outside the mesh");
-    // only the half spectrum (what ComplexField holds): no local mode beyond the Nyquist plane
-    PMX_REQUIRE(start[2] + size[2] <= nmesh[2] / 2 + 1, PMX_EUNSUPPORTED,
-                "the full (c2c) spectrum form of the generator is not built");
+    PMX_REQUIRE(start[2] + size[2] <= nmesh[2], PMX_EINVAL, "block outside the mesh");
+    // a block that holds modes beyond the Nyquist plane asks for the full (uncompressed) spectrum
+    // of a complex-to-complex mesh: two passes, the negative k2 first (_whitenoise_generics.h:47-66)
+    const bool full = start[2] + size[2] > nmesh[2] / 2 + 1;
     const int64_t ncol = size[0] * size[1];
     if (ncol == 0 || size[2] == 0) return PMX_OK;
     PMX_REQUIRE(canvas != nullptr, PMX_EINVAL, "canvas is NULL");
@@ -269,7 +279,8 @@ extern "C" int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nme
     g.unitary = unitary ? 1 : 0;
     g.elsize = elsize;
     dim3 grid((unsigned)((ncol + WN_BLOCK - 1) / WN_BLOCK), 2);
-    whitenoise_kernel<<<grid, WN_BLOCK, 0, st>>>(g, dseed, dseed + ncol, (char *)canvas);
+    if (full) whitenoise_kernel<<<grid, WN_BLOCK, 0, st>>>(g, dseed, dseed + ncol, (char *)canvas, -1);
+    whitenoise_kernel<<<grid, WN_BLOCK, 0, st>>>(g, dseed, dseed + ncol, (char *)canvas, +1);
     hipError_t e3 = hipGetLastError();
     // the host vectors go out of scope on return: wait for the copies and the kernel
     hipError_t e4 = hipStreamSynchronize(st);

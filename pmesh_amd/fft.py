@@ -91,14 +91,14 @@ class Partition(object):
         nd = self.ndim
         np_ = procmesh.np
         P = procmesh.comm.size
-        if is_c2c:
-            raise NotImplementedError('complex-to-complex meshes (dtype c8/c16) are outside the '
-                                      'PM-cycle scope built so far')
+        self.is_c2c = bool(is_c2c)
         if nd == 1 and P > 1:
             raise ValueError("Running 1d transforms on multiple ranks is not supported")
         self.nproc = P
         self.pencil = len(np_) == 2 and P > 1 and min(np_) > 1
         if self.pencil:
+            if is_c2c:
+                raise NotImplementedError('complex-to-complex meshes on a pencil decomposition')
             if nd != 3:
                 raise ValueError('a 2-d process mesh needs a 3-d mesh')
             if not transposed:
@@ -108,7 +108,8 @@ class Partition(object):
             return
         r = procmesh.comm.rank
         Nc = self.Nmesh.copy()
-        Nc[-1] = Nc[-1] // 2 + 1
+        if not is_c2c:
+            Nc[-1] = Nc[-1] // 2 + 1           # r2c: the non-negative half of the last axis
         self.cshape_o = Nc
         # real space: axis 0 distributed
         self.i_edges = [block_edges(self.Nmesh[0], P)] + \
@@ -137,6 +138,19 @@ class Partition(object):
         # the array, and every tile row of the column FFT and of the window kernels, starts
         # on a line boundary.  Consumers are stride agnostic (as in the reference, pm.py:97).
         pitch_c = int(Nc[-1])
+        if is_c2c:
+            # complex-to-complex meshes (ParticleMesh(dtype='c16')): configuration space holds
+            # complex elements too; dense C-order on both sides, strides in complex elements
+            self.pitch_c = self.pitch_i = pitch_c
+            self.plane_c = None
+            self.i_strides = _c_strides([int(x) for x in self.local_i_shape])
+            self.i_alloc = int(numpy.prod(self.local_i_shape, dtype='i8'))
+            self.o_strides = _c_strides([int(x) for x in self.local_o_shape])
+            self.o_alloc = int(numpy.prod(self.local_o_shape, dtype='i8'))
+            n0loc = int(self.local_i_shape[0])
+            mid = n0loc * int(numpy.prod(Nc[1:], dtype='i8'))
+            self.alloc_reals = max(2 * self.i_alloc, 2 * self.o_alloc, 2 * mid, 2)
+            return
         if P == 1 and nd == 3:
             q = 128 // (2 * itemsize)
             pitch_c = -(-pitch_c // q) * q
@@ -294,6 +308,9 @@ class LocalBuffer(object):
 
     def view_input(self):
         p = self.partition
+        if getattr(p, 'is_c2c', False):
+            c = torch.view_as_complex(self.storage.view(-1, 2))
+            return torch.as_strided(c, [int(x) for x in p.local_i_shape], p.i_strides)
         return torch.as_strided(self.storage, [int(x) for x in p.local_i_shape], p.i_strides)
 
     def view_output(self):
@@ -331,6 +348,12 @@ class Plan(object):
 
     def execute(self, bufin, bufout, transfer=None):
         p = self.partition
+        if getattr(p, 'is_c2c', False):
+            if transfer is not None:
+                raise NotImplementedError('fused transfer on a complex-to-complex mesh')
+            if p.nproc > 1 and not p.transposed:
+                return self._execute_slab_untransposed(bufin, bufout)
+            return self._execute_c2c(bufin, bufout)
         if p.nproc == 1:
             self._execute_local(bufin, bufout, transfer)
         else:
@@ -442,7 +465,7 @@ class Plan(object):
     def can_fuse(self):
         """True if execute(..., transfer=) can fold a transfer function into the transform"""
         p = self.partition
-        if self.forward or p.ndim != 3:
+        if self.forward or p.ndim != 3 or getattr(p, 'is_c2c', False):
             return False
         if p.nproc != 1:
             return (not getattr(p, 'pencil', False)) and p.transposed and self._slab_own(backend.get())
@@ -688,6 +711,71 @@ class Plan(object):
                     shape = [n0loc] + inner_real
                     dst = torch.as_strided(bufout.storage, shape, [plane_r] + list(inner_strides_r))
                     dst.copy_(W1[:int(numpy.prod(shape, dtype='i8'))].view(shape))
+
+    def _execute_c2c(self, bufin, bufout):
+        """complex-to-complex transform (forward: fftn / prod(N), backward: ifftn * prod(N)) with
+        rocFFT: one n-d plan on one rank; on a slab decomposition the (n-1)-d transform of the
+        local planes, the global transpose, and the strided 1-d transform along axis 0"""
+        be = backend.get()
+        p = self.partition
+        n = [int(x) for x in p.Nmesh]
+        norm = 1.0 / float(numpy.prod(p.Nmesh, dtype='f8'))
+        kind = _abi.PMX_FFT_C2C_FWD if self.forward else _abi.PMX_FFT_C2C_BWD
+        scale = norm if self.forward else 1.0
+        same = bufin.storage.data_ptr() == bufout.storage.data_ptr()
+        if p.nproc == 1:
+            def make():
+                return be.fft_create(kind, self.elsize, n, p.i_strides, p.i_alloc, p.o_strides, p.o_alloc, 1,
+                                     scale, same)
+            be.fft_execute(self._native(('c2c', same), make), bufin.storage, bufout.storage)
+            return
+        comm = p.procmesh.comm
+        P = p.nproc
+        N0 = n[0]
+        n0loc = int(p.local_i_shape[0])
+        N1 = n[1]
+        n1loc = int(p.local_o_shape[1])
+        n2 = 1
+        for x in n[2:]:
+            n2 *= x
+        e0 = [int(x) for x in p.i_edges[0]]
+        e1 = [int(x) for x in p.o_edges[1]]
+        elb = 2 * self.elsize
+        rdt = bufin.storage.dtype
+        need = max(2 * n0loc * N1 * n2, 2 * n1loc * N0 * n2, 2)
+        if self._work is None or self._work[0].numel() < need or self._work[0].dtype != rdt:
+            self._work = [torch.empty(need, dtype=rdt, device=bufin.storage.device) for _ in range(3)]
+        W0, W1, W2 = self._work
+        send_splits = [2 * n0loc * (e1[r + 1] - e1[r]) * n2 for r in range(P)]
+        recv_splits = [2 * (e0[s + 1] - e0[s]) * n1loc * n2 for s in range(P)]
+        inner = n[1:]
+        inner_strides = _c_strides(inner)
+        plane = N1 * n2
+        nb = n1loc * n2
+
+        def make1():
+            return be.fft_create(kind, self.elsize, inner, inner_strides, plane, inner_strides, plane, n0loc,
+                                 scale, False)
+
+        def make2():
+            return be.fft_create(kind, self.elsize, [N0], [nb], 1, [nb], 1, nb, 1.0, True)
+        if self.forward:
+            if n0loc:
+                be.fft_execute(self._native('c2c1', make1), bufin.storage, W0)
+            be.slab_pack(W0, W1, n0loc, N1, n2, e1, elb)
+            out = bufout.storage
+            comm.alltoall(W1[:sum(send_splits)], out[:sum(recv_splits)], send_splits, recv_splits)
+            if nb:
+                be.fft_execute(self._native('c2c2', make2), out, out)
+        else:
+            ncplx = 2 * n1loc * N0 * n2
+            W0[:ncplx].copy_(bufin.storage[:ncplx])            # the input is preserved
+            if nb:
+                be.fft_execute(self._native('c2c2', make2), W0, W0)
+            comm.alltoall(W0[:sum(recv_splits)], W1[:sum(send_splits)], recv_splits, send_splits)
+            be.slab_pack(W1, W2, n0loc, N1, n2, e1, elb, inverse=True)
+            if n0loc:
+                be.fft_execute(self._native('c2c1', make1), W2, bufout.storage)
 
     def _chunks(self, be, p, P, N0, N1, N2c, n0loc, n1loc, e0, e1):
         """[(first column, width)] of the last axis if the transposes can be pipelined: equal

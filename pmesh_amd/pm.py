@@ -191,7 +191,7 @@ class Field(NDArrayLike):
     def __init__(self, pm, base=None):
         """ Used internally to add shortcuts of attributes from pm (pm.py:220-265) """
         partition = pm._get_partition(type(self))
-        base = _fft.LocalBuffer(partition, pm.dtype, base=base)
+        base = _fft.LocalBuffer(partition, pm._rdtype, base=base)
         self._base = base
         self.pm = pm
         self._partition = partition
@@ -1077,10 +1077,12 @@ class ParticleMesh(object):
         self.np = list(np)
         self._use_padded = True
         dtype = numpy.dtype(dtype)
-        if dtype not in (numpy.dtype('f8'), numpy.dtype('f4')):
-            if dtype in (numpy.dtype('complex128'), numpy.dtype('complex64')):
-                raise NotImplementedError('c2c meshes are outside the PM-cycle scope built so far')
+        if dtype not in (numpy.dtype('f8'), numpy.dtype('f4'), numpy.dtype('c16'), numpy.dtype('c8')):
             raise ValueError("dtype must be f8, f4, c16 or c8")
+        # a complex dtype makes the transforms complex-to-complex (pm.py:1270, 1326-1331): the
+        # configuration-space field holds complex values and the spectrum is not compressed
+        is_c2c = dtype.kind == 'c'
+        rdtype = numpy.dtype('f%d' % (dtype.itemsize // 2)) if is_c2c else dtype
         self.Nmesh = numpy.array(Nmesh, dtype='i8')
         self.ndim = len(self.Nmesh)
         if self.ndim > 3:
@@ -1091,14 +1093,17 @@ class ParticleMesh(object):
 
         procmesh = _fft.ProcMesh(self.np, comm) if len(self.np) else _fft.ProcMesh([1], comm)
         plans = OrderedDict()
-        plans['partitionT'] = _fft.Partition(self.Nmesh, procmesh, transposed=True, itemsize=dtype.itemsize)
-        plans['partitionU'] = _fft.Partition(self.Nmesh, procmesh, transposed=False, itemsize=dtype.itemsize)
+        plans['partitionT'] = _fft.Partition(self.Nmesh, procmesh, transposed=True, is_c2c=is_c2c,
+                                             itemsize=rdtype.itemsize)
+        plans['partitionU'] = _fft.Partition(self.Nmesh, procmesh, transposed=False, is_c2c=is_c2c,
+                                             itemsize=rdtype.itemsize)
         for T in 'TU':
             part = plans['partition' + T]
-            plans['forward' + T] = _fft.Plan(part, True, dtype, inplace=False)
-            plans['backward' + T] = _fft.Plan(part, False, dtype, inplace=False)
-            plans['ipforward' + T] = _fft.Plan(part, True, dtype, inplace=True)
-            plans['ipbackward' + T] = _fft.Plan(part, False, dtype, inplace=True)
+            plans['forward' + T] = _fft.Plan(part, True, rdtype, inplace=False)
+            plans['backward' + T] = _fft.Plan(part, False, rdtype, inplace=False)
+            plans['ipforward' + T] = _fft.Plan(part, True, rdtype, inplace=True)
+            plans['ipbackward' + T] = _fft.Plan(part, False, rdtype, inplace=True)
+        self._rdtype = rdtype
 
         for k in ('forward', 'backward'):
             # out of place in both cases: the transposed plan works into / out of a scratch buffer
@@ -1145,9 +1150,9 @@ class ParticleMesh(object):
             partition = self._get_partition(field_type)
             dev = backend.get().device
             if issubclass(field_type, RealField):
-                self._coords[field_type] = _init_i_coords(partition, self.Nmesh, self.BoxSize, self.dtype, dev)
+                self._coords[field_type] = _init_i_coords(partition, self.Nmesh, self.BoxSize, self._rdtype, dev)
             else:
-                self._coords[field_type] = _init_o_coords(partition, self.Nmesh, self.BoxSize, self.dtype, dev)
+                self._coords[field_type] = _init_o_coords(partition, self.Nmesh, self.BoxSize, self._rdtype, dev)
         x, i = self._coords[field_type]
         if return_indices:
             return [ii.clone() for ii in i]
@@ -1430,7 +1435,7 @@ def _pm_upsample(self, source, resampler=None, keep_mean=False):
         pixel positions of this pm (pm.py:1937-1986).  keep_mean conserves the mean rather than
         the total mass in the overlapped region.  Returns a new RealField. """
     assert isinstance(source, RealField)
-    q = self.mesh_coordinates(dtype=self.dtype)
+    q = self.mesh_coordinates(dtype=self._rdtype)
     # transform from my mesh to source's mesh
     transform = Affine(self.ndim, translate=-source.start, scale=1.0 * source.Nmesh / self.Nmesh,
                        period=source.Nmesh)
@@ -1449,7 +1454,7 @@ def _pm_downsample(self, source, resampler=None, keep_mean=False):
     """ Resample an image with the downsample method: paint the value of the image at the
         pixel positions of the source (pm.py:1988-2027).  Returns a new RealField. """
     assert isinstance(source, RealField)
-    q = source.pm.mesh_coordinates(dtype=self.dtype)
+    q = source.pm.mesh_coordinates(dtype=self._rdtype)
     f = source.readout(q, resampler='nnb', transform=source.pm.affine_grid)
     # transform from source's mesh to my mesh
     transform = self.affine_grid.rescale(1.0 * self.Nmesh / source.Nmesh)

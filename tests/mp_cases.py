@@ -384,6 +384,31 @@ def case_untransposed(be, comm):
     assert_array_equal(gather_field(comm, f1, (8, 8, 5)), gather_field(comm, f2, (8, 8, 5)))
 
 
+def case_c2c(be, comm):
+    """complex-to-complex meshes on a slab decomposition (test_pm.py:196-226): fftn / ifftn of the
+    gathered field, transposed and untransposed spectra, paint into the real part"""
+    from pmesh_amd.pm import ParticleMesh, UntransposedComplexField
+    for Nmesh in ([8, 12, 10], [9, 7]):
+        pm = ParticleMesh(BoxSize=4.0, Nmesh=Nmesh, comm=comm, dtype='c16', np=[comm.size])
+        rs = numpy.random.RandomState(41)
+        data = rs.normal(size=Nmesh) + 1j * rs.normal(size=Nmesh)
+        real = pm.create('real', value=data[pm.create('real').slices])
+        ref = numpy.fft.fftn(data) / numpy.prod(Nmesh)
+        ck = real.r2c()
+        assert tuple(ck.cshape) == tuple(Nmesh)
+        full = gather_field(comm, ck, Nmesh)
+        assert numpy.sqrt((abs(full - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < 1e-13
+        back = ck.c2r()
+        assert_allclose(numpy.asarray(back), data[back.slices], rtol=0, atol=1e-12)     # (ranks may hold nothing)
+        cu = real.r2c(out=UntransposedComplexField(pm))
+        assert numpy.sqrt((abs(gather_field(comm, cu, Nmesh) - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < 1e-13
+        assert_allclose(numpy.asarray(cu.c2r()), data[back.slices], rtol=0, atol=1e-12)
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], comm=comm, dtype='c16', np=[comm.size])
+    pos = numpy.random.RandomState(3 + comm.rank).uniform(0, 8, size=(50, 3))
+    rho = pm.paint(pos, layout=pm.decompose(pos))
+    assert abs(rho.csum() - 50 * comm.size) < 1e-10
+
+
 def case_cycle(be, comm):
     """the whole PM cycle on P ranks == the serial oracle cycle"""
     from pmesh_amd.pm import ParticleMesh
@@ -459,7 +484,7 @@ def case_pencil(be, comm):
 
 
 CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
-         case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_cycle]
+         case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 
 def main():

@@ -589,3 +589,77 @@ def test_tile_order(be):
     a = numpy.asarray(pm.paint(pos))
     b = numpy.asarray(pm.paint(pos[o]))
     assert_allclose(a, b, rtol=0, atol=1e-12 * abs(a).max())
+
+
+# ---- complex-to-complex meshes (ParticleMesh(dtype='c16' | 'c8')) ----------------------------
+
+def test_c2c(be):                             # test_pm.py:196-226
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='complex128')
+    Npar = 100
+    pos = 1.0 * (numpy.arange(Npar * len(pm.Nmesh))).reshape(-1, len(pm.Nmesh)) * (7, 7)
+    pos %= (pm.Nmesh + 1)
+    layout = pm.decompose(pos)
+    npos = layout.exchange(pos)
+    real = pm.paint(npos)
+    cplx = real.r2c()
+    real2 = cplx.c2r()
+    assert numpy.iscomplexobj(numpy.asarray(real))
+    assert numpy.iscomplexobj(numpy.asarray(real2))
+    assert numpy.iscomplexobj(numpy.asarray(cplx))
+    assert_array_equal(cplx.cshape, pm.Nmesh)
+    assert_array_equal(real2.cshape, pm.Nmesh)
+    assert_array_equal(real.cshape, pm.Nmesh)
+    assert not cplx.compressed
+    real.readout(npos)
+    assert_almost_equal(numpy.asarray(real), numpy.asarray(real2), decimal=7)
+
+
+@pytest.mark.parametrize('Nmesh,dtype,tol', [([8, 6, 10], 'c16', 1e-13), ([5, 7, 9], 'c16', 1e-13), ([12, 10], 'c16', 1e-13),
+                                             ([16], 'c16', 1e-13), ([64, 64, 128], 'c16', 1e-13), ([8, 8, 8], 'c8', 5e-6)])
+def test_c2c_vs_numpy(be, Nmesh, dtype, tol):
+    """r2c == fftn / prod(N), c2r == ifftn * prod(N) on the full spectrum; complex values in
+    configuration space are transformed as they are; in place and out of place"""
+    pm = ParticleMesh(BoxSize=2.0, Nmesh=Nmesh, dtype=dtype)
+    rs = numpy.random.RandomState(6)
+    data = (rs.normal(size=Nmesh) + 1j * rs.normal(size=Nmesh)).astype(dtype)
+    real = pm.create(type='real', value=data)
+    ref = numpy.fft.fftn(data.astype('c16')) / numpy.prod(Nmesh)
+    ck = real.r2c()
+    assert tuple(ck.shape) == tuple(Nmesh)
+    assert rel_l2(ck, ref) < tol
+    assert_array_equal(numpy.asarray(real), data)
+    assert rel_l2(ck.c2r(), data) < 4 * tol
+    ck2 = real.r2c(out=Ellipsis)
+    assert rel_l2(ck2, ref) < tol
+    assert rel_l2(ck2.c2r(out=Ellipsis), data) < 4 * tol
+    # Parseval on the uncompressed spectrum: every mode counts once
+    assert abs(ck.cnorm() - (abs(ref) ** 2).sum()) < 100 * tol * (abs(ref) ** 2).sum()
+
+
+def test_c2c_r2c_edges(be):                   # test_pm.py:816-826
+    pm1 = ParticleMesh(BoxSize=8.0, Nmesh=[5, 7, 9], dtype='c16')
+    pm2 = ParticleMesh(BoxSize=8.0, Nmesh=[5, 7, 9], dtype='f8')
+    real1 = pm1.create(type='real')
+    real2 = pm2.create(type='real')
+    for d in range(3):
+        assert_allclose(real1.x[d].cpu().numpy(), real2.x[d].cpu().numpy())
+
+
+def test_c2c_paint_cycle(be, oracle):
+    """paint writes the real part of a complex canvas (window.py:161-162); the cycle through the
+    complex-to-complex transforms equals the real one"""
+    N, L = 16, 10.0
+    rs = numpy.random.RandomState(4)
+    pos = rs.uniform(0, L, size=(500, 3))
+    res = {}
+    for dtype in ('f8', 'c16'):
+        pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype=dtype, resampler='tsc')
+        rho = pm.paint(pos)
+        if dtype == 'c16':
+            assert float(rho.value.imag.abs().max()) == 0
+        back = rho.r2c().apply(Transfer.potential()).c2r()
+        res[dtype] = (numpy.asarray(rho), numpy.asarray(back), numpy.asarray(back.readout(pos)))
+    assert_allclose(res['c16'][0].real, res['f8'][0], rtol=0, atol=1e-14)
+    assert_allclose(res['c16'][1].real, res['f8'][1], rtol=0, atol=1e-10 * abs(res['f8'][1]).max())
+    assert abs(res['c16'][1].imag).max() < 1e-10 * abs(res['f8'][1]).max()
+    assert_allclose(res['c16'][2], res['f8'][2], rtol=0, atol=1e-10 * abs(res['f8'][2]).max())

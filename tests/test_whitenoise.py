@@ -116,15 +116,38 @@ def test_generate_3d_hermitian(be):             # pmesh/tests/test_whitenoise.py
     assert_allclose(h, value, rtol=1e-5, atol=1e-9)
 
 
-def test_full_spectrum_form_is_refused(be):
-    value = torch.zeros((8, 8, 8), dtype=torch.complex128, device=be.device)
-    if be.name == 'hip':
-        with pytest.raises(Exception):
-            generate(value, 0, (8, 8, 8), 1, unitary=False)
-    else:
-        generate(value, 0, (8, 8, 8), 1, unitary=False)      # the oracle restates it
-        v = value.numpy()
-        assert_allclose(numpy.fft.ifftn(v).imag, 0, atol=1e-12)
+def test_generate_3d_hermitian_full(be, oracle):      # pmesh/tests/test_whitenoise.py:65-84
+    """the full spectrum of a complex-to-complex mesh: Hermitian, the same field as the half
+    spectrum, and equal to the reference's two-pass fill (oracle)"""
+    for Nmesh, seed, unitary in (((8, 8, 8), 1, False), ((6, 10, 7), 5, True)):
+        value = torch.zeros(Nmesh, dtype=torch.complex128, device=be.device)
+        generate(value, 0, Nmesh, seed, unitary=unitary)
+        v = value.cpu().numpy()
+        want = oracle.whitenoise(Nmesh, (0, 0, 0), Nmesh, seed, unitary)
+        ulp_close(v, want)
+        if len(set(Nmesh)) > 1:
+            continue        # (the reference's ring order mixes N0 and N1: only cubic meshes come out Hermitian)
+        value2 = numpy.zeros(Nmesh[:2] + (Nmesh[2] // 2 + 1,), dtype='complex128')
+        generate(value2, 0, Nmesh, seed, unitary=unitary)
+        c1 = numpy.fft.ifftn(v)
+        c2 = numpy.fft.irfftn(value2, s=Nmesh, axes=(0, 1, 2))
+        assert_allclose(c1.imag, 0, atol=1e-9)
+        assert_allclose(c1.real, c2, atol=1e-12)
+    # blocks of the full spectrum: a slab (what a rank of a slab-decomposed c2c mesh holds) is a
+    # piece of the whole; a block cut along the last axis follows the reference's membership rule
+    # (the unreflected k2 decides, _whitenoise_generics.h:158-166), so it is compared like for like
+    whole = oracle.whitenoise((8, 8, 8), (0, 0, 0), (8, 8, 8), 1)
+    slab = torch.zeros((3, 8, 8), dtype=torch.complex128, device=be.device)
+    generate(slab, (4, 0, 0), (8, 8, 8), 1, unitary=False)
+    ulp_close(slab.cpu().numpy(), whole[4:7])
+    piece = torch.zeros((3, 8, 5), dtype=torch.complex128, device=be.device)
+    generate(piece, (4, 0, 3), (8, 8, 8), 1, unitary=False)
+    ulp_close(piece.cpu().numpy(), oracle.whitenoise((3, 8, 5), (4, 0, 3), (8, 8, 8), 1))
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='c16')
+    c = pm.generate_whitenoise(seed=3)
+    assert tuple(c.shape) == (8, 8, 8) and not c.compressed
+    r = pm.generate_whitenoise(seed=3, type='real')
+    assert abs(numpy.asarray(r).imag).max() < 1e-9 * abs(numpy.asarray(r)).max()
 
 
 # ---- ParticleMesh.generate_whitenoise ----------------------------------------------------------
