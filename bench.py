@@ -298,6 +298,8 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
           for _ in range(args.steps)]
 
+    result = torch.empty(nloc, dtype=torch.float64, device=be.device)
+
     def cycle(marks=None):
         def mark(i):
             if marks is not None:
@@ -320,7 +322,9 @@ def main():
         mark(4)
         back = rhok.c2r(out=Ellipsis, transfer=transfer if args.fuse_apply else None)
         mark(5)
-        f = back.readout(pos, gradient=args.gradient, layout=layout)
+        # the result goes into a buffer that lives across cycles, as a time-stepping caller keeps it:
+        # a fresh 1 GB tensor per cycle occasionally costs a hipMalloc (~20 ms) inside the timed loop
+        f = back.readout(pos, gradient=args.gradient, layout=layout, out=result)
         mark(6)
         return f
 

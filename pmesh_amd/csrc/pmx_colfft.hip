@@ -276,10 +276,10 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     const int64_t tilesB = (g.B + W - 1) / W;
     const int64_t ntiles = g.A * tilesB;
     const int col = tid % W, tj = tid / W;   // W consecutive lanes = one 128-byte row segment
-    // REMAP (chunk passes): launched with one workgroup per tile; saying so lets the optimiser
-    // drop what it would otherwise keep alive across the tile loop (156 -> ~110 VGPRs: two
-    // workgroups per CU)
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += REMAP ? ntiles : (int64_t)gridDim.x) {
+    // REMAP (chunk passes) and APPLY (fused transfer) are launched with one workgroup per tile;
+    // saying so lets the optimiser drop what it would otherwise keep alive across the tile loop
+    // (156 / 166 -> ~100 VGPRs: two workgroups per CU; the fused pass 680 -> 520 us at 512^3)
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += (REMAP || APPLY) ? ntiles : (int64_t)gridDim.x) {
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
         const bool colok = b0 + col < g.B;
         // plain: one base per tile, lanes add their column; REMAP: a base per lane
@@ -505,7 +505,7 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     size_t lds = (size_t)(N * W + N) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
-    if (RM) {
+    if (RM || apply) {
         PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "too many tiles in a chunk pass");
         grid = (unsigned)tiles;
     }

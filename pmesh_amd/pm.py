@@ -662,11 +662,17 @@ class RealField(Field):
             # the partial sums of their ghosts on other ranks added on the way back
             be = backend.get()
             dpos, host = to_device(pos, be.device, 'pos')
-            res = resampler.readout(self.value, dpos, transform=transform, diffdir=gradient)
+            # a caller's device buffer takes the result directly (no fresh tensor per call)
+            direct = (is_tensor(out) and out.device == be.device and out.dtype == torch.float64 and
+                      out.dim() == 1 and out.shape[0] == dpos.shape[0] and out.is_contiguous())
+            res = resampler.readout(self.value, dpos, out=out if direct else None, transform=transform,
+                                    diffdir=gradient)
             if layout.comm.size > 1:
                 rpos = layout.exchange_remote(dpos)
                 rres = resampler.readout(self.value, rpos, transform=transform, diffdir=gradient)
                 layout.gather_remote_add(rres, res)
+            if direct:
+                return out
             if out is not None:
                 if is_tensor(out):
                     out.copy_(res)
