@@ -276,10 +276,11 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     const int64_t tilesB = (g.B + W - 1) / W;
     const int64_t ntiles = g.A * tilesB;
     const int col = tid % W, tj = tid / W;   // W consecutive lanes = one 128-byte row segment
-    // REMAP (chunk passes) and APPLY (fused transfer) are launched with one workgroup per tile;
-    // saying so lets the optimiser drop what it would otherwise keep alive across the tile loop
-    // (156 / 166 -> ~100 VGPRs: two workgroups per CU; the fused pass 680 -> 520 us at 512^3)
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += (REMAP || APPLY) ? ntiles : (int64_t)gridDim.x) {
+    // One workgroup per tile (grid = ntiles), and the loop says so: with a grid-stride loop the
+    // optimiser keeps everything tile-invariant alive across the FFT passes — 156 / 166 / 212
+    // VGPRs for the chunk, fused-transfer and float variants, i.e. one workgroup per CU instead of
+    // two (fused pass 680 -> 490 us at 512^3, float passes 343 -> 250 us).
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += ntiles) {
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
         const bool colok = b0 + col < g.B;
         // plain: one base per tile, lanes add their column; REMAP: a base per lane
@@ -504,11 +505,8 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     constexpr int NT = N / Rpt<T, LOGN>::value * W;
     size_t lds = (size_t)(N * W + N) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
-    unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
-    if (RM || apply) {
-        PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "too many tiles in a chunk pass");
-        grid = (unsigned)tiles;
-    }
+    PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
+    unsigned grid = (unsigned)tiles;
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
         auto k = colfft_kernel<T, LOGN, INV, AP, RB, RM>;                                                      \

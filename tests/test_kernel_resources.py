@@ -46,6 +46,9 @@ def test_column_fft_budgets():
         assert v['ScratchSize'] == 0, k
     n512 = [v for k, v in plain.items() if 'Li9E' in k]
     assert len(n512) == 2 and all(v['VGPRs'] <= 128 for v in n512), n512
+    # float: 512 threads per workgroup at N = 512 as well (16 lines per thread): <= 128 VGPRs
+    f512 = [v for k, v in t.items() if 'colfft_kernelIfLi9E' in k]
+    assert len(f512) >= 4 and all(v['VGPRs'] <= 128 and v['ScratchSize'] == 0 for v in f512), f512
     # the chunk passes of the pipelined transposes (REMAP), with and without the fused transfer
     chunk = [v for k, v in t.items() if 'colfft_kernelIdLi9E' in k and k.split('ELi128E')[1].startswith('Lb1E')]
     assert len(chunk) == 4 and all(v['VGPRs'] <= 128 and v['ScratchSize'] == 0 for v in chunk), chunk
