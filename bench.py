@@ -219,12 +219,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`'
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # PMESH_AMD_SHARE_GPU=1 + PMESH_AMD_DIST_BACKEND=gloo: a rehearsal of the multi-process run on a
+    # box with one GPU (all ranks on cuda:0, exchanges staged by gloo) -- it checks the flow and the
+    # host-side cost, its throughput means nothing.  The real run is one rank per GPU over RCCL.
+    share = os.environ.get('PMESH_AMD_SHARE_GPU') == '1'
+    torch.cuda.set_device(0 if share else local_rank)
     launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ      # under torch.distributed.run
     if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('PMESH_AMD_DIST_BACKEND', 'nccl'))
 
     from pmesh_amd import backend
     from pmesh_amd._arrays import vec
