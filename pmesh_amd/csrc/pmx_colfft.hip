@@ -152,7 +152,9 @@ template <typename T, int RB = 128> __device__ __forceinline__ int lds_index(int
 // One pass of the Stockham autosort FFT over the LDS-resident tile.  Lane mapping: the W
 // columns of a row are W consecutive lanes (col fastest), so a wave works on 64/W
 // butterflies of all W columns at once.
-template <typename T, bool INV, int R, int RB = 128>
+// HALFTW: `tw` holds only the first N/2 entries of the table (w[m + N/2] = -w[m]); used where the
+// full table would not fit beside the tile (N = 2048 in double).
+template <typename T, bool INV, int R, int RB = 128, bool HALFTW = false>
 __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int N, int Ns, int tpc /*threads per column*/,
                                               int col, int tj, int twstride = 1)
 {
@@ -171,7 +173,13 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
             if (r > 0 && Ns > 1) {
                 // twiddle exp(-+ 2 pi i r k / (Ns R)) from the length-N table
                 int m = r * k * (N / (Ns * R));
-                cpx<T> w = tw[m * twstride];
+                cpx<T> w;
+                if (HALFTW) {
+                    w = tw[m & (N / 2 - 1)];
+                    if (m & (N / 2)) { w.x = -w.x; w.y = -w.y; }
+                } else {
+                    w = tw[m * twstride];
+                }
                 if (INV) w.y = -w.y;
                 x = cmul(x, w);
             }
@@ -254,6 +262,15 @@ template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = 16; }
 // N = 1024 in double: the tile takes 147 KB of LDS, one workgroup per CU; 512 threads with 16
 // lines each keep twice the loads in flight per workgroup
 template <> struct Rpt<double, 10> { static constexpr int value = PMX_RPT_D1024; };
+// N = 2048: 64-byte row segments (8 float / 4 double columns per tile) keep the tile inside the
+// 160 KB of LDS; 16 lines per thread in both precisions (1024 / 512 threads)
+template <> struct Rpt<double, 11> { static constexpr int value = 16; };
+
+// the twiddle table shares the LDS with the tile; where the pair would exceed ~150 KB only its
+// first half is kept (see stockham_pass)
+template <typename T, int LOGN, int RB> struct HalfTw {
+    static constexpr bool value = ((size_t)((1 << LOGN) * (RB / (int)sizeof(cpx<T>)) + (1 << LOGN)) * sizeof(cpx<T>)) > 150 * 1024;
+};
 
 // REMAP: the columns go through col_offset (chunks of a pipelined transpose).  A template
 // parameter because the per-lane column offsets cost the plain passes 34 VGPRs (156 instead of
@@ -270,8 +287,9 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     extern __shared__ __align__(16) unsigned char smem[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
     cpx<T> *tw = buf + N * W;
+    constexpr bool HT = HalfTw<T, LOGN, RB>::value;
     const int tid = threadIdx.x;
-    for (int n = tid; n < N; n += NT) tw[n] = twiddle[n];
+    for (int n = tid; n < (HT ? N / 2 : N); n += NT) tw[n] = twiddle[n];
 
     const int64_t tilesB = (g.B + W - 1) / W;
     const int64_t ntiles = g.A * tilesB;
@@ -309,21 +327,21 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         int Ns = 1;
         using Rd = Radices<LOGN>;
         // passes (compile-time radices)
-        if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
+        if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
         Ns *= Rd::r[0];
         if (Rd::n > 1) {
-            if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
-            if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
-            if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, N, Ns, TPC, col, tj);
+            if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[3];
         }
         // store
@@ -349,13 +367,13 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 //   X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) w^k (Z[k] - conj Z[M-k]),   w = exp(-2 pi i / N)
 // (inverse: Z[k] = (X[k] + conj X[M-k]) + i conj(w)^k (X[k] - conj X[M-k]), then the inverse
 // FFT; unnormalised like rocFFT's C2R).  One read and one write of the array.
-template <typename T, int LOGM, bool INV>
-__global__ void __launch_bounds__((1 << LOGM) / 8 * (128 / (int)sizeof(cpx<T>)))
+template <typename T, int LOGM, bool INV, int RB>
+__global__ void __launch_bounds__((1 << LOGM) / 8 * (RB / (int)sizeof(cpx<T>)))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
               int64_t rpp, int64_t plane_extra)
 {
     constexpr int M = 1 << LOGM;
-    constexpr int W = 128 / (int)sizeof(cpx<T>);
+    constexpr int W = RB / (int)sizeof(cpx<T>);   // rows per tile
     constexpr int TPC = M / 8;
     constexpr int NT = TPC * W;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -386,7 +404,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             int flat = tid + u * NT;
-            buf[lds_index<T>(flat % M, flat / M)] = ld[u];
+            buf[lds_index<T, RB>(flat % M, flat / M)] = ld[u];
         }
         __syncthreads();
         if (INV) {
@@ -394,8 +412,8 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             for (int q = tid; q < W * (M / 2 + 1); q += NT) {
                 int r = q / (M / 2 + 1), k = q % (M / 2 + 1);
                 int k2 = M - k;
-                cpx<T> xk = buf[lds_index<T>(k, r)];
-                cpx<T> xq = (k == 0) ? xm[r] : buf[lds_index<T>(k2, r)];
+                cpx<T> xk = buf[lds_index<T, RB>(k, r)];
+                cpx<T> xq = (k == 0) ? xm[r] : buf[lds_index<T, RB>(k2, r)];
                 // the DC and Nyquist modes of a real row are real: their imaginary parts are
                 // ignored, as FFTW's c2r (behind PFFT) and numpy.fft.irfft do — it matters for
                 // spectra that are not exactly Hermitian, e.g. after i k / k^2 on the Nyquist planes
@@ -405,7 +423,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 cpx<T> w = tw[k];
                 w.y = -w.y;                                  // conj(w)^k = exp(+2 pi i k / N)
                 cpx<T> B = cmul(w, D);
-                buf[lds_index<T>(k, r)] = {A.x - B.y, A.y + B.x};            // A + i B
+                buf[lds_index<T, RB>(k, r)] = {A.x - B.y, A.y + B.x};            // A + i B
                 if (k != 0 && k2 != k) {
                     // Z[M-k] = conj(A) + i conj(w')... computed from the same pair:
                     // A' = xq + conj(xk) = conj(A),  D' = xq - conj(xk) = -conj(D),  w' = exp(+2 pi i (M-k)/N) = -conj(w)
@@ -413,27 +431,27 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                     cpx<T> Dc = {-D.x, D.y};
                     cpx<T> wc = {-w.x, w.y};
                     cpx<T> Bc = cmul(wc, Dc);
-                    buf[lds_index<T>(k2, r)] = {Ac.x - Bc.y, Ac.y + Bc.x};
+                    buf[lds_index<T, RB>(k2, r)] = {Ac.x - Bc.y, Ac.y + Bc.x};
                 }
             }
             __syncthreads();
         }
         int Ns = 1;
-        if (Rd::r[0] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
+        if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
         Ns *= Rd::r[0];
         if (Rd::n > 1) {
-            if (Rd::r[1] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
-            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4>(buf, tw, M, Ns, TPC, col, tj, 2);
+            if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
-            if (Rd::r[2] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
-            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4>(buf, tw, M, Ns, TPC, col, tj, 2);
+            if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
-            if (Rd::r[3] == 8) stockham_pass<T, INV, 8>(buf, tw, M, Ns, TPC, col, tj, 2);
-            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4>(buf, tw, M, Ns, TPC, col, tj, 2);
+            if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[3];
         }
         if (!INV) {
@@ -441,8 +459,8 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             for (int q = tid; q < W * (M + 1); q += NT) {
                 int r = q / (M + 1), k = q % (M + 1);
                 if (r0 + r >= nrows) continue;
-                cpx<T> zk = buf[lds_index<T>(k & (M - 1), r)];
-                cpx<T> zq = buf[lds_index<T>((M - k) & (M - 1), r)];
+                cpx<T> zk = buf[lds_index<T, RB>(k & (M - 1), r)];
+                cpx<T> zq = buf[lds_index<T, RB>((M - k) & (M - 1), r)];
                 cpx<T> E = {(T)0.5 * (zk.x + zq.x), (T)0.5 * (zk.y - zq.y)};       // (zk + conj zq)/2
                 cpx<T> D = {(T)0.5 * (zk.x - zq.x), (T)0.5 * (zk.y + zq.y)};       // (zk - conj zq)/2
                 cpx<T> w = (k == M) ? cpx<T>{(T)-1, (T)0} : tw[k];
@@ -458,7 +476,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 int flat = tid + u * NT;
                 int r = flat / M, n = flat % M;
                 if (r0 + r < nrows) {
-                    cpx<T> v = buf[lds_index<T>(n, r)];
+                    cpx<T> v = buf[lds_index<T, RB>(n, r)];
                     v.x *= sc; v.y *= sc;
                     data[(r0 + r) * pitch + n] = v;
                 }
@@ -503,7 +521,7 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     constexpr int N = 1 << LOGN;
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = N / Rpt<T, LOGN>::value * W;
-    size_t lds = (size_t)(N * W + N) * sizeof(cpx<T>);
+    size_t lds = (size_t)(N * W + (HalfTw<T, LOGN, RB>::value ? N / 2 : N)) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
     unsigned grid = (unsigned)tiles;
@@ -541,27 +559,28 @@ static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const voi
     case 8: return launch_colfft<T, 8, 128>(g, src, dst, tw, inverse, apply, st);
     case 9: return launch_colfft<T, 9, 128>(g, src, dst, tw, inverse, apply, st);
     case 10: return launch_colfft<T, 10, 128>(g, src, dst, tw, inverse, apply, st);
+    case 11: return launch_colfft<T, 11, 64>(g, src, dst, tw, inverse, apply, st);
     }
     set_error("pmx_colfft: length 2^%d is not built", g.logN);
     return PMX_EUNSUPPORTED;
 }
 
-template <typename T, int LOGM>
+template <typename T, int LOGM, int RB = 128>
 static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
                          int64_t rpp, int64_t plane_extra, hipStream_t st)
 {
     constexpr int M = 1 << LOGM;
-    constexpr int W = 128 / (int)sizeof(cpx<T>);
+    constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = M / 8 * W;
     size_t lds = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>);
     int64_t tiles = (nrows + W - 1) / W;
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
     if (inverse) {
-        auto k = rowfft_kernel<T, LOGM, true>;
+        auto k = rowfft_kernel<T, LOGM, true, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra);
     } else {
-        auto k = rowfft_kernel<T, LOGM, false>;
+        auto k = rowfft_kernel<T, LOGM, false, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra);
     }
@@ -578,6 +597,8 @@ static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, dou
     case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    // 2048 reals: 64-byte tile rows (8 float / 4 double rows per workgroup) keep 1024 / 512 threads
+    case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     }
     set_error("pmx_rowfft: length 2^%d is not built", logm + 1);
     return PMX_EUNSUPPORTED;
@@ -591,7 +612,7 @@ using namespace pmx;
 extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
-    if (n < 128 || n > 1024 || (n & (n - 1))) return PMX_EUNSUPPORTED;
+    if (n < 128 || n > 2048 || (n & (n - 1))) return PMX_EUNSUPPORTED;
     return PMX_OK;
 }
 
@@ -635,7 +656,7 @@ static ColAddr plain_addr(int64_t N, int64_t B)
 extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
-    if (n < 64 || n > 1024 || (n & (n - 1))) return PMX_EUNSUPPORTED;
+    if (n < 64 || n > 2048 || (n & (n - 1))) return PMX_EUNSUPPORTED;
     return PMX_OK;
 }
 

@@ -64,6 +64,23 @@ extern "C" int pmx_fft_create(pmx_fft **out, int32_t kind, int32_t elsize, int32
     case PMX_FFT_C2C_FWD: tt = rocfft_transform_type_complex_forward; it = ot = rocfft_array_type_complex_interleaved; break;
     default: tt = rocfft_transform_type_complex_inverse; it = ot = rocfft_array_type_complex_interleaved; break;
     }
+    // Measured on this ROCm (scripts/bigfft_probe.py): the in-place 3-d R2C/C2R of a 2048^3 mesh
+    // (4.3e9 complex elements) returns wrong numbers without an error, 2048x2048x1024 (2.1e9) is
+    // right.  Refuse spans of 2^32 elements or more rather than hand back a wrong field; the own
+    // kernels (pmx_rowfft / pmx_colfft, 64-bit offsets throughout) cover the power-of-two meshes.
+    {
+        double span_i = 0, span_o = 0;
+        for (int d = 0; d < ndim; d++) {
+            span_i += (double)(n[d] - 1) * (double)istride[d];
+            span_o += (double)(n[d] - 1) * (double)ostride[d];
+        }
+        span_i += (double)(batch - 1) * (double)idist;
+        span_o += (double)(batch - 1) * (double)odist;
+        const double lim = 4294967296.0 * (kind <= PMX_FFT_C2R ? 2.0 : 1.0);   // real side counts reals
+        bool real_in = kind == PMX_FFT_R2C, real_out = kind == PMX_FFT_C2R;
+        PMX_REQUIRE(span_i < (real_in ? lim : 4294967296.0) && span_o < (real_out ? lim : 4294967296.0),
+                    PMX_EUNSUPPORTED, "rocFFT transform spanning 2^32 or more complex elements");
+    }
     // rocFFT wants lengths/strides fastest axis first; the ABI is C order
     size_t len[3], is[3], os[3];
     for (int d = 0; d < ndim; d++) {

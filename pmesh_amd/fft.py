@@ -28,7 +28,7 @@ from . import _abi, backend
 from ._arrays import torch_dtype
 
 
-# 'auto': 3-d transforms whose axis-0/1 lengths are powers of two in 64..1024 run as
+# 'auto': 3-d transforms whose axis-0/1 lengths are powers of two in 64..2048 run as
 # rocFFT (unit-stride R2C/C2R along the contiguous axis) + the LDS-resident column FFT of
 # csrc/pmx_colfft.hip along the other two; 'never': everything through rocFFT.
 COLFFT = 'auto'
@@ -240,9 +240,9 @@ def _own_kernel_lengths(Nmesh, itemsize):
     """True if csrc/pmx_colfft.hip runs every stage of a 3-d transform of this mesh (the
     arithmetic of pmx_rowfft_supported / pmx_colfft_supported, needed here without a backend)"""
     n0, n1, n2 = [int(x) for x in Nmesh]
-    cmax = 1024
+    cmax = 2048
     pow2 = all(n & (n - 1) == 0 for n in (n0, n1, n2))
-    return pow2 and 64 <= n0 <= cmax and 64 <= n1 <= cmax and 128 <= n2 <= 1024 and n1 % 16 == 0
+    return pow2 and 64 <= n0 <= cmax and 64 <= n1 <= cmax and 128 <= n2 <= 2048 and n1 % 16 == 0
 
 
 def _pencil_init(self, np_, itemsize):

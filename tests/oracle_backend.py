@@ -107,7 +107,7 @@ class OracleBackend(object):
     # ---- column FFT (numpy restatement of csrc/pmx_colfft.hip) ------------
     def colfft_supported(self, n, elsize):
         n = int(n)
-        return 64 <= n <= 1024 and (n & (n - 1)) == 0
+        return 64 <= n <= 2048 and (n & (n - 1)) == 0
 
     def colfft(self, elsize, inverse, data, A, N, B, scale=1.0, transfer=None, n1=1, n2=1,
                start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0), a_stride=0, n_stride=0):
@@ -158,7 +158,7 @@ class OracleBackend(object):
 
     def rowfft_supported(self, n, elsize):
         n = int(n)
-        return 128 <= n <= 1024 and (n & (n - 1)) == 0
+        return 128 <= n <= 2048 and (n & (n - 1)) == 0
 
     def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0, rows_per_plane=0, plane_pitch=0):
         rdt, cdt = ('f4', 'c8') if elsize == 4 else ('f8', 'c16')

@@ -54,7 +54,12 @@ def test_column_fft_budgets():
     assert len(chunk) == 4 and all(v['VGPRs'] <= 128 and v['ScratchSize'] == 0 for v in chunk), chunk
     for k, v in t.items():
         if 'rowfft_kernel' in k:
-            assert v['ScratchSize'] == 0 and v['VGPRs'] <= 128, (k, v)
+            # the 2048-point variants (64-byte tile rows) run one workgroup per CU by their LDS
+            # tile anyway: only spills matter there
+            limit = 256 if k.split('rowfft_kernel')[1].count('ELi64E') else 128
+            assert v['ScratchSize'] == 0 and v['VGPRs'] <= limit, (k, v)
+        if 'colfft_kernel' in k and 'Li11E' in k:
+            assert v['ScratchSize'] == 0, (k, v)
 
 
 def test_tile_kernel_budgets():
