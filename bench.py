@@ -37,10 +37,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def algorithmic_bytes(stage, e, pe, nu=1.0):
-    """compulsory HBM bytes per particle: e mesh element, pe position element"""
+def algorithmic_bytes(stage, e, pe, nu=1.0, me=0):
+    """compulsory HBM bytes per particle: e mesh element, pe position element,
+    me per-particle mass element (0: scalar mass)"""
     return {
-        'paint': 3 * pe + 2 * e / nu,          # positions + one read and one write per cell
+        'paint': 3 * pe + me + 2 * e / nu,     # positions [+ mass] + one read and one write per cell
         'readout': 3 * pe + e + e / nu,        # positions + result + each cell once
         'r2c': 2 * e / nu, 'c2r': 2 * e / nu,  # real in, half-complex out (single pass)
         'apply': 2 * e / nu,                   # complex read + write
@@ -61,6 +62,11 @@ def parse():
                     help="uniform / clustered: SURVEY.md 8d, in lattice order; shuffled: the uniform set in "
                          "random order (diagnostic: no spatial coherence between neighbouring rows)")
     ap.add_argument('--gradient', type=int, default=None, help='gradient readout direction')
+    ap.add_argument('--double', type=int, default=0,
+                    help="1: 2 x particles^3 particles — the lattice plus a copy shifted by half a cell, same "
+                         "displacement field (SURVEY.md 8d, config 5)")
+    ap.add_argument('--mass', default='scalar', choices=['scalar', 'array'],
+                    help='array: a per-particle fp64 mass (config 5) instead of the scalar 1.0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-mesh', type=int, default=256)
     ap.add_argument('--binned', type=int, default=-1, help='1/0 force the tile-binned kernels on/off')
@@ -243,15 +249,19 @@ def main():
     L = 1000.0
     e = 8 if args.dtype == 'f8' else 4
     tdt = torch.float64 if args.dtype == 'f8' else torch.float32
-    ntot = Np_side ** 3
-    g0 = rank * ntot // world
-    g1 = (rank + 1) * ntot // world
-    nloc = g1 - g0
+    nlat = Np_side ** 3
+    copies = 2 if args.double else 1
+    ntot = copies * nlat
+    g0 = rank * nlat // world
+    g1 = (rank + 1) * nlat // world
+    nloc = copies * (g1 - g0)
 
     # ---- synthetic particles, generated in HBM ---------------------------------
     pos = torch.empty((nloc, 3), dtype=tdt, device=be.device)
-    pv = vec(pos)
+    if args.double and args.data != 'clustered':
+        raise SystemExit('--double is defined for --data clustered (the shifted copy of the lattice)')
     if args.data in ('uniform', 'shuffled'):
+        pv = vec(pos)
         be.call('synth_uniform', C.byref(pv), Np_side, L, 42, g0, nloc, be.stream())
         if args.data == 'shuffled':
             gen = torch.Generator(device=be.device)
@@ -259,8 +269,17 @@ def main():
             pos = pos[torch.randperm(nloc, device=be.device, generator=gen)].contiguous()
     else:
         modes = zeldovich_modes(numpy, Np_side, L)
-        be.call('synth_clustered', C.byref(pv), Np_side, L,
-                modes.ctypes.data_as(C.POINTER(C.c_double)), len(modes), 0.0, g0, nloc, be.stream())
+        for c in range(copies):
+            part = pos[c * (g1 - g0):(c + 1) * (g1 - g0)]
+            pv = vec(part)
+            be.call('synth_clustered', C.byref(pv), Np_side, L,
+                    modes.ctypes.data_as(C.POINTER(C.c_double)), len(modes), 0.5 * c, g0, g1 - g0, be.stream())
+    mass = 1.0
+    mtot = float(ntot)
+    if args.mass == 'array':
+        # deterministic, order 1, exactly summable: 0.5 + (row mod 1024) / 1024
+        mass = 0.5 + (torch.arange(nloc, device=be.device, dtype=torch.int64) % 1024).to(torch.float64) / 1024.0
+        mtot = float(comm.allreduce(float(mass.sum()))) if world > 1 else float(mass.sum())
 
     pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype=args.dtype, resampler=args.window,
                       np=[world])
@@ -317,7 +336,7 @@ def main():
         if layout is None or args.ghosts_only:
             pm.resampler.prebin(rho.value, pos, pm.affine)      # tile binning, shared by paint+readout
         mark(1)
-        pm.paint(pos, hold=False, layout=layout, out=rho)        # includes the zero fill
+        pm.paint(pos, mass=mass, hold=False, layout=layout, out=rho)   # includes the zero fill
         mark(2)
         rhok = rho.r2c(out=Ellipsis)
         mark(3)
@@ -349,9 +368,9 @@ def main():
         stage_ms[s] = sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
 
     # sanity: mass conservation and a finite result (size-independent properties)
-    check = pm.paint(pos, layout=layout)
+    check = pm.paint(pos, mass=mass, layout=layout)
     msum = check.csum()
-    assert abs(msum - ntot) <= 1e-9 * ntot if args.dtype == 'f8' else abs(msum - ntot) <= 1e-3 * ntot, msum
+    assert abs(msum - mtot) <= 1e-9 * mtot if args.dtype == 'f8' else abs(msum - mtot) <= 1e-3 * mtot, (msum, mtot)
     assert bool(torch.isfinite(f).all())
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -364,7 +383,8 @@ def main():
         single = {'paint': stage_ms['paint'], 'readout': stage_ms['readout'], 'apply': stage_ms['apply']}
         dom = max(single, key=single.get)
         units = nloc
-        ach = algorithmic_bytes(dom, e, pe, nu) * units / (single[dom] * 1e-3) / 1e9
+        me = 8 if args.mass == 'array' else 0
+        ach = algorithmic_bytes(dom, e, pe, nu, me) * units / (single[dom] * 1e-3) / 1e9
         binned = any(e[3] for e in _window.bin_cache().entries)
         if binned:
             kname = {'paint': 'paint_tile_kernel+halo_merge_kernel', 'readout': 'readout_tile_kernel',
@@ -389,25 +409,26 @@ def main():
             'data': 'synthetic',
             'config': {'workload': '%d^3 mesh, %d^3 %s particles (lattice + %s), %s window, %s, '
                                    'paint->r2c->apply(i kx/k^2)->c2r->readout%s'
-                                   % (N, Np_side, args.data,
+                                   % (N, Np_side, ('2 x ' if args.double else '') + args.data,
                                       {'uniform': 'hashed jitter', 'shuffled': 'hashed jitter, rows in random order'}.get(
                                           args.data, "Zel'dovich plane waves"),
                                       args.window.upper(), 'fp64' if args.dtype == 'f8' else 'fp32',
-                                      '' if args.gradient is None else ' (gradient %d)' % args.gradient),
+                                      ('' if args.gradient is None else ' (gradient %d)' % args.gradient) +
+                                      (', per-particle fp64 mass' if args.mass == 'array' else '')),
                        'decomposition': ('single GPU' if world == 1 else
                                          'slab np=[%d], particle exchange included (%s)'
                                          % (world, 'ghosts only' if args.ghosts_only else 'all particles')),
                        'particles': ntot, 'apply': 'fused into c2r' if args.fuse_apply else 'separate kernel',
-                       'fft': 'rocFFT z + LDS column FFT' if args.colfft else 'rocFFT 3-d'},
+                       'fft': 'LDS row + column FFT kernels' if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'decompose_ms': round(1e3 * t_decompose, 3),
             'tile_order_ms': round(1e3 * t_order, 3),
-            'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu) for s in
+            'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu, me) for s in
                                         ('paint', 'r2c', 'apply', 'c2r', 'readout')) * units /
                                     (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': ach, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_particle': algorithmic_bytes(dom, e, pe, nu),
+                         'algorithmic_bytes_per_particle': algorithmic_bytes(dom, e, pe, nu, me),
                          'particles_per_launch': units, 'ms_per_launch': single[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
