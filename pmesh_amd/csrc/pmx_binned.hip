@@ -41,7 +41,10 @@ namespace pmx {
 constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
 constexpr int TCELLS = T0 * T1 * T2;
 constexpr int TBLOCK = 256;
-constexpr int UNROLL = 4;             // particles in flight per lane in the tile kernels
+#ifndef PMX_UNROLL
+#define PMX_UNROLL 2
+#endif
+constexpr int UNROLL = PMX_UNROLL;    // particles in flight per lane in the tile kernels
 #ifndef PMX_ONEPASS_U
 #define PMX_ONEPASS_U 2
 #endif
