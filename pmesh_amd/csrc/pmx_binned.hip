@@ -41,6 +41,12 @@ namespace pmx {
 constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
 constexpr int TCELLS = T0 * T1 * T2;
 constexpr int TBLOCK = 256;
+#ifndef PMX_TILE_THREADS
+#define PMX_TILE_THREADS 512
+#endif
+#ifndef PMX_TILE_THREADS_RF4
+#define PMX_TILE_THREADS_RF4 256
+#endif
 #ifndef PMX_UNROLL
 #define PMX_UNROLL 2
 #endif
@@ -422,8 +428,17 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
     }
 }
 
-template <int KIND, typename T>
-__global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
+// Threads of a tile workgroup.  The LDS region fixes the workgroups per CU (4 / 3 / 2 for CIC /
+// TSC / PCS in double); with 256 threads that left 16 / 12 / 8 waves per CU on kernels that spend
+// 60 % of their cycles parked on memory.  512 threads double the waves at the same LDS and still
+// fit the registers (59-83 VGPRs): readout 1.46 -> 1.26 (CIC), 2.39 -> 1.78 (TSC), 3.83 -> 2.67 ms
+// (PCS), PCS paint 3.77 -> 3.17 ms at 512^3.  The float readout already runs 7-8 workgroups of
+// 256 per CU on its half-size region and keeps them.
+template <typename T> struct TileThreads { static constexpr int readout = PMX_TILE_THREADS; };
+template <> struct TileThreads<float> { static constexpr int readout = PMX_TILE_THREADS_RF4; };
+
+template <int KIND, typename T, int TTHREADS>
+__global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
                                                             const uint32_t *counts, T *halo, int overwrite)
@@ -441,16 +456,16 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
         const int64_t start = offsets[tile];
         const int count = (int)counts[tile];
         if (count == 0 && !overwrite) continue;   // nothing to add; uniform per workgroup
-        for (int q = threadIdx.x; q < Rg::CELLS; q += TBLOCK) lds[q] = 0;
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) lds[q] = 0;
         __syncthreads();
         // UNROLL particles per thread and trip: all index and position loads are issued before
         // the first use, so several dependent gathers are in flight per lane
-        for (int j0 = threadIdx.x; j0 < count; j0 += TBLOCK * UNROLL) {
+        for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
             int64_t idx[UNROLL];
             double x[UNROLL][3], m[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                int j = j0 + u * TBLOCK;
+                int j = j0 + u * TTHREADS;
                 idx[u] = j < count ? (int64_t)list[start + j] : -1;
             }
 #pragma unroll
@@ -481,7 +496,7 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
         }
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
-        for (int q = threadIdx.x; q < TCELLS; q += TBLOCK) {
+        for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
             int c = q % T2, r = q / T2;
             int b = r % T1, a = r / T1;
             int64_t goff;
@@ -503,7 +518,7 @@ __global__ void __launch_bounds__(TBLOCK) paint_tile_kernel(pmx_painter p, BinGe
         // halo -> staging (compact numbering, contiguous writes)
         if (S > 1) {
             T *hbase = halo + tile * (int64_t)Rg::HALO;
-            for (int h = threadIdx.x; h < Rg::HALO; h += TBLOCK) {
+            for (int h = threadIdx.x; h < Rg::HALO; h += TTHREADS) {
                 int a, b, c;
                 Rg::halo_decode(h, &a, &b, &c);
                 hbase[h] = (T)lds[(a * R1 + b) * R2 + c];
@@ -549,8 +564,8 @@ __global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint32_t *li
         out.set((int64_t)list[start + j], 0, 0.0);
 }
 
-template <int KIND, typename T>
-__global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, BinGeom g, const char *canvas,
+template <int KIND, typename T, int TTHREADS>
+__global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                               DVec pos, DVec out, const uint32_t *list,
                                                               const int64_t *offsets, const uint32_t *counts)
 {
@@ -565,7 +580,7 @@ __global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, Bin
         int t[3];
         tile_coords(g, tile, t);
 #pragma unroll 4
-        for (int q = threadIdx.x; q < Rg::CELLS; q += TBLOCK) {
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             int c = q % R2, r = q / R2;
             int b = r % R1, a = r / R1;
             int64_t goff;
@@ -573,12 +588,12 @@ __global__ void __launch_bounds__(TBLOCK) readout_tile_kernel(pmx_painter p, Bin
             lds[q] = in ? *(const T *)(canvas + goff) : (T)0;   // outside the block reads as 0
         }
         __syncthreads();
-        for (int j0 = threadIdx.x; j0 < count; j0 += TBLOCK * UNROLL) {
+        for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
             int64_t idx[UNROLL];
             double x[UNROLL][3];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                int j = j0 + u * TBLOCK;
+                int j = j0 + u * TTHREADS;
                 idx[u] = j < count ? (int64_t)list[start + j] : -1;
             }
 #pragma unroll
@@ -827,7 +842,7 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     if (rc) return rc;
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
     T *halo = (T *)pl->halo;
-#define PT(K) paint_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite)
+#define PT(K) paint_tile_kernel<K, T, PMX_TILE_THREADS><<<grid, PMX_TILE_THREADS, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite)
 #define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
@@ -871,7 +886,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     // particles that touch no local cell are in no tile: they read 0
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-#define RT(K, T) readout_tile_kernel<K, T><<<grid, TBLOCK, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
+#define RT(K, T) readout_tile_kernel<K, T, TileThreads<T>::readout><<<grid, TileThreads<T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
     if (p.canvas_elsize == 8) {
         switch (p.kind) {
         case PMX_TUNED_NNB: RT(PMX_TUNED_NNB, double); break;

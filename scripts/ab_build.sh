@@ -7,7 +7,7 @@ i=0
 for flags in "$@"; do
   i=$((i+1))
   (cd pmesh_amd/csrc && touch pmx_binned.hip && make EXTRA="$flags" 2>&1 | grep -E "error|warning: v" | head -3)
-  for cfg in "--window cic" "--window tsc" "--window pcs" "--window tsc --dtype f4 --gradient 0" "--data clustered"; do
+  for cfg in "--window cic" "--window tsc" "--window pcs" "--window tsc --dtype f4 --gradient 0" "--dtype f4" "--data clustered" "--mesh 256"; do
     timeout 300 python bench.py $cfg --no-cpu-baseline --steps 10 --warmup 3 > $out/r.json 2>$out/r.err
     python - "$flags" "$cfg" <<'PY'
 import json, sys
