@@ -89,11 +89,39 @@ template <typename T, bool INV> __device__ __forceinline__ void fft8(cpx<T> *v)
     v[1] = o[0]; v[3] = o[1]; v[5] = o[2]; v[7] = o[3];
 }
 
+// 3 points: w = exp(-+ 2 pi i / 3) = -1/2 -+ i sqrt(3)/2
+template <typename T, bool INV> __device__ __forceinline__ void fft3(cpx<T> *v)
+{
+    const T s = (T)0.86602540378443864676;
+    cpx<T> t1 = cadd(v[1], v[2]);
+    cpx<T> t2 = {v[0].x - (T)0.5 * t1.x, v[0].y - (T)0.5 * t1.y};
+    cpx<T> t3 = {s * (v[1].x - v[2].x), s * (v[1].y - v[2].y)};
+    cpx<T> r = rot90<T, INV>(t3);          // -+ i t3
+    v[0] = cadd(v[0], t1);
+    v[1] = cadd(t2, r);
+    v[2] = csub(t2, r);
+}
+
 template <typename T, bool INV, int R> __device__ __forceinline__ void fftR(cpx<T> *v)
 {
     if (R == 8) fft8<T, INV>(v);
     else if (R == 4) fft4<T, INV>(v);
+    else if (R == 3) fft3<T, INV>(v);
     else fft2<T, INV>(v);
+}
+
+// Length codes of the kernel templates: LC < 16 is N = 2^LC, LC = 16 + k is N = 3 * 2^k
+// (192, 384, 768, 1536 — the 3 * 2^k meshes of production runs).
+template <int LC> struct Len { static constexpr int N = LC < 16 ? (1 << LC) : (3 << (LC - 16)); };
+static inline int length_code(int64_t n)
+{
+    if (n <= 0) return -1;
+    if ((n & (n - 1)) == 0) { int l = 0; while ((1ll << l) < n) l++; return l; }
+    if (n % 3 == 0) {
+        int64_t q = n / 3;
+        if ((q & (q - 1)) == 0) { int k = 0; while ((1ll << k) < q) k++; return 16 + k; }
+    }
+    return -1;
 }
 
 // Addressing of element (a, n, b): a*sa + (n >> sh)*shi + (n & mask)*sn + b.  The plain
@@ -160,12 +188,13 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
 {
     // every thread handles (N/R)/tpc butterflies of its column
     const int nb = N / R;
-    const int per = nb / tpc;
+    const int per = (nb + tpc - 1) / tpc;   // radix 3 with tpc = N/8: 8/3 -> 3 trips, the last one partial
     cpx<T> v[4][8];   // up to 4 butterflies of radix <= 8 per thread (tpc = N/8, R = 2 -> 4)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (q >= per) break;
         int j = tj + q * tpc;
+        if (j >= nb) break;
         int k = j % Ns;
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -192,6 +221,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
     for (int q = 0; q < 4; q++) {
         if (q >= per) break;
         int j = tj + q * tpc;
+        if (j >= nb) break;
         int k = j % Ns;
         int base = (j - k) * R + k;
 #pragma unroll
@@ -251,6 +281,10 @@ template <> struct Radices<8>  { static constexpr int n = 3; static constexpr in
 template <> struct Radices<9>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 8, 1}; };
 template <> struct Radices<10> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
 template <> struct Radices<11> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
+template <> struct Radices<22> { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 3, 1}; };   // 192
+template <> struct Radices<23> { static constexpr int n = 4; static constexpr int r[4] = {8, 4, 4, 3}; };   // 384
+template <> struct Radices<24> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 3}; };   // 768
+template <> struct Radices<25> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 3}; };   // 1536
 
 #ifndef PMX_RPT_D1024
 #define PMX_RPT_D1024 16
@@ -258,7 +292,9 @@ template <> struct Radices<11> { static constexpr int n = 4; static constexpr in
 // lines of a column per thread: 8 for double; 16 for float, whose 8-byte elements would
 // otherwise keep only half the bytes in flight per thread (measured 3.1 vs 4.6 TB/s per pass)
 template <typename T, int LOGN> struct Rpt { static constexpr int value = 8; };
-template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = 16; };
+// (3 * 2^k lengths: 8 in both precisions — the radix-3 pass of a thread with 16 lines would need
+// 6 butterflies in registers)
+template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = LOGN >= 16 ? 8 : 16; };
 // N = 1024 in double: the tile takes 147 KB of LDS, one workgroup per CU; 512 threads with 16
 // lines each keep twice the loads in flight per workgroup
 template <> struct Rpt<double, 10> { static constexpr int value = PMX_RPT_D1024; };
@@ -269,17 +305,18 @@ template <> struct Rpt<double, 11> { static constexpr int value = 16; };
 // the twiddle table shares the LDS with the tile; where the pair would exceed ~150 KB only its
 // first half is kept (see stockham_pass)
 template <typename T, int LOGN, int RB> struct HalfTw {
-    static constexpr bool value = ((size_t)((1 << LOGN) * (RB / (int)sizeof(cpx<T>)) + (1 << LOGN)) * sizeof(cpx<T>)) > 150 * 1024;
+    static constexpr bool value = (LOGN < 16) &&
+        ((size_t)(Len<LOGN>::N * (RB / (int)sizeof(cpx<T>)) + Len<LOGN>::N) * sizeof(cpx<T>)) > 150 * 1024;
 };
 
 // REMAP: the columns go through col_offset (chunks of a pipelined transpose).  A template
 // parameter because the per-lane column offsets cost the plain passes 34 VGPRs (156 instead of
 // 122 at N = 512: one workgroup per CU instead of two, 541 instead of 476 us per pass).
 template <typename T, int LOGN, bool INV, bool APPLY, int RB, bool REMAP>
-__global__ void __launch_bounds__(((1 << LOGN) / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))))
+__global__ void __launch_bounds__((Len<LOGN>::N / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))))
 colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 {
-    constexpr int N = 1 << LOGN;
+    constexpr int N = Len<LOGN>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);    // columns per tile: RB-byte row segments
     constexpr int RPT = Rpt<T, LOGN>::value;       // lines per thread
     constexpr int TPC = N / RPT;                   // threads per column
@@ -332,16 +369,19 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         if (Rd::n > 1) {
             if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
             if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
             if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[3];
         }
         // store
@@ -368,11 +408,11 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 // (inverse: Z[k] = (X[k] + conj X[M-k]) + i conj(w)^k (X[k] - conj X[M-k]), then the inverse
 // FFT; unnormalised like rocFFT's C2R).  One read and one write of the array.
 template <typename T, int LOGM, bool INV, int RB>
-__global__ void __launch_bounds__((1 << LOGM) / 8 * (RB / (int)sizeof(cpx<T>)))
+__global__ void __launch_bounds__(Len<LOGM>::N / 8 * (RB / (int)sizeof(cpx<T>)))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
               int64_t rpp, int64_t plane_extra)
 {
-    constexpr int M = 1 << LOGM;
+    constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);   // rows per tile
     constexpr int TPC = M / 8;
     constexpr int NT = TPC * W;
@@ -442,16 +482,19 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
         if (Rd::n > 1) {
             if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
             if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
             if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[3];
         }
         if (!INV) {
@@ -459,8 +502,8 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             for (int q = tid; q < W * (M + 1); q += NT) {
                 int r = q / (M + 1), k = q % (M + 1);
                 if (r0 + r >= nrows) continue;
-                cpx<T> zk = buf[lds_index<T, RB>(k & (M - 1), r)];
-                cpx<T> zq = buf[lds_index<T, RB>((M - k) & (M - 1), r)];
+                cpx<T> zk = buf[lds_index<T, RB>(k == M ? 0 : k, r)];
+                cpx<T> zq = buf[lds_index<T, RB>(k == 0 ? 0 : M - k, r)];
                 cpx<T> E = {(T)0.5 * (zk.x + zq.x), (T)0.5 * (zk.y - zq.y)};       // (zk + conj zq)/2
                 cpx<T> D = {(T)0.5 * (zk.x - zq.x), (T)0.5 * (zk.y + zq.y)};       // (zk - conj zq)/2
                 cpx<T> w = (k == M) ? cpx<T>{(T)-1, (T)0} : tw[k];
@@ -518,7 +561,7 @@ template <typename T, int LOGN, int RB, bool RM>
 static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
                             hipStream_t st)
 {
-    constexpr int N = 1 << LOGN;
+    constexpr int N = Len<LOGN>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = N / Rpt<T, LOGN>::value * W;
     size_t lds = (size_t)(N * W + (HalfTw<T, LOGN, RB>::value ? N / 2 : N)) * sizeof(cpx<T>);
@@ -549,6 +592,9 @@ static int launch_colfft(const ColGeom &g, const void *src, void *dst, const voi
 // (A 256-byte-row variant, RB = 256 with one workgroup per CU, was measured for the axis-0
 // pass, whose rows are a whole plane apart: no gain at 512^3 — 1.42 vs 1.44 ms forward, and
 // the fused-transfer pass got slower — so only the 128-byte tiles are instantiated.)
+#ifndef PMX_RB768
+#define PMX_RB768 (sizeof(T) == 4 ? 64 : 128)
+#endif
 template <typename T>
 static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
                          hipStream_t st)
@@ -560,8 +606,16 @@ static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const voi
     case 9: return launch_colfft<T, 9, 128>(g, src, dst, tw, inverse, apply, st);
     case 10: return launch_colfft<T, 10, 128>(g, src, dst, tw, inverse, apply, st);
     case 11: return launch_colfft<T, 11, 64>(g, src, dst, tw, inverse, apply, st);
+    // 3 * 2^k: 8 lines per thread in both precisions; the row width keeps the workgroup within
+    // 1024 threads and the tile within the LDS
+    case 22: return launch_colfft<T, 22, 128>(g, src, dst, tw, inverse, apply, st);
+    case 23: return launch_colfft<T, 23, 128>(g, src, dst, tw, inverse, apply, st);
+    case 24: return launch_colfft<T, 24, PMX_RB768>(g, src, dst, tw, inverse, apply, st);
+    case 25:
+        if constexpr (sizeof(T) == 8) return launch_colfft<T, 25, 64>(g, src, dst, tw, inverse, apply, st);
+        break;
     }
-    set_error("pmx_colfft: length 2^%d is not built", g.logN);
+    set_error("pmx_colfft: length code %d is not built", g.logN);
     return PMX_EUNSUPPORTED;
 }
 
@@ -569,7 +623,7 @@ template <typename T, int LOGM, int RB = 128>
 static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
                          int64_t rpp, int64_t plane_extra, hipStream_t st)
 {
-    constexpr int M = 1 << LOGM;
+    constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = M / 8 * W;
     size_t lds = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>);
@@ -599,8 +653,12 @@ static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, dou
     case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     // 2048 reals: 64-byte tile rows (8 float / 4 double rows per workgroup) keep 1024 / 512 threads
     case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    // n = 384, 768, 1536 reals: M = 192, 384, 768
+    case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 24: return launch_rowfft<T, 24, (sizeof(T) == 4 ? 64 : 128)>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     }
-    set_error("pmx_rowfft: length 2^%d is not built", logm + 1);
+    set_error("pmx_rowfft: length code %d is not built", logm);
     return PMX_EUNSUPPORTED;
 }
 
@@ -612,8 +670,10 @@ using namespace pmx;
 extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
-    if (n < 128 || n > 2048 || (n & (n - 1))) return PMX_EUNSUPPORTED;
-    return PMX_OK;
+    int lc = length_code(n);
+    if (lc < 0) return PMX_EUNSUPPORTED;
+    if (lc < 16) return (n >= 128 && n <= 2048) ? PMX_OK : PMX_EUNSUPPORTED;
+    return (n >= 384 && n <= 1536) ? PMX_OK : PMX_EUNSUPPORTED;      // 3 * 2^k: 384, 768, 1536
 }
 
 // In-place real <-> half-complex transform of `nrows` rows of n reals (inverse = 0: r2c,
@@ -638,8 +698,7 @@ extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t n
     void *tw = nullptr;
     rc = get_twiddles((int)n, elsize, &tw, st);
     if (rc) return rc;
-    int logm = 0;
-    while ((2ll << logm) < n) logm++;
+    int logm = length_code(n / 2);
     if (elsize == 8)
         return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
     return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
@@ -656,8 +715,11 @@ static ColAddr plain_addr(int64_t N, int64_t B)
 extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
-    if (n < 64 || n > 2048 || (n & (n - 1))) return PMX_EUNSUPPORTED;
-    return PMX_OK;
+    int lc = length_code(n);
+    if (lc < 0) return PMX_EUNSUPPORTED;
+    if (lc < 16) return (n >= 64 && n <= 2048) ? PMX_OK : PMX_EUNSUPPORTED;
+    if (n < 192 || n > 1536) return PMX_EUNSUPPORTED;                // 3 * 2^k: 192 ... 1536
+    return (n == 1536 && elsize == 4) ? PMX_EUNSUPPORTED : PMX_OK;   // (float 1536 would need 1536 threads)
 }
 
 // In-place FFT along the middle axis of the (A, N, B) complex array `data`.
@@ -676,8 +738,7 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     if (A == 0 || B == 0) return PMX_OK;
     ColGeom g;
     g.A = A; g.B = B; g.N = (int32_t)N; g.scale = scale;
-    g.logN = 0;
-    while ((1ll << g.logN) < N) g.logN++;
+    g.logN = length_code(N);
     g.n1 = 1; g.n2 = 1;
     g.in = g.out = plain_addr(N, B);
     // padded layouts: a_stride = elements between successive a, n_stride between successive n
@@ -729,8 +790,7 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     if (A == 0 || B == 0) return PMX_OK;
     ColGeom g;
     g.A = A; g.B = B; g.N = (int32_t)N; g.scale = scale;
-    g.logN = 0;
-    while ((1ll << g.logN) < N) g.logN++;
+    g.logN = length_code(N);
     g.n1 = 1; g.n2 = 1;
     ColAddr split;
     split.sh = 0;
@@ -776,8 +836,7 @@ extern "C" int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, vo
     const int64_t B = n1 * cw;
     ColGeom g;
     g.A = 1; g.B = B; g.N = (int32_t)N; g.scale = scale;
-    g.logN = 0;
-    while ((1ll << g.logN) < N) g.logN++;
+    g.logN = length_code(N);
     g.n1 = 1; g.n2 = 1;
     ColAddr dense = plain_addr(N, B);
     ColAddr mapped = plain_addr(N, n1 * pitch);

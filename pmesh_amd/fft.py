@@ -28,7 +28,7 @@ from . import _abi, backend
 from ._arrays import torch_dtype
 
 
-# 'auto': 3-d transforms whose axis-0/1 lengths are powers of two in 64..2048 run as
+# 'auto': 3-d transforms whose axis lengths are powers of two up to 2048 or 3 * 2^k up to 1536 run as
 # rocFFT (unit-stride R2C/C2R along the contiguous axis) + the LDS-resident column FFT of
 # csrc/pmx_colfft.hip along the other two; 'never': everything through rocFFT.
 COLFFT = 'auto'
@@ -236,13 +236,29 @@ def _async_exchange_works(comm):
 PLANE_PAD = True
 
 
+def _col_length_ok(n, itemsize):
+    """pmx_colfft_supported: powers of two 64..2048, or 3 * 2^k in 192..1536 (not 1536 in fp32)"""
+    n = int(n)
+    if n > 0 and n & (n - 1) == 0:
+        return 64 <= n <= 2048
+    if n % 3 == 0 and (n // 3) & (n // 3 - 1) == 0:
+        return 192 <= n <= 1536 and not (n == 1536 and itemsize == 4)
+    return False
+
+
+def _row_length_ok(n):
+    """pmx_rowfft_supported: powers of two 128..2048, or 384 / 768 / 1536"""
+    n = int(n)
+    if n > 0 and n & (n - 1) == 0:
+        return 128 <= n <= 2048
+    return n in (384, 768, 1536)
+
+
 def _own_kernel_lengths(Nmesh, itemsize):
     """True if csrc/pmx_colfft.hip runs every stage of a 3-d transform of this mesh (the
     arithmetic of pmx_rowfft_supported / pmx_colfft_supported, needed here without a backend)"""
     n0, n1, n2 = [int(x) for x in Nmesh]
-    cmax = 2048
-    pow2 = all(n & (n - 1) == 0 for n in (n0, n1, n2))
-    return pow2 and 64 <= n0 <= cmax and 64 <= n1 <= cmax and 128 <= n2 <= 2048 and n1 % 16 == 0
+    return _col_length_ok(n0, itemsize) and _col_length_ok(n1, itemsize) and _row_length_ok(n2) and n1 % 16 == 0
 
 
 def _pencil_init(self, np_, itemsize):

@@ -172,7 +172,8 @@ def case_slab_fft(be, comm):
              ([16, 8, 8], 'f4', 5e-6),
              ([64, 64, 128], 'f8', 1e-13)]        # power-of-two: the LDS row/column kernels
     if be.name == 'hip':
-        cases += [([64, 128, 128], 'f4', 5e-6), ([128, 64, 256], 'f8', 1e-13)]
+        cases += [([64, 128, 128], 'f4', 5e-6), ([128, 64, 256], 'f8', 1e-13),
+                  ([192, 192, 384], 'f8', 1e-13)]      # 3 * 2^k: radix-3 kernels, unfused pack
     for Nmesh, dtype, tol in cases:
         pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, comm=comm, dtype=dtype, np=[comm.size])
         if Nmesh == [64, 64, 128] and comm.size in (2, 4, 8):

@@ -106,8 +106,8 @@ class OracleBackend(object):
 
     # ---- column FFT (numpy restatement of csrc/pmx_colfft.hip) ------------
     def colfft_supported(self, n, elsize):
-        n = int(n)
-        return 64 <= n <= 2048 and (n & (n - 1)) == 0
+        from pmesh_amd.fft import _col_length_ok
+        return _col_length_ok(n, elsize)
 
     def colfft(self, elsize, inverse, data, A, N, B, scale=1.0, transfer=None, n1=1, n2=1,
                start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0), a_stride=0, n_stride=0):
@@ -157,8 +157,8 @@ class OracleBackend(object):
             ch[...] = y
 
     def rowfft_supported(self, n, elsize):
-        n = int(n)
-        return 128 <= n <= 2048 and (n & (n - 1)) == 0
+        from pmesh_amd.fft import _row_length_ok
+        return _row_length_ok(n)
 
     def rowfft(self, elsize, inverse, data, nrows, n, pitch, scale=1.0, rows_per_plane=0, plane_pitch=0):
         rdt, cdt = ('f4', 'c8') if elsize == 4 else ('f8', 'c16')

@@ -282,7 +282,8 @@ def test_vjp_compositions(be):                # test_gradient.py: paint/readout 
 
 
 @pytest.mark.parametrize('dtype,tol', [('f8', 1e-13), ('f4', 5e-6)])
-@pytest.mark.parametrize('Nmesh', [[64, 64, 64], [128, 64, 20], [64, 256, 34], [64, 128, 256], [64, 64, 1024]])
+@pytest.mark.parametrize('Nmesh', [[64, 64, 64], [128, 64, 20], [64, 256, 34], [64, 128, 256], [64, 64, 1024],
+                                   [192, 64, 384], [64, 384, 768], [64, 192, 128]])
 def test_fft_column_path_vs_numpy(be, dtype, tol, Nmesh):
     """The hybrid 3-d transform (rocFFT along the contiguous axis + LDS-resident column FFTs,
     csrc/pmx_colfft.hip) obeys the same contract and equals the all-rocFFT path."""
@@ -309,7 +310,7 @@ def test_fft_column_path_vs_numpy(be, dtype, tol, Nmesh):
     assert rel_l2(res['auto'], res['never']) < 2 * tol
 
 
-@pytest.mark.parametrize('Nmesh', [[8, 6, 10], [16, 16, 16], [64, 64, 40], [64, 64, 128], [12, 10]])
+@pytest.mark.parametrize('Nmesh', [[8, 6, 10], [16, 16, 16], [64, 64, 40], [64, 64, 128], [12, 10], [64, 192, 384]])
 def test_c2r_of_a_non_hermitian_spectrum(be, Nmesh):
     """c2r == irfftn * prod(N) also for spectra that are not exactly Hermitian (what
     i k_d / k^2 leaves on the Nyquist planes): like FFTW's c2r behind PFFT, numpy ignores the
