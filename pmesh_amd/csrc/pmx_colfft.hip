@@ -656,7 +656,7 @@ static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, dou
     // n = 384, 768, 1536 reals: M = 192, 384, 768
     case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
-    case 24: return launch_rowfft<T, 24, (sizeof(T) == 4 ? 64 : 128)>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     }
     set_error("pmx_rowfft: length code %d is not built", logm);
     return PMX_EUNSUPPORTED;
