@@ -287,7 +287,7 @@ template <> struct Radices<24> { static constexpr int n = 4; static constexpr in
 template <> struct Radices<25> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 3}; };   // 1536
 
 #ifndef PMX_RPT_D1024
-#define PMX_RPT_D1024 16
+#define PMX_RPT_D1024 8
 #endif
 // lines of a column per thread: 8 for double; 16 for float, whose 8-byte elements would
 // otherwise keep only half the bytes in flight per thread (measured 3.1 vs 4.6 TB/s per pass)
@@ -295,8 +295,10 @@ template <typename T, int LOGN> struct Rpt { static constexpr int value = 8; };
 // (3 * 2^k lengths: 8 in both precisions — the radix-3 pass of a thread with 16 lines would need
 // 6 butterflies in registers)
 template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = LOGN >= 16 ? 8 : 16; };
-// N = 1024 in double: the tile takes 147 KB of LDS, one workgroup per CU; 512 threads with 16
-// lines each keep twice the loads in flight per workgroup
+// N = 1024 in double: the tile takes 147 KB of LDS, one workgroup per CU.  1024 threads with 8
+// lines each: r2c / c2r 12.7 / 12.7 ms at 1024^3 against 13.4 / 13.5 ms with 512 threads of 16
+// lines (which was the faster one while the tile loop kept 156 VGPRs alive); 64-byte tile rows
+// with two workgroups per CU measured the same as this (13.0 / 12.7 ms).
 template <> struct Rpt<double, 10> { static constexpr int value = PMX_RPT_D1024; };
 // N = 2048: 64-byte row segments (8 float / 4 double columns per tile) keep the tile inside the
 // 160 KB of LDS; 16 lines per thread in both precisions (1024 / 512 threads)
@@ -305,8 +307,9 @@ template <> struct Rpt<double, 11> { static constexpr int value = 16; };
 // the twiddle table shares the LDS with the tile; where the pair would exceed ~150 KB only its
 // first half is kept (see stockham_pass)
 template <typename T, int LOGN, int RB> struct HalfTw {
-    static constexpr bool value = (LOGN < 16) &&
-        ((size_t)(Len<LOGN>::N * (RB / (int)sizeof(cpx<T>)) + Len<LOGN>::N) * sizeof(cpx<T>)) > 150 * 1024;
+    static constexpr size_t full = (size_t)(Len<LOGN>::N * (RB / (int)sizeof(cpx<T>)) + Len<LOGN>::N) * sizeof(cpx<T>);
+    // (also where the half table lets two workgroups share a CU: 2 x 80 KB would fill the LDS to the byte)
+    static constexpr bool value = (LOGN < 16) && (full > 150 * 1024 || (full > 76 * 1024 && full <= 80 * 1024));
 };
 
 // REMAP: the columns go through col_offset (chunks of a pipelined transpose).  A template
@@ -592,6 +595,9 @@ static int launch_colfft(const ColGeom &g, const void *src, void *dst, const voi
 // (A 256-byte-row variant, RB = 256 with one workgroup per CU, was measured for the axis-0
 // pass, whose rows are a whole plane apart: no gain at 512^3 — 1.42 vs 1.44 ms forward, and
 // the fused-transfer pass got slower — so only the 128-byte tiles are instantiated.)
+#ifndef PMX_RB_D1024
+#define PMX_RB_D1024 128
+#endif
 #ifndef PMX_RB768
 #define PMX_RB768 (sizeof(T) == 4 ? 64 : 128)
 #endif
@@ -604,7 +610,7 @@ static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const voi
     case 7: return launch_colfft<T, 7, 128>(g, src, dst, tw, inverse, apply, st);
     case 8: return launch_colfft<T, 8, 128>(g, src, dst, tw, inverse, apply, st);
     case 9: return launch_colfft<T, 9, 128>(g, src, dst, tw, inverse, apply, st);
-    case 10: return launch_colfft<T, 10, 128>(g, src, dst, tw, inverse, apply, st);
+    case 10: return launch_colfft<T, 10, (sizeof(T) == 8 ? PMX_RB_D1024 : 128)>(g, src, dst, tw, inverse, apply, st);
     case 11: return launch_colfft<T, 11, 64>(g, src, dst, tw, inverse, apply, st);
     // 3 * 2^k: 8 lines per thread in both precisions; the row width keeps the workgroup within
     // 1024 threads and the tile within the LDS
