@@ -291,10 +291,16 @@ template <> struct Radices<25> { static constexpr int n = 4; static constexpr in
 #endif
 // lines of a column per thread: 8 for double; 16 for float, whose 8-byte elements would
 // otherwise keep only half the bytes in flight per thread (measured 3.1 vs 4.6 TB/s per pass)
-template <typename T, int LOGN> struct Rpt { static constexpr int value = 8; };
+#ifndef PMX_RPT_D
+#define PMX_RPT_D 8
+#endif
+#ifndef PMX_RPT_F
+#define PMX_RPT_F 16
+#endif
+template <typename T, int LOGN> struct Rpt { static constexpr int value = LOGN >= 16 ? 8 : PMX_RPT_D; };
 // (3 * 2^k lengths: 8 in both precisions — the radix-3 pass of a thread with 16 lines would need
 // 6 butterflies in registers)
-template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = LOGN >= 16 ? 8 : 16; };
+template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = LOGN >= 16 ? 8 : PMX_RPT_F; };
 // N = 1024 in double: the tile takes 147 KB of LDS, one workgroup per CU.  1024 threads with 8
 // lines each: r2c / c2r 12.7 / 12.7 ms at 1024^3 against 13.4 / 13.5 ms with 512 threads of 16
 // lines (which was the faster one while the tile loop kept 156 VGPRs alive); 64-byte tile rows
@@ -410,14 +416,18 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 //   X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) w^k (Z[k] - conj Z[M-k]),   w = exp(-2 pi i / N)
 // (inverse: Z[k] = (X[k] + conj X[M-k]) + i conj(w)^k (X[k] - conj X[M-k]), then the inverse
 // FFT; unnormalised like rocFFT's C2R).  One read and one write of the array.
+#ifndef PMX_ROW_LPT
+#define PMX_ROW_LPT 8
+#endif
 template <typename T, int LOGM, bool INV, int RB>
-__global__ void __launch_bounds__(Len<LOGM>::N / 8 * (RB / (int)sizeof(cpx<T>)))
+__global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
               int64_t rpp, int64_t plane_extra)
 {
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);   // rows per tile
-    constexpr int TPC = M / 8;
+    constexpr int LPT = PMX_ROW_LPT;   // row elements per thread
+    constexpr int TPC = M / LPT;
     constexpr int NT = TPC * W;
     extern __shared__ __align__(16) unsigned char smem[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
@@ -436,16 +446,16 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
         cpx<T> *data = data_ + (rpp > 0 ? (r0 / rpp) * plane_extra : 0);
         __syncthreads();
         // load W rows, consecutive lanes along the row
-        cpx<T> ld[8];
+        cpx<T> ld[LPT];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < LPT; u++) {
             int flat = tid + u * NT;
             int r = flat / M, n = flat % M;
             ld[u] = (r0 + r < nrows) ? data[(r0 + r) * pitch + n] : cpx<T>{0, 0};
         }
         if (INV && tid < W) xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < LPT; u++) {
             int flat = tid + u * NT;
             buf[lds_index<T, RB>(flat % M, flat / M)] = ld[u];
         }
@@ -518,7 +528,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < LPT; u++) {
                 int flat = tid + u * NT;
                 int r = flat / M, n = flat % M;
                 if (r0 + r < nrows) {
@@ -631,7 +641,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
 {
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
-    constexpr int NT = M / 8 * W;
+    constexpr int NT = M / PMX_ROW_LPT * W;
     size_t lds = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>);
     int64_t tiles = (nrows + W - 1) / W;
     unsigned grid = (unsigned)(tiles < 256 * 64 ? tiles : 256 * 64);
