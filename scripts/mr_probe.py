@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--window', default='cic')
     ap.add_argument('--ghosts-only', type=int, default=1)
     ap.add_argument('--fuse', type=int, default=1)
+    ap.add_argument('--check', type=int, default=0,
+                    help='1: compare the result of every rank with the one-rank cycle on the same particles')
     args = ap.parse_args()
 
     import torch
@@ -74,8 +76,28 @@ def main():
         torch.cuda.synchronize()
         comm.Barrier()
         results[r] = (time.perf_counter() - t0, float(f.sum()), int(layout.remote_recvlength))
+        if args.check:
+            parts[r] = f.clone()
 
+    parts = {}
     run_ranks(P, rank_main)
+    if args.check:
+        # the same cycle on one rank (the single-GPU path, itself pinned to the oracle at this size
+        # by tests/test_binned.py::test_baseline_cycle_equals_oracle)
+        _window.clear_bin_cache()
+        pos = torch.empty((ntot, 3), dtype=torch.float64, device=be.device)
+        pv = vec(pos)
+        be.call('synth_uniform', C.byref(pv), N, L, 42, 0, ntot, be.stream())
+        pm1 = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype='f8', resampler=args.window)
+        one = pm1.paint(pos).r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=Transfer.dx1(0)).readout(pos)
+        scale = float(one.abs().max())
+        worst = 0.0
+        for r in range(P):
+            g0, g1 = r * ntot // P, (r + 1) * ntot // P
+            worst = max(worst, float((parts[r] - one[g0:g1]).abs().max()))
+        print('distributed (%d ranks) vs one rank: max |diff| = %.3e (result scale %.3e) -> %.2e relative'
+              % (P, worst, scale, worst / scale))
+        assert worst <= 1e-11 * scale
     t = max(v[0] for v in results.values()) / args.steps
     print('ranks %d mesh %d: %.3f ms wall per cycle (all ranks on one GPU), ghosts received per rank %s, '
           'checksum %.6e' % (P, N, 1e3 * t, [v[2] for v in results.values()][:4],
