@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--window', default='cic')
     ap.add_argument('--ghosts-only', type=int, default=1)
     ap.add_argument('--fuse', type=int, default=1)
+    ap.add_argument('--np', default='', help="process mesh, e.g. 2x4 (pencils); default: [ranks] slabs")
     ap.add_argument('--check', type=int, default=0,
                     help='1: compare the result of every rank with the one-rank cycle on the same particles')
     args = ap.parse_args()
@@ -50,7 +51,8 @@ def main():
         pos = torch.empty((g1 - g0, 3), dtype=torch.float64, device=be.device)
         pv = vec(pos)
         be.call('synth_uniform', C.byref(pv), N, L, 42, g0, g1 - g0, be.stream())
-        pm = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler=args.window, np=[P])
+        np_ = [int(x) for x in args.np.split('x')] if args.np else [P]
+        pm = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler=args.window, np=np_)
         T = Transfer.dx1(0)
         rho = pm.create('real')
         layout = pm.decompose(pos)
