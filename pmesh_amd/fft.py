@@ -374,9 +374,7 @@ class Plan(object):
             self._execute_local(bufin, bufout, transfer)
         else:
             if getattr(p, 'pencil', False):
-                if transfer is not None:
-                    raise NotImplementedError('fused transfer on a pencil decomposition')
-                self._execute_pencil(bufin, bufout)
+                self._execute_pencil(bufin, bufout, transfer)
             else:
                 self._execute_slab(bufin, bufout, transfer)
 
@@ -413,13 +411,15 @@ class Plan(object):
             sub = buf[2 * a * N * B:]
             be.fft_execute(plan, sub, sub)
 
-    def _execute_pencil(self, bufin, bufout):
+    def _execute_pencil(self, bufin, bufout, transfer=None):
         """Pencil-decomposed 3-d transform: two transposes, on the row and the column
         sub-communicators of the (P0, P1) process mesh (PFFT's scheme for np=[P0, P1])."""
         be = backend.get()
         p = self.partition
         if getattr(p, '_unsupported', None):
             raise NotImplementedError(p._unsupported)
+        if transfer is not None and (self.forward or not self.can_fuse()):
+            raise NotImplementedError('fused transfer needs the column-FFT first stage of c2r')
         rowc, colc = p.procmesh.subcomms()
         P0, P1 = p.P0, p.P1
         N0, N1, N2 = [int(x) for x in p.Nmesh]
@@ -466,7 +466,14 @@ class Plan(object):
                 ncplx = 2 * N0 * m1 * m2
                 W0[:ncplx].copy_(bufin.storage[:ncplx])
                 S = W0
-            self._col(be, S, 1, N0, m1 * m2, True)
+            if transfer is not None and m1 * m2:
+                # the local block is (N0, m1, m2) at the global start the caller passes
+                # (0, o_start[1], o_start[2]): the transfer rides on the axis-0 pass as on slabs
+                t, start, nmesh, boxsize = transfer
+                be.colfft(self.elsize, True, S, 1, N0, m1 * m2, transfer=t, n1=m1, n2=m2,
+                          start=start, nmesh=nmesh, boxsize=boxsize)
+            else:
+                self._col(be, S, 1, N0, m1 * m2, True)
             colc.alltoall(S[:sum(r2)], W1[:sum(s2)], r2, s2)
             Y = W2
             be.slab_pack(W1, Y, n0l, N1, m2, e1o, elb, inverse=True)
@@ -484,7 +491,12 @@ class Plan(object):
         if self.forward or p.ndim != 3 or getattr(p, 'is_c2c', False):
             return False
         if p.nproc != 1:
-            return (not getattr(p, 'pencil', False)) and p.transposed and self._slab_own(backend.get())
+            be = backend.get()
+            if getattr(p, 'pencil', False):
+                # the transfer rides on the first stage, the axis-0 column pass
+                return (not getattr(p, '_unsupported', None) and COLFFT != 'never' and hasattr(be, 'colfft') and
+                        be.colfft_supported(int(p.Nmesh[0]), self.elsize))
+            return p.transposed and self._slab_own(be)
         return self._use_colfft(backend.get(), [int(x) for x in p.Nmesh[:2]])
 
     def _slab_own(self, be):

@@ -469,6 +469,21 @@ def case_pencil(be, comm):
         back2 = ck2.c2r(out=Ellipsis)
         loc = data[back2.slices]
         assert numpy.sqrt(((numpy.asarray(back2) - loc) ** 2).sum() / max((loc ** 2).sum(), 1e-300)) < 4 * tol
+    # c2r(transfer=T) on pencils: the transfer rides on the axis-0 pass of the first stage
+    Nmesh = [64, 64, 128]
+    pm = ParticleMesh(BoxSize=[3.0, 2.0, 5.0], Nmesh=Nmesh, comm=comm, dtype='f8', np=np_)
+    data = numpy.random.RandomState(5).normal(size=Nmesh)
+    ck = pm.create('real', value=data[pm.create('real').slices]).r2c()
+    assert pm.plans['backwardT'].can_fuse()
+    for T in (Transfer.dx1(0), Transfer.dx1(2), Transfer.potential(), Transfer.force(1)):
+        before = numpy.asarray(ck.value.cpu()).copy()
+        want = numpy.asarray(ck.apply(T).c2r().value.cpu())
+        got = numpy.asarray(ck.c2r(transfer=T).value.cpu())
+        assert_allclose(numpy.asarray(ck.value.cpu()), before, rtol=0, atol=0)
+        scale = comm.allreduce(float(abs(want).max()) if want.size else 0.0, op='max')
+        assert_allclose(got, want, rtol=0, atol=1e-12 * scale)
+        got2 = numpy.asarray(ck.copy().c2r(out=Ellipsis, transfer=T).value.cpu())
+        assert_allclose(got2, want, rtol=0, atol=1e-12 * scale)
     # the cycle on pencils
     N, L = 16, 1000.0
     allpos = O.synth_uniform(N, L)

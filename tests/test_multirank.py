@@ -78,7 +78,7 @@ def test_headline_cycle_distributed_equals_one_rank(nproc, window, np_):
     cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'mr_probe.py'), '--ranks', str(nproc), '--mesh', '512',
            '--steps', '1', '--warmup', '1', '--check', '1', '--window', window]
     if np_:
-        cmd += ['--np', np_, '--fuse', '0']
+        cmd += ['--np', np_]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + '\n' + out.stderr[-4000:]
     assert 'vs one rank' in out.stdout
