@@ -230,6 +230,14 @@ int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N
 int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N,
                      int64_t B, int64_t nsplit, double scale, int64_t plain_pitch, void *stream);
 
+/* The axis-1 pass of a pencil transform (PFFT's 2-d process mesh, pm.py:1417-1434) between its two
+ * global transposes: src is the (A, N, B) array cut into ranges of nsplit_in lines (the receive
+ * buffer of one all-to-all), dst the same array cut into ranges of nsplit_out lines (the send
+ * buffer of the other); 0 = plain dense.  Replaces two pmx_slab_pack sweeps around pmx_colfft.
+ * nsplit: 0 or a power of two dividing N.  src and dst must not overlap. */
+int pmx_colfft_resplit(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N,
+                       int64_t B, int64_t nsplit_in, int64_t nsplit_out, double scale, void *stream);
+
 /* The axis-0 pass on one chunk [coff, coff + cw) of the last axis of the (N, n1, pitch) block
  * `full` (pipelined slab transposes: the all-to-all of one chunk overlaps the passes of its
  * neighbours; PFFT has no such overlap).  `chunk` is the dense (N, n1, cw) buffer the

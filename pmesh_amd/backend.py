@@ -107,6 +107,12 @@ class HipBackend(object):
         self.call('colfft_split', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), A, N, B,
                   int(nsplit), float(scale), int(plain_pitch), self.stream())
 
+    def colfft_resplit(self, elsize, inverse, src, dst, A, N, B, nsplit_in, nsplit_out, scale=1.0):
+        """column FFT between two split layouts (the axis-1 pass of a pencil transform with the
+        unpack before and the pack after it fused in); nsplit 0 = plain"""
+        self.call('colfft_resplit', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), A, N, B,
+                  int(nsplit_in), int(nsplit_out), float(scale), self.stream())
+
     def colfft_chunk(self, elsize, inverse, chunk, full, N, n1, cw, pitch, coff, to_full, scale=1.0,
                      transfer=None, start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
         """axis-0 pass on the columns [coff, coff+cw) of the (N, n1, pitch) block `full`, through the

@@ -830,6 +830,46 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     return dispatch_logn<float>(g, src, dst, tw, inverse != 0, false, st);
 }
 
+// The axis-1 pass of a PENCIL transform, between its two global transposes: both sides are split
+// layouts of the same (A, N, B) array — src cut into ranges of nsplit_in lines (what the
+// all-to-all of one process-mesh direction delivered), dst into ranges of nsplit_out lines (what
+// the all-to-all of the other direction sends); 0 = plain dense.  The unpack before and the pack
+// after the pass (two pmx_slab_pack sweeps over the block) ride on its load and store.
+extern "C" int pmx_colfft_resplit(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A,
+                                  int64_t N, int64_t B, int64_t nsplit_in, int64_t nsplit_out, double scale,
+                                  void *stream)
+{
+    int rc = pmx_colfft_supported(N, elsize);
+    if (rc) { set_error("pmx_colfft_resplit: unsupported length %lld", (long long)N); return rc; }
+    PMX_REQUIRE(src != nullptr && dst != nullptr && src != dst && A >= 0 && B >= 0, PMX_EINVAL, "bad arguments");
+    for (int64_t ns : {nsplit_in, nsplit_out})
+        PMX_REQUIRE(ns == 0 || (ns >= 1 && ns <= N && (ns & (ns - 1)) == 0 && N % ns == 0), PMX_EUNSUPPORTED,
+                    "nsplit must be 0 or a power of two dividing N");
+    if (A == 0 || B == 0) return PMX_OK;
+    ColGeom g;
+    g.A = A; g.B = B; g.N = (int32_t)N; g.scale = scale;
+    g.logN = length_code(N);
+    g.n1 = 1; g.n2 = 1;
+    auto make = [&](int64_t nsplit) {
+        if (nsplit == 0) return plain_addr(N, B);
+        ColAddr a;
+        a.sh = 0;
+        while ((1ll << a.sh) < nsplit) a.sh++;
+        a.mask = (int32_t)(nsplit - 1);
+        a.sa = nsplit * B; a.sn = B; a.cw = 0; a.cpitch = 0;
+        a.shi = A * nsplit * B;
+        return a;
+    };
+    g.in = make(nsplit_in);
+    g.out = make(nsplit_out);
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)N, elsize, &tw, st);
+    if (rc) return rc;
+    if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, false, st);
+    return dispatch_logn<float>(g, src, dst, tw, inverse != 0, false, st);
+}
+
 // The axis-0 pass of a slab transform on ONE chunk of the last axis (pipelined transposes: the
 // all-to-all of chunk c overlaps the passes of chunks c-1 and c+1).  `full` is the standard
 // (N, n1, pitch) block of the transposed complex field; the chunk is its columns

@@ -444,6 +444,12 @@ class Plan(object):
         # transpose 2 (column group, P0 ranks): (n0l, N1, m2) <-> (N0, m1, m2)
         s2 = [2 * n0l * (e1o[q + 1] - e1o[q]) * m2 for q in range(P0)]
         r2 = [2 * (e0i[q + 1] - e0i[q]) * m1 * m2 for q in range(P0)]
+        # equal power-of-two ranges of axis 1 in both directions of the process mesh: the unpack
+        # before and the pack after the axis-1 pass ride on the column kernel (pmx_colfft_resplit)
+        fuse1 = (COLFFT != 'never' and hasattr(be, 'colfft_resplit') and be.colfft_supported(N1, self.elsize) and
+                 n1l * P1 == N1 and m1 * P0 == N1 and n1l & (n1l - 1) == 0 and m1 & (m1 - 1) == 0 and
+                 all(e1i[q + 1] - e1i[q] == n1l for q in range(P1)) and
+                 all(e1o[q + 1] - e1o[q] == m1 for q in range(P0)))
         if self.forward:
             X = bufin.storage
             if not same:
@@ -453,10 +459,15 @@ class Plan(object):
             self._row(be, X, n0l * n1l, N2, N2c, False)
             be.slab_pack(X, W1, n0l * n1l, N2c, 1, e2o, elb)                 # split the last axis
             rowc.alltoall(W1[:sum(s1)], W2[:sum(r1)], s1, r1)
-            Y = X if X is W0 else W0
-            be.slab_pack(W2, Y, n0l, N1, m2, e1i, elb, inverse=True)        # blocks -> (n0l, N1, m2)
-            self._col(be, Y, n0l, N1, m2, False)
-            be.slab_pack(Y, W1, n0l, N1, m2, e1o, elb)                      # split axis 1 by P0
+            if fuse1:
+                # unpack, axis-1 pass and pack in one kernel: split by P1 in, split by P0 out
+                if n0l and m2:
+                    be.colfft_resplit(self.elsize, False, W2, W1, n0l, N1, m2, n1l, m1)
+            else:
+                Y = X if X is W0 else W0
+                be.slab_pack(W2, Y, n0l, N1, m2, e1i, elb, inverse=True)    # blocks -> (n0l, N1, m2)
+                self._col(be, Y, n0l, N1, m2, False)
+                be.slab_pack(Y, W1, n0l, N1, m2, e1o, elb)                  # split axis 1 by P0
             out = bufout.storage
             colc.alltoall(W1[:sum(s2)], out[:sum(r2)], s2, r2)              # row ranges of (N0, m1, m2)
             self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
@@ -475,10 +486,15 @@ class Plan(object):
             else:
                 self._col(be, S, 1, N0, m1 * m2, True)
             colc.alltoall(S[:sum(r2)], W1[:sum(s2)], r2, s2)
-            Y = W2
-            be.slab_pack(W1, Y, n0l, N1, m2, e1o, elb, inverse=True)
-            self._col(be, Y, n0l, N1, m2, True)
-            be.slab_pack(Y, W1, n0l, N1, m2, e1i, elb)
+            if fuse1:
+                if n0l and m2:
+                    be.colfft_resplit(self.elsize, True, W1, W2, n0l, N1, m2, m1, n1l)
+                W1, W2 = W2, W1
+            else:
+                Y = W2
+                be.slab_pack(W1, Y, n0l, N1, m2, e1o, elb, inverse=True)
+                self._col(be, Y, n0l, N1, m2, True)
+                be.slab_pack(Y, W1, n0l, N1, m2, e1i, elb)
             Z = S if S is W0 else W0
             rowc.alltoall(W1[:sum(r1)], Z[:sum(s1)], r1, s1)
             out = bufout.storage

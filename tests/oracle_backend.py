@@ -141,6 +141,23 @@ class OracleBackend(object):
             y = numpy.fft.fft(plain.astype('c16'), axis=1) * scale
             split.reshape(R, A, nsplit, B)[...] = y.reshape(A, R, nsplit, B).transpose(1, 0, 2, 3)
 
+    def colfft_resplit(self, elsize, inverse, src, dst, A, N, B, nsplit_in, nsplit_out, scale=1.0):
+        cdt = 'c8' if elsize == 4 else 'c16'
+
+        def view(t, ns):
+            flat = t.detach().numpy().reshape(-1).view(cdt)[:A * N * B]
+            if ns == 0:
+                return flat.reshape(A, N, B), None
+            return flat.reshape(N // ns, A, ns, B), ns
+        sv, sn = view(src, nsplit_in)
+        x = (sv if sn is None else sv.transpose(1, 0, 2, 3).reshape(A, N, B)).astype('c16')
+        y = (numpy.fft.ifft(x, axis=1) * N if inverse else numpy.fft.fft(x, axis=1)) * scale
+        dv, dn = view(dst, nsplit_out)
+        if dn is None:
+            dv[...] = y
+        else:
+            dv[...] = y.reshape(A, N // dn, dn, B).transpose(1, 0, 2, 3)
+
     def colfft_chunk(self, elsize, inverse, chunk, full, N, n1, cw, pitch, coff, to_full, scale=1.0,
                      transfer=None, start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0)):
         cdt = 'c8' if elsize == 4 else 'c16'

@@ -104,6 +104,32 @@ def test_colfft_split(be, elsize, tol, N, nsplit):
         assert rel(back.cpu().numpy().view(cdt).reshape(A, N, B), x) < 2 * tol * numpy.log2(N)
 
 
+@pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
+@pytest.mark.parametrize('N,nin,nout', [(64, 16, 32), (128, 64, 16), (256, 128, 0), (64, 0, 8), (192, 64, 0)])
+def test_colfft_resplit(be, elsize, tol, N, nin, nout):
+    """the axis-1 pass of the pencil transform: input in the split layout of one transpose,
+    output in the split layout of the other == unpack (slab_pack inverse), colfft, slab_pack"""
+    if not be.colfft_supported(N, elsize):
+        pytest.skip('length not built for this precision')
+    cdt = 'c16' if elsize == 8 else 'c8'
+    rs = numpy.random.RandomState(N + nin + nout)
+
+    def to_split(a, ns):       # (A, N, B) -> flat split layout
+        A, _, B = a.shape
+        return a if ns == 0 else numpy.ascontiguousarray(a.reshape(A, N // ns, ns, B).transpose(1, 0, 2, 3))
+
+    for A, B in ((3, 9), (1, 33)):
+        x = (rs.normal(size=(A, N, B)) + 1j * rs.normal(size=(A, N, B))).astype(cdt)
+        for inverse in (False, True):
+            src = torch.view_as_real(torch.from_numpy(to_split(x, nin).reshape(-1).copy())).reshape(-1).to(be.device)
+            dst = torch.zeros_like(src)
+            be.colfft_resplit(elsize, inverse, src, dst, A, N, B, nin, nout, scale=0.5)
+            y = (numpy.fft.ifft(x.astype('c16'), axis=1) * N if inverse else numpy.fft.fft(x.astype('c16'), axis=1)) * 0.5
+            got = dst.cpu().numpy().view(cdt).reshape(-1)
+            assert rel(got, to_split(y, nout).reshape(-1)) < tol * numpy.log2(N), (A, B, inverse)
+            assert numpy.array_equal(src.cpu().numpy().view(cdt).reshape(-1), to_split(x, nin).reshape(-1))
+
+
 def test_colfft_fused_transfer(be, oracle):
     """element (i0, i1, i2) * T(k) before the inverse axis-0 pass == apply_transfer + ifft"""
     N0, n1, n2 = 64, 6, 9
