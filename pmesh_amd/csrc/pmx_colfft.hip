@@ -286,6 +286,10 @@ template <> struct Radices<23> { static constexpr int n = 4; static constexpr in
 template <> struct Radices<24> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 3}; };   // 768
 template <> struct Radices<25> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 3}; };   // 1536
 
+// column kernel: lengths from this one on walk their tiles with a grid-stride loop
+#ifndef PMX_COL_STRIDE_FROM
+#define PMX_COL_STRIDE_FROM 1000000
+#endif
 #ifndef PMX_RPT_D1024
 #define PMX_RPT_D1024 8
 #endif
@@ -344,7 +348,8 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     // optimiser keeps everything tile-invariant alive across the FFT passes — 156 / 166 / 212
     // VGPRs for the chunk, fused-transfer and float variants, i.e. one workgroup per CU instead of
     // two (fused pass 680 -> 490 us at 512^3, float passes 343 -> 250 us).
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += ntiles) {
+    constexpr bool ONE_TILE = N < PMX_COL_STRIDE_FROM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += (ONE_TILE ? ntiles : (int64_t)gridDim.x)) {
         const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
         const bool colok = b0 + col < g.B;
         // plain: one base per tile, lanes add their column; REMAP: a base per lane
@@ -588,7 +593,7 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     size_t lds = (size_t)(N * W + (HalfTw<T, LOGN, RB>::value ? N / 2 : N)) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
-    unsigned grid = (unsigned)tiles;
+    unsigned grid = (unsigned)((N < PMX_COL_STRIDE_FROM) ? tiles : (tiles < 256 * 16 ? tiles : 256 * 16));
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
         auto k = colfft_kernel<T, LOGN, INV, AP, RB, RM>;                                                      \
