@@ -109,6 +109,44 @@ def test_binned_equals_direct(hip, oracle, name, case):
     assert_allclose(c3.cpu().numpy(), c2.cpu().numpy() + 7.0, rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs'])
+@pytest.mark.parametrize('period', [(16, 32, 256), (0, 0, 0)])
+def test_sparse_clusters_across_tile_faces(hip, oracle, name, period):
+    """paint_tile_kernel carries the z-halo of a tile in LDS into the next tile of its z segment
+    (4 tiles) and stages it only at the end of a segment.  Small clusters that straddle a z face
+    inside a segment, at a segment end and at the periodic wrap, with every other tile EMPTY (the
+    tile behind a cluster is processed only because of the carry), accumulate (hold) and overwrite
+    mode: dyadic positions and masses, so CIC and TSC must equal the oracle bit for bit."""
+    shape = (16, 32, 256)           # 2 x 2 x 8 tiles of 8 x 16 x 32: two z segments per column
+    W = windows[name]
+    aff = Affine(3, scale=1.0, translate=0.0, period=period)
+    oaff = oracle.Affine(3, scale=1.0, translate=0.0, period=period)
+    rs = numpy.random.RandomState(3)
+    for zc in (31.5, 32.0, 63.75, 127.5, 128.0, 255.5, 0.25, 95.0, 223.5):
+        # a cluster of 200 particles within +-1.5 cells of z = zc in ONE (x, y) tile column
+        pos_h = numpy.empty((200, 3))
+        pos_h[:, 0] = 3.0 + rs.randint(0, 32, size=200) / 16.0
+        pos_h[:, 1] = 20.0 + rs.randint(0, 64, size=200) / 16.0
+        pos_h[:, 2] = (zc + rs.randint(-24, 25, size=200) / 16.0) % 256
+        mass_h = rs.randint(1, 5, size=200).astype('f8')
+        pos = torch.from_numpy(pos_h).to(hip.device)
+        mass = torch.from_numpy(mass_h).to(hip.device)
+        base = rs.randint(-3, 4, size=shape).astype('f8')
+        want = base.copy()
+        oracle.Window(W.kind).paint(want, pos_h, mass=mass_h, transform=oaff)
+        window.BINNED = 'always'
+        window.clear_bin_cache()
+        c = torch.from_numpy(base.copy()).to(hip.device)
+        W.paint(c, pos, mass=mass, transform=aff)                       # accumulate
+        assert_binned_ran()
+        # (the cubic weights carry a 1/6: exact sums only for CIC and TSC)
+        check = assert_array_equal if name != 'pcs' else (lambda a, b: assert_allclose(a, b, rtol=0, atol=1e-12))
+        check(c.cpu().numpy(), want)
+        c = torch.full(shape, 9.0, dtype=torch.float64, device=hip.device)
+        W.paint(c, pos, mass=mass, transform=aff, _overwrite=True)      # every cell written once
+        check(c.cpu().numpy(), want - base)
+
+
 @pytest.mark.parametrize('name', ['nnb', 'cic', 'tsc'])
 def test_binned_dyadic_bit_exact(hip, oracle, name):
     """positions on a 1/16-cell lattice, small integer masses: exact partial sums =>
