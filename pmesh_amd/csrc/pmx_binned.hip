@@ -438,8 +438,19 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
 // fit the registers (59-83 VGPRs): readout 1.46 -> 1.26 (CIC), 2.39 -> 1.78 (TSC), 3.83 -> 2.67 ms
 // (PCS), PCS paint 3.77 -> 3.17 ms at 512^3.  The float readout already runs 7-8 workgroups of
 // 256 per CU on its half-size region and keeps them.
-template <typename T> struct TileThreads { static constexpr int readout = PMX_TILE_THREADS; };
-template <> struct TileThreads<float> { static constexpr int readout = PMX_TILE_THREADS_RF4; };
+// (PCS with 768 threads — two workgroups per CU by its 58 KB region, six waves per SIMD by its
+// registers — measured 3 % faster before the z-halo carry and 25 % slower in paint with it: 512.)
+#ifndef PMX_TILE_THREADS_PCS
+#define PMX_TILE_THREADS_PCS 512
+#endif
+template <int KIND, typename T> struct TileThreads {
+    static constexpr int paint = KIND == PMX_TUNED_PCS ? PMX_TILE_THREADS_PCS : PMX_TILE_THREADS;
+    static constexpr int readout = KIND == PMX_TUNED_PCS ? PMX_TILE_THREADS_PCS : PMX_TILE_THREADS;
+};
+template <int KIND> struct TileThreads<KIND, float> {
+    static constexpr int paint = KIND == PMX_TUNED_PCS ? PMX_TILE_THREADS_PCS : PMX_TILE_THREADS;
+    static constexpr int readout = PMX_TILE_THREADS_RF4;
+};
 
 template <int KIND, typename T, int TTHREADS>
 __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
@@ -899,7 +910,7 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     const int64_t nwork = (g.ntiles / g.nt[2]) * ((g.nt[2] + ZSEG - 1) / ZSEG);   // z segments of tiles
     unsigned pgrid = (unsigned)(nwork < 65535 * 8 ? nwork : 65535 * 8);
     T *halo = (T *)pl->halo;
-#define PT(K) paint_tile_kernel<K, T, PMX_TILE_THREADS><<<pgrid, PMX_TILE_THREADS, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite)
+#define PT(K) paint_tile_kernel<K, T, TileThreads<K, T>::paint><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite)
 #define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
@@ -943,7 +954,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     // particles that touch no local cell are in no tile: they read 0
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-#define RT(K, T) readout_tile_kernel<K, T, TileThreads<T>::readout><<<grid, TileThreads<T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
+#define RT(K, T) readout_tile_kernel<K, T, TileThreads<K, T>::readout><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
     if (p.canvas_elsize == 8) {
         switch (p.kind) {
         case PMX_TUNED_NNB: RT(PMX_TUNED_NNB, double); break;
