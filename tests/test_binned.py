@@ -296,6 +296,7 @@ def test_full_size_properties(hip, name, dtype):
     (512, 'cic', 'f8', None, 1e-11, 'uniform'),     # the headline workload of bench.py (measured 3.9e-15)
     (512, 'tsc', 'f4', 0, 2e-5, 'uniform'),         # BASELINE config 3: TSC + gradient readout, fp32 (1.3e-6)
     (512, 'cic', 'f8', None, 1e-11, 'clustered'),   # the headline on the Zel'dovich-displaced set
+    (256, 'pcs', 'f8', None, 1e-11, 'clustered'),   # config 5's window on the clustered set
 ])
 def test_baseline_cycle_equals_oracle(hip, oracle, N, name, dtype, gradient, tol, data):
     """BASELINE.json's single-GPU configurations at their FULL size — uniform particles (the
