@@ -203,7 +203,7 @@ int pmx_fft_create(pmx_fft **plan, int32_t kind, int32_t elsize, int32_t ndim, c
 int pmx_fft_execute(pmx_fft *plan, void *in, void *out, void *stream);
 int pmx_fft_destroy(pmx_fft *plan);
 
-/* Batched strided ("column") complex FFT, in place, lengths 2^k in 64..2048 and 3 * 2^k in 192..1536, with the
+/* Batched strided ("column") complex FFT, in place, lengths 2^k in 64..2048, 3 * 2^k in 192..1536 and 5 * 2^k in 320..1280, with the
  * columns resident in LDS (csrc/pmx_colfft.hip): the passes of a 3-d transform along the
  * non-contiguous axes.  `data` is an (A, N, B) complex array in C order; the transform runs
  * along the middle axis.  inverse = 0: exp(-i k x); 1: exp(+i k x); unnormalised, the result
@@ -251,7 +251,7 @@ int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, void *full, i
 
 /* Real <-> half-complex transform along the contiguous axis, in place, with the rows
  * resident in LDS (csrc/pmx_colfft.hip): `nrows` rows of n reals (n a power of two in
- * 128..2048, or 384 / 768 / 1536) at a pitch of `pitch` complex elements <-> n/2+1 modes.  inverse = 0: r2c,
+ * 128..2048, or 384 / 768 / 1536 / 640 / 1280) at a pitch of `pitch` complex elements <-> n/2+1 modes.  inverse = 0: r2c,
  * 1: c2r; unnormalised, times `scale`.  rows_per_plane > 0: row r starts at
  * (r / rows_per_plane) * plane_pitch + (r % rows_per_plane) * pitch complex elements (padded
  * plane stride; rows_per_plane a multiple of 8 (f8) / 16 (f4)); 0: r * pitch. */

@@ -102,17 +102,36 @@ template <typename T, bool INV> __device__ __forceinline__ void fft3(cpx<T> *v)
     v[2] = csub(t2, r);
 }
 
+// 5 points
+template <typename T, bool INV> __device__ __forceinline__ void fft5(cpx<T> *v)
+{
+    const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;   // cos(2 pi/5), cos(4 pi/5)
+    const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;    // sin(2 pi/5), sin(4 pi/5)
+    cpx<T> t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    cpx<T> a1 = {v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y};
+    cpx<T> a2 = {v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y};
+    cpx<T> b1 = rot90<T, INV>(cpx<T>{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y});
+    cpx<T> b2 = rot90<T, INV>(cpx<T>{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y});
+    v[0] = cadd(v[0], cadd(t1, t2));
+    v[1] = cadd(a1, b1);
+    v[4] = csub(a1, b1);
+    v[2] = cadd(a2, b2);
+    v[3] = csub(a2, b2);
+}
+
 template <typename T, bool INV, int R> __device__ __forceinline__ void fftR(cpx<T> *v)
 {
     if (R == 8) fft8<T, INV>(v);
     else if (R == 4) fft4<T, INV>(v);
     else if (R == 3) fft3<T, INV>(v);
+    else if (R == 5) fft5<T, INV>(v);
     else fft2<T, INV>(v);
 }
 
 // Length codes of the kernel templates: LC < 16 is N = 2^LC, LC = 16 + k is N = 3 * 2^k
 // (192, 384, 768, 1536 — the 3 * 2^k meshes of production runs).
-template <int LC> struct Len { static constexpr int N = LC < 16 ? (1 << LC) : (3 << (LC - 16)); };
+// and LC = 32 + k is N = 5 * 2^k (320, 640, 1280).
+template <int LC> struct Len { static constexpr int N = LC < 16 ? (1 << LC) : (LC < 32 ? (3 << (LC - 16)) : (5 << (LC - 32))); };
 static inline int length_code(int64_t n)
 {
     if (n <= 0) return -1;
@@ -120,6 +139,10 @@ static inline int length_code(int64_t n)
     if (n % 3 == 0) {
         int64_t q = n / 3;
         if ((q & (q - 1)) == 0) { int k = 0; while ((1ll << k) < q) k++; return 16 + k; }
+    }
+    if (n % 5 == 0) {
+        int64_t q = n / 5;
+        if ((q & (q - 1)) == 0) { int k = 0; while ((1ll << k) < q) k++; return 32 + k; }
     }
     return -1;
 }
@@ -285,6 +308,9 @@ template <> struct Radices<22> { static constexpr int n = 3; static constexpr in
 template <> struct Radices<23> { static constexpr int n = 4; static constexpr int r[4] = {8, 4, 4, 3}; };   // 384
 template <> struct Radices<24> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 3}; };   // 768
 template <> struct Radices<25> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 3}; };   // 1536
+template <> struct Radices<38> { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 5, 1}; };   // 320
+template <> struct Radices<39> { static constexpr int n = 4; static constexpr int r[4] = {8, 4, 4, 5}; };   // 640
+template <> struct Radices<40> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 5}; };   // 1280
 
 // column kernel: lengths from this one on walk their tiles with a grid-stride loop
 #ifndef PMX_COL_STRIDE_FROM
@@ -384,18 +410,21 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
             if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[1] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
             if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[2] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
             if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+            else if (Rd::r[3] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
             Ns *= Rd::r[3];
         }
         // store
@@ -509,18 +538,21 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[1] == 5) stockham_pass<T, INV, 5, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[1];
         }
         if (Rd::n > 2) {
             if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[2] == 5) stockham_pass<T, INV, 5, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[2];
         }
         if (Rd::n > 3) {
             if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
+            else if (Rd::r[3] == 5) stockham_pass<T, INV, 5, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[3];
         }
         if (!INV) {
@@ -643,6 +675,12 @@ static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const voi
     case 25:
         if constexpr (sizeof(T) == 8) return launch_colfft<T, 25, 64>(g, src, dst, tw, inverse, apply, st);
         break;
+    // 5 * 2^k
+    case 38: return launch_colfft<T, 38, 128>(g, src, dst, tw, inverse, apply, st);
+    case 39: return launch_colfft<T, 39, (sizeof(T) == 4 ? 64 : 128)>(g, src, dst, tw, inverse, apply, st);
+    case 40:
+        if constexpr (sizeof(T) == 8) return launch_colfft<T, 40, 64>(g, src, dst, tw, inverse, apply, st);
+        break;
     }
     set_error("pmx_colfft: length code %d is not built", g.logN);
     return PMX_EUNSUPPORTED;
@@ -687,6 +725,9 @@ static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, dou
     case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    // n = 640, 1280 reals: M = 320, 640
+    case 38: return launch_rowfft<T, 38>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 39: return launch_rowfft<T, 39, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     }
     set_error("pmx_rowfft: length code %d is not built", logm);
     return PMX_EUNSUPPORTED;
@@ -703,7 +744,8 @@ extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
     int lc = length_code(n);
     if (lc < 0) return PMX_EUNSUPPORTED;
     if (lc < 16) return (n >= 128 && n <= 2048) ? PMX_OK : PMX_EUNSUPPORTED;
-    return (n >= 384 && n <= 1536) ? PMX_OK : PMX_EUNSUPPORTED;      // 3 * 2^k: 384, 768, 1536
+    if (lc < 32) return (n >= 384 && n <= 1536) ? PMX_OK : PMX_EUNSUPPORTED;      // 3 * 2^k: 384, 768, 1536
+    return (n == 640 || n == 1280) ? PMX_OK : PMX_EUNSUPPORTED;                   // 5 * 2^k
 }
 
 // In-place real <-> half-complex transform of `nrows` rows of n reals (inverse = 0: r2c,
@@ -748,8 +790,12 @@ extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
     int lc = length_code(n);
     if (lc < 0) return PMX_EUNSUPPORTED;
     if (lc < 16) return (n >= 64 && n <= 2048) ? PMX_OK : PMX_EUNSUPPORTED;
-    if (n < 192 || n > 1536) return PMX_EUNSUPPORTED;                // 3 * 2^k: 192 ... 1536
-    return (n == 1536 && elsize == 4) ? PMX_EUNSUPPORTED : PMX_OK;   // (float 1536 would need 1536 threads)
+    if (lc < 32) {
+        if (n < 192 || n > 1536) return PMX_EUNSUPPORTED;                // 3 * 2^k: 192 ... 1536
+        return (n == 1536 && elsize == 4) ? PMX_EUNSUPPORTED : PMX_OK;   // (float 1536 would need 1536 threads)
+    }
+    if (n < 320 || n > 1280) return PMX_EUNSUPPORTED;                    // 5 * 2^k: 320, 640, 1280
+    return (n == 1280 && elsize == 4) ? PMX_EUNSUPPORTED : PMX_OK;
 }
 
 // In-place FFT along the middle axis of the (A, N, B) complex array `data`.

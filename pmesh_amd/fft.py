@@ -28,7 +28,7 @@ from . import _abi, backend
 from ._arrays import torch_dtype
 
 
-# 'auto': 3-d transforms whose axis lengths are powers of two up to 2048 or 3 * 2^k up to 1536 run as
+# 'auto': 3-d transforms whose axis lengths are 2^k up to 2048, 3 * 2^k up to 1536 or 5 * 2^k up to 1280 run as
 # rocFFT (unit-stride R2C/C2R along the contiguous axis) + the LDS-resident column FFT of
 # csrc/pmx_colfft.hip along the other two; 'never': everything through rocFFT.
 COLFFT = 'auto'
@@ -237,21 +237,24 @@ PLANE_PAD = True
 
 
 def _col_length_ok(n, itemsize):
-    """pmx_colfft_supported: powers of two 64..2048, or 3 * 2^k in 192..1536 (not 1536 in fp32)"""
+    """pmx_colfft_supported: powers of two 64..2048, 3 * 2^k in 192..1536 (not 1536 in fp32),
+    5 * 2^k in 320..1280 (not 1280 in fp32)"""
     n = int(n)
     if n > 0 and n & (n - 1) == 0:
         return 64 <= n <= 2048
     if n % 3 == 0 and (n // 3) & (n // 3 - 1) == 0:
         return 192 <= n <= 1536 and not (n == 1536 and itemsize == 4)
+    if n % 5 == 0 and (n // 5) & (n // 5 - 1) == 0:
+        return 320 <= n <= 1280 and not (n == 1280 and itemsize == 4)
     return False
 
 
 def _row_length_ok(n):
-    """pmx_rowfft_supported: powers of two 128..2048, or 384 / 768 / 1536"""
+    """pmx_rowfft_supported: powers of two 128..2048, or 384 / 768 / 1536 / 640 / 1280"""
     n = int(n)
     if n > 0 and n & (n - 1) == 0:
         return 128 <= n <= 2048
-    return n in (384, 768, 1536)
+    return n in (384, 768, 1536, 640, 1280)
 
 
 def _own_kernel_lengths(Nmesh, itemsize):

@@ -16,7 +16,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
-@pytest.mark.parametrize('N', [64, 128, 256, 512, 1024, 2048, 192, 384, 768, 1536])
+@pytest.mark.parametrize('N', [64, 128, 256, 512, 1024, 2048, 192, 384, 768, 1536, 320, 640, 1280])
 def test_colfft_lengths(be, elsize, tol, N):
     if not be.colfft_supported(N, elsize):
         pytest.skip('length not built for this precision')
@@ -33,7 +33,7 @@ def test_colfft_lengths(be, elsize, tol, N):
 
 
 @pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
-@pytest.mark.parametrize('n', [128, 256, 512, 1024, 2048, 384, 768, 1536])
+@pytest.mark.parametrize('n', [128, 256, 512, 1024, 2048, 384, 768, 1536, 640, 1280])
 def test_rowfft_lengths(be, elsize, tol, n):
     if not be.rowfft_supported(n, elsize):
         pytest.skip('length not built for this precision')

@@ -283,7 +283,7 @@ def test_vjp_compositions(be):                # test_gradient.py: paint/readout 
 
 @pytest.mark.parametrize('dtype,tol', [('f8', 1e-13), ('f4', 5e-6)])
 @pytest.mark.parametrize('Nmesh', [[64, 64, 64], [128, 64, 20], [64, 256, 34], [64, 128, 256], [64, 64, 1024],
-                                   [192, 64, 384], [64, 384, 384], [64, 192, 128]])
+                                   [192, 64, 384], [64, 384, 384], [64, 192, 128], [64, 320, 640]])
 def test_fft_column_path_vs_numpy(be, dtype, tol, Nmesh):
     """The hybrid 3-d transform (rocFFT along the contiguous axis + LDS-resident column FFTs,
     csrc/pmx_colfft.hip) obeys the same contract and equals the all-rocFFT path."""
