@@ -337,8 +337,12 @@ template <int LOGN> struct Rpt<float, LOGN> { static constexpr int value = LOGN 
 // with two workgroups per CU measured the same as this (13.0 / 12.7 ms).
 template <> struct Rpt<double, 10> { static constexpr int value = PMX_RPT_D1024; };
 // N = 2048: 64-byte row segments (8 float / 4 double columns per tile) keep the tile inside the
-// 160 KB of LDS; 16 lines per thread in both precisions (1024 / 512 threads)
-template <> struct Rpt<double, 11> { static constexpr int value = 16; };
+// 160 KB of LDS; 16 lines per thread in float, 8 in double (1024 threads each; 16 lines / 512
+// threads in double measured 3 % slower at 2048^3)
+#ifndef PMX_RPT_D2048
+#define PMX_RPT_D2048 8
+#endif
+template <> struct Rpt<double, 11> { static constexpr int value = PMX_RPT_D2048; };
 
 // the twiddle table shares the LDS with the tile; where the pair would exceed ~150 KB only its
 // first half is kept (see stockham_pass)
