@@ -626,6 +626,7 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     constexpr int N = Len<LOGN>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = N / Rpt<T, LOGN>::value * W;
+    static_assert(NT <= 1024 && NT % 64 == 0, "column kernel: workgroup size");
     size_t lds = (size_t)(N * W + (HalfTw<T, LOGN, RB>::value ? N / 2 : N)) * sizeof(cpx<T>);
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
@@ -697,6 +698,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = M / PMX_ROW_LPT * W;
+    static_assert(NT <= 1024 && NT % 64 == 0, "row kernel: workgroup size");
     size_t lds = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>);
     int64_t tiles = (nrows + W - 1) / W;
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 row tiles in one pass");
