@@ -19,6 +19,16 @@ def is_tensor(x):
     return isinstance(x, torch.Tensor)
 
 
+def touched(*tensors):
+    """Tell torch that the library wrote into these tensors through their raw pointers (the
+    kernels do not go through torch, so nothing else bumps the version counter).  The bin-plan
+    cache (window._BinCache) and the Layout memos key on (data_ptr, _version): without the bump
+    a tensor rewritten by readout(out=), gather or an FFT would be served a stale plan."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor):
+            torch.autograd.graph.increment_version(t)
+
+
 def to_device(x, device, what='array', allow_int=False):
     """-> (tensor on `device`, came_from_host).  Lists become float64."""
     if is_tensor(x):

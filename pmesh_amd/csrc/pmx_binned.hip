@@ -41,9 +41,6 @@ namespace pmx {
 constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
 constexpr int TCELLS = T0 * T1 * T2;
 constexpr int TBLOCK = 256;
-#ifndef PMX_EXPERIMENT_LDS
-#define PMX_EXPERIMENT_LDS 0
-#endif
 #ifndef PMX_ZSEG
 #define PMX_ZSEG 4
 #endif
@@ -519,9 +516,6 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
         }
         // UNROLL particles per thread and trip: all index and position loads are issued before
         // the first use, so several dependent gathers are in flight per lane
-#if PMX_EXPERIMENT_LDS == 2
-        double sink = 0;
-#endif
         for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
             int64_t idx[UNROLL];
             double x[UNROLL][3], m[UNROLL];
@@ -543,6 +537,9 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int lb[3];
                 double V[3][S];
                 particle_setup<KIND>(p, g, t, x[u], V, lb);
+                // a plan that no longer matches the positions (rewritten behind the cache's back)
+                // must not index outside the LDS region
+                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
 #pragma unroll
                 for (int a = 0; a < S; a++) V[0][a] *= m[u];
 #pragma unroll
@@ -553,20 +550,11 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                         int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
 #pragma unroll
                         for (int c = 0; c < S; c++) {
-#if PMX_EXPERIMENT_LDS == 1        // timing experiments (scripts/ab_paint_only.sh): WRONG results
-                            lds[rowoff + c] = fb * V[2][c];                       // plain store
-#elif PMX_EXPERIMENT_LDS == 2
-                            sink += fb * V[2][c] * (double)(rowoff + c);          // no LDS traffic
-#else
                             unsafeAtomicAdd(&lds[rowoff + c], fb * V[2][c]);
-#endif
                         }
                     }
             }
         }
-#if PMX_EXPERIMENT_LDS == 2
-        if (sink == 12345.678) lds[0] = sink;
-#endif
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -691,6 +679,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
                 int lb[3];
                 double V[3][S];
                 particle_setup<KIND>(p, g, t, x[u], V, lb);
+                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
                 double value = 0;
 #pragma unroll
                 for (int a = 0; a < S; a++)

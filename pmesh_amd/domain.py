@@ -23,7 +23,7 @@ import numpy
 import torch
 
 from . import _abi, backend
-from ._arrays import to_device, vec, is_tensor, torch_dtype
+from ._arrays import touched, to_device, vec, is_tensor, torch_dtype
 from .comm import default_comm
 
 
@@ -54,6 +54,15 @@ def _scatter_add(be, values, indices, nout):
     ncol = 1
     for s in values.shape[1:]:
         ncol *= s
+    if values.dtype not in (torch.float32, torch.float64):
+        # pmx_scatter_add adds float / double bit patterns; integer (and any other) payloads are
+        # reduced by torch's index_add_, as the reference's bincountv does for them
+        # (domain.py:30-47): exact, order independent
+        if values.dtype == torch.bool or values.is_complex():
+            raise TypeError('cannot sum rows of dtype %s' % (values.dtype,))
+        out = torch.zeros((nout,) + tuple(values.shape[1:]), dtype=values.dtype, device=be.device)
+        out.index_add_(0, indices.to(torch.int64), values)
+        return out
     out = torch.empty((nout,) + tuple(values.shape[1:]), dtype=values.dtype, device=be.device)
     be.call('scatter_add', values.data_ptr(), values.element_size(), ncol, indices.data_ptr(),
             indices.element_size(), values.shape[0], out.data_ptr(), nout, be.stream())
@@ -230,8 +239,12 @@ class Layout(object):
             for s in back.shape[1:]:
                 ncol *= s
             # nout = 0: accumulate into `out` without clearing it (include/pmesh_amd.h)
+            if out.dtype not in (torch.float32, torch.float64):
+                out.index_add_(0, idx.to(torch.int64), back)
+                return out
             be.call('scatter_add', back.data_ptr(), back.element_size(), ncol, idx.data_ptr(),
                     idx.element_size(), nsend, out.data_ptr(), 0, be.stream())
+            touched(out)
         return out
 
     def gather(self, data, mode='sum', out=None):

@@ -17,7 +17,7 @@ import numpy
 import torch
 
 from . import _abi, backend
-from ._arrays import to_device, vec, vec_ref, real_view, is_tensor
+from ._arrays import to_device, vec, vec_ref, real_view, is_tensor, touched
 
 
 def _mkarr(var, shape, dtype):
@@ -371,6 +371,7 @@ class ResampleWindow(object):
                 canvas.zero_()
             be.call('paint', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv), mass_scalar,
                     vec_ref(hv), n, be.stream())
+        touched(canvas)
         if writeback is not None:
             writeback()
 
@@ -427,6 +428,7 @@ class ResampleWindow(object):
         else:
             be.call('readout', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(hv), C.byref(ov), n,
                     be.stream())
+        touched(dout)
         if host_out is not None:
             host_out[...] = dout.cpu().numpy()
             return host_out
