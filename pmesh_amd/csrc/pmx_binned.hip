@@ -32,138 +32,11 @@
 // cells with l in [max(0, t*T-o), min(size, (t+1)*T-o)), everything else valid is halo.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
-#include "pmx_common.h"
-#include "pmx_window_dev.h"
-
-namespace pmx {
-
-constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
-constexpr int TCELLS = T0 * T1 * T2;
-constexpr int TBLOCK = 256;
-#ifndef PMX_ZSEG
-#define PMX_ZSEG 4
-#endif
-constexpr int ZSEG = PMX_ZSEG;        // tiles per z segment of paint_tile_kernel
-#ifndef PMX_TILE_THREADS
-#define PMX_TILE_THREADS 512
-#endif
-#ifndef PMX_TILE_THREADS_RF4
-#define PMX_TILE_THREADS_RF4 256
-#endif
-#ifndef PMX_UNROLL
-#define PMX_UNROLL 2
-#endif
-constexpr int UNROLL = PMX_UNROLL;    // particles in flight per lane in the tile kernels
-#ifndef PMX_ONEPASS_U
-#define PMX_ONEPASS_U 2
-#endif
-
-struct BinGeom {
-    int32_t kind, S;
-    int32_t nt[3];        // tiles per axis
-    int32_t o[3];         // tile-space offset per axis (S-1 unless the axis is the full period)
-    int64_t ntiles;
-};
-
-template <int S> struct Region {
-    static constexpr int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
-    static constexpr int CELLS = R0 * R1 * R2;
-    // compact numbering of the halo (region minus the T0 x T1 x T2 box)
-    static constexpr int NA = (S - 1) * R1 * R2;     // a >= T0
-    static constexpr int NB = T0 * (S - 1) * R2;     // a < T0, b >= T1
-    static constexpr int NC = T0 * T1 * (S - 1);     // a < T0, b < T1, c >= T2
-    static constexpr int HALO = NA + NB + NC;
-    __device__ static __forceinline__ int halo_index(int a, int b, int c)
-    {
-        if (a >= T0) return ((a - T0) * R1 + b) * R2 + c;
-        if (b >= T1) return NA + (a * (S - 1) + (b - T1)) * R2 + c;
-        return NA + NB + (a * T1 + b) * (S - 1) + (c - T2);
-    }
-    __device__ static __forceinline__ void halo_decode(int h, int *a, int *b, int *c)
-    {
-        if (h < NA) {
-            *c = h % R2; int r = h / R2; *b = r % R1; *a = T0 + r / R1;
-        } else if (h < NA + NB) {
-            h -= NA;
-            *c = h % R2; int r = h / R2; *b = T1 + r % (S - 1 > 0 ? S - 1 : 1); *a = r / (S - 1 > 0 ? S - 1 : 1);
-        } else {
-            h -= NA + NB;
-            *c = T2 + h % (S - 1 > 0 ? S - 1 : 1); int r = h / (S - 1 > 0 ? S - 1 : 1); *b = r % T1; *a = r / T1;
-        }
-    }
-};
-
-}  // namespace pmx
-
-struct pmx_binplan {
-    pmx::BinGeom g;
-    pmx_painter painter;        // geometry the plan was built for
-    int64_t npart = 0;
-    bool built = false;
-    // device arrays
-    int32_t *tid = nullptr;     // tile id per particle (-1 = touches no local cell)
-    uint32_t *list = nullptr;   // particle indices, tile major
-    size_t cap_part = 0;
-    size_t cap_list = 0;        // entries of `list`: npart + slack (see slot_capacity)
-    uint32_t *counts = nullptr; // particles per tile; entry [ntiles] = particles that touch no local cell
-    int64_t *offsets = nullptr; // first list slot of every tile (ntiles + 2 entries): tile t owns
-                                // slots [offsets[t], offsets[t+1]), of which counts[t] are used
-    unsigned long long *cursor = nullptr;   // next free slot per tile while scattering
-    size_t cap_tiles = 0;
-    uint32_t *flags = nullptr;  // [0] != 0: the single-pass build ran out of slots in some tile
-    uint32_t *host_flag = nullptr;          // pinned, device-visible: overflows seen so far
-    void *halo = nullptr;       // staging of the halo cells: ntiles * Region<S>::HALO elements
-    size_t cap_halo = 0;
-    // history for the single-pass build: the slot ranges of the previous build of the same
-    // geometry and particle count are reused (particles move little between time steps)
-    bool have_history = false;
-    uint32_t seen_overflows = 0;
-    int distrust = 0, skip = 0;  // back-off after an overflow
-};
+#include "pmx_binplan.h"
 
 namespace pmx {
-
-__device__ __forceinline__ int tile_ext(int d) { return d == 0 ? T0 : (d == 1 ? T1 : T2); }
-
-// true modulo with a fast path for indices within one period of the box
-__device__ __forceinline__ int wrap_fast(int i, int64_t n)
-{
-    if (n <= 0) return i;
-    int m = (int)n;
-    if (i < 0) { i += m; if (i < 0) { i %= m; if (i < 0) i += m; } }
-    else if (i >= m) { i -= m; if (i >= m) i %= m; }
-    return i;
-}
-
-// wrap an index that is at most one period outside [0, period) (guaranteed by
-// pmx_binplan_supported: every axis spans at least one tile region)
-__device__ __forceinline__ int wrap_near(int l, int64_t period)
-{
-    if (period > 0) {
-        if (l < 0) l += (int)period;
-        else if (l >= period) l -= (int)period;
-    }
-    return l;
-}
-
-// first stencil index of a particle along axis d in the local frame (see header);
-// returns false if the particle touches no local cell along this axis
-template <int KIND>
-__device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, int *i0w)
-{
-    constexpr int S = Tuned<KIND>::S;
-    int w = wrap_fast(I0, p.period[d]);
-    if (p.period[d] > 0) {
-        if (w < p.size[d]) *i0w = w;
-        else if (w >= p.period[d] - (S - 1)) *i0w = w - (int)p.period[d];
-        else return false;
-    } else {
-        if (w < -(S - 1) || w >= p.size[d]) return false;
-        *i0w = w;
-    }
-    return true;
-}
 
 // DENSE: positions are a contiguous (n, 3) array.  A lane-per-particle load of 3 elements
 // at a 24-byte stride touches three times the cache lines per instruction that a dense
@@ -180,7 +53,7 @@ __host__ __device__ __forceinline__ int64_t slot_capacity(int64_t c) { return c 
 // Particles that touch no local cell go to bucket `ntiles`.  gate != NULL: do nothing unless
 // *gate != 0 (the fallback launches after a single-pass build are always enqueued and only
 // run if it overflowed — no host synchronisation).
-template <int KIND, bool DENSE, int MODE>
+template <int KIND, bool DENSE, int MODE, bool WALK>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
                                                            int32_t *tid, uint32_t *counts, uint32_t *flags,
                                                            const int64_t *offsets, uint32_t *list,
@@ -255,9 +128,13 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                     Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
                     int i0w = 0;
                     ok = ok && local_base<KIND>(p, d, I[0], &i0w);
-                    tt[d] = (i0w + g.o[d]) / tile_ext(d);
+                    tt[d] = (i0w + g.o[d]) / bucket_ext<WALK>(d);
                 }
-                t[u] = ok ? (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2] : (int)g.ntiles;
+                // tile form: tiles in C order; walk form: the planes of a patch column follow
+                // each other (a workgroup walks along axis 0)
+                const int64_t tb = WALK ? ((int64_t)tt[1] * g.nt[2] + tt[2]) * g.nt[0] + tt[0]
+                                        : ((int64_t)tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+                t[u] = ok ? (int)tb : (int)g.ntiles;
             }
             // wave-aggregated counting: find the lanes that share my tile (ballots only)
             same[u] = 0;
@@ -697,7 +574,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
     }
 }
 
-static int ensure(void **ptr, size_t *cap, size_t need)
+int plan_ensure(void **ptr, size_t *cap, size_t need)
 {
     if (need <= *cap) return PMX_OK;
     if (*ptr) (void)hipFree(*ptr);
@@ -718,6 +595,18 @@ static bool same_geometry(const pmx_painter &a, const pmx_painter &b)
     return true;
 }
 
+// mean particles per cell from which the walk kernels are chosen for S >= 3 (PMX_WALK_MIN_DENSITY)
+static double walk_min_density()
+{
+    static double v = -1;
+    if (v < 0) {
+        const char *e = getenv("PMX_WALK_MIN_DENSITY");
+        v = e ? atof(e) : 0.25;
+        if (!(v >= 0)) v = 0.25;
+    }
+    return v;
+}
+
 static int halo_cells(int S)
 {
     int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
@@ -735,6 +624,15 @@ extern "C" int pmx_binplan_create(pmx_binplan **plan)
     return PMX_OK;
 }
 
+extern "C" int pmx_binplan_configure(pmx_binplan *pl, int32_t form)
+{
+    PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
+    PMX_REQUIRE(form >= -1 && form <= 1, PMX_EINVAL, "form must be -1 (auto), 0 (tiles) or 1 (walk)");
+    if (pl->form != form) pl->have_history = false;
+    pl->form = form;
+    return PMX_OK;
+}
+
 extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
 {
     if (!pl) return PMX_OK;
@@ -746,6 +644,7 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->flags) (void)hipFree(pl->flags);
     if (pl->host_flag) (void)hipHostFree(pl->host_flag);
     if (pl->halo) (void)hipFree(pl->halo);
+    if (pl->unit_flags) (void)hipFree(pl->unit_flags);
     delete pl;
     return PMX_OK;
 }
@@ -789,10 +688,17 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     PMX_REQUIRE(npart == 0 || (vec_ok(pos) && pos->ncol >= 3), PMX_EINVAL, "pos must be (n, >=3) f4/f8");
     hipStream_t st = (hipStream_t)stream;
     pmx_painter p = *p_;
-    const int T[3] = {T0, T1, T2};
     BinGeom g;
     g.kind = p.kind;
     g.S = native_support(p.kind);
+    // Which form: the walk kernels (pmx_walk.hip) pay per mesh plane and per particle with S^2
+    // instead of S^3 LDS operations: TSC / PCS at a density of the order of one particle per
+    // cell; the tile kernels otherwise (sparse batches, CIC / NNB).
+    double cells = (double)p.size[0] * (double)p.size[1] * (double)p.size[2];
+    bool walk = pl->form == 1 || (pl->form < 0 && g.S >= 3 && (double)npart >= walk_min_density() * cells);
+    if (g.S < 2) walk = false;
+    g.walk = walk ? 1 : 0;
+    const int T[3] = {walk ? 1 : T0, walk ? P1 : T1, walk ? P2 : T2};
     g.ntiles = 1;
     for (int d = 0; d < 3; d++) {
         bool full = p.period[d] > 0 && p.size[d] == p.period[d];
@@ -800,11 +706,25 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         g.nt[d] = (int32_t)((p.size[d] + g.o[d] + T[d] - 1) / T[d]);
         g.ntiles *= g.nt[d];
     }
+    g.lseg = g.nseg = 0;
+    g._pad = 0;
+    g.nunits = 0;
+    if (walk) {
+        // segments of the walk along axis 0: long (the S-1 trailing planes of a segment are staged
+        // like halo cells) but enough units to fill 256 CUs a few times over
+        const int64_t patches = (int64_t)g.nt[1] * g.nt[2];
+        int lseg = 64;
+        while (lseg > 16 && patches * ((g.nt[0] + lseg - 1) / lseg) < 2048) lseg /= 2;
+        g.lseg = lseg;
+        g.nseg = (g.nt[0] + lseg - 1) / lseg;
+        g.nunits = patches * g.nseg;
+    }
+    PMX_REQUIRE(g.ntiles < 2147483647ll, PMX_EUNSUPPORTED, "more than 2^31 buckets");
     // The slot ranges of the previous build can be reused when it was for the same geometry
     // and particle count (a time-stepping caller: particles move a fraction of a tile per
     // step) and reuse has not just failed (back-off after an overflow).
     bool reuse = pl->built && pl->have_history && pl->npart == npart && npart > 0 &&
-                 same_geometry(p, pl->painter) && pl->g.ntiles == g.ntiles;
+                 same_geometry(p, pl->painter) && pl->g.ntiles == g.ntiles && pl->g.walk == g.walk;
     if (pl->host_flag) {
         uint32_t seen = *(volatile uint32_t *)pl->host_flag;   // stale at worst: a hint only
         if (seen != pl->seen_overflows) {
@@ -830,8 +750,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         if (pl->tid) (void)hipFree(pl->tid);
         if (pl->list) (void)hipFree(pl->list);
         pl->tid = nullptr; pl->list = nullptr; pl->cap_part = 0; pl->cap_list = 0;
-        rc = ensure((void **)&pl->tid, &c1, np1 * 4); if (rc) return rc;
-        rc = ensure((void **)&pl->list, &c3, nlist * 4); if (rc) return rc;
+        rc = plan_ensure((void **)&pl->tid, &c1, np1 * 4); if (rc) return rc;
+        rc = plan_ensure((void **)&pl->list, &c3, nlist * 4); if (rc) return rc;
         pl->cap_part = np1 * 4;
         pl->cap_list = nlist;
         reuse = false;
@@ -842,9 +762,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         if (pl->offsets) (void)hipFree(pl->offsets);
         if (pl->cursor) (void)hipFree(pl->cursor);
         pl->counts = nullptr; pl->offsets = nullptr; pl->cursor = nullptr; pl->cap_tiles = 0;
-        rc = ensure((void **)&pl->counts, &c1, (size_t)(nbuckets + 1) * 4); if (rc) return rc;
-        rc = ensure((void **)&pl->offsets, &c2, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
-        rc = ensure((void **)&pl->cursor, &c3, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
+        rc = plan_ensure((void **)&pl->counts, &c1, (size_t)(nbuckets + 1) * 4); if (rc) return rc;
+        rc = plan_ensure((void **)&pl->offsets, &c2, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
+        rc = plan_ensure((void **)&pl->cursor, &c3, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
         pl->cap_tiles = (size_t)(nbuckets + 1);
         reuse = false;
     }
@@ -862,20 +782,20 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         // contiguous (n, 3) rows on a 16-byte boundary take the dense staging path
         const bool dense = pos->stride1 == pos->elsize && pos->stride0 == 3 * (int64_t)pos->elsize &&
                            (((uintptr_t)pos->data) & 15) == 0;
-#define BC(K, MODE, GRID, GATE)                                                                                 \
+#define BC(K, MODE, GRID, GATE, W)                                                                                 \
     do {                                                                                                        \
-        if (dense) bin_count_kernel<K, true, MODE><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
+        if (dense) bin_count_kernel<K, true, MODE, W><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
                 pl->flags, pl->offsets, pl->list, pl->host_flag, GATE);                                         \
-        else bin_count_kernel<K, false, MODE><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
+        else bin_count_kernel<K, false, MODE, W><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
                 pl->flags, pl->offsets, pl->list, pl->host_flag, GATE);                                         \
     } while (0)
 #define BCK(MODE, GRID, GATE)                                                                                   \
     do {                                                                                                        \
         switch (p.kind) {                                                                                       \
-        case PMX_TUNED_NNB: BC(PMX_TUNED_NNB, MODE, GRID, GATE); break;                                         \
-        case PMX_TUNED_CIC: BC(PMX_TUNED_CIC, MODE, GRID, GATE); break;                                         \
-        case PMX_TUNED_TSC: BC(PMX_TUNED_TSC, MODE, GRID, GATE); break;                                         \
-        default: BC(PMX_TUNED_PCS, MODE, GRID, GATE); break;                                                    \
+        case PMX_TUNED_NNB: BC(PMX_TUNED_NNB, MODE, GRID, GATE, false); break;                                  \
+        case PMX_TUNED_CIC: if (walk) BC(PMX_TUNED_CIC, MODE, GRID, GATE, true); else BC(PMX_TUNED_CIC, MODE, GRID, GATE, false); break; \
+        case PMX_TUNED_TSC: if (walk) BC(PMX_TUNED_TSC, MODE, GRID, GATE, true); else BC(PMX_TUNED_TSC, MODE, GRID, GATE, false); break; \
+        default: if (walk) BC(PMX_TUNED_PCS, MODE, GRID, GATE, true); else BC(PMX_TUNED_PCS, MODE, GRID, GATE, false); break; \
         }                                                                                                       \
     } while (0)
         const uint32_t *nogate = nullptr;
@@ -910,7 +830,7 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
 {
     const BinGeom &g = pl->g;
     size_t need = (size_t)g.ntiles * (size_t)halo_cells(g.S) * sizeof(T);
-    int rc = ensure(&pl->halo, &pl->cap_halo, need > 0 ? need : 16);
+    int rc = plan_ensure(&pl->halo, &pl->cap_halo, need > 0 ? need : 16);
     if (rc) return rc;
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
     const int64_t nwork = (g.ntiles / g.nt[2]) * ((g.nt[2] + ZSEG - 1) / ZSEG);   // z segments of tiles
@@ -940,6 +860,7 @@ extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *ca
     PMX_REQUIRE(pl->npart == 0 || vec_ok(pos), PMX_EINVAL, "pos");
     pmx_painter p = *p_;
     hipStream_t st = (hipStream_t)stream;
+    if (pl->g.walk) return paint_walk(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
     if (p.canvas_elsize == 8) return paint_binned_t<double>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
     return paint_binned_t<float>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
 }
@@ -959,6 +880,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     DVec dout = dvec(out), dpos = dvec(pos);
     // particles that touch no local cell are in no tile: they read 0
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout);
+    if (g.walk) return readout_walk(pl, p, canvas, dpos, dout, st);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
 #define RT(K, T) readout_tile_kernel<K, T, TileThreads<K, T>::readout><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
     if (p.canvas_elsize == 8) {

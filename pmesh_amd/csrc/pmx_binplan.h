@@ -1,0 +1,162 @@
+// pmx_binplan.h — the bin plan (particles ordered by mesh tile / plane bucket) shared by the
+// tile kernels (pmx_binned.hip) and the walk kernels (pmx_walk.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "pmx_common.h"
+#include "pmx_window_dev.h"
+
+namespace pmx {
+
+constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
+constexpr int TCELLS = T0 * T1 * T2;
+constexpr int TBLOCK = 256;
+#ifndef PMX_ZSEG
+#define PMX_ZSEG 4
+#endif
+constexpr int ZSEG = PMX_ZSEG;        // tiles per z segment of paint_tile_kernel
+#ifndef PMX_TILE_THREADS
+#define PMX_TILE_THREADS 512
+#endif
+#ifndef PMX_TILE_THREADS_RF4
+#define PMX_TILE_THREADS_RF4 256
+#endif
+#ifndef PMX_UNROLL
+#define PMX_UNROLL 2
+#endif
+constexpr int UNROLL = PMX_UNROLL;    // particles in flight per lane in the tile kernels
+#ifndef PMX_ONEPASS_U
+#define PMX_ONEPASS_U 2
+#endif
+
+// Walk form (pmx_walk.hip): buckets are single mesh planes of a patch of P1 x P2 columns; a
+// workgroup walks a segment of `lseg` planes of one patch along axis 0.
+constexpr int P1 = 16, P2 = 32;
+constexpr int WTHREADS = P1 * P2;     // one thread per column of the patch
+
+struct BinGeom {
+    int32_t kind, S;
+    int32_t nt[3];        // tiles per axis (walk form: nt[0] = planes of a patch column)
+    int32_t o[3];         // tile-space offset per axis (S-1 unless the axis is the full period)
+    int64_t ntiles;       // buckets: tiles, or planes x patches in the walk form
+    int32_t walk;         // 0: tiles of T0 x T1 x T2 cells; 1: plane buckets of 1 x P1 x P2 cells
+    int32_t lseg;         // walk form: planes per segment
+    int32_t nseg;         // walk form: segments per patch column
+    int32_t _pad;
+    int64_t nunits;       // walk form: patches x segments (one workgroup each)
+};
+
+template <int S> struct Region {
+    static constexpr int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
+    static constexpr int CELLS = R0 * R1 * R2;
+    // compact numbering of the halo (region minus the T0 x T1 x T2 box)
+    static constexpr int NA = (S - 1) * R1 * R2;     // a >= T0
+    static constexpr int NB = T0 * (S - 1) * R2;     // a < T0, b >= T1
+    static constexpr int NC = T0 * T1 * (S - 1);     // a < T0, b < T1, c >= T2
+    static constexpr int HALO = NA + NB + NC;
+    __device__ static __forceinline__ int halo_index(int a, int b, int c)
+    {
+        if (a >= T0) return ((a - T0) * R1 + b) * R2 + c;
+        if (b >= T1) return NA + (a * (S - 1) + (b - T1)) * R2 + c;
+        return NA + NB + (a * T1 + b) * (S - 1) + (c - T2);
+    }
+    __device__ static __forceinline__ void halo_decode(int h, int *a, int *b, int *c)
+    {
+        if (h < NA) {
+            *c = h % R2; int r = h / R2; *b = r % R1; *a = T0 + r / R1;
+        } else if (h < NA + NB) {
+            h -= NA;
+            *c = h % R2; int r = h / R2; *b = T1 + r % (S - 1 > 0 ? S - 1 : 1); *a = r / (S - 1 > 0 ? S - 1 : 1);
+        } else {
+            h -= NA + NB;
+            *c = T2 + h % (S - 1 > 0 ? S - 1 : 1); int r = h / (S - 1 > 0 ? S - 1 : 1); *b = r % T1; *a = r / T1;
+        }
+    }
+};
+
+}  // namespace pmx
+
+struct pmx_binplan {
+    pmx::BinGeom g;
+    pmx_painter painter;        // geometry the plan was built for
+    int64_t npart = 0;
+    bool built = false;
+    // device arrays
+    int32_t *tid = nullptr;     // tile id per particle (-1 = touches no local cell)
+    uint32_t *list = nullptr;   // particle indices, tile major
+    size_t cap_part = 0;
+    size_t cap_list = 0;        // entries of `list`: npart + slack (see slot_capacity)
+    uint32_t *counts = nullptr; // particles per tile; entry [ntiles] = particles that touch no local cell
+    int64_t *offsets = nullptr; // first list slot of every tile (ntiles + 2 entries): tile t owns
+                                // slots [offsets[t], offsets[t+1]), of which counts[t] are used
+    unsigned long long *cursor = nullptr;   // next free slot per tile while scattering
+    size_t cap_tiles = 0;
+    uint32_t *flags = nullptr;  // [0] != 0: the single-pass build ran out of slots in some tile
+    uint32_t *host_flag = nullptr;          // pinned, device-visible: overflows seen so far
+    void *halo = nullptr;       // staging of the halo cells: ntiles * Region<S>::HALO elements
+    size_t cap_halo = 0;
+    uint32_t *unit_flags = nullptr;   // walk form: unit was painted (its staging is valid)
+    size_t cap_units = 0;
+    int form = -1;              // -1: chosen per build; 0: tile kernels; 1: walk kernels
+    // history for the single-pass build: the slot ranges of the previous build of the same
+    // geometry and particle count are reused (particles move little between time steps)
+    bool have_history = false;
+    uint32_t seen_overflows = 0;
+    int distrust = 0, skip = 0;  // back-off after an overflow
+};
+
+namespace pmx {
+
+__device__ __forceinline__ int tile_ext(int d) { return d == 0 ? T0 : (d == 1 ? T1 : T2); }
+template <bool WALK> __device__ __forceinline__ int bucket_ext(int d)
+{
+    return WALK ? (d == 0 ? 1 : (d == 1 ? P1 : P2)) : tile_ext(d);
+}
+
+// true modulo with a fast path for indices within one period of the box
+__device__ __forceinline__ int wrap_fast(int i, int64_t n)
+{
+    if (n <= 0) return i;
+    int m = (int)n;
+    if (i < 0) { i += m; if (i < 0) { i %= m; if (i < 0) i += m; } }
+    else if (i >= m) { i -= m; if (i >= m) i %= m; }
+    return i;
+}
+
+// wrap an index that is at most one period outside [0, period) (guaranteed by
+// pmx_binplan_supported: every axis spans at least one tile region)
+__device__ __forceinline__ int wrap_near(int l, int64_t period)
+{
+    if (period > 0) {
+        if (l < 0) l += (int)period;
+        else if (l >= period) l -= (int)period;
+    }
+    return l;
+}
+
+// first stencil index of a particle along axis d in the local frame (see header);
+// returns false if the particle touches no local cell along this axis
+template <int KIND>
+__device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, int *i0w)
+{
+    constexpr int S = Tuned<KIND>::S;
+    int w = wrap_fast(I0, p.period[d]);
+    if (p.period[d] > 0) {
+        if (w < p.size[d]) *i0w = w;
+        else if (w >= p.period[d] - (S - 1)) *i0w = w - (int)p.period[d];
+        else return false;
+    } else {
+        if (w < -(S - 1) || w >= p.size[d]) return false;
+        *i0w = w;
+    }
+    return true;
+}
+
+// launchers of pmx_walk.hip
+int paint_walk(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
+               int overwrite, hipStream_t st);
+int readout_walk(pmx_binplan *pl, const pmx_painter &p, const void *canvas, DVec pos, DVec out, hipStream_t st);
+int plan_ensure(void **ptr, size_t *cap, size_t need);
+
+}  // namespace pmx

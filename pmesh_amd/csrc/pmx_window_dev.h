@@ -66,6 +66,8 @@ template <int KIND> struct Tuned;
 
 template <> struct Tuned<PMX_TUNED_NNB> {
     static constexpr int S = 1;
+    // first stencil index alone (the same expression as in axis())
+    __device__ static __forceinline__ int first(double X) { return (int)floor(X + 0.5); }
     __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
     {
         I[0] = (int)floor(X + 0.5);
@@ -75,6 +77,7 @@ template <> struct Tuned<PMX_TUNED_NNB> {
 
 template <> struct Tuned<PMX_TUNED_CIC> {
     static constexpr int S = 2;
+    __device__ static __forceinline__ int first(double X) { return (int)floor(X); }
     __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
     {
         I[0] = (int)floor(X);
@@ -91,6 +94,7 @@ template <> struct Tuned<PMX_TUNED_CIC> {
 
 template <> struct Tuned<PMX_TUNED_TSC> {
     static constexpr int S = 3;
+    __device__ static __forceinline__ int first(double X) { return (int)floor(X + 0.5) - 1; }
     __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
     {
         I[1] = (int)floor(X + 0.5);
@@ -110,6 +114,7 @@ template <> struct Tuned<PMX_TUNED_TSC> {
 
 template <> struct Tuned<PMX_TUNED_PCS> {
     static constexpr int S = 4;
+    __device__ static __forceinline__ int first(double X) { return (int)floor(X) - 1; }
     __device__ static __forceinline__ void axis(double X, int order, double scale, int *I, double *V)
     {
         I[1] = (int)floor(X);

@@ -10,6 +10,7 @@ replace the per-particle C API of pmesh/_window_imp.h:76-86 and the Cython loop
 of pmesh/_window.pyx:128-205.
 """
 import ctypes as C
+import os
 
 import threading
 
@@ -72,6 +73,11 @@ BINNED_MIN_PARTICLES = 1 << 17
 # point).  Measured break-even on a 64 x 512 x 512 block (scripts/thresh_probe.py):
 # CIC 2^20 particles, PCS 2^17; thin ghost bands at a slab face sit well below both.
 BINNED_MIN_DENSITY = {1: 0.06, 2: 0.06, 3: 0.02, 4: 0.008}
+# Which binned kernels: 'auto' (the library decides per batch: the walk form of
+# csrc/pmx_walk.hip for TSC / PCS at ~1 particle per cell, the tile form otherwise),
+# 'never' (tile form only), 'always' (walk form for every window of support >= 2).
+WALK = os.environ.get('PMESH_AMD_WALK', 'auto')
+_FORMS = {'auto': -1, 'never': 0, 'always': 1}
 
 
 class _BinCache(object):
@@ -87,7 +93,7 @@ class _BinCache(object):
         self.clock = 0
 
     def _key(self, pos, painter):
-        return (pos.data_ptr(), pos._version, tuple(pos.shape), pos.stride(), pos.dtype,
+        return (pos.data_ptr(), pos._version, tuple(pos.shape), pos.stride(), pos.dtype, WALK,
                 painter.kind, tuple(painter.scale), tuple(painter.translate),
                 tuple(painter.period), tuple(painter.size))
 
@@ -113,6 +119,7 @@ class _BinCache(object):
         else:
             e = min(free or [q for q in self.entries if q[5] == shape] or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape
+        be.call('binplan_configure', e[1], _FORMS[WALK])
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
         e[3] = True
         e[4] = self._tick()

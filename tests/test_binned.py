@@ -30,11 +30,20 @@ def hip():
     from pmesh_amd import backend
     backend.reset()
     b = backend.get()
-    old = window.BINNED
+    old, oldw = window.BINNED, window.WALK
     yield b
-    window.BINNED = old
+    window.BINNED, window.WALK = old, oldw
     window.clear_bin_cache()
     backend.reset()
+
+
+@pytest.fixture(params=['tiles', 'walk'])
+def form(request, hip):
+    """both forms of the binned kernels: the tile kernels (csrc/pmx_binned.hip) and the walk
+    kernels (csrc/pmx_walk.hip; windows of support >= 2, NNB stays on the tiles)"""
+    window.WALK = 'never' if request.param == 'tiles' else 'always'
+    window.clear_bin_cache()
+    return request.param
 
 
 def both(W, fn):
@@ -63,7 +72,7 @@ def assert_binned_ran():
 
 @pytest.mark.parametrize('name', TUNED)
 @pytest.mark.parametrize('case', range(len(CASES)))
-def test_binned_equals_direct(hip, oracle, name, case):
+def test_binned_equals_direct(hip, form, oracle, name, case):
     shape, period, scale, translate = CASES[case]
     W = windows[name]
     rs = numpy.random.RandomState(100 + case)
@@ -111,7 +120,7 @@ def test_binned_equals_direct(hip, oracle, name, case):
 
 @pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs'])
 @pytest.mark.parametrize('period', [(16, 32, 256), (0, 0, 0)])
-def test_sparse_clusters_across_tile_faces(hip, oracle, name, period):
+def test_sparse_clusters_across_tile_faces(hip, form, oracle, name, period):
     """paint_tile_kernel carries the z-halo of a tile in LDS into the next tile of its z segment
     (4 tiles) and stages it only at the end of a segment.  Small clusters that straddle a z face
     inside a segment, at a segment end and at the periodic wrap, with every other tile EMPTY (the
@@ -148,7 +157,7 @@ def test_sparse_clusters_across_tile_faces(hip, oracle, name, period):
 
 
 @pytest.mark.parametrize('name', ['nnb', 'cic', 'tsc'])
-def test_binned_dyadic_bit_exact(hip, oracle, name):
+def test_binned_dyadic_bit_exact(hip, form, oracle, name):
     """positions on a 1/16-cell lattice, small integer masses: exact partial sums =>
     the binned scatter must reproduce the reference bit for bit (indexing parity)."""
     W = windows[name]
@@ -193,7 +202,7 @@ def test_plan_is_shared_and_invalidated(hip):
 
 
 @pytest.mark.parametrize('name', ['nnb', 'cic', 'tsc', 'pcs'])
-def test_rebuild_from_history_and_overflow(hip, oracle, name):
+def test_rebuild_from_history_and_overflow(hip, form, oracle, name):
     """A plan that already served the same geometry and particle count rebuilds in a single
     pass into the slot ranges of its previous build (time-stepping callers).  Results must
     not depend on that: (1) slightly moved particles (ranges hold), (2) a completely different
@@ -229,7 +238,7 @@ def test_rebuild_from_history_and_overflow(hip, oracle, name):
         assert [e[1].value for e in window.bin_cache().entries if e[3]] == serving
 
 
-def test_rebuild_drops_and_nonperiodic(hip, oracle):
+def test_rebuild_drops_and_nonperiodic(hip, form, oracle):
     """history rebuilds with particles that touch no local cell (their own bucket) on a
     non-periodic sub-block: dropped particles read 0 and paint nothing"""
     W = windows['tsc']
