@@ -696,7 +696,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     // cell; the tile kernels otherwise (sparse batches, CIC / NNB).
     double cells = (double)p.size[0] * (double)p.size[1] * (double)p.size[2];
     bool walk = pl->form == 1 || (pl->form < 0 && g.S >= 3 && (double)npart >= walk_min_density() * cells);
-    if (g.S < 2) walk = false;
+    if (g.S < 3 || !walk_layout_ok(pos)) walk = false;      // built for TSC / PCS; rows gathered by LDS-DMA
     g.walk = walk ? 1 : 0;
     const int T[3] = {walk ? 1 : T0, walk ? P1 : T1, walk ? P2 : T2};
     g.ntiles = 1;
@@ -860,7 +860,13 @@ extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *ca
     PMX_REQUIRE(pl->npart == 0 || vec_ok(pos), PMX_EINVAL, "pos");
     pmx_painter p = *p_;
     hipStream_t st = (hipStream_t)stream;
-    if (pl->g.walk) return paint_walk(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
+    if (pl->g.walk) {
+        PMX_REQUIRE(walk_layout_ok(pos), PMX_EINVAL, "positions are not laid out as at pmx_binplan_build");
+        PMX_REQUIRE(!(mass && mass->data) || (mass->stride0 % 4 == 0 && ((uintptr_t)mass->data) % 4 == 0 &&
+                                              (mass->elsize == 4 || mass->elsize == 8)),
+                    PMX_EINVAL, "mass must be float / double on 4-byte boundaries");
+        return paint_walk(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
+    }
     if (p.canvas_elsize == 8) return paint_binned_t<double>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
     return paint_binned_t<float>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
 }
@@ -880,7 +886,10 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     DVec dout = dvec(out), dpos = dvec(pos);
     // particles that touch no local cell are in no tile: they read 0
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout);
-    if (g.walk) return readout_walk(pl, p, canvas, dpos, dout, st);
+    if (g.walk) {
+        PMX_REQUIRE(walk_layout_ok(pos), PMX_EINVAL, "positions are not laid out as at pmx_binplan_build");
+        return readout_walk(pl, p, canvas, dpos, dout, st);
+    }
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
 #define RT(K, T) readout_tile_kernel<K, T, TileThreads<K, T>::readout><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
     if (p.canvas_elsize == 8) {

@@ -158,5 +158,6 @@ int paint_walk(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DV
                int overwrite, hipStream_t st);
 int readout_walk(pmx_binplan *pl, const pmx_painter &p, const void *canvas, DVec pos, DVec out, hipStream_t st);
 int plan_ensure(void **ptr, size_t *cap, size_t need);
+bool walk_layout_ok(const pmx_vec *pos);
 
 }  // namespace pmx

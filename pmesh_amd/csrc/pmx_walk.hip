@@ -8,15 +8,23 @@
 // per step.  Thread (b, c) owns column (b, c): it keeps the S x S x S stencil values of "its"
 // cell in REGISTERS — a window that slides along axis 0 — and processes the particles whose
 // stencil starts in cell (a, b, c) at step a.  Per step and thread only the plane that leaves
-// the window touches LDS: S^2 operations per CELL (9 / 16 instead of 27 / 64 per particle),
-// with lane <-> c contiguous, i.e. free of bank conflicts and of same-address collisions.
-// The particles of a plane bucket arrive in list order; they are matched to their owner
-// threads through LDS (a counter per cell hands out ranks, the first KOWN particles of a
-// cell go to its owner, the rest — clustered inputs — take the scatter form on a compact
-// list: S^3 LDS operations spread over all threads, exactly the tile kernels' arithmetic).
+// (paint) or enters (readout) the window touches LDS: S^2 operations per CELL (9 / 16 instead
+// of 27 / 64 per particle), with lane <-> c contiguous, i.e. free of bank conflicts and of
+// same-address collisions.  The particles of a plane bucket arrive in list order; they are
+// matched to their owner threads through LDS (a counter per cell hands out ranks, the first
+// KOWN particles of a cell go to its owner, the rest — clustered inputs — take the scatter
+// form on a compact list: S^3 LDS operations spread over all threads, exactly the tile
+// kernels' arithmetic).
 //
-// LDS: a ring of S+1 mesh planes of the patch plus its halo ((P1+S-1) x (P2+S-1) cells), the
-// particle records of one step, the per-cell counters.  Paint: plane a is complete once every
+// Latency: with the window in registers only 1-2 workgroups fit a CU, so nothing hides a
+// dependent index -> position gather.  The positions (and masses / list entries) of plane a+1
+// are therefore gathered straight into LDS by LDS-DMA (global_load_lds, per-lane source
+// address, no VGPR destination) while plane a is processed; the list entries that address them
+// are loaded two planes ahead.  One s_waitcnt vmcnt(0) per step, placed after the arithmetic
+// of the step and before the barrier that ends it, retires them.
+//
+// LDS: two raw particle buffers, a ring of S+1 mesh planes of the patch plus its halo
+// ((P1+S-1) x (P2+S-1) cells), the per-cell counters.  Paint: plane a is complete once every
 // owner has flushed the oldest plane of its window at step a; its P1 x P2 box goes to the
 // canvas with plain row stores, the ring around it (and the S-1 planes that trail a segment)
 // to the halo staging buffer, which halo_merge_walk_kernel adds with atomics after the kernel
@@ -39,7 +47,7 @@ namespace pmx {
 #define PMX_WALK_K 2
 #endif
 constexpr int KOWN = PMX_WALK_K;     // particles per cell and step that the owner thread takes
-constexpr int NREC = 2 * WTHREADS;   // particle records per sub-step
+constexpr int LSEGMAX = 64;          // planes per segment (pmx_binplan_build keeps lseg <= this)
 
 template <int KIND> struct Walk {
     static constexpr int S = Tuned<KIND>::S;
@@ -47,6 +55,15 @@ template <int KIND> struct Walk {
     static constexpr int PLANE = R1 * R2;
     static constexpr int NR = S + 1;                       // ring slots
     static constexpr int RING = (S - 1) * (R2 + P1);       // cells of a plane outside the box
+    // particle records per chunk: 1.5 x the mean population of a plane at one particle per
+    // cell; PCS runs one workgroup per CU (registers) and has the LDS for more.  Both raw
+    // buffers stay below 64 KB of LDS (the DMA destination travels in M0)
+#ifdef PMX_WALK_NREC
+    static constexpr int NREC = PMX_WALK_NREC;
+#else
+    static constexpr int NREC = S >= 4 ? 2 * WTHREADS : 3 * WTHREADS / 2;
+#endif
+    static constexpr int REPS = (NREC + WTHREADS - 1) / WTHREADS;
     // compact numbering of the cells of a plane outside the P1 x P2 box
     __device__ static __forceinline__ int ring_index(int b, int c)
     {
@@ -65,15 +82,55 @@ template <int KIND> __host__ __device__ inline int64_t unit_halo_cells(int lseg)
     return (int64_t)lseg * Walk<KIND>::RING + (int64_t)(Walk<KIND>::S - 1) * Walk<KIND>::PLANE;
 }
 
-struct __align__(16) WRec {
-    double x[3];     // grid coordinates pos * scale + translate
-    double m;        // paint: mass; readout: the particle's row index
-};
-
-template <typename E> __device__ __forceinline__ double ld_elem(const DVec &v, int64_t i, int c)
+// ---- LDS-DMA ------------------------------------------------------------------------------
+// global_load_lds_*: every active lane copies BYTES from its own global address to
+// LDS[m0 + lane * BYTES] (dwordx3: lane * 16; scripts/glds_probe.hip); inactive lanes are skipped;
+// no VGPR destination, counted by vmcnt.  M0 is reserved by the
+// compiler: saved and restored inside the statement (cdna_hip_programming.md, inline asm).
+template <int BYTES> __device__ __forceinline__ void glds(const void *gsrc, uint32_t lds_dst)
 {
-    return (double)*(const E *)(v.data + i * v.stride0 + c * v.stride1);
+    unsigned keep;
+    static_assert(BYTES == 4 || BYTES == 12 || BYTES == 16, "LDS-DMA widths on gfx950");
+    if constexpr (BYTES == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else if constexpr (BYTES == 12)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+
+// every vector memory operation of this wave has completed (LDS-DMA included: the compiler does
+// not count the asm statements above)
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Layout of the dynamic LDS of the walk kernels (byte offsets).  The raw particle buffers come
+// first (the DMA destination travels in M0).
+//   PE: position element (float / double); XB: bytes of the extra per-particle word that
+//   travels with the position (paint: mass element size, 0 = scalar mass; readout: 4 = the list
+//   entry); RT: element of the mesh ring (double for paint, the canvas type for readout).
+template <int KIND, typename PE, int XB, typename RT> struct Smem {
+    using W = Walk<KIND>;
+    static constexpr int NREC = W::NREC;
+    static constexpr bool F8 = sizeof(PE) == 8;
+    // one raw buffer
+    static constexpr int XY = 0;                                   // f8: (x, y) 16 B; f4: (x, y, z, -) 16 B
+    static constexpr int ZLO = 16 * NREC, ZHI = 20 * NREC;         // f8 only
+    static constexpr int POSB = F8 ? 24 * NREC : 16 * NREC;
+    static constexpr int XLO = POSB, XHI = POSB + 4 * NREC;        // the extra word (low / high dword)
+    static constexpr int RAWB = (POSB + XB * NREC + 15) & ~15;
+    static constexpr int RING = 2 * RAWB;
+    static constexpr int CNT = RING + ((W::NR * W::PLANE * (int)sizeof(RT) + 15) & ~15);
+    static constexpr int SLOT = CNT + 4 * WTHREADS;
+    static constexpr int XLIST = SLOT + 2 * WTHREADS * KOWN;
+    static constexpr int XKEY = XLIST + 2 * NREC;
+    static constexpr int NX = XKEY + 2 * NREC;
+    static constexpr int SCNT = NX + 16;
+    static constexpr int SOFF = SCNT + 4 * (LSEGMAX + 4);
+    static constexpr int TOTAL = SOFF + 8 * (LSEGMAX + 4);
+};
 
 struct UnitCoords {
     int B, C, a0, a1;
@@ -93,71 +150,166 @@ __device__ __forceinline__ UnitCoords unit_coords(const BinGeom &g, int64_t unit
     return u;
 }
 
-// Phase A of a step, shared by paint and readout: the particles [j0, j0 + nsub) of the
-// plane bucket are loaded, checked against the bucket (a stale plan must not index outside
-// LDS), recorded and matched to the owner threads of their cells.
-template <int KIND, typename PE, bool PAINT>
-__device__ __forceinline__ void walk_sort(const pmx_painter &p, const BinGeom &g, const UnitCoords &u, int a,
-                                          const DVec &pos, const DVec &mass, double mass_scalar,
-                                          const uint32_t *list, int64_t j0, int nsub, WRec *rec, uint32_t *cnt,
-                                          uint16_t *slot, uint16_t *xlist, uint16_t *xkey, uint32_t *nxc)
-{
-    for (int jj = threadIdx.x; jj < nsub; jj += WTHREADS) {
-        const int64_t idx = (int64_t)list[j0 + jj];
-        double X[3];
-        int cc[3];
-        bool ok = true;
+// What paint and readout share: the particle pipeline of a unit.
+template <int KIND, typename PE, int XB, typename RT> struct Pipe {
+    using SM = Smem<KIND, PE, XB, RT>;
+    using W = Walk<KIND>;
+    static constexpr int NREC = W::NREC, REPS = W::REPS;
+
+    // gather the rows idx[r] of chunk [j0, j0 + nsub) of the list into raw buffer `rawoff`
+    // (asynchronous).  xsrc: the array the extra word is gathered from by row index (mass), or
+    // NULL with XB == 4: the list entries themselves (contiguous).
+    __device__ static __forceinline__ void issue(unsigned char *smem, int rawoff, const DVec &pos, const DVec &xvec,
+                                                 const uint32_t *list, int64_t j0, int nsub, const uint32_t *idx)
+    {
+        const uint32_t base = (uint32_t)(uintptr_t)smem + rawoff;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            X[d] = ld_elem<PE>(pos, idx, d) * p.scale[d] + p.translate[d];
-            ok = ok && (fabs(X[d]) < 1073741824.0);
-            int i0w = 0;
-            ok = ok && local_base<KIND>(p, d, Tuned<KIND>::first(ok ? X[d] : 0.0), &i0w);
-            cc[d] = i0w + g.o[d];
-        }
-        const int b = cc[1] - u.B * P1, c = cc[2] - u.C * P2;
-        ok = ok && cc[0] == a && (unsigned)b < (unsigned)P1 && (unsigned)c < (unsigned)P2;
-        if (ok) {
-            WRec r;
-            r.x[0] = X[0]; r.x[1] = X[1]; r.x[2] = X[2];
-            if (PAINT) r.m = mass.data ? mass.get(idx, 0) : mass_scalar;
-            else r.m = (double)idx;
-            rec[jj] = r;
-            const int key = b * P2 + c;
-            const uint32_t rank = atomicAdd(&cnt[key], 1u);
-            if (rank < (uint32_t)KOWN) slot[key * KOWN + rank] = (uint16_t)jj;
-            else {
-                const uint32_t e = atomicAdd(nxc, 1u);
-                xlist[e] = (uint16_t)jj;
-                xkey[e] = (uint16_t)key;
+        for (int r = 0; r < REPS; r++) {
+            const int jj = r * WTHREADS + threadIdx.x;
+            const uint32_t wb = (uint32_t)(r * WTHREADS + wave * 64);   // first record of this wave-instruction
+            if (jj < nsub) {
+                const char *row = pos.data + (int64_t)idx[r] * pos.stride0;
+                if constexpr (SM::F8) {
+                    glds<16>(row, base + SM::XY + wb * 16);
+                    glds<4>(row + 16, base + SM::ZLO + wb * 4);
+                    glds<4>(row + 20, base + SM::ZHI + wb * 4);
+                } else {
+                    glds<12>(row, base + SM::XY + wb * 16);      // dwordx3 lands at a 16-byte lane stride
+                }
+                if constexpr (XB > 0) {
+                    const char *x = xvec.data ? xvec.data + (int64_t)idx[r] * xvec.stride0
+                                              : (const char *)(list + j0 + jj);
+                    glds<4>(x, base + SM::XLO + wb * 4);
+                    if constexpr (XB == 8) glds<4>(x + 4, base + SM::XHI + wb * 4);
+                }
             }
         }
     }
+
+    // list entries of chunk [j0, j0 + nsub) -> registers (ordinary loads: the compiler waits
+    // for them where they are used, one step later)
+    __device__ static __forceinline__ void load_idx(const uint32_t *list, int64_t j0, int nsub, uint32_t *idx)
+    {
+#pragma unroll
+        for (int r = 0; r < REPS; r++) {
+            const int jj = r * WTHREADS + threadIdx.x;
+            idx[r] = jj < nsub ? list[j0 + jj] : 0u;
+        }
+    }
+
+    __device__ static __forceinline__ void read_pos(const unsigned char *smem, int rawoff, int j, double *x)
+    {
+        const unsigned char *b = smem + rawoff;
+        if constexpr (SM::F8) {
+            const double2 xy = *(const double2 *)(b + SM::XY + j * 16);
+            const int lo = *(const int *)(b + SM::ZLO + j * 4), hi = *(const int *)(b + SM::ZHI + j * 4);
+            x[0] = xy.x; x[1] = xy.y; x[2] = __hiloint2double(hi, lo);
+        } else {
+            const float *f = (const float *)(b + SM::XY + j * 16);
+            x[0] = (double)f[0]; x[1] = (double)f[1]; x[2] = (double)f[2];
+        }
+    }
+
+    __device__ static __forceinline__ double read_mass(const unsigned char *smem, int rawoff, int j)
+    {
+        const unsigned char *b = smem + rawoff;
+        if constexpr (XB == 8)
+            return __hiloint2double(*(const int *)(b + SM::XHI + j * 4), *(const int *)(b + SM::XLO + j * 4));
+        else
+            return (double)*(const float *)(b + SM::XLO + j * 4);
+    }
+
+    __device__ static __forceinline__ uint32_t read_index(const unsigned char *smem, int rawoff, int j)
+    {
+        return *(const uint32_t *)(smem + rawoff + SM::XLO + j * 4);
+    }
+
+    // the records of a chunk are matched to the owner threads of their cells; a record that
+    // does not belong to bucket (patch, a) — a plan that no longer matches the positions —
+    // is ignored, so nothing indexes outside LDS
+    __device__ static __forceinline__ void sort(const pmx_painter &p, const BinGeom &g, const UnitCoords &u, int a,
+                                                unsigned char *smem, int rawoff, int nsub, uint32_t *nxc)
+    {
+        uint32_t *cnt = (uint32_t *)(smem + SM::CNT);
+        uint16_t *slot = (uint16_t *)(smem + SM::SLOT);
+        uint16_t *xlist = (uint16_t *)(smem + SM::XLIST), *xkey = (uint16_t *)(smem + SM::XKEY);
+#pragma unroll
+        for (int r = 0; r < REPS; r++) {
+            const int jj = r * WTHREADS + threadIdx.x;
+            if (jj < nsub) {
+                double x[3];
+                read_pos(smem, rawoff, jj, x);
+                int cc[3];
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double X = x[d] * p.scale[d] + p.translate[d];
+                    ok = ok && (fabs(X) < 1073741824.0);
+                    int i0w = 0;
+                    ok = ok && local_base<KIND>(p, d, Tuned<KIND>::first(ok ? X : 0.0), &i0w);
+                    cc[d] = i0w + g.o[d];
+                }
+                const int b = cc[1] - u.B * P1, c = cc[2] - u.C * P2;
+                ok = ok && cc[0] == a && (unsigned)b < (unsigned)P1 && (unsigned)c < (unsigned)P2;
+                if (ok) {
+                    const int key = b * P2 + c;
+                    const uint32_t rank = atomicAdd(&cnt[key], 1u);
+                    if (rank < (uint32_t)KOWN) slot[key * KOWN + rank] = (uint16_t)jj;
+                    else {
+                        const uint32_t e = atomicAdd(nxc, 1u);
+                        xlist[e] = (uint16_t)jj;
+                        xkey[e] = (uint16_t)key;
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int KIND>
+__device__ __forceinline__ void weights(const pmx_painter &p, const double *x, double (*V)[Tuned<KIND>::S])
+{
+    constexpr int S = Tuned<KIND>::S;
+    int I[S];
+#pragma unroll
+    for (int d = 0; d < 3; d++) Tuned<KIND>::axis(x[d] * p.scale[d] + p.translate[d], p.order[d], p.scale[d], I, V[d]);
 }
 
-template <int KIND, typename T, typename PE>
+// XB: 0 scalar mass, 4 / 8: per-particle float / double mass
+template <int KIND, typename T, typename PE, int XB>
 __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                              DVec mass, double mass_scalar, const uint32_t *list,
                                                              const int64_t *offsets, const uint32_t *counts,
                                                              T *halo, uint32_t *unit_flags, int overwrite)
 {
     using W = Walk<KIND>;
-    constexpr int S = W::S, R2 = W::R2, PLANE = W::PLANE, NR = W::NR, RING = W::RING;
-    __shared__ double ring[NR * PLANE];
-    __shared__ WRec rec[NREC];
-    __shared__ uint32_t cnt[WTHREADS];
-    __shared__ uint16_t slot[WTHREADS * KOWN];
-    __shared__ uint16_t xlist[NREC], xkey[NREC];
-    __shared__ uint32_t nx[2];
+    using SM = Smem<KIND, PE, XB, double>;
+    using PP = Pipe<KIND, PE, XB, double>;
+    constexpr int S = W::S, R2 = W::R2, PLANE = W::PLANE, NR = W::NR, RING = W::RING, NREC = W::NREC, REPS = W::REPS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ring = (double *)(smem + SM::RING);
+    uint32_t *cnt = (uint32_t *)(smem + SM::CNT);
+    uint16_t *slot = (uint16_t *)(smem + SM::SLOT);
+    uint16_t *xlist = (uint16_t *)(smem + SM::XLIST), *xkey = (uint16_t *)(smem + SM::XKEY);
+    uint32_t *nx = (uint32_t *)(smem + SM::NX);
+    uint32_t *scnt = (uint32_t *)(smem + SM::SCNT);
+    int64_t *soff = (int64_t *)(smem + SM::SOFF);
     const int tid = threadIdx.x, tb = tid / P2, tc = tid % P2;
     const int64_t unit_halo = unit_halo_cells<KIND>(g.lseg);
     for (int64_t unit = blockIdx.x; unit < g.nunits; unit += gridDim.x) {
         const UnitCoords u = unit_coords(g, unit);
         const int Lu = u.a1 - u.a0;
+        // populations and list ranges of the planes of this unit (+ zeros behind the end)
+        if (tid < LSEGMAX + 4) {
+            scnt[tid] = tid < Lu ? counts[u.bucket0 + u.a0 + tid] : 0u;
+            soff[tid] = tid < Lu ? offsets[u.bucket0 + u.a0 + tid] : 0;
+        }
         // nothing to add in this unit (uniform per workgroup): skip it, its staging stays unused
-        const int any = __syncthreads_or(tid < Lu && counts[u.bucket0 + u.a0 + tid] != 0);
+        const int any = __syncthreads_or(tid < Lu && scnt[tid] != 0);
         if (!any && !overwrite) {
             if (tid == 0) unit_flags[unit] = 0;
+            __syncthreads();
             continue;
         }
         if (tid == 0) { unit_flags[unit] = 1; nx[0] = 0; nx[1] = 0; }
@@ -172,72 +324,112 @@ __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, Bin
 #pragma unroll
                 for (int k = 0; k < S; k++) acc[i][j][k] = 0;
         int phase = 0;
+        // prologue: the first chunk of plane a0 lands in raw buffer 0, the list entries of the
+        // first chunk of plane a0+1 are in flight
+        uint32_t idx[REPS];
+        {
+            const int n0 = (int)(scnt[0] < (uint32_t)NREC ? scnt[0] : (uint32_t)NREC);
+            PP::load_idx(list, soff[0], n0, idx);
+            PP::issue(smem, 0, pos, mass, list, soff[0], n0, idx);
+            const int n1 = (int)(scnt[1] < (uint32_t)NREC ? scnt[1] : (uint32_t)NREC);
+            PP::load_idx(list, soff[1], n1, idx);
+        }
+        vm_drain();
         __syncthreads();
 
-        auto step = [&](auto rot, const int a) {
+        // the owner part and the scatter part of one chunk whose records are in `rawoff`
+        auto accumulate = [&](auto rot, const int sl0, const int rawoff, uint32_t *nxc) __attribute__((always_inline)) {
             constexpr int ROT = decltype(rot)::value;
-            const uint32_t n = a < u.a1 ? counts[u.bucket0 + a] : 0u;
-            const int64_t start = a < u.a1 ? offsets[u.bucket0 + a] : 0;
+            {
+                const uint32_t cn = cnt[tid];
+                cnt[tid] = 0;
+                const int nown = cn < (uint32_t)KOWN ? (int)cn : KOWN;
+                for (int r = 0; r < nown; r++) {
+                    const int j = slot[tid * KOWN + r];
+                    double x[3], V[3][S];
+                    PP::read_pos(smem, rawoff, j, x);
+                    const double m = XB ? PP::read_mass(smem, rawoff, j) : mass_scalar;
+                    weights<KIND>(p, x, V);
+#pragma unroll
+                    for (int i = 0; i < S; i++) V[0][i] *= m;
+#pragma unroll
+                    for (int i = 0; i < S; i++)
+#pragma unroll
+                        for (int jb = 0; jb < S; jb++) {
+                            const double fb = V[0][i] * V[1][jb];
+#pragma unroll
+                            for (int k = 0; k < S; k++) acc[(i + ROT) % S][jb][k] += fb * V[2][k];
+                        }
+                }
+            }
+            // the rest of crowded cells: scatter form, spread over all threads
+            const uint32_t nxv = *nxc;
+            for (uint32_t e = tid; e < nxv; e += WTHREADS) {
+                const int j = xlist[e];
+                const int key = xkey[e];
+                const int b = key / P2, c = key % P2;
+                double x[3], V[3][S];
+                PP::read_pos(smem, rawoff, j, x);
+                const double m = XB ? PP::read_mass(smem, rawoff, j) : mass_scalar;
+                weights<KIND>(p, x, V);
+#pragma unroll
+                for (int i = 0; i < S; i++) V[0][i] *= m;
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    int sl = sl0 + i;
+                    if (sl >= NR) sl -= NR;
+#pragma unroll
+                    for (int jb = 0; jb < S; jb++) {
+                        const double fb = V[0][i] * V[1][jb];
+                        const int rowoff = sl * PLANE + (b + jb) * R2 + c;
+#pragma unroll
+                        for (int k = 0; k < S; k++) unsafeAtomicAdd(&ring[rowoff + k], fb * V[2][k]);
+                    }
+                }
+            }
+        };
+
+        auto step = [&](auto rot, const int a) __attribute__((always_inline)) {
+            constexpr int ROT = decltype(rot)::value;
+            const int pa = a - u.a0;
+            const int par = pa & 1;
+            const int rawoff = par * SM::RAWB;
+            const uint32_t n = scnt[pa < LSEGMAX + 4 ? pa : LSEGMAX + 3];      // 0 behind the segment
+            const int64_t start = soff[pa < LSEGMAX + 4 ? pa : LSEGMAX + 3];
             const int sl0 = a % NR;
-            for (uint32_t sub0 = 0; sub0 < n; sub0 += NREC) {
-                const int nsub = (int)((n - sub0) < (uint32_t)NREC ? (n - sub0) : (uint32_t)NREC);
+            // records of the next plane -> the other raw buffer; list entries of the plane after it
+            if (pa + 1 < Lu) {
+                const uint32_t n1 = scnt[pa + 1];
+                PP::issue(smem, SM::RAWB - rawoff, pos, mass, list, soff[pa + 1], (int)(n1 < (uint32_t)NREC ? n1 : (uint32_t)NREC), idx);
+                if (pa + 2 < Lu) {
+                    const uint32_t n2 = scnt[pa + 2];
+                    PP::load_idx(list, soff[pa + 2], (int)(n2 < (uint32_t)NREC ? n2 : (uint32_t)NREC), idx);
+                }
+            }
+            if (n > 0) {
+                const int nsub = (int)(n < (uint32_t)NREC ? n : (uint32_t)NREC);
                 uint32_t *nxc = &nx[phase & 1];
-                walk_sort<KIND, PE, true>(p, g, u, a, pos, mass, mass_scalar, list, start + sub0, nsub, rec, cnt,
-                                          slot, xlist, xkey, nxc);
+                PP::sort(p, g, u, a, smem, rawoff, nsub, nxc);
                 if (tid == 0) nx[(phase + 1) & 1] = 0;
                 __syncthreads();
-                // owner: the first KOWN particles of my cell go into the register window
-                {
-                    const uint32_t cn = cnt[tid];
-                    cnt[tid] = 0;
-                    const int nown = cn < (uint32_t)KOWN ? (int)cn : KOWN;
-                    for (int r = 0; r < nown; r++) {
-                        const WRec R = rec[slot[tid * KOWN + r]];
-                        double V[3][S];
-                        int I[S];
-#pragma unroll
-                        for (int d = 0; d < 3; d++) Tuned<KIND>::axis(R.x[d], p.order[d], p.scale[d], I, V[d]);
-#pragma unroll
-                        for (int i = 0; i < S; i++) V[0][i] *= R.m;
-#pragma unroll
-                        for (int i = 0; i < S; i++)
-#pragma unroll
-                            for (int j = 0; j < S; j++) {
-                                const double fb = V[0][i] * V[1][j];
-#pragma unroll
-                                for (int k = 0; k < S; k++) acc[(i + ROT) % S][j][k] += fb * V[2][k];
-                            }
-                    }
-                }
-                // the rest of crowded cells: scatter form, spread over all threads
-                {
-                    const uint32_t nxv = *nxc;
-                    for (uint32_t e = tid; e < nxv; e += WTHREADS) {
-                        const WRec R = rec[xlist[e]];
-                        const int key = xkey[e];
-                        const int b = key / P2, c = key % P2;
-                        double V[3][S];
-                        int I[S];
-#pragma unroll
-                        for (int d = 0; d < 3; d++) Tuned<KIND>::axis(R.x[d], p.order[d], p.scale[d], I, V[d]);
-#pragma unroll
-                        for (int i = 0; i < S; i++) V[0][i] *= R.m;
-#pragma unroll
-                        for (int i = 0; i < S; i++) {
-                            int sl = sl0 + i;
-                            if (sl >= NR) sl -= NR;
-#pragma unroll
-                            for (int j = 0; j < S; j++) {
-                                const double fb = V[0][i] * V[1][j];
-                                const int rowoff = sl * PLANE + (b + j) * R2 + c;
-#pragma unroll
-                                for (int k = 0; k < S; k++) unsafeAtomicAdd(&ring[rowoff + k], fb * V[2][k]);
-                            }
-                        }
-                    }
-                }
+                accumulate(rot, sl0, rawoff, nxc);
                 phase++;
-                if (sub0 + NREC < n) __syncthreads();      // the next sub-step reuses the records
+                // crowded planes: the chunks behind the first one are fetched on the spot
+                for (uint32_t sub0 = NREC; sub0 < n; sub0 += NREC) {
+                    const int ns = (int)((n - sub0) < (uint32_t)NREC ? (n - sub0) : (uint32_t)NREC);
+                    uint32_t idx2[REPS];
+                    PP::load_idx(list, start + sub0, ns, idx2);
+                    __syncthreads();                       // the records of the previous chunk are done with
+                    PP::issue(smem, rawoff, pos, mass, list, start + sub0, ns, idx2);
+                    vm_drain();
+                    __syncthreads();
+                    nxc = &nx[phase & 1];
+                    PP::sort(p, g, u, a, smem, rawoff, ns, nxc);
+                    if (tid == 0) nx[(phase + 1) & 1] = 0;
+                    __syncthreads();
+                    accumulate(rot, sl0, rawoff, nxc);
+                    phase++;
+                }
             }
             // the oldest plane of the window is complete for this thread: add it to ring plane a
 #pragma unroll
@@ -247,10 +439,10 @@ __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, Bin
                     unsafeAtomicAdd(&ring[sl0 * PLANE + (tb + j) * R2 + tc + k], acc[ROT][j][k]);
                     acc[ROT][j][k] = 0;
                 }
+            vm_drain();                 // the next plane's records have landed (this wave's share)
             __syncthreads();
             // plane a is complete: box -> canvas (plain row stores), ring -> staging
             {
-                const int pa = a - u.a0;
                 const bool trailing = a >= u.a1;
                 const int l0 = a - g.o[0];
                 const bool in0 = !trailing && l0 >= 0 && l0 < p.size[0];
@@ -325,37 +517,76 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
                                                                const uint32_t *counts)
 {
     using W = Walk<KIND>;
-    constexpr int S = W::S, R2 = W::R2, PLANE = W::PLANE, NR = W::NR;
-    __shared__ T ring[NR * PLANE];
-    __shared__ WRec rec[NREC];
-    __shared__ uint32_t cnt[WTHREADS];
-    __shared__ uint16_t slot[WTHREADS * KOWN];
-    __shared__ uint16_t xlist[NREC], xkey[NREC];
-    __shared__ uint32_t nx[2];
+    using SM = Smem<KIND, PE, 4, T>;
+    using PP = Pipe<KIND, PE, 4, T>;
+    constexpr int S = W::S, R2 = W::R2, PLANE = W::PLANE, NR = W::NR, NREC = W::NREC, REPS = W::REPS;
+    constexpr int NPL = (PLANE + WTHREADS - 1) / WTHREADS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *ring = (T *)(smem + SM::RING);
+    uint32_t *cnt = (uint32_t *)(smem + SM::CNT);
+    uint16_t *slot = (uint16_t *)(smem + SM::SLOT);
+    uint16_t *xlist = (uint16_t *)(smem + SM::XLIST), *xkey = (uint16_t *)(smem + SM::XKEY);
+    uint32_t *nx = (uint32_t *)(smem + SM::NX);
+    uint32_t *scnt = (uint32_t *)(smem + SM::SCNT);
+    int64_t *soff = (int64_t *)(smem + SM::SOFF);
     const int tid = threadIdx.x, tb = tid / P2, tc = tid % P2;
-    const DVec nomass = {nullptr, 0, 0, 8};
+    const DVec nox = {nullptr, 0, 0, 8};
     for (int64_t unit = blockIdx.x; unit < g.nunits; unit += gridDim.x) {
         const UnitCoords u = unit_coords(g, unit);
         const int Lu = u.a1 - u.a0;
-        const int any = __syncthreads_or(tid < Lu && counts[u.bucket0 + u.a0 + tid] != 0);
-        if (!any) continue;
+        if (tid < LSEGMAX + 4) {
+            scnt[tid] = tid < Lu ? counts[u.bucket0 + u.a0 + tid] : 0u;
+            soff[tid] = tid < Lu ? offsets[u.bucket0 + u.a0 + tid] : 0;
+        }
+        const int any = __syncthreads_or(tid < Lu && scnt[tid] != 0);
+        if (!any) {
+            __syncthreads();
+            continue;
+        }
         if (tid == 0) { nx[0] = 0; nx[1] = 0; }
         cnt[tid] = 0;
-        // stage plane `pl` (tile-space) of the patch + halo; cells outside the block read 0
-        auto load_plane = [&](const int pl) {
-            int sl = pl % NR;
+        // cells of plane `pl` (tile-space) of the patch + halo that this thread stages;
+        // cells outside the block read 0
+        auto fetch_plane = [&](const int pl, T *v) __attribute__((always_inline)) {
             const int l0 = wrap_near(pl - g.o[0], p.period[0]);
             const bool in0 = l0 >= 0 && l0 < p.size[0];
-            for (int q = tid; q < PLANE; q += WTHREADS) {
-                const int b = q / R2, c = q - b * R2;
-                const int l1 = wrap_near(u.B * P1 - g.o[1] + b, p.period[1]);
-                const int l2 = wrap_near(u.C * P2 - g.o[2] + c, p.period[2]);
-                const bool in = in0 && l1 >= 0 && l1 < p.size[1] && l2 >= 0 && l2 < p.size[2];
-                ring[sl * PLANE + q] = in ? *(const T *)(canvas + l0 * p.strides[0] + l1 * p.strides[1] + l2 * p.strides[2]) : (T)0;
+#pragma unroll
+            for (int r = 0; r < NPL; r++) {
+                const int q = tid + r * WTHREADS;
+                v[r] = (T)0;
+                if (q < PLANE) {
+                    const int b = q / R2, c = q - b * R2;
+                    const int l1 = wrap_near(u.B * P1 - g.o[1] + b, p.period[1]);
+                    const int l2 = wrap_near(u.C * P2 - g.o[2] + c, p.period[2]);
+                    if (in0 && l1 >= 0 && l1 < p.size[1] && l2 >= 0 && l2 < p.size[2])
+                        v[r] = *(const T *)(canvas + l0 * p.strides[0] + l1 * p.strides[1] + l2 * p.strides[2]);
+                }
             }
         };
+        auto store_plane = [&](const int pl, const T *v) __attribute__((always_inline)) {
+            const int sl = pl % NR;
 #pragma unroll
-        for (int k = 0; k < S - 1; k++) load_plane(u.a0 + k);
+            for (int r = 0; r < NPL; r++) {
+                const int q = tid + r * WTHREADS;
+                if (q < PLANE) ring[sl * PLANE + q] = v[r];
+            }
+        };
+        T pv[NPL];
+#pragma unroll
+        for (int k = 0; k < S - 1; k++) {
+            fetch_plane(u.a0 + k, pv);
+            store_plane(u.a0 + k, pv);
+        }
+        fetch_plane(u.a0 + S - 1, pv);          // enters the ring at the first step
+        uint32_t idx[REPS];
+        {
+            const int n0 = (int)(scnt[0] < (uint32_t)NREC ? scnt[0] : (uint32_t)NREC);
+            PP::load_idx(list, soff[0], n0, idx);
+            PP::issue(smem, 0, pos, nox, list, soff[0], n0, idx);
+            const int n1 = (int)(scnt[1] < (uint32_t)NREC ? scnt[1] : (uint32_t)NREC);
+            PP::load_idx(list, soff[1], n1, idx);
+        }
+        vm_drain();
         __syncthreads();
         T win[S][S][S];
 #pragma unroll
@@ -367,80 +598,107 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
                     win[i][j][k] = i < S - 1 ? ring[((u.a0 + i) % NR) * PLANE + (tb + j) * R2 + tc + k] : (T)0;
         int phase = 0;
 
-        auto step = [&](auto rot, const int a) {
+        auto gather = [&](auto rot, const int sl0, const int rawoff, uint32_t *nxc) __attribute__((always_inline)) {
             constexpr int ROT = decltype(rot)::value;
-            const uint32_t n = counts[u.bucket0 + a];
-            const int64_t start = offsets[u.bucket0 + a];
-            const int sl0 = a % NR;
-            load_plane(a + S - 1);
-            bool fresh = true;      // the window has not taken plane a+S-1 yet
-            uint32_t sub0 = 0;
-            do {
-                const int nsub = (int)((n - sub0) < (uint32_t)NREC ? (n - sub0) : (uint32_t)NREC);
-                uint32_t *nxc = &nx[phase & 1];
-                walk_sort<KIND, PE, false>(p, g, u, a, pos, nomass, 0.0, list, start + sub0, nsub, rec, cnt, slot,
-                                           xlist, xkey, nxc);
-                if (tid == 0) nx[(phase + 1) & 1] = 0;
-                __syncthreads();
-                if (fresh) {
-                    int sl = sl0 + S - 1;
+            {
+                const uint32_t cn = cnt[tid];
+                cnt[tid] = 0;
+                const int nown = cn < (uint32_t)KOWN ? (int)cn : KOWN;
+                for (int r = 0; r < nown; r++) {
+                    const int j = slot[tid * KOWN + r];
+                    double x[3], V[3][S];
+                    PP::read_pos(smem, rawoff, j, x);
+                    weights<KIND>(p, x, V);
+                    double value = 0;
+#pragma unroll
+                    for (int i = 0; i < S; i++)
+#pragma unroll
+                        for (int jb = 0; jb < S; jb++) {
+                            const double fb = V[0][i] * V[1][jb];
+#pragma unroll
+                            for (int k = 0; k < S; k++) value += (double)win[(i + ROT) % S][jb][k] * (fb * V[2][k]);
+                        }
+                    out.set((int64_t)PP::read_index(smem, rawoff, j), 0, value);
+                }
+            }
+            const uint32_t nxv = *nxc;
+            for (uint32_t e = tid; e < nxv; e += WTHREADS) {
+                const int j = xlist[e];
+                const int key = xkey[e];
+                const int b = key / P2, c = key % P2;
+                double x[3], V[3][S];
+                PP::read_pos(smem, rawoff, j, x);
+                weights<KIND>(p, x, V);
+                double value = 0;
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    int sl = sl0 + i;
                     if (sl >= NR) sl -= NR;
 #pragma unroll
-                    for (int j = 0; j < S; j++)
+                    for (int jb = 0; jb < S; jb++) {
+                        const double fb = V[0][i] * V[1][jb];
+                        const int rowoff = sl * PLANE + (b + jb) * R2 + c;
 #pragma unroll
-                        for (int k = 0; k < S; k++) win[(S - 1 + ROT) % S][j][k] = ring[sl * PLANE + (tb + j) * R2 + tc + k];
-                    fresh = false;
+                        for (int k = 0; k < S; k++) value += (double)ring[rowoff + k] * (fb * V[2][k]);
+                    }
                 }
-                if (nsub > 0) {
-                    const uint32_t cn = cnt[tid];
-                    cnt[tid] = 0;
-                    const int nown = cn < (uint32_t)KOWN ? (int)cn : KOWN;
-                    for (int r = 0; r < nown; r++) {
-                        const WRec R = rec[slot[tid * KOWN + r]];
-                        double V[3][S];
-                        int I[S];
+                out.set((int64_t)PP::read_index(smem, rawoff, j), 0, value);
+            }
+        };
+
+        auto step = [&](auto rot, const int a) __attribute__((always_inline)) {
+            constexpr int ROT = decltype(rot)::value;
+            const int pa = a - u.a0;
+            const int par = pa & 1;
+            const int rawoff = par * SM::RAWB;
+            const uint32_t n = scnt[pa];
+            const int64_t start = soff[pa];
+            const int sl0 = a % NR;
+            // plane a+S-1 (fetched during the previous step) enters the ring; the next one is requested
+            store_plane(a + S - 1, pv);
+            if (pa + 1 < Lu) {
+                fetch_plane(a + S, pv);
+                const uint32_t n1 = scnt[pa + 1];
+                PP::issue(smem, SM::RAWB - rawoff, pos, nox, list, soff[pa + 1], (int)(n1 < (uint32_t)NREC ? n1 : (uint32_t)NREC), idx);
+                if (pa + 2 < Lu) {
+                    const uint32_t n2 = scnt[pa + 2];
+                    PP::load_idx(list, soff[pa + 2], (int)(n2 < (uint32_t)NREC ? n2 : (uint32_t)NREC), idx);
+                }
+            }
+            const int nsub = (int)(n < (uint32_t)NREC ? n : (uint32_t)NREC);
+            uint32_t *nxc = &nx[phase & 1];
+            PP::sort(p, g, u, a, smem, rawoff, nsub, nxc);
+            if (tid == 0) nx[(phase + 1) & 1] = 0;
+            __syncthreads();
+            {
+                int sl = sl0 + S - 1;
+                if (sl >= NR) sl -= NR;
 #pragma unroll
-                        for (int d = 0; d < 3; d++) Tuned<KIND>::axis(R.x[d], p.order[d], p.scale[d], I, V[d]);
-                        double value = 0;
+                for (int j = 0; j < S; j++)
 #pragma unroll
-                        for (int i = 0; i < S; i++)
-#pragma unroll
-                            for (int j = 0; j < S; j++) {
-                                const double fb = V[0][i] * V[1][j];
-#pragma unroll
-                                for (int k = 0; k < S; k++) value += (double)win[(i + ROT) % S][j][k] * (fb * V[2][k]);
-                            }
-                        out.set((int64_t)R.m, 0, value);
-                    }
-                    const uint32_t nxv = *nxc;
-                    for (uint32_t e = tid; e < nxv; e += WTHREADS) {
-                        const WRec R = rec[xlist[e]];
-                        const int key = xkey[e];
-                        const int b = key / P2, c = key % P2;
-                        double V[3][S];
-                        int I[S];
-#pragma unroll
-                        for (int d = 0; d < 3; d++) Tuned<KIND>::axis(R.x[d], p.order[d], p.scale[d], I, V[d]);
-                        double value = 0;
-#pragma unroll
-                        for (int i = 0; i < S; i++) {
-                            int sl = sl0 + i;
-                            if (sl >= NR) sl -= NR;
-#pragma unroll
-                            for (int j = 0; j < S; j++) {
-                                const double fb = V[0][i] * V[1][j];
-                                const int rowoff = sl * PLANE + (b + j) * R2 + c;
-#pragma unroll
-                                for (int k = 0; k < S; k++) value += (double)ring[rowoff + k] * (fb * V[2][k]);
-                            }
-                        }
-                        out.set((int64_t)R.m, 0, value);
-                    }
+                    for (int k = 0; k < S; k++) win[(S - 1 + ROT) % S][j][k] = ring[sl * PLANE + (tb + j) * R2 + tc + k];
+            }
+            if (n > 0) {
+                gather(rot, sl0, rawoff, nxc);
+                phase++;
+                for (uint32_t sub0 = NREC; sub0 < n; sub0 += NREC) {
+                    const int ns = (int)((n - sub0) < (uint32_t)NREC ? (n - sub0) : (uint32_t)NREC);
+                    uint32_t idx2[REPS];
+                    PP::load_idx(list, start + sub0, ns, idx2);
+                    __syncthreads();
+                    PP::issue(smem, rawoff, pos, nox, list, start + sub0, ns, idx2);
+                    vm_drain();
+                    __syncthreads();
+                    nxc = &nx[phase & 1];
+                    PP::sort(p, g, u, a, smem, rawoff, ns, nxc);
+                    if (tid == 0) nx[(phase + 1) & 1] = 0;
+                    __syncthreads();
+                    gather(rot, sl0, rawoff, nxc);
                     phase++;
-                    __syncthreads();       // the records are free for the next step
                 }
-                sub0 += NREC;
-            } while (sub0 < n);
+            }
+            vm_drain();
+            __syncthreads();       // records and counters are free, the next plane's records have landed
         };
 
         for (int a = u.a0; a < u.a1; a += S) {
@@ -451,6 +709,37 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
         }
         __syncthreads();
     }
+}
+
+// the walk kernels gather whole rows by LDS-DMA: columns of a row contiguous, rows (and the
+// mass entries) on 4-byte boundaries
+bool walk_layout_ok(const pmx_vec *pos)
+{
+    return pos && pos->data && pos->ncol >= 3 && pos->stride1 == pos->elsize && pos->stride0 % 4 == 0 &&
+           ((uintptr_t)pos->data) % 4 == 0;
+}
+
+template <typename K> static int set_lds(K kernel, int bytes)
+{
+    PMX_HIP_CHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return PMX_OK;
+}
+
+template <int KIND, typename T, typename PE, int XB>
+static int paint_walk_launch(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
+                             int overwrite, unsigned grid, hipStream_t st)
+{
+    using SM = Smem<KIND, PE, XB, double>;
+    auto k = paint_walk_kernel<KIND, T, PE, XB>;
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds(k, SM::TOTAL);
+        if (rc) return rc;
+        configured = true;
+    }
+    k<<<grid, WTHREADS, SM::TOTAL, st>>>(p, pl->g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts,
+                                         (T *)pl->halo, pl->unit_flags, overwrite);
+    return PMX_OK;
 }
 
 template <int KIND, typename T>
@@ -466,14 +755,18 @@ static int paint_walk_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVe
     if (rc) return rc;
     pl->cap_units = capb / 4;
     const unsigned grid = (unsigned)(g.nunits < 65535 * 8 ? g.nunits : 65535 * 8);
-    T *halo = (T *)pl->halo;
-    if (pos.elsize == 8)
-        paint_walk_kernel<KIND, T, double><<<grid, WTHREADS, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list,
-                                                                     pl->offsets, pl->counts, halo, pl->unit_flags, overwrite);
-    else
-        paint_walk_kernel<KIND, T, float><<<grid, WTHREADS, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list,
-                                                                    pl->offsets, pl->counts, halo, pl->unit_flags, overwrite);
-    halo_merge_walk_kernel<KIND, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->unit_flags);
+    const int xb = mass.data ? mass.elsize : 0;
+    if (pos.elsize == 8) {
+        if (xb == 0) rc = paint_walk_launch<KIND, T, double, 0>(pl, p, canvas, pos, mass, ms, overwrite, grid, st);
+        else if (xb == 8) rc = paint_walk_launch<KIND, T, double, 8>(pl, p, canvas, pos, mass, ms, overwrite, grid, st);
+        else rc = paint_walk_launch<KIND, T, double, 4>(pl, p, canvas, pos, mass, ms, overwrite, grid, st);
+    } else {
+        if (xb == 0) rc = paint_walk_launch<KIND, T, float, 0>(pl, p, canvas, pos, mass, ms, overwrite, grid, st);
+        else if (xb == 8) rc = paint_walk_launch<KIND, T, float, 8>(pl, p, canvas, pos, mass, ms, overwrite, grid, st);
+        else rc = paint_walk_launch<KIND, T, float, 4>(pl, p, canvas, pos, mass, ms, overwrite, grid, st);
+    }
+    if (rc) return rc;
+    halo_merge_walk_kernel<KIND, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, (const T *)pl->halo, pl->unit_flags);
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }
@@ -483,9 +776,6 @@ int paint_walk(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DV
 {
     const bool f8 = p.canvas_elsize == 8;
     switch (p.kind) {
-    case PMX_TUNED_CIC:
-        return f8 ? paint_walk_t<PMX_TUNED_CIC, double>(pl, p, canvas, pos, mass, ms, overwrite, st)
-                  : paint_walk_t<PMX_TUNED_CIC, float>(pl, p, canvas, pos, mass, ms, overwrite, st);
     case PMX_TUNED_TSC:
         return f8 ? paint_walk_t<PMX_TUNED_TSC, double>(pl, p, canvas, pos, mass, ms, overwrite, st)
                   : paint_walk_t<PMX_TUNED_TSC, float>(pl, p, canvas, pos, mass, ms, overwrite, st);
@@ -497,28 +787,36 @@ int paint_walk(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DV
     return PMX_EUNSUPPORTED;
 }
 
+template <int KIND, typename T, typename PE>
+static int readout_walk_launch(pmx_binplan *pl, const pmx_painter &p, const void *canvas, DVec pos, DVec out,
+                               hipStream_t st)
+{
+    using SM = Smem<KIND, PE, 4, T>;
+    auto k = readout_walk_kernel<KIND, T, PE>;
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds(k, SM::TOTAL);
+        if (rc) return rc;
+        configured = true;
+    }
+    const BinGeom &g = pl->g;
+    const unsigned grid = (unsigned)(g.nunits < 65535 * 8 ? g.nunits : 65535 * 8);
+    k<<<grid, WTHREADS, SM::TOTAL, st>>>(p, g, (const char *)canvas, pos, out, pl->list, pl->offsets, pl->counts);
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
 template <int KIND, typename T>
 static int readout_walk_t(pmx_binplan *pl, const pmx_painter &p, const void *canvas, DVec pos, DVec out, hipStream_t st)
 {
-    const BinGeom &g = pl->g;
-    const unsigned grid = (unsigned)(g.nunits < 65535 * 8 ? g.nunits : 65535 * 8);
-    if (pos.elsize == 8)
-        readout_walk_kernel<KIND, T, double><<<grid, WTHREADS, 0, st>>>(p, g, (const char *)canvas, pos, out, pl->list,
-                                                                       pl->offsets, pl->counts);
-    else
-        readout_walk_kernel<KIND, T, float><<<grid, WTHREADS, 0, st>>>(p, g, (const char *)canvas, pos, out, pl->list,
-                                                                      pl->offsets, pl->counts);
-    PMX_HIP_CHECK(hipGetLastError());
-    return PMX_OK;
+    if (pos.elsize == 8) return readout_walk_launch<KIND, T, double>(pl, p, canvas, pos, out, st);
+    return readout_walk_launch<KIND, T, float>(pl, p, canvas, pos, out, st);
 }
 
 int readout_walk(pmx_binplan *pl, const pmx_painter &p, const void *canvas, DVec pos, DVec out, hipStream_t st)
 {
     const bool f8 = p.canvas_elsize == 8;
     switch (p.kind) {
-    case PMX_TUNED_CIC:
-        return f8 ? readout_walk_t<PMX_TUNED_CIC, double>(pl, p, canvas, pos, out, st)
-                  : readout_walk_t<PMX_TUNED_CIC, float>(pl, p, canvas, pos, out, st);
     case PMX_TUNED_TSC:
         return f8 ? readout_walk_t<PMX_TUNED_TSC, double>(pl, p, canvas, pos, out, st)
                   : readout_walk_t<PMX_TUNED_TSC, float>(pl, p, canvas, pos, out, st);
