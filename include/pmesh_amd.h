@@ -136,9 +136,10 @@ int pmx_binplan_destroy(pmx_binplan *plan);
 /* Which kernels the next builds of this plan serve: 0 = tile form (one workgroup accumulates a
  * tile of 8 x 16 x 32 cells in LDS, S^3 LDS operations per particle), 1 = walk form (a workgroup
  * walks a patch of 16 x 32 columns plane by plane with the stencil of every cell in registers,
- * S^2 LDS operations per cell: csrc/pmx_walk.hip; windows of support >= 2), -1 (default) = walk
- * for TSC / PCS batches of at least ~1/4 particle per cell, tiles otherwise.  Same results either
- * way (readout bit-identical, paint up to the order of the additions into a cell). */
+ * S^2 LDS operations per cell: csrc/pmx_walk.hip; TSC and PCS, rows of `pos` contiguous),
+ * -1 (default) = the library's choice, today always the tiles (the walk form measured no faster
+ * on MI355X: DESIGN.md).  Same results either way (readout bit-identical, paint up to the order
+ * of the additions into a cell). */
 int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
 /* PMX_OK if (painter, npart) can use the binned kernels */
 int pmx_binplan_supported(const pmx_painter *p, int64_t npart);

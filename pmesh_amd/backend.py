@@ -29,7 +29,8 @@ class PmxError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, LIBNAME)
+    # PMESH_AMD_LIBRARY: another build of the same ABI (A/B timing of compile-time switches)
+    return os.environ.get('PMESH_AMD_LIBRARY') or os.path.join(_HERE, LIBNAME)
 
 
 def load_library(path=None):

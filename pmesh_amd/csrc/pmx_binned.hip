@@ -595,14 +595,15 @@ static bool same_geometry(const pmx_painter &a, const pmx_painter &b)
     return true;
 }
 
-// mean particles per cell from which the walk kernels are chosen for S >= 3 (PMX_WALK_MIN_DENSITY)
+// mean particles per cell from which form -1 chooses the walk kernels for S >= 3
+// (environment PMX_WALK_MIN_DENSITY; default 0 = never)
 static double walk_min_density()
 {
     static double v = -1;
     if (v < 0) {
         const char *e = getenv("PMX_WALK_MIN_DENSITY");
-        v = e ? atof(e) : 0.25;
-        if (!(v >= 0)) v = 0.25;
+        v = e ? atof(e) : 0.0;         // 0: never chosen automatically
+        if (!(v >= 0)) v = 0.0;
     }
     return v;
 }
@@ -695,7 +696,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     // instead of S^3 LDS operations: TSC / PCS at a density of the order of one particle per
     // cell; the tile kernels otherwise (sparse batches, CIC / NNB).
     double cells = (double)p.size[0] * (double)p.size[1] * (double)p.size[2];
-    bool walk = pl->form == 1 || (pl->form < 0 && g.S >= 3 && (double)npart >= walk_min_density() * cells);
+    // (form -1, "auto", stays with the tiles: on MI355X the walk kernels measured no faster —
+    // DESIGN.md "walk form" — unless PMX_WALK_MIN_DENSITY asks for them)
+    bool walk = pl->form == 1 || (pl->form < 0 && g.S >= 3 && walk_min_density() > 0 &&
+                                   (double)npart >= walk_min_density() * cells);
     if (g.S < 3 || !walk_layout_ok(pos)) walk = false;      // built for TSC / PCS; rows gathered by LDS-DMA
     g.walk = walk ? 1 : 0;
     const int T[3] = {walk ? 1 : T0, walk ? P1 : T1, walk ? P2 : T2};

@@ -32,7 +32,10 @@ constexpr int UNROLL = PMX_UNROLL;    // particles in flight per lane in the til
 
 // Walk form (pmx_walk.hip): buckets are single mesh planes of a patch of P1 x P2 columns; a
 // workgroup walks a segment of `lseg` planes of one patch along axis 0.
-constexpr int P1 = 16, P2 = 32;
+#ifndef PMX_WALK_P1
+#define PMX_WALK_P1 16
+#endif
+constexpr int P1 = PMX_WALK_P1, P2 = 32;
 constexpr int WTHREADS = P1 * P2;     // one thread per column of the patch
 
 struct BinGeom {

@@ -44,10 +44,16 @@
 namespace pmx {
 
 #ifndef PMX_WALK_K
-#define PMX_WALK_K 2
+#define PMX_WALK_K 1
 #endif
 constexpr int KOWN = PMX_WALK_K;     // particles per cell and step that the owner thread takes
 constexpr int LSEGMAX = 64;          // planes per segment (pmx_binplan_build keeps lseg <= this)
+// waves per SIMD the register allocation aims at: TSC two workgroups per CU (<= 128 VGPRs),
+// PCS one (its window alone is 128 registers)
+#ifndef PMX_WALK_WAVES_TSC
+#define PMX_WALK_WAVES_TSC 4
+#endif
+template <int KIND> constexpr int walk_waves() { return Tuned<KIND>::S >= 4 ? 2 : PMX_WALK_WAVES_TSC; }
 
 template <int KIND> struct Walk {
     static constexpr int S = Tuned<KIND>::S;
@@ -55,13 +61,13 @@ template <int KIND> struct Walk {
     static constexpr int PLANE = R1 * R2;
     static constexpr int NR = S + 1;                       // ring slots
     static constexpr int RING = (S - 1) * (R2 + P1);       // cells of a plane outside the box
-    // particle records per chunk: 1.5 x the mean population of a plane at one particle per
-    // cell; PCS runs one workgroup per CU (registers) and has the LDS for more.  Both raw
-    // buffers stay below 64 KB of LDS (the DMA destination travels in M0)
+    // particle records per chunk: 1.25 x the mean population of a plane at one particle per
+    // cell (three raw buffers of TSC and the rest fit 80 KB: two workgroups per CU); PCS runs
+    // one workgroup per CU (registers) and has the LDS for more
 #ifdef PMX_WALK_NREC
     static constexpr int NREC = PMX_WALK_NREC;
 #else
-    static constexpr int NREC = S >= 4 ? 2 * WTHREADS : 3 * WTHREADS / 2;
+    static constexpr int NREC = S >= 4 ? 2 * WTHREADS : 5 * WTHREADS / 4;
 #endif
     static constexpr int REPS = (NREC + WTHREADS - 1) / WTHREADS;
     // compact numbering of the cells of a plane outside the P1 x P2 box
@@ -106,11 +112,12 @@ template <int BYTES> __device__ __forceinline__ void glds(const void *gsrc, uint
 // not count the asm statements above)
 __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Layout of the dynamic LDS of the walk kernels (byte offsets).  The raw particle buffers come
-// first (the DMA destination travels in M0).
+// Layout of the dynamic LDS of the walk kernels (byte offsets).
 //   PE: position element (float / double); XB: bytes of the extra per-particle word that
 //   travels with the position (paint: mass element size, 0 = scalar mass; readout: 4 = the list
 //   entry); RT: element of the mesh ring (double for paint, the canvas type for readout).
+// Three raw particle buffers (plane k is consumed while k+1 is sorted and k+2 lands), two
+// sets of per-cell counters / owner slots / overflow lists, three overflow counters.
 template <int KIND, typename PE, int XB, typename RT> struct Smem {
     using W = Walk<KIND>;
     static constexpr int NREC = W::NREC;
@@ -121,15 +128,19 @@ template <int KIND, typename PE, int XB, typename RT> struct Smem {
     static constexpr int POSB = F8 ? 24 * NREC : 16 * NREC;
     static constexpr int XLO = POSB, XHI = POSB + 4 * NREC;        // the extra word (low / high dword)
     static constexpr int RAWB = (POSB + XB * NREC + 15) & ~15;
-    static constexpr int RING = 2 * RAWB;
-    static constexpr int CNT = RING + ((W::NR * W::PLANE * (int)sizeof(RT) + 15) & ~15);
-    static constexpr int SLOT = CNT + 4 * WTHREADS;
-    static constexpr int XLIST = SLOT + 2 * WTHREADS * KOWN;
-    static constexpr int XKEY = XLIST + 2 * NREC;
-    static constexpr int NX = XKEY + 2 * NREC;
+    static constexpr int RING = 3 * RAWB;
+    static constexpr int CNT = RING + ((W::NR * W::PLANE * (int)sizeof(RT) + 15) & ~15);   // [2][WTHREADS] u32
+    static constexpr int SLOT = CNT + 2 * 4 * WTHREADS;                                    // [2][WTHREADS * KOWN] u16
+    static constexpr int XLIST = SLOT + 2 * 2 * WTHREADS * KOWN;                           // [2][NREC] u16
+    static constexpr int XKEY = XLIST + 2 * 2 * NREC;                                      // [2][NREC] u16
+    static constexpr int NX = XKEY + 2 * 2 * NREC;                                         // [4] u32
     static constexpr int SCNT = NX + 16;
     static constexpr int SOFF = SCNT + 4 * (LSEGMAX + 4);
     static constexpr int TOTAL = SOFF + 8 * (LSEGMAX + 4);
+    __device__ static __forceinline__ uint32_t *cnt(unsigned char *smem, int set) { return (uint32_t *)(smem + CNT) + set * WTHREADS; }
+    __device__ static __forceinline__ uint16_t *slot(unsigned char *smem, int set) { return (uint16_t *)(smem + SLOT) + set * WTHREADS * KOWN; }
+    __device__ static __forceinline__ uint16_t *xlist(unsigned char *smem, int set) { return (uint16_t *)(smem + XLIST) + set * NREC; }
+    __device__ static __forceinline__ uint16_t *xkey(unsigned char *smem, int set) { return (uint16_t *)(smem + XKEY) + set * NREC; }
 };
 
 struct UnitCoords {
@@ -157,8 +168,8 @@ template <int KIND, typename PE, int XB, typename RT> struct Pipe {
     static constexpr int NREC = W::NREC, REPS = W::REPS;
 
     // gather the rows idx[r] of chunk [j0, j0 + nsub) of the list into raw buffer `rawoff`
-    // (asynchronous).  xsrc: the array the extra word is gathered from by row index (mass), or
-    // NULL with XB == 4: the list entries themselves (contiguous).
+    // (asynchronous).  xvec: the array the extra word is gathered from by row index (mass), or
+    // no data with XB == 4: the list entries themselves (contiguous).
     __device__ static __forceinline__ void issue(unsigned char *smem, int rawoff, const DVec &pos, const DVec &xvec,
                                                  const uint32_t *list, int64_t j0, int nsub, const uint32_t *idx)
     {
@@ -169,7 +180,7 @@ template <int KIND, typename PE, int XB, typename RT> struct Pipe {
             const int jj = r * WTHREADS + threadIdx.x;
             const uint32_t wb = (uint32_t)(r * WTHREADS + wave * 64);   // first record of this wave-instruction
             if (jj < nsub) {
-                const char *row = pos.data + (int64_t)idx[r] * pos.stride0;
+                const char *row = pos.data + (uint64_t)idx[r] * (uint32_t)pos.stride0;   // v_mad_u64_u32
                 if constexpr (SM::F8) {
                     glds<16>(row, base + SM::XY + wb * 16);
                     glds<4>(row + 16, base + SM::ZLO + wb * 4);
@@ -178,7 +189,7 @@ template <int KIND, typename PE, int XB, typename RT> struct Pipe {
                     glds<12>(row, base + SM::XY + wb * 16);      // dwordx3 lands at a 16-byte lane stride
                 }
                 if constexpr (XB > 0) {
-                    const char *x = xvec.data ? xvec.data + (int64_t)idx[r] * xvec.stride0
+                    const char *x = xvec.data ? xvec.data + (uint64_t)idx[r] * (uint32_t)xvec.stride0
                                               : (const char *)(list + j0 + jj);
                     glds<4>(x, base + SM::XLO + wb * 4);
                     if constexpr (XB == 8) glds<4>(x + 4, base + SM::XHI + wb * 4);
@@ -225,34 +236,31 @@ template <int KIND, typename PE, int XB, typename RT> struct Pipe {
         return *(const uint32_t *)(smem + rawoff + SM::XLO + j * 4);
     }
 
-    // the records of a chunk are matched to the owner threads of their cells; a record that
-    // does not belong to bucket (patch, a) — a plan that no longer matches the positions —
-    // is ignored, so nothing indexes outside LDS
-    __device__ static __forceinline__ void sort(const pmx_painter &p, const BinGeom &g, const UnitCoords &u, int a,
-                                                unsigned char *smem, int rawoff, int nsub, uint32_t *nxc)
+    // the records of a chunk are matched to the owner threads of their cells (counter / slot /
+    // overflow set `set`).  Only the column (b, c) inside the patch is computed here; a record
+    // that falls outside the patch — a plan that no longer matches the positions — is ignored,
+    // so nothing indexes outside LDS (the plane is not checked: the window and the ring are
+    // addressed relative to the step).
+    __device__ static __forceinline__ void sort(const pmx_painter &p, const BinGeom &g, const UnitCoords &u,
+                                                unsigned char *smem, int rawoff, int nsub, int set, uint32_t *nxc)
     {
-        uint32_t *cnt = (uint32_t *)(smem + SM::CNT);
-        uint16_t *slot = (uint16_t *)(smem + SM::SLOT);
-        uint16_t *xlist = (uint16_t *)(smem + SM::XLIST), *xkey = (uint16_t *)(smem + SM::XKEY);
+        uint32_t *cnt = SM::cnt(smem, set);
+        uint16_t *slot = SM::slot(smem, set);
+        uint16_t *xlist = SM::xlist(smem, set), *xkey = SM::xkey(smem, set);
+        const int org1 = u.B * P1 - g.o[1], org2 = u.C * P2 - g.o[2];
+        const int per1 = (int)p.period[1], per2 = (int)p.period[2], size1 = (int)p.size[1], size2 = (int)p.size[2];
 #pragma unroll
         for (int r = 0; r < REPS; r++) {
             const int jj = r * WTHREADS + threadIdx.x;
             if (jj < nsub) {
                 double x[3];
                 read_pos(smem, rawoff, jj, x);
-                int cc[3];
-                bool ok = true;
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const double X = x[d] * p.scale[d] + p.translate[d];
-                    ok = ok && (fabs(X) < 1073741824.0);
-                    int i0w = 0;
-                    ok = ok && local_base<KIND>(p, d, Tuned<KIND>::first(ok ? X : 0.0), &i0w);
-                    cc[d] = i0w + g.o[d];
-                }
-                const int b = cc[1] - u.B * P1, c = cc[2] - u.C * P2;
-                ok = ok && cc[0] == a && (unsigned)b < (unsigned)P1 && (unsigned)c < (unsigned)P2;
-                if (ok) {
+                int w1 = wrap_fast(Tuned<KIND>::first(x[1] * p.scale[1] + p.translate[1]), per1);
+                int w2 = wrap_fast(Tuned<KIND>::first(x[2] * p.scale[2] + p.translate[2]), per2);
+                if (per1 > 0 && w1 >= size1) w1 -= per1;
+                if (per2 > 0 && w2 >= size2) w2 -= per2;
+                const int b = w1 - org1, c = w2 - org2;
+                if ((unsigned)b < (unsigned)P1 && (unsigned)c < (unsigned)P2) {
                     const int key = b * P2 + c;
                     const uint32_t rank = atomicAdd(&cnt[key], 1u);
                     if (rank < (uint32_t)KOWN) slot[key * KOWN + rank] = (uint16_t)jj;
@@ -276,9 +284,17 @@ __device__ __forceinline__ void weights(const pmx_painter &p, const double *x, d
     for (int d = 0; d < 3; d++) Tuned<KIND>::axis(x[d] * p.scale[d] + p.translate[d], p.order[d], p.scale[d], I, V[d]);
 }
 
+__device__ __forceinline__ int min_u(uint32_t a, int b) { return a < (uint32_t)b ? (int)a : b; }
+
+// One step of the walk handles three planes at once, so that their latencies overlap inside
+// every wave and a single barrier ends the step:
+//   plane k+2: the gather of its records is issued (LDS-DMA), the list entries of k+3 requested;
+//   plane k+1: its records (landed during the previous step) are matched to their owners;
+//   plane k  : the owners accumulate, crowded cells scatter, the window gives up its oldest plane;
+//   plane k-1: complete since the previous barrier, it leaves for the canvas / the staging.
 // XB: 0 scalar mass, 4 / 8: per-particle float / double mass
 template <int KIND, typename T, typename PE, int XB>
-__global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
+__global__ void __launch_bounds__(WTHREADS, walk_waves<KIND>()) paint_walk_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                              DVec mass, double mass_scalar, const uint32_t *list,
                                                              const int64_t *offsets, const uint32_t *counts,
                                                              T *halo, uint32_t *unit_flags, int overwrite)
@@ -289,9 +305,6 @@ __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, Bin
     constexpr int S = W::S, R2 = W::R2, PLANE = W::PLANE, NR = W::NR, RING = W::RING, NREC = W::NREC, REPS = W::REPS;
     extern __shared__ __align__(16) unsigned char smem[];
     double *ring = (double *)(smem + SM::RING);
-    uint32_t *cnt = (uint32_t *)(smem + SM::CNT);
-    uint16_t *slot = (uint16_t *)(smem + SM::SLOT);
-    uint16_t *xlist = (uint16_t *)(smem + SM::XLIST), *xkey = (uint16_t *)(smem + SM::XKEY);
     uint32_t *nx = (uint32_t *)(smem + SM::NX);
     uint32_t *scnt = (uint32_t *)(smem + SM::SCNT);
     int64_t *soff = (int64_t *)(smem + SM::SOFF);
@@ -312,9 +325,10 @@ __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, Bin
             __syncthreads();
             continue;
         }
-        if (tid == 0) { unit_flags[unit] = 1; nx[0] = 0; nx[1] = 0; }
+        if (tid == 0) { unit_flags[unit] = 1; nx[0] = nx[1] = nx[2] = nx[3] = 0; }
         for (int q = tid; q < NR * PLANE; q += WTHREADS) ring[q] = 0;
-        cnt[tid] = 0;
+        SM::cnt(smem, 0)[tid] = 0;
+        SM::cnt(smem, 1)[tid] = 0;
         T *hbase = halo + unit * unit_halo;
         double acc[S][S][S];
 #pragma unroll
@@ -323,23 +337,35 @@ __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, Bin
             for (int j = 0; j < S; j++)
 #pragma unroll
                 for (int k = 0; k < S; k++) acc[i][j][k] = 0;
-        int phase = 0;
-        // prologue: the first chunk of plane a0 lands in raw buffer 0, the list entries of the
-        // first chunk of plane a0+1 are in flight
-        uint32_t idx[REPS];
-        {
-            const int n0 = (int)(scnt[0] < (uint32_t)NREC ? scnt[0] : (uint32_t)NREC);
-            PP::load_idx(list, soff[0], n0, idx);
-            PP::issue(smem, 0, pos, mass, list, soff[0], n0, idx);
-            const int n1 = (int)(scnt[1] < (uint32_t)NREC ? scnt[1] : (uint32_t)NREC);
-            PP::load_idx(list, soff[1], n1, idx);
+        // per-thread constants of the write-out: my cell of the box, my cell of the ring
+        const int l1c = u.B * P1 - g.o[1] + tb, l2c = u.C * P2 - g.o[2] + tc;
+        const bool cell_ok = l1c >= 0 && l1c < p.size[1] && l2c >= 0 && l2c < p.size[2];
+        const int64_t cell_off = l1c * p.strides[1] + l2c * p.strides[2];
+        int ringq = 0;
+        if (tid < RING) {
+            int b, c;
+            W::ring_decode(tid, &b, &c);
+            ringq = b * R2 + c;
         }
+        // prologue: the first chunks of planes 0 and 1 land in raw buffers 0 and 1, the list
+        // entries of plane 2 are in flight, plane 0 is sorted
+        uint32_t idx[REPS];
+        PP::load_idx(list, soff[0], min_u(scnt[0], NREC), idx);
+        PP::issue(smem, 0, pos, mass, list, soff[0], min_u(scnt[0], NREC), idx);
+        PP::load_idx(list, soff[1], min_u(scnt[1], NREC), idx);
+        PP::issue(smem, SM::RAWB, pos, mass, list, soff[1], min_u(scnt[1], NREC), idx);
+        PP::load_idx(list, soff[2], min_u(scnt[2], NREC), idx);
         vm_drain();
+        __syncthreads();
+        PP::sort(p, g, u, smem, 0, min_u(scnt[0], NREC), 0, &nx[0]);
         __syncthreads();
 
         // the owner part and the scatter part of one chunk whose records are in `rawoff`
-        auto accumulate = [&](auto rot, const int sl0, const int rawoff, uint32_t *nxc) __attribute__((always_inline)) {
+        auto accumulate = [&](auto rot, const int a, const int sl0, const int rawoff, const int set, const uint32_t nxv) __attribute__((always_inline)) {
             constexpr int ROT = decltype(rot)::value;
+            uint32_t *cnt = SM::cnt(smem, set);
+            const uint16_t *slot = SM::slot(smem, set);
+            const uint16_t *xlist = SM::xlist(smem, set), *xkey = SM::xkey(smem, set);
             {
                 const uint32_t cn = cnt[tid];
                 cnt[tid] = 0;
@@ -357,14 +383,17 @@ __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, Bin
 #pragma unroll
                         for (int jb = 0; jb < S; jb++) {
                             const double fb = V[0][i] * V[1][jb];
+                            // one rounding instead of two: the order of the additions into a cell
+                            // already differs from the reference's (see the header)
 #pragma unroll
-                            for (int k = 0; k < S; k++) acc[(i + ROT) % S][jb][k] += fb * V[2][k];
+                            for (int k = 0; k < S; k++)
+                                acc[(i + ROT) % S][jb][k] = __builtin_fma(fb, V[2][k], acc[(i + ROT) % S][jb][k]);
                         }
                 }
             }
-            // the rest of crowded cells: scatter form, spread over all threads
-            const uint32_t nxv = *nxc;
-            for (uint32_t e = tid; e < nxv; e += WTHREADS) {
+            // the rest of crowded cells: scatter form on a compact list, taken by a different
+            // wave first every step (the SIMDs that host the first waves would do all of it)
+            for (uint32_t e = (uint32_t)((tid - 64 * a) & (WTHREADS - 1)); e < nxv; e += WTHREADS) {
                 const int j = xlist[e];
                 const int key = xkey[e];
                 const int b = key / P2, c = key % P2;
@@ -389,88 +418,90 @@ __global__ void __launch_bounds__(WTHREADS) paint_walk_kernel(pmx_painter p, Bin
             }
         };
 
-        auto step = [&](auto rot, const int a) __attribute__((always_inline)) {
-            constexpr int ROT = decltype(rot)::value;
-            const int pa = a - u.a0;
-            const int par = pa & 1;
-            const int rawoff = par * SM::RAWB;
-            const uint32_t n = scnt[pa < LSEGMAX + 4 ? pa : LSEGMAX + 3];      // 0 behind the segment
-            const int64_t start = soff[pa < LSEGMAX + 4 ? pa : LSEGMAX + 3];
-            const int sl0 = a % NR;
-            // records of the next plane -> the other raw buffer; list entries of the plane after it
-            if (pa + 1 < Lu) {
-                const uint32_t n1 = scnt[pa + 1];
-                PP::issue(smem, SM::RAWB - rawoff, pos, mass, list, soff[pa + 1], (int)(n1 < (uint32_t)NREC ? n1 : (uint32_t)NREC), idx);
-                if (pa + 2 < Lu) {
-                    const uint32_t n2 = scnt[pa + 2];
-                    PP::load_idx(list, soff[pa + 2], (int)(n2 < (uint32_t)NREC ? n2 : (uint32_t)NREC), idx);
-                }
-            }
-            if (n > 0) {
-                const int nsub = (int)(n < (uint32_t)NREC ? n : (uint32_t)NREC);
-                uint32_t *nxc = &nx[phase & 1];
-                PP::sort(p, g, u, a, smem, rawoff, nsub, nxc);
-                if (tid == 0) nx[(phase + 1) & 1] = 0;
-                __syncthreads();
-                accumulate(rot, sl0, rawoff, nxc);
-                phase++;
-                // crowded planes: the chunks behind the first one are fetched on the spot
-                for (uint32_t sub0 = NREC; sub0 < n; sub0 += NREC) {
-                    const int ns = (int)((n - sub0) < (uint32_t)NREC ? (n - sub0) : (uint32_t)NREC);
-                    uint32_t idx2[REPS];
-                    PP::load_idx(list, start + sub0, ns, idx2);
-                    __syncthreads();                       // the records of the previous chunk are done with
-                    PP::issue(smem, rawoff, pos, mass, list, start + sub0, ns, idx2);
-                    vm_drain();
-                    __syncthreads();
-                    nxc = &nx[phase & 1];
-                    PP::sort(p, g, u, a, smem, rawoff, ns, nxc);
-                    if (tid == 0) nx[(phase + 1) & 1] = 0;
-                    __syncthreads();
-                    accumulate(rot, sl0, rawoff, nxc);
-                    phase++;
-                }
-            }
-            // the oldest plane of the window is complete for this thread: add it to ring plane a
-#pragma unroll
-            for (int j = 0; j < S; j++)
-#pragma unroll
-                for (int k = 0; k < S; k++) {
-                    unsafeAtomicAdd(&ring[sl0 * PLANE + (tb + j) * R2 + tc + k], acc[ROT][j][k]);
-                    acc[ROT][j][k] = 0;
-                }
-            vm_drain();                 // the next plane's records have landed (this wave's share)
-            __syncthreads();
-            // plane a is complete: box -> canvas (plain row stores), ring -> staging
-            {
-                const bool trailing = a >= u.a1;
+        // plane `pk` (index in the unit) leaves the ring: box -> canvas (plain row stores),
+        // ring around it (and whole planes behind the segment) -> staging
+        auto write_out = [&](const int pk) __attribute__((always_inline)) {
+            const int a = u.a0 + pk;
+            const int sl = a % NR;
+            if (pk < Lu) {
                 const int l0 = a - g.o[0];
-                const bool in0 = !trailing && l0 >= 0 && l0 < p.size[0];
-                T *hplane = trailing ? hbase + (int64_t)Lu * RING + (int64_t)(pa - Lu) * PLANE : hbase + (int64_t)pa * RING;
+                const int q = tb * R2 + tc;
+                const double v = ring[sl * PLANE + q];
+                ring[sl * PLANE + q] = 0;
+                if (cell_ok && l0 >= 0 && l0 < p.size[0]) {
+                    T *dst = (T *)(canvas + l0 * p.strides[0] + cell_off);
+                    if (overwrite) *dst = (T)v;
+                    else *dst += (T)v;
+                }
+                if (tid < RING) {
+                    hbase[(int64_t)pk * RING + tid] = (T)ring[sl * PLANE + ringq];
+                    ring[sl * PLANE + ringq] = 0;
+                }
+            } else {
+                T *hplane = hbase + (int64_t)Lu * RING + (int64_t)(pk - Lu) * PLANE;
                 for (int q = tid; q < PLANE; q += WTHREADS) {
-                    const int b = q / R2, c = q - b * R2;
-                    const double v = ring[sl0 * PLANE + q];
-                    ring[sl0 * PLANE + q] = 0;
-                    if (trailing) hplane[q] = (T)v;
-                    else if (b < P1 && c < P2) {
-                        const int l1 = u.B * P1 - g.o[1] + b, l2 = u.C * P2 - g.o[2] + c;
-                        if (in0 && l1 >= 0 && l1 < p.size[1] && l2 >= 0 && l2 < p.size[2]) {
-                            T *dst = (T *)(canvas + l0 * p.strides[0] + l1 * p.strides[1] + l2 * p.strides[2]);
-                            if (overwrite) *dst = (T)v;
-                            else *dst += (T)v;
-                        }
-                    } else hplane[W::ring_index(b, c)] = (T)v;
+                    hplane[q] = (T)ring[sl * PLANE + q];
+                    ring[sl * PLANE + q] = 0;
                 }
             }
         };
 
-        const int aend = u.a1 + S - 1;
-        for (int a = u.a0; a < aend; a += S) {
-            step(std::integral_constant<int, 0>(), a);
-            if (S > 1 && a + 1 < aend) step(std::integral_constant<int, 1 % S>(), a + 1);
-            if (S > 2 && a + 2 < aend) step(std::integral_constant<int, 2 % S>(), a + 2);
-            if (S > 3 && a + 3 < aend) step(std::integral_constant<int, 3 % S>(), a + 3);
+        auto step = [&](auto rot, const int k) __attribute__((always_inline)) {
+            constexpr int ROT = decltype(rot)::value;
+            const int a = u.a0 + k;
+            const int sl0 = a % NR;
+            const uint32_t n = scnt[k];                    // 0 behind the segment
+            int b0 = k % 3, b1 = b0 + 1, b2 = b0 + 2;      // raw buffers of planes k, k+1, k+2
+            if (b1 >= 3) b1 -= 3;
+            if (b2 >= 3) b2 -= 3;
+            if (tid == 0) nx[(k + 2) & 3] = 0;             // counter of plane k+2: last read two steps ago
+            // plane k+2: gather its records; list entries of plane k+3
+            if (k + 2 < Lu) {
+                PP::issue(smem, b2 * SM::RAWB, pos, mass, list, soff[k + 2], min_u(scnt[k + 2], NREC), idx);
+                if (k + 3 < Lu) PP::load_idx(list, soff[k + 3], min_u(scnt[k + 3], NREC), idx);
+            }
+            // plane k+1: match its records to their owners
+            if (k + 1 < Lu) PP::sort(p, g, u, smem, b1 * SM::RAWB, min_u(scnt[k + 1], NREC), (k + 1) & 1, &nx[(k + 1) & 3]);
+            // plane k: accumulate
+            if (n > 0) {
+                accumulate(rot, a, sl0, b0 * SM::RAWB, k & 1, nx[k & 3]);
+                // crowded planes: the chunks behind the first one are fetched on the spot
+                for (uint32_t sub0 = NREC; sub0 < n; sub0 += NREC) {
+                    const int ns = min_u(n - sub0, NREC);
+                    uint32_t idx2[REPS];
+                    PP::load_idx(list, soff[k] + sub0, ns, idx2);
+                    __syncthreads();                       // the records of the previous chunk are done with
+                    if (tid == 0) nx[k & 3] = 0;
+                    PP::issue(smem, b0 * SM::RAWB, pos, mass, list, soff[k] + sub0, ns, idx2);
+                    vm_drain();
+                    __syncthreads();
+                    PP::sort(p, g, u, smem, b0 * SM::RAWB, ns, k & 1, &nx[k & 3]);
+                    __syncthreads();
+                    accumulate(rot, a, sl0, b0 * SM::RAWB, k & 1, nx[k & 3]);
+                }
+            }
+            // the oldest plane of the window is complete for this thread: add it to ring plane k
+#pragma unroll
+            for (int j = 0; j < S; j++)
+#pragma unroll
+                for (int kk = 0; kk < S; kk++) {
+                    unsafeAtomicAdd(&ring[sl0 * PLANE + (tb + j) * R2 + tc + kk], acc[ROT][j][kk]);
+                    acc[ROT][j][kk] = 0;
+                }
+            // plane k-1 is complete since the last barrier
+            if (k > 0) write_out(k - 1);
+            vm_drain();                 // the records of plane k+2 have landed (this wave's share)
+            __syncthreads();
+        };
+
+        const int nsteps = Lu + S - 1;
+        for (int k = 0; k < nsteps; k += S) {
+            step(std::integral_constant<int, 0>(), k);
+            if (S > 1 && k + 1 < nsteps) step(std::integral_constant<int, 1 % S>(), k + 1);
+            if (S > 2 && k + 2 < nsteps) step(std::integral_constant<int, 2 % S>(), k + 2);
+            if (S > 3 && k + 3 < nsteps) step(std::integral_constant<int, 3 % S>(), k + 3);
         }
+        write_out(nsteps - 1);
         __syncthreads();
     }
 }
@@ -511,8 +542,11 @@ __global__ void __launch_bounds__(TBLOCK) halo_merge_walk_kernel(pmx_painter p, 
     }
 }
 
+// The same pipeline for readout: plane a+S of the mesh is requested (registers) while plane
+// a+S-1... — one step: records of plane k+2 gathered, plane k+1 sorted, the window of plane k
+// shifted by one mesh plane (staged in the ring during the previous step) and read out.
 template <int KIND, typename T, typename PE>
-__global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, BinGeom g, const char *canvas, DVec pos,
+__global__ void __launch_bounds__(WTHREADS, walk_waves<KIND>()) readout_walk_kernel(pmx_painter p, BinGeom g, const char *canvas, DVec pos,
                                                                DVec out, const uint32_t *list, const int64_t *offsets,
                                                                const uint32_t *counts)
 {
@@ -523,9 +557,6 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
     constexpr int NPL = (PLANE + WTHREADS - 1) / WTHREADS;
     extern __shared__ __align__(16) unsigned char smem[];
     T *ring = (T *)(smem + SM::RING);
-    uint32_t *cnt = (uint32_t *)(smem + SM::CNT);
-    uint16_t *slot = (uint16_t *)(smem + SM::SLOT);
-    uint16_t *xlist = (uint16_t *)(smem + SM::XLIST), *xkey = (uint16_t *)(smem + SM::XKEY);
     uint32_t *nx = (uint32_t *)(smem + SM::NX);
     uint32_t *scnt = (uint32_t *)(smem + SM::SCNT);
     int64_t *soff = (int64_t *)(smem + SM::SOFF);
@@ -543,25 +574,28 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
             __syncthreads();
             continue;
         }
-        if (tid == 0) { nx[0] = 0; nx[1] = 0; }
-        cnt[tid] = 0;
-        // cells of plane `pl` (tile-space) of the patch + halo that this thread stages;
-        // cells outside the block read 0
+        if (tid == 0) nx[0] = nx[1] = nx[2] = nx[3] = 0;
+        SM::cnt(smem, 0)[tid] = 0;
+        SM::cnt(smem, 1)[tid] = 0;
+        // the cells of a plane of the patch + halo that this thread stages: their place in the
+        // canvas is the same for every plane (cells outside the block read 0)
+        int64_t poff[NPL];
+        bool pok[NPL];
+#pragma unroll
+        for (int r = 0; r < NPL; r++) {
+            const int q = tid + r * WTHREADS;
+            const int b = q / R2, c = q - b * R2;
+            const int l1 = wrap_near(u.B * P1 - g.o[1] + b, p.period[1]);
+            const int l2 = wrap_near(u.C * P2 - g.o[2] + c, p.period[2]);
+            pok[r] = q < PLANE && l1 >= 0 && l1 < p.size[1] && l2 >= 0 && l2 < p.size[2];
+            poff[r] = l1 * p.strides[1] + l2 * p.strides[2];
+        }
         auto fetch_plane = [&](const int pl, T *v) __attribute__((always_inline)) {
             const int l0 = wrap_near(pl - g.o[0], p.period[0]);
             const bool in0 = l0 >= 0 && l0 < p.size[0];
+            const char *base = canvas + l0 * p.strides[0];
 #pragma unroll
-            for (int r = 0; r < NPL; r++) {
-                const int q = tid + r * WTHREADS;
-                v[r] = (T)0;
-                if (q < PLANE) {
-                    const int b = q / R2, c = q - b * R2;
-                    const int l1 = wrap_near(u.B * P1 - g.o[1] + b, p.period[1]);
-                    const int l2 = wrap_near(u.C * P2 - g.o[2] + c, p.period[2]);
-                    if (in0 && l1 >= 0 && l1 < p.size[1] && l2 >= 0 && l2 < p.size[2])
-                        v[r] = *(const T *)(canvas + l0 * p.strides[0] + l1 * p.strides[1] + l2 * p.strides[2]);
-                }
-            }
+            for (int r = 0; r < NPL; r++) v[r] = (in0 && pok[r]) ? *(const T *)(base + poff[r]) : (T)0;
         };
         auto store_plane = [&](const int pl, const T *v) __attribute__((always_inline)) {
             const int sl = pl % NR;
@@ -571,23 +605,24 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
                 if (q < PLANE) ring[sl * PLANE + q] = v[r];
             }
         };
+        // prologue: planes a0 .. a0+S-1 of the mesh in the ring, plane a0+S requested; records
+        // of planes 0 and 1 landed, list entries of plane 2 in flight, plane 0 sorted
         T pv[NPL];
 #pragma unroll
-        for (int k = 0; k < S - 1; k++) {
+        for (int k = 0; k < S; k++) {
             fetch_plane(u.a0 + k, pv);
             store_plane(u.a0 + k, pv);
         }
-        fetch_plane(u.a0 + S - 1, pv);          // enters the ring at the first step
+        fetch_plane(u.a0 + S, pv);
         uint32_t idx[REPS];
-        {
-            const int n0 = (int)(scnt[0] < (uint32_t)NREC ? scnt[0] : (uint32_t)NREC);
-            PP::load_idx(list, soff[0], n0, idx);
-            PP::issue(smem, 0, pos, nox, list, soff[0], n0, idx);
-            const int n1 = (int)(scnt[1] < (uint32_t)NREC ? scnt[1] : (uint32_t)NREC);
-            PP::load_idx(list, soff[1], n1, idx);
-        }
+        PP::load_idx(list, soff[0], min_u(scnt[0], NREC), idx);
+        PP::issue(smem, 0, pos, nox, list, soff[0], min_u(scnt[0], NREC), idx);
+        PP::load_idx(list, soff[1], min_u(scnt[1], NREC), idx);
+        PP::issue(smem, SM::RAWB, pos, nox, list, soff[1], min_u(scnt[1], NREC), idx);
+        PP::load_idx(list, soff[2], min_u(scnt[2], NREC), idx);
         vm_drain();
         __syncthreads();
+        PP::sort(p, g, u, smem, 0, min_u(scnt[0], NREC), 0, &nx[0]);
         T win[S][S][S];
 #pragma unroll
         for (int i = 0; i < S; i++)
@@ -596,10 +631,13 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
 #pragma unroll
                 for (int k = 0; k < S; k++)
                     win[i][j][k] = i < S - 1 ? ring[((u.a0 + i) % NR) * PLANE + (tb + j) * R2 + tc + k] : (T)0;
-        int phase = 0;
+        __syncthreads();
 
-        auto gather = [&](auto rot, const int sl0, const int rawoff, uint32_t *nxc) __attribute__((always_inline)) {
+        auto gather = [&](auto rot, const int a, const int sl0, const int rawoff, const int set, const uint32_t nxv) __attribute__((always_inline)) {
             constexpr int ROT = decltype(rot)::value;
+            uint32_t *cnt = SM::cnt(smem, set);
+            const uint16_t *slot = SM::slot(smem, set);
+            const uint16_t *xlist = SM::xlist(smem, set), *xkey = SM::xkey(smem, set);
             {
                 const uint32_t cn = cnt[tid];
                 cnt[tid] = 0;
@@ -621,8 +659,7 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
                     out.set((int64_t)PP::read_index(smem, rawoff, j), 0, value);
                 }
             }
-            const uint32_t nxv = *nxc;
-            for (uint32_t e = tid; e < nxv; e += WTHREADS) {
+            for (uint32_t e = (uint32_t)((tid - 64 * a) & (WTHREADS - 1)); e < nxv; e += WTHREADS) {
                 const int j = xlist[e];
                 const int key = xkey[e];
                 const int b = key / P2, c = key % P2;
@@ -646,66 +683,60 @@ __global__ void __launch_bounds__(WTHREADS) readout_walk_kernel(pmx_painter p, B
             }
         };
 
-        auto step = [&](auto rot, const int a) __attribute__((always_inline)) {
+        auto step = [&](auto rot, const int k) __attribute__((always_inline)) {
             constexpr int ROT = decltype(rot)::value;
-            const int pa = a - u.a0;
-            const int par = pa & 1;
-            const int rawoff = par * SM::RAWB;
-            const uint32_t n = scnt[pa];
-            const int64_t start = soff[pa];
+            const int a = u.a0 + k;
             const int sl0 = a % NR;
-            // plane a+S-1 (fetched during the previous step) enters the ring; the next one is requested
-            store_plane(a + S - 1, pv);
-            if (pa + 1 < Lu) {
-                fetch_plane(a + S, pv);
-                const uint32_t n1 = scnt[pa + 1];
-                PP::issue(smem, SM::RAWB - rawoff, pos, nox, list, soff[pa + 1], (int)(n1 < (uint32_t)NREC ? n1 : (uint32_t)NREC), idx);
-                if (pa + 2 < Lu) {
-                    const uint32_t n2 = scnt[pa + 2];
-                    PP::load_idx(list, soff[pa + 2], (int)(n2 < (uint32_t)NREC ? n2 : (uint32_t)NREC), idx);
-                }
+            const uint32_t n = scnt[k];
+            int b0 = k % 3, b1 = b0 + 1, b2 = b0 + 2;
+            if (b1 >= 3) b1 -= 3;
+            if (b2 >= 3) b2 -= 3;
+            if (tid == 0) nx[(k + 2) & 3] = 0;
+            // mesh plane a+S (requested during the previous step) enters the ring for the next
+            // step, plane a+S+1 is requested
+            if (k + 1 < Lu) {
+                store_plane(a + S, pv);
+                if (k + 2 < Lu) fetch_plane(a + S + 1, pv);
             }
-            const int nsub = (int)(n < (uint32_t)NREC ? n : (uint32_t)NREC);
-            uint32_t *nxc = &nx[phase & 1];
-            PP::sort(p, g, u, a, smem, rawoff, nsub, nxc);
-            if (tid == 0) nx[(phase + 1) & 1] = 0;
-            __syncthreads();
+            if (k + 2 < Lu) {
+                PP::issue(smem, b2 * SM::RAWB, pos, nox, list, soff[k + 2], min_u(scnt[k + 2], NREC), idx);
+                if (k + 3 < Lu) PP::load_idx(list, soff[k + 3], min_u(scnt[k + 3], NREC), idx);
+            }
+            if (k + 1 < Lu) PP::sort(p, g, u, smem, b1 * SM::RAWB, min_u(scnt[k + 1], NREC), (k + 1) & 1, &nx[(k + 1) & 3]);
+            // the window takes mesh plane a+S-1 (in the ring since the previous barrier)
             {
                 int sl = sl0 + S - 1;
                 if (sl >= NR) sl -= NR;
 #pragma unroll
                 for (int j = 0; j < S; j++)
 #pragma unroll
-                    for (int k = 0; k < S; k++) win[(S - 1 + ROT) % S][j][k] = ring[sl * PLANE + (tb + j) * R2 + tc + k];
+                    for (int kk = 0; kk < S; kk++) win[(S - 1 + ROT) % S][j][kk] = ring[sl * PLANE + (tb + j) * R2 + tc + kk];
             }
             if (n > 0) {
-                gather(rot, sl0, rawoff, nxc);
-                phase++;
+                gather(rot, a, sl0, b0 * SM::RAWB, k & 1, nx[k & 3]);
                 for (uint32_t sub0 = NREC; sub0 < n; sub0 += NREC) {
-                    const int ns = (int)((n - sub0) < (uint32_t)NREC ? (n - sub0) : (uint32_t)NREC);
+                    const int ns = min_u(n - sub0, NREC);
                     uint32_t idx2[REPS];
-                    PP::load_idx(list, start + sub0, ns, idx2);
+                    PP::load_idx(list, soff[k] + sub0, ns, idx2);
                     __syncthreads();
-                    PP::issue(smem, rawoff, pos, nox, list, start + sub0, ns, idx2);
+                    if (tid == 0) nx[k & 3] = 0;
+                    PP::issue(smem, b0 * SM::RAWB, pos, nox, list, soff[k] + sub0, ns, idx2);
                     vm_drain();
                     __syncthreads();
-                    nxc = &nx[phase & 1];
-                    PP::sort(p, g, u, a, smem, rawoff, ns, nxc);
-                    if (tid == 0) nx[(phase + 1) & 1] = 0;
+                    PP::sort(p, g, u, smem, b0 * SM::RAWB, ns, k & 1, &nx[k & 3]);
                     __syncthreads();
-                    gather(rot, sl0, rawoff, nxc);
-                    phase++;
+                    gather(rot, a, sl0, b0 * SM::RAWB, k & 1, nx[k & 3]);
                 }
             }
             vm_drain();
-            __syncthreads();       // records and counters are free, the next plane's records have landed
+            __syncthreads();
         };
 
-        for (int a = u.a0; a < u.a1; a += S) {
-            step(std::integral_constant<int, 0>(), a);
-            if (S > 1 && a + 1 < u.a1) step(std::integral_constant<int, 1 % S>(), a + 1);
-            if (S > 2 && a + 2 < u.a1) step(std::integral_constant<int, 2 % S>(), a + 2);
-            if (S > 3 && a + 3 < u.a1) step(std::integral_constant<int, 3 % S>(), a + 3);
+        for (int k = 0; k < Lu; k += S) {
+            step(std::integral_constant<int, 0>(), k);
+            if (S > 1 && k + 1 < Lu) step(std::integral_constant<int, 1 % S>(), k + 1);
+            if (S > 2 && k + 2 < Lu) step(std::integral_constant<int, 2 % S>(), k + 2);
+            if (S > 3 && k + 3 < Lu) step(std::integral_constant<int, 3 % S>(), k + 3);
         }
         __syncthreads();
     }
