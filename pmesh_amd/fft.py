@@ -32,6 +32,14 @@ from ._arrays import torch_dtype
 # rocFFT (unit-stride R2C/C2R along the contiguous axis) + the LDS-resident column FFT of
 # csrc/pmx_colfft.hip along the other two; 'never': everything through rocFFT.
 COLFFT = 'auto'
+# one-rank 3-d transforms: bytes of mesh planes whose row pass and axis-1 pass run back to back so
+# that the second pass finds part of them in the 256 MiB Infinity Cache (0 = whole-array passes).
+# Measured on MI355X (scripts/fft_block.sh, profiles/r02_fft_l3_block.txt): 512^3 fp64 r2c
+# 1.38 -> 1.19 ms and c2r 1.32 -> 1.23 ms at 224-256 MB, nothing at 96 MB (a block is read AND
+# written between its two uses, and launches of a few dozen planes fill the chip badly), a loss
+# for meshes of several GB (768^3: +5 %; 1024^3: +15 %): applied to arrays up to L3_BLOCK_MAX_ARRAY.
+L3_BLOCK_BYTES = int(os.environ.get('PMESH_AMD_L3_BLOCK_MB', '224')) << 20
+L3_BLOCK_MAX_ARRAY = 3 << 29          # 1.5 GiB
 
 
 def split_size_2d(s):
@@ -569,6 +577,39 @@ class Plan(object):
             bufin = bufout
             inplace = True
         own_rows = inplace and be.rowfft_supported(N2, self.elsize)
+        # Infinity-Cache blocking: the row pass and the axis-1 pass both work inside single
+        # planes, so they can run back to back on a block of planes that fits the 256 MiB
+        # last-level cache: the second touch of a block is served on die instead of from HBM
+        # (3 HBM passes -> ~2).  L3_BLOCK_BYTES = 0 switches it off.
+        nblk = 1
+        if own_rows and plane and L3_BLOCK_BYTES > 0 and N0 * plane * 2 * self.elsize <= L3_BLOCK_MAX_ARRAY:
+            plane_bytes = plane * 2 * self.elsize
+            per = max(1, int(L3_BLOCK_BYTES // plane_bytes))
+            if per < N0:
+                nblk = (N0 + per - 1) // per
+        if nblk > 1:
+            st = bufin.storage
+            es = 2                                  # real elements per complex element
+            if self.forward:
+                for b in range(nblk):
+                    i0, i1 = b * per, min(N0, (b + 1) * per)
+                    blk = st[i0 * plane * es:]
+                    be.rowfft(self.elsize, False, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
+                    be.colfft(self.elsize, False, blk, i1 - i0, N1, N2c, a_stride=sa)
+                be.colfft(self.elsize, False, st, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
+            else:
+                if transfer is not None:
+                    t, start, nmesh, boxsize = transfer
+                    be.colfft(self.elsize, True, st, 1, N0, N1 * N2c, transfer=t, n1=N1, n2=N2c,
+                              start=start, nmesh=nmesh, boxsize=boxsize, n_stride=sn)
+                else:
+                    be.colfft(self.elsize, True, st, 1, N0, N1 * N2c, n_stride=sn)
+                for b in range(nblk):
+                    i0, i1 = b * per, min(N0, (b + 1) * per)
+                    blk = st[i0 * plane * es:]
+                    be.colfft(self.elsize, True, blk, i1 - i0, N1, N2c, a_stride=sa)
+                    be.rowfft(self.elsize, True, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
+            return
         if self.forward:
             if own_rows:
                 be.rowfft(self.elsize, False, bufin.storage, rows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
