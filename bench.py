@@ -10,7 +10,10 @@ per GPU over RCCL.  W untimed warm-up cycles, then exactly K cycles timed betwee
 barrier + synchronize on both sides; the MAX over ranks is used; rank 0 prints ONE
 JSON line.  The workload is BASELINE.json's headline: 512^3 mesh, 512^3 uniform
 particles (lattice + hashed jitter), CIC, f64, generated in HBM —
-a "step" is one PM cycle over that particle set, inputs resident in HBM.
+a "step" is one PM cycle over that particle set, inputs resident in HBM.  Consecutive
+cycles see the particles moved by N(0, --drift) cells (default 0.1) like a time-stepping caller:
+the bin plan is rebuilt from moved positions every cycle (`bin_overflows` counts the rebuilds
+that needed the two-pass repair).
 
 For N > 1 the mesh is slab-decomposed, particles start on the rank that generated
 them (rank r: lattice ids [r, r+1) * N^3 / P) and every cycle includes the particle
@@ -79,6 +82,11 @@ def parse():
     ap.add_argument('--ghosts-only', type=int, default=1,
                     help='0: the literal exchange-everything scheme of the reference for paint/readout '
                          'with a layout; 1: own particles in place, only ghosts travel')
+    ap.add_argument('--drift', type=float, default=0.1,
+                    help='rms displacement, in mesh cells per axis, of the particles between two cycles (a '
+                         'time-stepping caller): the cycles walk through 3 position sets, each the previous one '
+                         'plus N(0, drift) — the single-pass rebuild of the bin plan then works on moved '
+                         'particles and its overflow / repair path can trigger; 0: identical positions every cycle')
     ap.add_argument('--fuse-apply', type=int, default=1,
                     help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
     return ap.parse_args()
@@ -294,6 +302,16 @@ def main():
         torch.cuda.synchronize()
         t_order = time.perf_counter() - t0
 
+    # a time-stepping caller: the positions of consecutive cycles differ by a small random step
+    psets = [pos]
+    if args.drift > 0:
+        gen = torch.Generator(device=be.device)
+        gen.manual_seed(4321 + rank)
+        for k in range(2):
+            step = torch.randn(pos.shape, dtype=tdt, device=be.device, generator=gen) * (args.drift * L / N)
+            psets.append(psets[-1] + step)
+            del step
+    layouts = [None] * len(psets)
     layout = None
     t_decompose = 0.0
     if not args.ghosts_only:
@@ -308,6 +326,7 @@ def main():
         layout = pm.decompose(pos)
         torch.cuda.synchronize()
         t_decompose = time.perf_counter() - t0
+        layouts = [layout] + [pm.decompose(q) for q in psets[1:]]
 
     from pmesh_amd import window as _window
     if args.binned == 0:
@@ -323,10 +342,15 @@ def main():
 
     result = torch.empty(nloc, dtype=torch.float64, device=be.device)
 
+    ncycle = [0]
+
     def cycle(marks=None):
         def mark(i):
             if marks is not None:
                 marks[i].record()
+        pos = psets[ncycle[0] % len(psets)]
+        layout = layouts[ncycle[0] % len(psets)]
+        ncycle[0] += 1
         # a new time step: positions are "new", nothing binned or exchanged is reused
         _window.clear_bin_cache()
         if layout is not None:
@@ -424,12 +448,20 @@ def main():
                        'fft': 'LDS row + column FFT kernels' if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'decompose_ms': round(1e3 * t_decompose, 3),
+            'drift_cells': args.drift,
+            'bin_overflows': _window.bin_cache().overflows(be),
             'tile_order_ms': round(1e3 * t_order, 3),
             'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu, me) for s in
                                         ('paint', 'r2c', 'apply', 'c2r', 'readout')) * units /
                                     (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': ach, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                         # the bin pass exists only to feed paint and readout and has no algorithmic
+                         # bytes of its own: their bytes over the time of all three
+                         'with_bin_frac': ((algorithmic_bytes('paint', e, pe, nu, me) +
+                                            algorithmic_bytes('readout', e, pe, nu, 0)) * units /
+                                           ((stage_ms['bin'] + stage_ms['paint'] + stage_ms['readout']) * 1e-3)
+                                           / 1e9) / HBM_PEAK_GBS,
                          'algorithmic_bytes_per_particle': algorithmic_bytes(dom, e, pe, nu, me),
                          'particles_per_launch': units, 'ms_per_launch': single[dom]},
         }

@@ -141,6 +141,10 @@ int pmx_binplan_destroy(pmx_binplan *plan);
  * on MI355X: DESIGN.md).  Same results either way (readout bit-identical, paint up to the order
  * of the additions into a cell). */
 int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
+/* How many builds of this plan so far found the slot ranges of their previous build too small
+ * (particles moved a lot) and fell back to the exact two-pass build on the device.  Host
+ * counter, written by the device: exact once the stream has been synchronised. */
+int pmx_binplan_overflows(pmx_binplan *plan, uint32_t *count);
 /* PMX_OK if (painter, npart) can use the binned kernels */
 int pmx_binplan_supported(const pmx_painter *p, int64_t npart);
 /* bin the batch: tile id + slot per particle, per-tile counts, scan, index lists */

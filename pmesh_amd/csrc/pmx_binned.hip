@@ -634,6 +634,13 @@ extern "C" int pmx_binplan_configure(pmx_binplan *pl, int32_t form)
     return PMX_OK;
 }
 
+extern "C" int pmx_binplan_overflows(pmx_binplan *pl, uint32_t *count)
+{
+    PMX_REQUIRE(pl != nullptr && count != nullptr, PMX_EINVAL, "NULL argument");
+    *count = pl->host_flag ? *(volatile uint32_t *)pl->host_flag : 0u;
+    return PMX_OK;
+}
+
 extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
 {
     if (!pl) return PMX_OK;

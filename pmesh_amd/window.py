@@ -129,6 +129,16 @@ class _BinCache(object):
         self.clock += 1
         return self.clock
 
+    def overflows(self, be):
+        """single-pass rebuilds of the pooled plans that had to be repaired by the two-pass
+        build so far (synchronise the stream first for an exact count)"""
+        total = 0
+        for e in self.entries:
+            c = C.c_uint32(0)
+            be.call('binplan_overflows', e[1], C.byref(c))
+            total += int(c.value)
+        return total
+
     def clear(self):
         """forget which batches are binned (the pooled device buffers are kept)"""
         for e in self.entries:
