@@ -301,6 +301,7 @@ def test_full_size_properties(hip, name, dtype):
 
 
 @pytest.mark.parametrize('N,name,dtype,gradient,tol,data', [
+    (64, 'cic', 'f8', None, 1e-11, 'uniform'),      # BASELINE config 1 (the reference's own CPU-runnable case)
     (256, 'cic', 'f8', None, 1e-11, 'uniform'),     # BASELINE config 2 (measured 2.6e-15)
     (512, 'cic', 'f8', None, 1e-11, 'uniform'),     # the headline workload of bench.py (measured 3.9e-15)
     (512, 'tsc', 'f4', 0, 2e-5, 'uniform'),         # BASELINE config 3: TSC + gradient readout, fp32 (1.3e-6)
