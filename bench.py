@@ -87,6 +87,10 @@ def parse():
                          'time-stepping caller): the cycles walk through 3 position sets, each the previous one '
                          'plus N(0, drift) — the single-pass rebuild of the bin plan then works on moved '
                          'particles and its overflow / repair path can trigger; 0: identical positions every cycle')
+    ap.add_argument('--host-arrays', type=int, default=0,
+                    help='1: positions and results are numpy arrays in host memory, as an unmodified nbodykit / '
+                         'fastpm caller passes them: every paint / readout stages them over PCIe (diagnostic: '
+                         'the reported rate then is PCIe inclusive and is NOT the headline metric)')
     ap.add_argument('--fuse-apply', type=int, default=1,
                     help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
     return ap.parse_args()
@@ -311,6 +315,10 @@ def main():
             step = torch.randn(pos.shape, dtype=tdt, device=be.device, generator=gen) * (args.drift * L / N)
             psets.append(psets[-1] + step)
             del step
+    if args.host_arrays:
+        if world > 1 or args.exchange:
+            raise SystemExit('--host-arrays is a single-GPU diagnostic')
+        psets = [q.cpu().numpy() for q in psets]
     layouts = [None] * len(psets)
     layout = None
     t_decompose = 0.0
@@ -341,6 +349,8 @@ def main():
           for _ in range(args.steps)]
 
     result = torch.empty(nloc, dtype=torch.float64, device=be.device)
+    if args.host_arrays:
+        result = numpy.empty(nloc, dtype='f8')
 
     ncycle = [0]
 
@@ -357,7 +367,7 @@ def main():
             layout._memo = None
             layout._memo_remote = None
         mark(0)
-        if layout is None or args.ghosts_only:
+        if (layout is None or args.ghosts_only) and not args.host_arrays:
             pm.resampler.prebin(rho.value, pos, pm.affine)      # tile binning, shared by paint+readout
         mark(1)
         pm.paint(pos, mass=mass, hold=False, layout=layout, out=rho)   # includes the zero fill
@@ -397,7 +407,7 @@ def main():
     if os.environ.get('PMESH_AMD_BENCH_NOCHECK') == '1':      # timing experiments with wrong results
         msum = mtot
     assert abs(msum - mtot) <= 1e-9 * mtot if args.dtype == 'f8' else abs(msum - mtot) <= 1e-3 * mtot, (msum, mtot)
-    assert bool(torch.isfinite(f).all())
+    assert bool(numpy.isfinite(f).all()) if args.host_arrays else bool(torch.isfinite(f).all())
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = ntot / (elapsed / args.steps)
@@ -449,6 +459,7 @@ def main():
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'decompose_ms': round(1e3 * t_decompose, 3),
             'drift_cells': args.drift,
+            'host_arrays': bool(args.host_arrays),
             'bin_overflows': _window.bin_cache().overflows(be),
             'tile_order_ms': round(1e3 * t_order, 3),
             'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu, me) for s in

@@ -6,6 +6,7 @@ are accepted for drop-in compatibility and staged through the device (the
 PCIe-inclusive path; results are copied back into the caller's array).
 """
 import ctypes as C
+import os
 
 import numpy
 import torch
@@ -27,6 +28,36 @@ def touched(*tensors):
     for t in tensors:
         if isinstance(t, torch.Tensor):
             torch.autograd.graph.increment_version(t)
+
+
+# ---- host <-> device staging for numpy callers -------------------------------------------
+# The reference is numpy in / numpy out; a drop-in caller hands pageable host arrays on every
+# call.  Uploads go through torch's own pageable path (measured on the MI355X box: 3.2 GB of
+# positions in ~60 ms, ~53 GB/s — a hand-rolled pair of pinned bounce buffers on a side stream
+# was 5x slower, scripts in the history of this file); downloads land directly in the
+# caller's array when there is one, instead of in a fresh host tensor that is copied again.
+def upload(host, device):
+    """host tensor -> device"""
+    return host.to(device)
+
+
+def to_numpy(t, out=None):
+    """device (or host) tensor -> numpy array; `out`: a numpy array to fill in place"""
+    if out is not None:
+        if (t.device.type == 'cuda' and out.flags.c_contiguous and out.flags.writeable and
+                out.dtype == numpy_dtype_of(t) and out.shape == tuple(t.shape)):
+            torch.from_numpy(out).copy_(t)
+        else:
+            out[...] = t.cpu().numpy()
+        return out
+    return t.cpu().numpy()
+
+
+def numpy_dtype_of(t):
+    try:
+        return numpy_dtype(t.dtype)
+    except KeyError:
+        return None
 
 
 def to_device(x, device, what='array', allow_int=False):
@@ -52,7 +83,7 @@ def to_device(x, device, what='array', allow_int=False):
         raise TypeError('%s must be float32 or float64, got %s '
                         '(Function call with ambiguous argument types)' % (what, t.dtype))
     if t.device != device:
-        t = t.to(device)
+        t = upload(t, device) if host else t.to(device)
     return t, host
 
 

@@ -23,7 +23,7 @@ import numpy
 import torch
 
 from . import _abi, backend
-from ._arrays import touched, to_device, vec, is_tensor, torch_dtype
+from ._arrays import touched, to_device, vec, is_tensor, torch_dtype, to_numpy
 from .comm import default_comm
 
 
@@ -41,9 +41,9 @@ def bincountv(x, weights, minlength=None, dtype=None, out=None):
         if is_tensor(out):
             out.copy_(r)
         else:
-            out[...] = r.cpu().numpy()
+            to_numpy(r, out=out)
         return out
-    return r.cpu().numpy() if host else r
+    return to_numpy(r) if host else r
 
 
 def _scatter_add(be, values, indices, nout):
@@ -164,7 +164,7 @@ class Layout(object):
         else:
             recvbuffer = torch.empty((self.recvlength,) + trailing, dtype=data.dtype, device=be.device)
             self.comm.alltoallv(buffer, self.sendcounts, recvbuffer, self.recvcounts)
-        return recvbuffer.cpu().numpy() if host else recvbuffer
+        return to_numpy(recvbuffer) if host else recvbuffer
 
     # ---- ghosts-only routing --------------------------------------------------------
     # The rows a rank sends to itself are usually almost all of them (particles live on the
@@ -267,9 +267,9 @@ class Layout(object):
                 if is_tensor(out):
                     out.copy_(r)
                 else:
-                    out[...] = r.cpu().numpy()
+                    to_numpy(r, out=out)
                 return out
-            return r.cpu().numpy() if host else r
+            return to_numpy(r) if host else r
 
         if mode == 'local':
             res = torch.empty((self.sendlength,) + trailing, dtype=data.dtype, device=be.device)
@@ -475,7 +475,7 @@ class GridND(object):
         pos, host = to_device(pos, be.device, 'pos')
         if self.primary_region is None:
             r = torch.zeros(len(pos), dtype=torch.bool, device=be.device)
-            return r.cpu().numpy() if host else r
+            return to_numpy(r) if host else r
         chunk = self._transform(pos, transform, be)[..., :self.ndim].to(torch.float64)
         if self.periodic:
             box = torch.tensor([self.edges[j][-1] for j in range(self.ndim)], dtype=torch.float64,
@@ -486,7 +486,7 @@ class GridND(object):
         x1 = torch.from_numpy(self.primary_region['end']).to(be.device)
         for j in range(len(x0)):
             r |= ((chunk >= x0[j]) & (chunk < x1[j])).all(dim=-1)
-        return r.cpu().numpy() if host else r
+        return to_numpy(r) if host else r
 
     @staticmethod
     def _transform(pos, transform, be):

@@ -28,7 +28,7 @@ from numpy.lib.mixins import NDArrayOperatorsMixin as NDArrayLike
 
 from . import backend, domain
 from . import fft as _fft
-from ._arrays import to_device, is_tensor, torch_dtype, numpy_dtype
+from ._arrays import to_device, is_tensor, torch_dtype, numpy_dtype, to_numpy
 from .comm import default_comm
 from .transfer import Transfer
 from .window import FindResampler, Affine
@@ -677,9 +677,9 @@ class RealField(Field):
                 if is_tensor(out):
                     out.copy_(res)
                 else:
-                    out[...] = res.cpu().numpy()
+                    to_numpy(res, out=out)
                 return out
-            return res.cpu().numpy() if host else res
+            return to_numpy(res) if host else res
         localpos = layout.exchange(pos)
         localhsml = exchange(layout, hsml)
         localresult = self.readout(localpos, hsml=localhsml, resampler=resampler, transform=transform,

@@ -18,7 +18,7 @@ import numpy
 import torch
 
 from . import _abi, backend
-from ._arrays import to_device, vec, vec_ref, real_view, is_tensor, touched
+from ._arrays import to_device, vec, vec_ref, real_view, is_tensor, touched, upload, to_numpy
 
 
 def _mkarr(var, shape, dtype):
@@ -299,10 +299,10 @@ class ResampleWindow(object):
         if numpy.iscomplexobj(host):
             host = host.real
         assert host.dtype.kind == 'f' and host.dtype.itemsize in (4, 8)
-        dev = torch.from_numpy(numpy.ascontiguousarray(host)).to(be.device)
+        dev = upload(torch.from_numpy(numpy.ascontiguousarray(host)), be.device)
 
         def writeback():
-            host[...] = dev.cpu().numpy()
+            to_numpy(dev, out=host)
         return dev, writeback
 
     def _particles(self, pos, hsml, be):
@@ -405,7 +405,7 @@ class ResampleWindow(object):
             host = numpy.asarray(real)
             if numpy.iscomplexobj(host):
                 host = host.real
-            canvas = torch.from_numpy(numpy.ascontiguousarray(host)).to(be.device)
+            canvas = upload(torch.from_numpy(numpy.ascontiguousarray(host)), be.device)
         if canvas.dtype not in (torch.float32, torch.float64):
             raise AssertionError("real.dtype.kind == 'f'")
         if transform is None:
@@ -447,10 +447,9 @@ class ResampleWindow(object):
                     be.stream())
         touched(dout)
         if host_out is not None:
-            host_out[...] = dout.cpu().numpy()
-            return host_out
+            return to_numpy(dout, out=host_out)
         if ret_host:
-            return dout.cpu().numpy()
+            return to_numpy(dout)
         return dout
 
 
