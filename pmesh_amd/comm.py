@@ -149,12 +149,21 @@ def _torch_subgroups(self, rank_lists):
 TorchComm.subgroups = _torch_subgroups
 
 
+_self_comm = SelfComm()
+_world_comm = {}
+
+
 def default_comm():
-    """WORLD if torch.distributed is initialised, else the single-process comm."""
+    """WORLD if torch.distributed is initialised, else the single-process comm.  The same
+    object every time (ParticleMesh recognises a communicator it has plans for by identity)."""
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            return TorchComm()
+            key = id(dist.group.WORLD)
+            if key not in _world_comm:
+                _world_comm.clear()
+                _world_comm[key] = TorchComm()
+            return _world_comm[key]
     except Exception:
         pass
-    return SelfComm()
+    return _self_comm

@@ -76,6 +76,23 @@ def promote(data, comm):
     return data
 
 
+def pack_arrays(seq):
+    """
+    Copy a sequence of host arrays of equal length into one structured array, one field per
+    array, each field keeping the trailing shape of its column (domain.py:59-80; what
+    Layout.exchange(pack=True) ships in the reference — here every array travels on its own).
+    """
+    cols = [numpy.asarray(a) for a in seq]
+    lengths = set(c.shape[0] for c in cols)
+    if len(lengths) > 1:
+        raise ValueError('the shape of the data does not match across different columns.')
+    dt = numpy.dtype([('', (c.dtype, c.shape[1:])) for c in cols])
+    out = numpy.empty(lengths.pop() if lengths else 0, dtype=dt)
+    for name, c in zip(dt.names, cols):
+        out[name] = c
+    return out
+
+
 class Layout(object):
     """
     The communication layout of a domain decomposition (domain.py:82-318).

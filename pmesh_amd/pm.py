@@ -20,6 +20,7 @@ import functools
 import numbers
 import operator
 import warnings
+import weakref
 from collections import OrderedDict
 
 import numpy
@@ -1046,6 +1047,11 @@ def _init_o_coords(partition, Nmesh, BoxSize, dtype, device):
     return k, o_ind
 
 
+# ParticleMesh objects by (Nmesh, communicator, process mesh, dtype, plan method): a new object that
+# matches a living one shares its process mesh and plans (pm.py:1362-1404: `_pm_cache`)
+_pm_cache = weakref.WeakValueDictionary()
+
+
 class ParticleMesh(object):
     """
     ParticleMesh provides an interface to solver for forces with particle mesh method
@@ -1063,9 +1069,10 @@ class ParticleMesh(object):
             plan_method : accepted for compatibility (`estimate`, `exhaustive`, `measure`);
                 rocFFT has one planner.
             resampler : string or ResampleWindow, the default window
-            np : the process mesh; None -> slab decomposition [comm.size] of the first axis
-                (the reference defaults 3-d meshes to a pencil pfft.split_size_2d(size),
-                pm.py:1319-1325; pass np=[P0, P1] for a pencil decomposition)
+            np : the process mesh; None -> as the reference (pm.py:1317-1325): 3-d meshes get the
+                pencil decomposition pfft.split_size_2d(comm.size) (8 ranks: [2, 4]), 2-d meshes a
+                slab.  [comm.size] asks for a slab: one global transpose per FFT instead of two,
+                the faster choice on 8 fully connected GPUs (bench.py uses it).
             Nmesh : tuple or alike; len(Nmesh) is the dimension of the system.
         """
         if comm is None:
@@ -1076,7 +1083,19 @@ class ParticleMesh(object):
         if plan_method not in ('estimate', 'measure', 'exhaustive'):
             raise KeyError(plan_method)
         if np is None:
-            if len(Nmesh) >= 2:
+            # the reference's default (pm.py:1317-1325): a 2-d process mesh for 3-d meshes, the
+            # most square factorisation of the communicator; a slab for 2-d meshes
+            if len(Nmesh) >= 3:
+                np = list(_fft.split_size_2d(self.comm.size))
+                if min(np) == 1:
+                    # [1, P] (P prime or 1): one transpose does it — built as the slab [P], which
+                    # distributes axis 0 where PFFT's 1 x P mesh distributes axis 1
+                    if self.comm.size > 1:
+                        warnings.warn('ParticleMesh(np=None) on %d ranks: the reference uses the process mesh %s '
+                                      '(axis 1 distributed); pmesh_amd uses the slab [%d] (axis 0 distributed)'
+                                      % (self.comm.size, np, self.comm.size), stacklevel=2)
+                    np = [self.comm.size]
+            elif len(Nmesh) == 2:
                 np = [self.comm.size]
             else:
                 np = []
@@ -1097,7 +1116,28 @@ class ParticleMesh(object):
         self.BoxSize[:] = BoxSize
         self.dtype = dtype
 
-        procmesh = _fft.ProcMesh(self.np, comm) if len(self.np) else _fft.ProcMesh([1], comm)
+        # A living ParticleMesh of the same mesh, communicator, process mesh and dtype lends its
+        # process mesh (sub-communicators are a limited resource) and its plans (work buffers,
+        # rocFFT plans): pm.py:1346-1404.  Collective: every rank must agree that it has one.
+        cache_key = (tuple(int(x) for x in self.Nmesh), id(comm), comm.rank, comm.size, tuple(self.np),
+                     dtype.str, plan_method, id(backend._current) if backend._current is not None else id(self))
+        template = _pm_cache.get(cache_key)
+        if comm.size > 1:
+            has = comm.allgather(template is not None)
+            if not all(has):
+                template = None
+        self._cache_key = cache_key
+        if template is not None:
+            procmesh = template.procmesh
+            plans = template.plans
+        else:
+            procmesh = _fft.ProcMesh(self.np, comm) if len(self.np) else _fft.ProcMesh([1], comm)
+            plans = self._make_plans(procmesh, is_c2c, rdtype)
+        self._rdtype = rdtype
+        self._finish_init(plans, procmesh, resampler)
+        _pm_cache[cache_key] = self
+
+    def _make_plans(self, procmesh, is_c2c, rdtype):
         plans = OrderedDict()
         plans['partitionT'] = _fft.Partition(self.Nmesh, procmesh, transposed=True, is_c2c=is_c2c,
                                              itemsize=rdtype.itemsize)
@@ -1109,12 +1149,13 @@ class ParticleMesh(object):
             plans['backward' + T] = _fft.Plan(part, False, rdtype, inplace=False)
             plans['ipforward' + T] = _fft.Plan(part, True, rdtype, inplace=True)
             plans['ipbackward' + T] = _fft.Plan(part, False, rdtype, inplace=True)
-        self._rdtype = rdtype
-
         for k in ('forward', 'backward'):
             # out of place in both cases: the transposed plan works into / out of a scratch buffer
             plans[k + 'U'].sibling = plans[k + 'T']
             plans['ip' + k + 'U'].sibling = plans[k + 'T']
+        return plans
+
+    def _finish_init(self, plans, procmesh, resampler):
         # use the transposed partition for configuration space edges (pm.py:1443-1461);
         # here rank r owns block r in C order, so DomainAssign is the identity ramp
         partition = plans['partitionT']

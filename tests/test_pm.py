@@ -664,3 +664,37 @@ def test_c2c_paint_cycle(be, oracle):
     assert_allclose(res['c16'][1].real, res['f8'][1], rtol=0, atol=1e-10 * abs(res['f8'][1]).max())
     assert abs(res['c16'][1].imag).max() < 1e-10 * abs(res['f8'][1]).max()
     assert_allclose(res['c16'][2], res['f8'][2], rtol=0, atol=1e-10 * abs(res['f8'][2]).max())
+
+
+def test_default_process_mesh_and_plan_cache(be):
+    """np=None follows pm.py:1317-1325 (3-d: pfft.split_size_2d, 2-d: a slab); a second ParticleMesh of
+    the same mesh / communicator / dtype shares the plans of the living one (pm.py:1362-1404)."""
+    from pmesh_amd.fft import split_size_2d
+    assert split_size_2d(8) == (2, 4) and split_size_2d(4) == (2, 2) and split_size_2d(6) == (3, 2)
+    assert split_size_2d(1) == (1, 1) and split_size_2d(7) == (1, 7)
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='f8')
+    assert pm.np == [1]                                   # one rank: [1, 1] collapses to the slab [1]
+    assert ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8').np == [1]
+    assert ParticleMesh(BoxSize=8.0, Nmesh=[8], dtype='f8').np == []
+    twin = ParticleMesh(BoxSize=4.0, Nmesh=[8, 8, 8], dtype='f8', resampler='tsc')
+    assert twin.plans is pm.plans and twin.procmesh is pm.procmesh
+    assert twin.resampler is not pm.resampler and float(twin.BoxSize[0]) == 4.0
+    other = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='f4')
+    assert other.plans is not pm.plans
+    # the shared plans serve both objects
+    r = pm.create('real', value=1.0)
+    t = twin.create('real', value=2.0)
+    assert abs(float(r.r2c().c2r().value.mean()) - 1.0) < 1e-12
+    assert abs(float(t.r2c().c2r().value.mean()) - 2.0) < 1e-12
+
+
+def test_pack_arrays():
+    from pmesh_amd.domain import pack_arrays          # domain.py:59-80
+    a = numpy.arange(12.0).reshape(4, 3)
+    b = numpy.arange(4, dtype='i4')
+    s = pack_arrays([a, b])
+    assert s.shape == (4,) and s.dtype[0].shape == (3,) and s.dtype[1] == numpy.dtype('i4')
+    assert_array_equal(s[s.dtype.names[0]], a)
+    assert_array_equal(s[s.dtype.names[1]], b)
+    with pytest.raises(ValueError):
+        pack_arrays([a, b[:3]])
