@@ -100,20 +100,20 @@ class slabiter(object):
 
 
 class xslabiter(slabiter):
-    """ iterating will yield the sparse coordinates of a list of slabs (pm.py:138-153) """
+    """ the coordinate side of a slab iteration: per slab, the broadcastable coordinate arrays
+    with the iteration axis cut down to that slab (pm.py:138-153) """
     def __init__(self, slabiter, axis, nslabs, optx):
-        self.axis = axis
-        self.BoxSize = slabiter.BoxSize
-        self.Nmesh = slabiter.Nmesh
-        self.nslabs = nslabs
-        self.optx = optx
+        self.axis, self.nslabs, self.optx = axis, nslabs, optx
+        self.BoxSize, self.Nmesh = slabiter.BoxSize, slabiter.Nmesh
+
+    def _coords_of(self, irow):
+        # every axis but the iterated one keeps its single broadcast entry
+        return [x[irow if d == self.axis else 0] for d, x in enumerate(self.optx)]
 
     def __iter__(self):
         for irow in range(self.nslabs):
-            kk = [x[0] if d != self.axis else x[irow] for d, x in enumerate(self.optx)]
-            slab = xslab(kk)
-            slab.BoxSize = self.BoxSize
-            slab.Nmesh = self.Nmesh
+            slab = xslab(self._coords_of(irow))
+            slab.BoxSize, slab.Nmesh = self.BoxSize, self.Nmesh
             yield slab
 
 
@@ -190,36 +190,28 @@ class Field(NDArrayLike):
         return self.pm.create(_gettype(self), value=self.value)
 
     def __init__(self, pm, base=None):
-        """ Used internally to add shortcuts of attributes from pm (pm.py:220-265) """
-        partition = pm._get_partition(type(self))
-        base = _fft.LocalBuffer(partition, pm._rdtype, base=base)
-        self._base = base
-        self.pm = pm
-        self._partition = partition
-        self.BoxSize = pm.BoxSize
-        self.Nmesh = pm.Nmesh
-        self.ndim = len(pm.Nmesh)
-
-        if isinstance(self, RealField):
-            self.value = base.view_input()
-            self.start = partition.local_i_start
-            self.cshape = numpy.array([e[-1] for e in partition.i_edges], dtype='intp')
-        elif isinstance(self, (TransposedComplexField, UntransposedComplexField)):
-            self.value = base.view_output()
-            self.start = partition.local_o_start
-            self.cshape = numpy.array([e[-1] for e in partition.o_edges], dtype='intp')
-            self.real = self.value.real
-            self.imag = self.value.imag
-            self.plain = torch.view_as_real(self.value)
-        else:
+        """ bind a local buffer of `pm`'s partition and mirror the attributes callers read off a
+        field (pm.py:220-265): value / start / cshape / shape / size / dtype / slices / csize """
+        if not isinstance(self, (RealField, TransposedComplexField, UntransposedComplexField)):
             raise TypeError("Only RealField and ComplexField. No more subclassing")
-
+        self.pm = pm
+        self.BoxSize, self.Nmesh, self.ndim = pm.BoxSize, pm.Nmesh, len(pm.Nmesh)
+        part = self._partition = pm._get_partition(type(self))
+        buf = self._base = _fft.LocalBuffer(part, pm._rdtype, base=base)
+        if isinstance(self, RealField):
+            self.value, self.start, edges = buf.view_input(), part.local_i_start, part.i_edges
+        else:
+            self.value, self.start, edges = buf.view_output(), part.local_o_start, part.o_edges
+            # views of the same memory: the components and the (…, 2) real layout
+            self.real, self.imag = self.value.real, self.value.imag
+            self.plain = torch.view_as_real(self.value)
+        self.cshape = numpy.array([e[-1] for e in edges], dtype='intp')       # the collective shape
+        self.csize = int(numpy.prod(self.cshape, dtype='i8'))
         self.shape = tuple(self.value.shape)
         self.size = int(numpy.prod(self.shape, dtype='i8'))
         self.dtype = numpy_dtype(self.value.dtype)
-        # the slices in the full array
-        self.slices = tuple([slice(int(s), int(s + n)) for s, n in zip(self.start, self.shape)])
-        self.csize = functools.reduce(operator.mul, [int(x) for x in self.cshape], 1)
+        # where the local block sits in the collective array
+        self.slices = tuple(slice(int(a), int(a) + int(n)) for a, n in zip(self.start, self.shape))
 
     # coordinates are built lazily: the fused kernels never read them
     @property
@@ -269,19 +261,21 @@ class Field(NDArrayLike):
             self.value[index] = t.to(self.value.dtype) if t.dtype != self.value.dtype else t
 
     def _ctol(self, index):
-        index = numpy.array(index, copy=True)
-        if len(index) == self.ndim + 1:
-            value = self.plain
-            index1 = index[:-1]
-        elif len(index) == self.ndim:
-            value = self.value
-            index1 = index
-        else:
+        """ collective index -> (array it addresses, local index or None if another rank owns it);
+        a complex field takes one extra entry, 0 / 1, for the real / imaginary part """
+        index = [int(i) for i in index]
+        nd = self.ndim
+        if len(index) not in (nd, nd + 1):
             raise IndexError("Only vector index in global indexing is supported. for complex append 0 or 1 for real and imag")
-        index1[index1 < 0] += self.Nmesh[index1 < 0]
-        if all(index1 >= self.start) and all(index1 < self.start + self.shape):
-            return value, tuple(list(index1 - self.start) + list(index[self.ndim:]))
-        return value, None
+        target = self.plain if len(index) == nd + 1 else self.value
+        local = []
+        for d in range(nd):
+            g = index[d] + int(self.Nmesh[d]) if index[d] < 0 else index[d]      # negative: from the end
+            l = g - int(self.start[d])
+            if not 0 <= l < self.shape[d]:
+                return target, None
+            local.append(l)
+        return target, tuple(local + index[nd:])
 
     def cgetitem(self, index):
         """ get a value from absolute index collectively (pm.py:287-296). """
@@ -910,8 +904,11 @@ def _ghosts_only(layout, resampler, transform, hsml):
     route = getattr(layout, '_route', None)
     if GHOSTS_ONLY == 'never' or route is None or hsml is not None:
         return False
-    smoothing, scale = route
-    if tuple(float(x) for x in numpy.asarray(transform.scale).ravel()) != scale:
+    smoothing, scale, translate, period = route
+    same = lambda a, b: tuple(float(x) for x in numpy.asarray(a).ravel()) == b
+    # a shifted or re-wrapped transform moves windows relative to the domains the particles were
+    # routed by: only the literal exchange reproduces the reference then
+    if not (same(transform.scale, scale) and same(transform.translate, translate) and same(transform.period, period)):
         return False
     return bool(numpy.all(smoothing >= 0.5 * resampler.support))
 
@@ -1120,7 +1117,8 @@ class ParticleMesh(object):
         # process mesh (sub-communicators are a limited resource) and its plans (work buffers,
         # rocFFT plans): pm.py:1346-1404.  Collective: every rank must agree that it has one.
         cache_key = (tuple(int(x) for x in self.Nmesh), id(comm), comm.rank, comm.size, tuple(self.np),
-                     dtype.str, plan_method, id(backend._current) if backend._current is not None else id(self))
+                     dtype.str, plan_method, bool(_fft.PLANE_PAD),
+                     id(backend._current) if backend._current is not None else id(self))
         template = _pm_cache.get(cache_key)
         if comm.size > 1:
             has = comm.allgather(template is not None)
@@ -1242,16 +1240,15 @@ class ParticleMesh(object):
             value : initialize the field with the values.
         """
         if mode is not None:
-            warnings.warn("argument mode is deprecated. use type=%s instead" % mode, DeprecationWarning, stacklevel=2)
-            if type is None:
-                type = mode
-            else:
+            # the old name of `type`; giving both is a mistake
+            if type is not None:
                 raise ValueError("both mode and type are specified, possiblity arguments are arranged in wrong order")
-        type = _typestr_to_type(type)
-        r = type(self, base=base)
+            warnings.warn("argument mode is deprecated. use type=%s instead" % mode, DeprecationWarning, stacklevel=2)
+            type = mode
+        field = _typestr_to_type(type)(self, base=base)
         if value is not None:
-            r[...] = value
-        return r
+            field[...] = value
+        return field
 
     def mesh_coordinates(self, dtype=None):
         """ integer coordinates of the local mesh points, (N, ndim) on the device (pm.py:1698-1703) """
@@ -1369,22 +1366,21 @@ class ParticleMesh(object):
             if given as a string or ResampleWindow, use 0.5 * support: the size of the buffer
             region around a domain.  Default: None, use self.resampler
         """
-        if smoothing is None:
-            smoothing = self.resampler
+        # a window (object or registered name) stands for half its support; numbers pass through
+        window = self.resampler if smoothing is None else smoothing
         try:
-            smoothing = FindResampler(smoothing)
-            smoothing = smoothing.support * 0.5
+            smoothing = 0.5 * FindResampler(window).support
         except TypeError:
-            pass
-        if transform is None:
-            transform = self.affine
+            smoothing = window
+        transform = self.affine if transform is None else transform
         # Transform from simulation unit to global grid unit: transform0(x) = scale * x; the
         # shift is local per processor, thus not used.  The scaling runs inside the kernel.
         layout = self.domain.decompose(pos, smoothing=smoothing, _scale=transform.scale)
         # what the routing guarantees (see _ghosts_only): every particle was sent to every rank
         # that holds a cell within `smoothing` cells of it
+        flat = lambda a: tuple(float(x) for x in numpy.asarray(a).ravel())
         layout._route = (numpy.broadcast_to(numpy.asarray(smoothing, dtype='f8'), (self.ndim,)).copy(),
-                         tuple(float(x) for x in numpy.asarray(transform.scale).ravel()))
+                         flat(transform.scale), flat(self.affine.translate), flat(self.affine.period))
         return layout
 
     def paint(self, pos, hsml=None, mass=1.0, resampler=None, transform=None, hold=False,
@@ -1399,13 +1395,9 @@ class ParticleMesh(object):
 
         The painter operation conserves the total mass. It is not the density.
         """
-        if not transform:
-            transform = self.affine
-        if resampler is None:
-            resampler = self.resampler
-        resampler = FindResampler(resampler)
-        if out is None:
-            out = self.create(type=RealField)
+        transform = transform or self.affine
+        resampler = FindResampler(self.resampler if resampler is None else resampler)
+        out = self.create(type=RealField) if out is None else out
         if layout is None:
             # hold=False: "out.value[...] = 0" (pm.py:1852-1853) is folded into the kernel
             resampler.paint(out.value, pos, hsml=hsml, mass=mass, transform=transform, diffdir=gradient,
