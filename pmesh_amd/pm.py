@@ -1085,9 +1085,10 @@ class ParticleMesh(object):
             if len(Nmesh) >= 3:
                 np = list(_fft.split_size_2d(self.comm.size))
                 if min(np) == 1:
-                    # [1, P] (P prime or 1): one transpose does it — built as the slab [P], which
-                    # distributes axis 0 where PFFT's 1 x P mesh distributes axis 1
-                    if self.comm.size > 1:
+                    # a degenerate process mesh is a slab.  [P, 1] distributes axis 0: exactly the
+                    # slab [P] built here.  [1, P] (P = 3, 5, 7, ...) distributes axis 1 under PFFT;
+                    # it is built as the slab [P] too (axis 0 distributed) — said aloud.
+                    if np[0] == 1 and np[1] > 1:
                         warnings.warn('ParticleMesh(np=None) on %d ranks: the reference uses the process mesh %s '
                                       '(axis 1 distributed); pmesh_amd uses the slab [%d] (axis 0 distributed)'
                                       % (self.comm.size, np, self.comm.size), stacklevel=2)
