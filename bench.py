@@ -387,6 +387,8 @@ def main():
 
     for _ in range(args.warmup):
         cycle()
+    from pmesh_amd import comm as _comm
+    records = _comm.trace(True) if world > 1 else None
     comm.Barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -397,6 +399,20 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = comm.allreduce(elapsed, op='max') if world > 1 else elapsed
 
+    comm_line = None
+    if records is not None:
+        _comm.trace(False)
+        cs = _comm.trace_summary([r for r in records if r[4] is not None])
+        XGMI_LINK_GBS = 153.0                      # MI355X: 7 point-to-point links per GPU, ~153 GB/s each
+        comm_line = {
+            'collectives_per_cycle': cs['collectives'] / float(args.steps),
+            'bytes_sent_per_rank_per_cycle': cs['bytes_sent'] / float(args.steps),
+            'sync_ms_per_cycle': cs['sync_ms'] / args.steps,
+            'overlapped_window_ms_per_cycle': cs['overlapped_window_ms'] / args.steps,
+            # the exchange step of the path against its own bound: one xGMI link per peer
+            'roofline': {'bound': 'xgmi link', 'achieved': cs['max_link_GBs'], 'peak': XGMI_LINK_GBS, 'unit': 'GB/s',
+                         'frac': cs['max_link_GBs'] / XGMI_LINK_GBS},
+        }
     stage_ms = {}
     for i, s in enumerate(stages):
         stage_ms[s] = sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
@@ -458,6 +474,10 @@ def main():
                        'fft': 'LDS row + column FFT kernels' if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'decompose_ms': round(1e3 * t_decompose, 3),
+            # the exchange reported both ways — `value` has decompose outside the cycle
+            'ms_per_step_with_decompose': ms_per_step + 1e3 * t_decompose,
+            'value_with_decompose': ntot / (elapsed / args.steps + t_decompose),
+            'comm': comm_line,
             'drift_cells': args.drift,
             'host_arrays': bool(args.host_arrays),
             'bin_overflows': _window.bin_cache().overflows(be),

@@ -20,6 +20,54 @@ import numpy
 import torch
 
 
+# ---- optional record of the collectives of the data path (bench.py --gpus N) ----------------
+# trace(True) starts a list of [kind, bytes this rank sends to OTHER ranks, peers, start, end,
+# overlapped]; start / end are CUDA events on the issuing stream (host clock readings for host
+# tensors).  `overlapped` marks exchanges issued asynchronously: their window contains the kernels
+# that ran underneath.
+_trace = None
+
+
+def trace(on=True):
+    global _trace
+    _trace = [] if on else None
+    return _trace
+
+
+def _stamp(t):
+    if t.is_cuda:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(t.device))
+        return e
+    import time
+    return time.perf_counter()
+
+
+def trace_summary(records):
+    """-> dict of totals over `records` (call after a device synchronisation)"""
+    out = {'collectives': len(records), 'bytes_sent': 0, 'sync_ms': 0.0, 'overlapped_window_ms': 0.0,
+           'max_link_GBs': 0.0}
+    for kind, nbytes, peers, a, b, overlapped in records:
+        ms = a.elapsed_time(b) if hasattr(a, 'elapsed_time') else 1e3 * (b - a)
+        out['bytes_sent'] += nbytes
+        out['overlapped_window_ms' if overlapped else 'sync_ms'] += ms
+        if not overlapped and peers and ms > 0:
+            # xGMI is point to point: one link per peer carries this rank's share for that peer
+            out['max_link_GBs'] = max(out['max_link_GBs'], nbytes / peers / (ms * 1e-3) / 1e9)
+    return out
+
+
+class _Traced(object):
+    """completes a trace record when the asynchronous exchange is waited for"""
+    def __init__(self, work, rec, t):
+        self.work, self.rec, self.t = work, rec, t
+
+    def wait(self):
+        r = self.work.wait()
+        self.rec[4] = _stamp(self.t)
+        return r
+
+
 class _Done(object):
     """handle of an exchange that has already happened"""
     def wait(self):
@@ -118,20 +166,42 @@ class TorchComm(object):
 
     def alltoallv(self, send, sendcounts, recv, recvcounts):
         """rows of `send` (first axis) split by sendcounts -> rows of `recv`."""
+        rec = None
+        if _trace is not None:
+            row = send.element_size() * (send.numel() // max(1, send.shape[0])) if send.dim() else send.element_size()
+            away = (int(numpy.sum(sendcounts)) - int(sendcounts[self.rank])) * row
+            rec = ['alltoallv', away, self.size - 1, _stamp(send), None, False]
         self._dist.all_to_all_single(recv, send,
                                      output_split_sizes=[int(c) for c in recvcounts],
                                      input_split_sizes=[int(c) for c in sendcounts],
                                      group=self.group)
+        if rec is not None:
+            rec[4] = _stamp(send)
+            _trace.append(rec)
 
     def alltoall(self, send, recv, send_splits=None, recv_splits=None, async_op=False):
         """async_op: returns a handle whose wait() orders the *current stream* (RCCL) / the host
         (gloo) after the exchange; the buffers must stay untouched until then"""
+        rec = None
+        if _trace is not None:
+            total = send.numel() * send.element_size()
+            if send_splits is None:
+                away = total - total // self.size
+            else:
+                row = total // max(1, send.shape[0])
+                away = (int(sum(send_splits)) - int(send_splits[self.rank])) * row
+            rec = ['alltoall', away, self.size - 1, _stamp(send), None, bool(async_op)]
         if send_splits is None:
             w = self._dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
         else:
             w = self._dist.all_to_all_single(recv, send, output_split_sizes=list(recv_splits),
                                              input_split_sizes=list(send_splits), group=self.group,
                                              async_op=async_op)
+        if rec is not None:
+            _trace.append(rec)
+            if async_op:
+                return _Traced(w, rec, send)
+            rec[4] = _stamp(send)
         return w if async_op else None
 
 

@@ -499,7 +499,31 @@ def case_pencil(be, comm):
     assert abs(f - out[share]).max() <= 1e-11 * abs(out).max()
 
 
-CASES = [case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+def case_comm_trace(be, comm):
+    """the record of the data-path collectives that bench.py --gpus N reports (pmesh_amd.comm.trace):
+    a slab FFT round trip moves the whole half spectrum twice, (P-1)/P of it off rank"""
+    from pmesh_amd import comm as C
+    from pmesh_amd.pm import ParticleMesh
+    if not hasattr(comm, '_dist'):
+        return                                       # thread ranks: no torch.distributed collectives
+    N = 16
+    pm = ParticleMesh(BoxSize=1.0, Nmesh=[N, N, N], comm=comm, dtype='f8', np=[comm.size])
+    rho = pm.create('real', value=1.0)
+    rec = C.trace(True)
+    back = rho.r2c().c2r()
+    C.trace(False)
+    assert abs(float(numpy.asarray(back.value).mean()) - 1.0) < 1e-12
+    s = C.trace_summary(rec)
+    assert s['collectives'] >= 2 and s['bytes_sent'] > 0 and s['sync_ms'] + s['overlapped_window_ms'] > 0
+    # both transposes together: 2 x (local share of the N x N x (N/2+1) complex128 spectrum) x (P-1)/P,
+    # up to the uneven split of the last rank
+    P = comm.size
+    total = comm.allreduce(float(s['bytes_sent']))
+    full = 2 * N * N * (N // 2 + 1) * 16.0 * (P - 1) / P
+    assert 0.7 * full <= total <= 1.3 * full, (total, full)
+
+
+CASES = [case_comm_trace, case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 
