@@ -1,26 +1,31 @@
 #!/bin/bash
-# the measured table of DESIGN.md: one bench.py line per configuration -> gpurun_out/sweep/*.json
-out=gpurun_out/sweep; mkdir -p $out
-i=0
-while read -r name args; do
-  [ -z "$name" ] && continue
-  timeout 900 python bench.py $args --no-cpu-baseline > $out/$name.json 2> $out/$name.err
-  python - "$name" <<'PY'
+# one bench.py line per configuration of the measured table in DESIGN.md -> gpurun_out/<tag>/*.json
+tag=${1:-sweep}; out=gpurun_out/$tag; mkdir -p $out
+run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline "$@" > $out/$name.json 2> $out/$name.err; python - $out/$name.json $name <<'PY'
 import json, sys
-n=sys.argv[1]
-d=json.loads(open("gpurun_out/sweep/%s.json" % n).read().strip().splitlines()[-1]); st=d["stages_ms"]
-print("%-14s %8.3f ms %.3e p/s  bin %.2f paint %.2f r2c %.2f c2r %.2f readout %.2f" % (n, d["ms_per_step"], d["value"], st["bin"], st["paint"], st["r2c"], st["c2r"], st["readout"]))
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); st = d['stages_ms']
+    print('%-22s %8.3f ms %.3e p/s  bin %.2f paint %.2f r2c %.2f c2r %.2f readout %.2f  frac %.3f with_bin %.3f ovf %d' % (
+        sys.argv[2], d['ms_per_step'], d['value'], st['bin'], st['paint'], st['r2c'], st['c2r'], st['readout'],
+        d['roofline']['frac'], d['roofline']['with_bin_frac'], d['bin_overflows']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
 PY
-done <<'CFG'
-headline --mesh 512
-clustered --mesh 512 --data clustered
-c2_256 --mesh 256
-c3_tsc_f4 --mesh 512 --window tsc --dtype f4 --gradient 0
-tsc_f8 --mesh 512 --window tsc
-pcs_f8 --mesh 512 --window pcs
-cic_f4 --mesh 512 --dtype f4
-m384 --mesh 384
-m768 --mesh 768
-m1024 --mesh 1024 --steps 5
-c5_shard --mesh 1024 --double 1 --mass array --window pcs --data clustered --steps 5
-CFG
+}
+run headline
+run headline_nodrift --drift 0
+run clustered --data clustered
+run config2_256 --mesh 256
+run config3_tsc_f4_grad --window tsc --dtype f4 --gradient 0
+run tsc_f8 --window tsc
+run pcs_f8 --window pcs
+run cic_f4 --dtype f4
+run m384 --mesh 384
+run m768 --mesh 768 --steps 5
+run m1024 --mesh 1024 --steps 5
+run c5_shard --mesh 1024 --double 1 --mass array --window pcs --data clustered --steps 3 --warmup 1
+run shuffled --data shuffled --steps 5
+run host_arrays --host-arrays 1 --steps 5
+PMESH_AMD_WALK=always run walk_tsc_f8 --window tsc
+PMESH_AMD_WALK=always run walk_pcs_f8 --window pcs
+PMESH_AMD_WALK=always run walk_config3 --window tsc --dtype f4 --gradient 0
