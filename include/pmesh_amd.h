@@ -141,6 +141,15 @@ int pmx_binplan_destroy(pmx_binplan *plan);
  * on MI355X: DESIGN.md).  Same results either way (readout bit-identical, paint up to the order
  * of the additions into a cell). */
 int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
+/* Rows without spatial coherence (catalogues in file order, shuffled sets) make every access
+ * through the index list a sector of its own.  A plan can instead carry a copy of the positions
+ * in tile order (one gather per build): paint and readout stream it, readout writes its results
+ * in tile order and pulls them back through the inverse list.  pref: -1 (default) = decided by
+ * the first build of a geometry from the measured coherence of the row order (more than 16
+ * distinct tiles per 64 consecutive rows), 0 = never, 1 = always, -2 = leave unchanged.
+ * is_sorted (optional): whether the plan as built carries the copy.  Results do not depend on it
+ * (readout bit-identical, paint up to the order of the additions). */
+int pmx_binplan_sorted(pmx_binplan *plan, int32_t pref, int32_t *is_sorted);
 /* How many builds of this plan so far found the slot ranges of their previous build too small
  * (particles moved a lot) and fell back to the exact two-pass build on the device.  Host
  * counter, written by the device: exact once the stream has been synchronised. */

@@ -53,12 +53,18 @@ __host__ __device__ __forceinline__ int64_t slot_capacity(int64_t c) { return c 
 // Particles that touch no local cell go to bucket `ntiles`.  gate != NULL: do nothing unless
 // *gate != 0 (the fallback launches after a single-pass build are always enqueued and only
 // run if it overflowed — no host synchronisation).
-template <int KIND, bool DENSE, int MODE, bool WALK>
+template <int KIND, bool DENSE, int MODE, bool WALK, bool SORTP>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
                                                            int32_t *tid, uint32_t *counts, uint32_t *flags,
                                                            const int64_t *offsets, uint32_t *list,
-                                                           uint32_t *host_flag, const uint32_t *gate)
+                                                           uint32_t *host_flag, const uint32_t *gate, uint32_t *inv_)
 {
+    // SORTP: the plan keeps a tile-ordered copy of the positions: the inverse list is recorded, and
+    constexpr bool noagg = SORTP && MODE == 1;
+    uint32_t *const inv = SORTP ? inv_ : nullptr;
+    // noagg: the rows are known to be in no spatial order (the plan keeps a tile-ordered copy):
+    // every lane then has a tile of its own and the search for equal tiles, up to 64 rounds of
+    // ballots per chunk, finds nothing to merge — every lane adds for itself
     constexpr int S = Tuned<KIND>::S;
     // particle chunks per trip: U independent load -> atomic chains per wave.  The single-pass
     // mode waits for its atomics to return: fewer registers / less LDS per block, more waves
@@ -73,6 +79,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
     // chunk (c mod G) * Q + c / G: G = 256 interleaved streams.
     const int64_t nchunks = (n + TBLOCK * U - 1) / (TBLOCK * U);
     const int64_t G = nchunks < 256 ? nchunks : 256, Q = (nchunks + G - 1) / G;
+    uint32_t nbreaks = 0, nsampled = 0;   // see below: one add per wave at the end, not one per chunk
     for (int64_t c = blockIdx.x; c < G * Q; c += gridDim.x) {
         const int64_t chunk = (c % G) * Q + c / G;
         if (chunk >= nchunks) continue;
@@ -138,15 +145,27 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
             }
             // wave-aggregated counting: find the lanes that share my tile (ballots only)
             same[u] = 0;
-            unsigned long long active = __ballot(t[u] >= 0);
-            while (active) {
-                int leader = __ffsll((long long)active) - 1;
-                int lt = __shfl(t[u], leader);
-                unsigned long long m = __ballot(t[u] == lt) & active;
-                if (t[u] == lt) same[u] = m;
-                active &= ~m;
+            if (noagg) {
+                if (t[u] >= 0) same[u] = 1ull << lane;
+            } else {
+                unsigned long long active = __ballot(t[u] >= 0);
+                while (active) {
+                    int leader = __ffsll((long long)active) - 1;
+                    int lt = __shfl(t[u], leader);
+                    unsigned long long m = __ballot(t[u] == lt) & active;
+                    if (t[u] == lt) same[u] = m;
+                    active &= ~m;
+                }
             }
         }
+        // coherence of the row order (flags[1]), sampled on one chunk in 32 (pseudo-randomly chosen): lanes whose tile differs
+        // from their neighbour's — a few per 64 rows in lattice order, ~63 for rows in random order
+        if ((((uint32_t)chunk * 2654435761u) >> 27) == 0) {      // (hashed: a regular stride would alias with the lattice)
+            const int tprev = __shfl_up(t[0], 1);
+            nbreaks += (uint32_t)__popcll(__ballot(lane > 0 && t[0] >= 0 && t[0] != tprev));
+            nsampled += (uint32_t)__popcll(__ballot(t[0] >= 0));
+        }
+
         // ONE atomicAdd instruction per chunk for the whole wave (the first lane of every
         // group adds the group's population)
         if (MODE == 0) {
@@ -179,11 +198,17 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                 const int64_t start = __shfl(o0[u], leader), end = __shfl(o1[u], leader);
                 if (t[u] >= 0) {
                     int64_t slot = start + bb + __popcll(same[u] & (((unsigned long long)1 << lane) - 1));
-                    if (slot < end) list[slot] = (uint32_t)i;
-                    else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
+                    if (slot < end) {
+                        list[slot] = (uint32_t)i;
+                        if (inv) inv[i] = (uint32_t)slot;
+                    } else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
                 }
             }
         }
+    }
+    if (lane == 0 && nsampled) {
+        atomicAdd(&flags[1], nbreaks);
+        atomicAdd(&flags[2], nsampled);
     }
 }
 
@@ -220,7 +245,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, 
 }
 
 __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
-                                                             uint32_t *list, const uint32_t *gate)
+                                                             uint32_t *list, const uint32_t *gate, uint32_t *inv)
 {
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
@@ -253,10 +278,40 @@ __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid,
             int64_t i = base + u * TBLOCK + threadIdx.x;
             const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
             unsigned long long bb = __shfl(b[u], leader);
-            if (t[u] >= 0)
-                list[bb + (unsigned long long)__popcll(same[u] & (((unsigned long long)1 << lane) - 1))] = (uint32_t)i;
+            if (t[u] >= 0) {
+                const unsigned long long slot = bb + (unsigned long long)__popcll(same[u] & (((unsigned long long)1 << lane) - 1));
+                list[slot] = (uint32_t)i;
+                if (inv) inv[i] = (uint32_t)slot;
+            }
         }
     }
+}
+
+// positions in list (tile) order: copy[slot] = pos[list[slot]] for the used slots of every bucket.
+// One lane per 4-byte word of the output: the words of a row are read by adjacent lanes, the output
+// is written in order.  WPR: words per row (3 floats: 3, 3 doubles: 6).
+template <int WPR>
+__global__ void __launch_bounds__(TBLOCK) sort_copy_kernel(const uint32_t *list, const int64_t *offsets,
+                                                           const uint32_t *counts, int64_t nbuckets, DVec pos, uint32_t *copy)
+{
+    constexpr int WPE = WPR / 3;                 // words per element
+    for (int64_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const int64_t start = offsets[b];
+        const int nwords = (int)counts[b] * WPR;
+        for (int w = threadIdx.x; w < nwords; w += TBLOCK) {
+            const int j = w / WPR, k = w - j * WPR;
+            const int64_t i = (int64_t)list[start + j];
+            const char *src = pos.data + i * pos.stride0 + (k / WPE) * pos.stride1 + (k % WPE) * 4;
+            copy[(start + j) * WPR + k] = *(const uint32_t *)src;
+        }
+    }
+}
+
+// out[i] = sorted[inv[i]]: the results of a readout in list order back into row order
+__global__ void __launch_bounds__(TBLOCK) unsort_kernel(const double *sorted, const uint32_t *inv, int64_t n, DVec out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * TBLOCK)
+        out.set(i, 0, sorted[inv[i]]);
 }
 
 __global__ void __launch_bounds__(TBLOCK) bin_zero_kernel(uint32_t *counts, int64_t nbuckets, const uint32_t *gate)
@@ -329,12 +384,15 @@ template <int KIND> struct TileThreads<KIND, float> {
     static constexpr int readout = PMX_TILE_THREADS_RF4;
 };
 
-template <int KIND, typename T, int TTHREADS>
+template <int KIND, typename T, int TTHREADS, bool SORTED>
 __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
                                                             const uint32_t *counts, T *halo, int overwrite)
 {
+    constexpr bool sorted = SORTED;
+    // SORTED: `pos` is the plan's copy of the positions in list order (row = list slot);
+    // the list itself is then only read for a per-particle mass
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
@@ -399,13 +457,14 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
                 int j = j0 + u * TTHREADS;
-                idx[u] = j < count ? (int64_t)list[start + j] : -1;
+                idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
                 if (idx[u] >= 0) {
                     x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
-                    m[u] = mass.data ? mass.get(idx[u], 0) : mass_scalar;
+                    // (sorted: idx is the list slot; a per-particle mass lives at the row the list names)
+                    m[u] = mass.data ? mass.get(sorted ? (int64_t)list[idx[u]] : idx[u], 0) : mass_scalar;
                 }
             }
 #pragma unroll
@@ -504,19 +563,22 @@ __global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGe
 
 // entries of `out` for particles that are in no tile (they touch no local cell) read 0
 __global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint32_t *list, const int64_t *offsets,
-                                                              const uint32_t *counts, int64_t ntiles, DVec out)
+                                                              const uint32_t *counts, int64_t ntiles, DVec out, int sorted)
 {
     const int64_t n = counts[ntiles];   // the common case: nothing was dropped
     const int64_t start = offsets[ntiles];
     for (int64_t j = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * TBLOCK)
-        out.set((int64_t)list[start + j], 0, 0.0);
+        out.set(sorted ? start + j : (int64_t)list[start + j], 0, 0.0);
 }
 
-template <int KIND, typename T, int TTHREADS>
+template <int KIND, typename T, int TTHREADS, bool SORTED>
 __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                               DVec pos, DVec out, const uint32_t *list,
                                                               const int64_t *offsets, const uint32_t *counts)
 {
+    constexpr bool sorted = SORTED;
+    // SORTED: `pos` is the plan's copy of the positions in list order and `out` its buffer of
+    // results in list order (unsort_kernel pulls them back): nothing is gathered or scattered
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
@@ -542,7 +604,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
                 int j = j0 + u * TTHREADS;
-                idx[u] = j < count ? (int64_t)list[start + j] : -1;
+                idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
@@ -634,6 +696,18 @@ extern "C" int pmx_binplan_configure(pmx_binplan *pl, int32_t form)
     return PMX_OK;
 }
 
+extern "C" int pmx_binplan_sorted(pmx_binplan *pl, int32_t pref, int32_t *is_sorted)
+{
+    PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
+    PMX_REQUIRE(pref >= -2 && pref <= 1, PMX_EINVAL, "pref must be -1 (auto), 0 (never), 1 (always) or -2 (query only)");
+    if (pref >= -1 && pl->sort_pref != pref) {
+        pl->sort_pref = pref;
+        pl->have_history = false;
+    }
+    if (is_sorted) *is_sorted = pl->built && pl->sorted ? 1 : 0;
+    return PMX_OK;
+}
+
 extern "C" int pmx_binplan_overflows(pmx_binplan *pl, uint32_t *count)
 {
     PMX_REQUIRE(pl != nullptr && count != nullptr, PMX_EINVAL, "NULL argument");
@@ -653,6 +727,10 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->host_flag) (void)hipHostFree(pl->host_flag);
     if (pl->halo) (void)hipFree(pl->halo);
     if (pl->unit_flags) (void)hipFree(pl->unit_flags);
+    if (pl->pos_copy) (void)hipFree(pl->pos_copy);
+    if (pl->inv) (void)hipFree(pl->inv);
+    if (pl->out_sorted) (void)hipFree(pl->out_sorted);
+    if (pl->host_groups) (void)hipHostFree(pl->host_groups);
     delete pl;
     return PMX_OK;
 }
@@ -735,7 +813,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     // and particle count (a time-stepping caller: particles move a fraction of a tile per
     // step) and reuse has not just failed (back-off after an overflow).
     bool reuse = pl->built && pl->have_history && pl->npart == npart && npart > 0 &&
-                 same_geometry(p, pl->painter) && pl->g.ntiles == g.ntiles && pl->g.walk == g.walk;
+                 same_geometry(p, pl->painter) && pl->g.ntiles == g.ntiles && pl->g.walk == g.walk &&
+                 (!pl->sorted || pl->cap_copy >= pl->cap_list * 3 * (size_t)pos->elsize);
     if (pl->host_flag) {
         uint32_t seen = *(volatile uint32_t *)pl->host_flag;   // stale at worst: a hint only
         if (seen != pl->seen_overflows) {
@@ -793,12 +872,17 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         // contiguous (n, 3) rows on a 16-byte boundary take the dense staging path
         const bool dense = pos->stride1 == pos->elsize && pos->stride0 == 3 * (int64_t)pos->elsize &&
                            (((uintptr_t)pos->data) & 15) == 0;
-#define BC(K, MODE, GRID, GATE, W)                                                                                 \
+#define BC2(K, MODE, GRID, GATE, W, SP)                                                                           \
     do {                                                                                                        \
-        if (dense) bin_count_kernel<K, true, MODE, W><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
-                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE);                                         \
-        else bin_count_kernel<K, false, MODE, W><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
-                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE);                                         \
+        if (dense) bin_count_kernel<K, true, MODE, W, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv);                                    \
+        else bin_count_kernel<K, false, MODE, W, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv);                                    \
+    } while (0)
+#define BC(K, MODE, GRID, GATE, W)                                                                              \
+    do {                                                                                                        \
+        if (inv != nullptr && !W) BC2(K, MODE, GRID, GATE, false, true);                                        \
+        else BC2(K, MODE, GRID, GATE, W, false);                                                                \
     } while (0)
 #define BCK(MODE, GRID, GATE)                                                                                   \
     do {                                                                                                        \
@@ -810,22 +894,69 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         }                                                                                                       \
     } while (0)
         const uint32_t *nogate = nullptr;
+        uint32_t *inv = nullptr;
+        if (!pl->host_groups) {
+            PMX_HIP_CHECK(hipHostMalloc((void **)&pl->host_groups, 64, hipHostMallocDefault));
+            pl->host_groups[0] = 0;                 // breaks of the tile sequence among ...
+            pl->host_groups[1] = 0;                 // ... this many sampled rows of the last build
+            pl->host_groups[2] = 0;                 // particles of that build
+        }
+        // breaks of the tile sequence per 64 consecutive rows above which the row order counts as
+        // incoherent (lattice order: a handful; random order: 63)
+        auto incoherent = [&](double breaks, double rows) { return breaks * 64.0 > 24.0 * rows; };
+        if (reuse && pl->sort_pref < 0 && !walk && pl->host_groups[2] == (uint32_t)npart && pl->host_groups[1] > 4096 &&
+            incoherent(pl->host_groups[0], (double)pl->host_groups[1]) != pl->sorted)
+            reuse = false;       // the order of the rows changed its character since the plan was built: start over
+        if (!reuse) pl->sorted = false;
         if (reuse) {
             // single pass into the previous slot ranges; if a tile overflowed (flags[0]) the
-            // exact two-pass build below runs, otherwise its kernels return at once
+            // exact two-pass build below runs, otherwise its kernels return at once.  Whether the
+            // plan carries the tile-ordered copy was decided by its first build.
+            inv = pl->sorted ? pl->inv : nullptr;
             BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
             const uint32_t *gate = pl->flags;
             bin_zero_kernel<<<64, TBLOCK, 0, st>>>(pl->counts, nbuckets, gate);
             BCK(0, small_grid, gate);
             bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, gate);
-            bin_scatter_kernel<<<small_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, gate);
+            bin_scatter_kernel<<<small_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, gate, inv);
         } else {
             BCK(0, full_grid, nogate);
+            // First build of a geometry: how coherent is the row order?  (the only host
+            // synchronisation of a plan's life; history rebuilds keep the answer)
+            bool want = pl->sort_pref == 1;
+            if (pl->sort_pref < 0 && !walk && npart >= (1 << 16)) {
+                PMX_HIP_CHECK(hipMemcpyAsync(pl->host_groups, pl->flags + 1, 8, hipMemcpyDeviceToHost, st));
+                PMX_HIP_CHECK(hipStreamSynchronize(st));
+                pl->host_groups[2] = (uint32_t)npart;
+                want = pl->host_groups[1] > 0 && incoherent(pl->host_groups[0], (double)pl->host_groups[1]);
+            }
+            if (want && !walk) {
+                const size_t es = (size_t)pos->elsize;
+                rc = plan_ensure(&pl->pos_copy, &pl->cap_copy, pl->cap_list * 3 * es); if (rc) return rc;
+                size_t ci = pl->cap_inv * 4;
+                rc = plan_ensure((void **)&pl->inv, &ci, np1 * 4); if (rc) return rc;
+                pl->cap_inv = ci / 4;
+                pl->sorted = true;
+                inv = pl->inv;
+            }
             bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate);
-            bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate);
+            bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate, inv);
         }
 #undef BCK
 #undef BC
+#undef BC2
+        if (reuse && pl->sort_pref < 0 && !walk) {
+            // what this build saw of the row order, read by the NEXT build (stale at worst: a hint)
+            PMX_HIP_CHECK(hipMemcpyAsync(pl->host_groups, pl->flags + 1, 8, hipMemcpyDeviceToHost, st));
+            pl->host_groups[2] = (uint32_t)npart;
+        }
+        if (pl->sorted) {
+            const unsigned cgrid = (unsigned)(nbuckets < 65535 * 8 ? nbuckets : 65535 * 8);
+            if (pos->elsize == 8)
+                sort_copy_kernel<6><<<cgrid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, nbuckets, dpos, (uint32_t *)pl->pos_copy);
+            else
+                sort_copy_kernel<3><<<cgrid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, nbuckets, dpos, (uint32_t *)pl->pos_copy);
+        }
     } else {
         bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nullptr);
     }
@@ -847,7 +978,16 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     const int64_t nwork = (g.ntiles / g.nt[2]) * ((g.nt[2] + ZSEG - 1) / ZSEG);   // z segments of tiles
     unsigned pgrid = (unsigned)(nwork < 65535 * 8 ? nwork : 65535 * 8);
     T *halo = (T *)pl->halo;
-#define PT(K) paint_tile_kernel<K, T, TileThreads<K, T>::paint><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite)
+    const int sorted = pl->sorted ? 1 : 0;
+    if (sorted) {
+        // stream the plan's copy of the positions (dense rows of 3 elements, list order)
+        const int es = pos.elsize;
+        pos.data = (const char *)pl->pos_copy;
+        pos.stride0 = 3 * es;
+        pos.stride1 = es;
+    }
+#define PT(K) do { if (sorted) paint_tile_kernel<K, T, TileThreads<K, T>::paint, true><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite); \
+                   else paint_tile_kernel<K, T, TileThreads<K, T>::paint, false><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite); } while (0)
 #define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
@@ -896,13 +1036,28 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     hipStream_t st = (hipStream_t)stream;
     DVec dout = dvec(out), dpos = dvec(pos);
     // particles that touch no local cell are in no tile: they read 0
-    zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout);
+    const int sorted = pl->sorted ? 1 : 0;
+    const DVec caller_out = dout;
+    if (sorted) {
+        size_t cb = pl->cap_out * 8;
+        int rc = plan_ensure((void **)&pl->out_sorted, &cb, pl->cap_list * 8);
+        if (rc) return rc;
+        pl->cap_out = cb / 8;
+        const int es = dpos.elsize;
+        dpos.data = (const char *)pl->pos_copy;
+        dpos.stride0 = 3 * es;
+        dpos.stride1 = es;
+        dout.data = (const char *)pl->out_sorted;
+        dout.stride0 = 8; dout.stride1 = 0; dout.elsize = 8;
+    }
+    zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
     if (g.walk) {
         PMX_REQUIRE(walk_layout_ok(pos), PMX_EINVAL, "positions are not laid out as at pmx_binplan_build");
         return readout_walk(pl, p, canvas, dpos, dout, st);
     }
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-#define RT(K, T) readout_tile_kernel<K, T, TileThreads<K, T>::readout><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts)
+#define RT(K, T) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
+                      else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)
     if (p.canvas_elsize == 8) {
         switch (p.kind) {
         case PMX_TUNED_NNB: RT(PMX_TUNED_NNB, double); break;
@@ -919,6 +1074,8 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         }
     }
 #undef RT
+    if (sorted)
+        unsort_kernel<<<grid_for(pl->npart, TBLOCK), TBLOCK, 0, st>>>(pl->out_sorted, pl->inv, pl->npart, caller_out);
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }

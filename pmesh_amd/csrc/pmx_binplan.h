@@ -102,6 +102,20 @@ struct pmx_binplan {
     uint32_t *unit_flags = nullptr;   // walk form: unit was painted (its staging is valid)
     size_t cap_units = 0;
     int form = -1;              // -1: chosen per build; 0: tile kernels; 1: walk kernels
+    // Rows whose order has no spatial coherence (catalogues in file order, shuffled sets): the
+    // index list then sends every position gather, and every result store of readout, to a
+    // sector of its own.  The plan keeps a copy of the positions in TILE ORDER instead (one
+    // gather per build), paint and readout stream it, readout writes its results in tile order
+    // and a last pass pulls them back through the inverse list.
+    int sort_pref = -1;         // -1: decided from the coherence measured by the first build; 0 / 1: forced
+    bool sorted = false;        // this plan carries the tile-ordered copy
+    void *pos_copy = nullptr;   // cap_list rows of 3 position elements (the element type of `pos`)
+    size_t cap_copy = 0;
+    uint32_t *inv = nullptr;    // slot of every particle in the list (the inverse of `list`)
+    size_t cap_inv = 0;
+    double *out_sorted = nullptr;   // results of readout in list order
+    size_t cap_out = 0;
+    uint32_t *host_groups = nullptr;   // pinned: coherence counter of the count pass
     // history for the single-pass build: the slot ranges of the previous build of the same
     // geometry and particle count are reused (particles move little between time steps)
     bool have_history = false;

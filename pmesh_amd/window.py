@@ -78,6 +78,9 @@ BINNED_MIN_DENSITY = {1: 0.06, 2: 0.06, 3: 0.02, 4: 0.008}
 # 'never' (tile form only), 'always' (walk form for every window of support >= 2).
 WALK = os.environ.get('PMESH_AMD_WALK', 'auto')
 _FORMS = {'auto': -1, 'never': 0, 'always': 1}
+# A tile-ordered copy of the positions inside the plan, for rows without spatial coherence
+# (include/pmesh_amd.h: pmx_binplan_sorted): 'auto' (measured by the first build), 'never', 'always'.
+SORTED = os.environ.get('PMESH_AMD_SORTED', 'auto')
 
 
 class _BinCache(object):
@@ -93,7 +96,7 @@ class _BinCache(object):
         self.clock = 0
 
     def _key(self, pos, painter):
-        return (pos.data_ptr(), pos._version, tuple(pos.shape), pos.stride(), pos.dtype, WALK,
+        return (pos.data_ptr(), pos._version, tuple(pos.shape), pos.stride(), pos.dtype, WALK, SORTED,
                 painter.kind, tuple(painter.scale), tuple(painter.translate),
                 tuple(painter.period), tuple(painter.size))
 
@@ -120,6 +123,7 @@ class _BinCache(object):
             e = min(free or [q for q in self.entries if q[5] == shape] or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape
         be.call('binplan_configure', e[1], _FORMS[WALK])
+        be.call('binplan_sorted', e[1], _FORMS[SORTED], None)
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
         e[3] = True
         e[4] = self._tick()
@@ -128,6 +132,16 @@ class _BinCache(object):
     def _tick(self):
         self.clock += 1
         return self.clock
+
+    def sorted_plans(self, be):
+        """how many of the built plans carry the tile-ordered copy of their positions"""
+        n = 0
+        for e in self.entries:
+            if e[3]:
+                c = C.c_int32(0)
+                be.call('binplan_sorted', e[1], -2, C.byref(c))
+                n += int(c.value)
+        return n
 
     def overflows(self, be):
         """single-pass rebuilds of the pooled plans that had to be repaired by the two-pass

@@ -30,18 +30,20 @@ def hip():
     from pmesh_amd import backend
     backend.reset()
     b = backend.get()
-    old, oldw = window.BINNED, window.WALK
+    old, oldw, olds = window.BINNED, window.WALK, window.SORTED
     yield b
-    window.BINNED, window.WALK = old, oldw
+    window.BINNED, window.WALK, window.SORTED = old, oldw, olds
     window.clear_bin_cache()
     backend.reset()
 
 
-@pytest.fixture(params=['tiles', 'walk'])
+@pytest.fixture(params=['tiles', 'walk', 'sorted'])
 def form(request, hip):
-    """both forms of the binned kernels: the tile kernels (csrc/pmx_binned.hip) and the walk
-    kernels (csrc/pmx_walk.hip; windows of support >= 2, NNB stays on the tiles)"""
-    window.WALK = 'never' if request.param == 'tiles' else 'always'
+    """the forms of the binned kernels: the tile kernels through the index list
+    (csrc/pmx_binned.hip), the walk kernels (csrc/pmx_walk.hip; TSC and PCS, the others stay on
+    the tiles) and the tile kernels on the plan's tile-ordered copy of the positions"""
+    window.WALK = 'always' if request.param == 'walk' else 'never'
+    window.SORTED = 'always' if request.param == 'sorted' else 'never'
     window.clear_bin_cache()
     return request.param
 
@@ -173,6 +175,36 @@ def test_binned_dyadic_bit_exact(hip, form, oracle, name):
             transform=Affine(3, period=N))
     assert_binned_ran()
     assert_array_equal(c.cpu().numpy(), want)
+
+
+def test_sorted_copy_is_chosen_for_incoherent_rows(hip, oracle):
+    """SORTED='auto': rows in lattice order keep the index list, the same rows shuffled make the first build
+    of the plan switch to the tile-ordered copy; results are the same either way."""
+    import ctypes as C
+    from pmesh_amd._arrays import vec
+    N, L = 128, 1000.0
+    W = windows['tsc']
+    window.BINNED, window.WALK, window.SORTED = 'always', 'never', 'auto'
+    pos = torch.empty((N ** 3, 3), dtype=torch.float64, device=hip.device)
+    pv = vec(pos)
+    hip.call('synth_uniform', C.byref(pv), N, L, 42, 0, N ** 3, hip.stream())
+    aff = Affine(3, scale=N / L, period=N)
+    gen = torch.Generator(device=hip.device)
+    gen.manual_seed(7)
+    perm = torch.randperm(N ** 3, device=hip.device, generator=gen)
+    field = torch.randn((N, N, N), dtype=torch.float64, device=hip.device, generator=gen)
+    res = []
+    for p, want_sorted in ((pos, 0), (pos[perm].contiguous(), 1)):
+        for build in range(3):
+            # (a plan that is rebuilt from its history learns of a change of the row order one build late)
+            window.clear_bin_cache()
+            c = torch.zeros((N, N, N), dtype=torch.float64, device=hip.device)
+            W.paint(c, p, transform=aff)
+            torch.cuda.synchronize()
+        assert window.bin_cache().sorted_plans(hip) == want_sorted, (want_sorted, window.bin_cache().entries)
+        res.append((c, W.readout(field, p, transform=aff)))
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-12 * float(res[0][0].abs().max())
+    assert torch.equal(res[0][1][perm], res[1][1])              # readout: bit-identical, row by row
 
 
 def test_plan_is_shared_and_invalidated(hip):
