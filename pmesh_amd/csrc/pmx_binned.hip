@@ -298,11 +298,26 @@ __global__ void __launch_bounds__(TBLOCK) sort_copy_kernel(const uint32_t *list,
     for (int64_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
         const int64_t start = offsets[b];
         const int nwords = (int)counts[b] * WPR;
-        for (int w = threadIdx.x; w < nwords; w += TBLOCK) {
-            const int j = w / WPR, k = w - j * WPR;
-            const int64_t i = (int64_t)list[start + j];
-            const char *src = pos.data + i * pos.stride0 + (k / WPE) * pos.stride1 + (k % WPE) * 4;
-            copy[(start + j) * WPR + k] = *(const uint32_t *)src;
+        // four independent list -> row gathers in flight per lane (the copy is bound by their latency)
+        for (int w0 = threadIdx.x; w0 < nwords; w0 += 4 * TBLOCK) {
+            uint32_t v[4];
+            int64_t i[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = w0 + u * TBLOCK;
+                i[u] = w < nwords ? (int64_t)list[start + w / WPR] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = w0 + u * TBLOCK;
+                const int k = w % WPR;
+                if (i[u] >= 0) v[u] = *(const uint32_t *)(pos.data + i[u] * pos.stride0 + (k / WPE) * pos.stride1 + (k % WPE) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = w0 + u * TBLOCK;
+                if (i[u] >= 0) copy[start * WPR + w] = v[u];
+            }
         }
     }
 }
@@ -310,8 +325,18 @@ __global__ void __launch_bounds__(TBLOCK) sort_copy_kernel(const uint32_t *list,
 // out[i] = sorted[inv[i]]: the results of a readout in list order back into row order
 __global__ void __launch_bounds__(TBLOCK) unsort_kernel(const double *sorted, const uint32_t *inv, int64_t n, DVec out)
 {
-    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * TBLOCK)
-        out.set(i, 0, sorted[inv[i]]);
+    const int64_t stride = (int64_t)gridDim.x * TBLOCK;
+    for (int64_t i0 = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint32_t s[4];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) s[u] = i0 + u * stride < n ? inv[i0 + u * stride] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = sorted[s[u]];            // four independent gathers in flight
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u * stride < n) out.set(i0 + u * stride, 0, v[u]);
+    }
 }
 
 __global__ void __launch_bounds__(TBLOCK) bin_zero_kernel(uint32_t *counts, int64_t nbuckets, const uint32_t *gate)
