@@ -57,7 +57,8 @@ template <int KIND, bool DENSE, int MODE, bool WALK, bool SORTP>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
                                                            int32_t *tid, uint32_t *counts, uint32_t *flags,
                                                            const int64_t *offsets, uint32_t *list,
-                                                           uint32_t *host_flag, const uint32_t *gate, uint32_t *inv_)
+                                                           uint32_t *host_flag, const uint32_t *gate, uint32_t *inv_,
+                                                           void *copy_)
 {
     // SORTP: the plan keeps a tile-ordered copy of the positions: the inverse list is recorded, and
     constexpr bool noagg = SORTP && MODE == 1;
@@ -201,6 +202,17 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                     if (slot < end) {
                         list[slot] = (uint32_t)i;
                         if (inv) inv[i] = (uint32_t)slot;
+                        if (SORTP && copy_) {
+                            // the tile-ordered copy of the positions, written where the row lands (the
+                            // values are in registers: no second, gathered pass over the positions)
+                            if (pos.elsize == 8) {
+                                double *c = (double *)copy_ + 3 * slot;
+                                c[0] = xin[u][0]; c[1] = xin[u][1]; c[2] = xin[u][2];
+                            } else {
+                                float *c = (float *)copy_ + 3 * slot;
+                                c[0] = (float)xin[u][0]; c[1] = (float)xin[u][1]; c[2] = (float)xin[u][2];
+                            }
+                        }
                     } else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
                 }
             }
@@ -292,9 +304,11 @@ __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid,
 // is written in order.  WPR: words per row (3 floats: 3, 3 doubles: 6).
 template <int WPR>
 __global__ void __launch_bounds__(TBLOCK) sort_copy_kernel(const uint32_t *list, const int64_t *offsets,
-                                                           const uint32_t *counts, int64_t nbuckets, DVec pos, uint32_t *copy)
+                                                           const uint32_t *counts, int64_t nbuckets, DVec pos, uint32_t *copy,
+                                                           const uint32_t *gate)
 {
     constexpr int WPE = WPR / 3;                 // words per element
+    if (gate != nullptr && *gate == 0) return;   // the single-pass rebuild wrote the copy itself
     for (int64_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
         const int64_t start = offsets[b];
         const int nwords = (int)counts[b] * WPR;
@@ -900,9 +914,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #define BC2(K, MODE, GRID, GATE, W, SP)                                                                           \
     do {                                                                                                        \
         if (dense) bin_count_kernel<K, true, MODE, W, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
-                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv);                                    \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp);                             \
         else bin_count_kernel<K, false, MODE, W, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
-                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv);                                    \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp);                             \
     } while (0)
 #define BC(K, MODE, GRID, GATE, W)                                                                              \
     do {                                                                                                        \
@@ -920,6 +934,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     } while (0)
         const uint32_t *nogate = nullptr;
         uint32_t *inv = nullptr;
+        void *copyp = nullptr;               // != NULL: the single-pass rebuild writes the tile-ordered copy itself
+        const uint32_t *copy_gate = nullptr; // the gather of the copy then only runs after an overflow repair
         if (!pl->host_groups) {
             PMX_HIP_CHECK(hipHostMalloc((void **)&pl->host_groups, 64, hipHostMallocDefault));
             pl->host_groups[0] = 0;                 // breaks of the tile sequence among ...
@@ -938,6 +954,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             // exact two-pass build below runs, otherwise its kernels return at once.  Whether the
             // plan carries the tile-ordered copy was decided by its first build.
             inv = pl->sorted ? pl->inv : nullptr;
+            copyp = pl->sorted ? pl->pos_copy : nullptr;
+            copy_gate = pl->sorted ? pl->flags : nullptr;
             BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
             const uint32_t *gate = pl->flags;
             bin_zero_kernel<<<64, TBLOCK, 0, st>>>(pl->counts, nbuckets, gate);
@@ -978,9 +996,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         if (pl->sorted) {
             const unsigned cgrid = (unsigned)(nbuckets < 65535 * 8 ? nbuckets : 65535 * 8);
             if (pos->elsize == 8)
-                sort_copy_kernel<6><<<cgrid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, nbuckets, dpos, (uint32_t *)pl->pos_copy);
+                sort_copy_kernel<6><<<cgrid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, nbuckets, dpos, (uint32_t *)pl->pos_copy, copy_gate);
             else
-                sort_copy_kernel<3><<<cgrid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, nbuckets, dpos, (uint32_t *)pl->pos_copy);
+                sort_copy_kernel<3><<<cgrid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, nbuckets, dpos, (uint32_t *)pl->pos_copy, copy_gate);
         }
     } else {
         bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nullptr);
