@@ -9,7 +9,16 @@
 
 namespace pmx {
 
-constexpr int T0 = 8, T1 = 16, T2 = 32;   // tile extents (cells) along axes 0, 1, 2
+#ifndef PMX_T0
+#define PMX_T0 8
+#endif
+#ifndef PMX_T1
+#define PMX_T1 16
+#endif
+#ifndef PMX_T2
+#define PMX_T2 32
+#endif
+constexpr int T0 = PMX_T0, T1 = PMX_T1, T2 = PMX_T2;   // tile extents (cells) along axes 0, 1, 2
 constexpr int TCELLS = T0 * T1 * T2;
 constexpr int TBLOCK = 256;
 #ifndef PMX_ZSEG
