@@ -36,10 +36,6 @@
 
 #include "pmx_binplan.h"
 
-#ifndef PMX_PAIR_LANES
-#define PMX_PAIR_LANES 0
-#endif
-
 namespace pmx {
 
 // DENSE: positions are a contiguous (n, 3) array.  A lane-per-particle load of 3 elements
@@ -499,13 +495,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
             double x[UNROLL][3], m[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-#if PMX_PAIR_LANES
-                // consecutive list entries — neighbours in space that often share their base cell — in ONE
-                // lane, i.e. in different ds_add instructions: no same-address atomics inside an instruction
-                int j = (j0 - (int)threadIdx.x) + (int)threadIdx.x * UNROLL + u;
-#else
                 int j = j0 + u * TTHREADS;
-#endif
                 idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
             }
 #pragma unroll
