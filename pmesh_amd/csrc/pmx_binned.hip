@@ -403,6 +403,106 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
     }
 }
 
+// The particles [start, start + count) of a tile's list are deposited into its LDS region.
+template <int KIND, int TTHREADS, bool SORTED>
+__device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
+                                             const DVec &mass, double mass_scalar, const uint32_t *list,
+                                             int64_t start, int count, double *lds)
+{
+    constexpr bool sorted = SORTED;
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    // UNROLL particles per thread and trip: all index and position loads are issued before
+    // the first use, so several dependent gathers are in flight per lane
+    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+        int64_t idx[UNROLL];
+        double x[UNROLL][3], m[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            int j = j0 + u * TTHREADS;
+            idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (idx[u] >= 0) {
+                x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
+                // (sorted: idx is the list slot; a per-particle mass lives at the row the list names)
+                m[u] = mass.data ? mass.get(sorted ? (int64_t)list[idx[u]] : idx[u], 0) : mass_scalar;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (idx[u] < 0) continue;
+            int lb[3];
+            double V[3][S];
+            particle_setup<KIND>(p, g, t, x[u], V, lb);
+            // a plan that no longer matches the positions (rewritten behind the cache's back)
+            // must not index outside the LDS region
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+#pragma unroll
+            for (int a = 0; a < S; a++) V[0][a] *= m[u];
+#pragma unroll
+            for (int a = 0; a < S; a++)
+#pragma unroll
+                for (int b = 0; b < S; b++) {
+                    double fb = V[0][a] * V[1][b];
+                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
+#pragma unroll
+                    for (int c = 0; c < S; c++) {
+                        unsafeAtomicAdd(&lds[rowoff + c], fb * V[2][c]);
+                    }
+                }
+        }
+    }
+}
+
+// The particles [start, start + count) of a tile's list read their values from its LDS region.
+template <int KIND, typename T, int TTHREADS, bool SORTED>
+__device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
+                                            const DVec &out, const uint32_t *list, int64_t start, int count,
+                                            const T *lds)
+{
+    constexpr bool sorted = SORTED;
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+        int64_t idx[UNROLL];
+        double x[UNROLL][3];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            int j = j0 + u * TTHREADS;
+            idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (idx[u] >= 0) {
+                x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (idx[u] < 0) continue;
+            int lb[3];
+            double V[3][S];
+            particle_setup<KIND>(p, g, t, x[u], V, lb);
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            double value = 0;
+#pragma unroll
+            for (int a = 0; a < S; a++)
+#pragma unroll
+                for (int b = 0; b < S; b++) {
+                    double fb = V[0][a] * V[1][b];
+                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
+#pragma unroll
+                    for (int c = 0; c < S; c++) value += (double)lds[rowoff + c] * (fb * V[2][c]);
+                }
+            out.set(idx[u], 0, value);
+        }
+    }
+}
+
 // Threads of a tile workgroup.  The LDS region fixes the workgroups per CU (4 / 3 / 2 for CIC /
 // TSC / PCS in double); with 256 threads that left 16 / 12 / 8 waves per CU on kernels that spend
 // 60 % of their cycles parked on memory.  512 threads double the waves at the same LDS and still
@@ -429,7 +529,6 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                                                             const uint32_t *list, const int64_t *offsets,
                                                             const uint32_t *counts, T *halo, int overwrite)
 {
-    constexpr bool sorted = SORTED;
     // SORTED: `pos` is the plan's copy of the positions in list order (row = list slot);
     // the list itself is then only read for a per-particle mass
     constexpr int S = Tuned<KIND>::S;
@@ -461,7 +560,8 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
         int t[3];
         tile_coords(g, tile, t);
         const int64_t start = offsets[tile];
-        const int count = (int)counts[tile];
+        // (what a crowded tile holds beyond g.chunk entries is painted by paint_heavy_kernel)
+        const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
         if (count == 0 && !overwrite && !live) continue;   // nothing to add; uniform per workgroup
         double carry[CPT];
         if (S > 1 && live) {
@@ -488,48 +588,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
             }
             __syncthreads();
         }
-        // UNROLL particles per thread and trip: all index and position loads are issued before
-        // the first use, so several dependent gathers are in flight per lane
-        for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
-            int64_t idx[UNROLL];
-            double x[UNROLL][3], m[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                int j = j0 + u * TTHREADS;
-                idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                if (idx[u] >= 0) {
-                    x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
-                    // (sorted: idx is the list slot; a per-particle mass lives at the row the list names)
-                    m[u] = mass.data ? mass.get(sorted ? (int64_t)list[idx[u]] : idx[u], 0) : mass_scalar;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                if (idx[u] < 0) continue;
-                int lb[3];
-                double V[3][S];
-                particle_setup<KIND>(p, g, t, x[u], V, lb);
-                // a plan that no longer matches the positions (rewritten behind the cache's back)
-                // must not index outside the LDS region
-                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
-#pragma unroll
-                for (int a = 0; a < S; a++) V[0][a] *= m[u];
-#pragma unroll
-                for (int a = 0; a < S; a++)
-#pragma unroll
-                    for (int b = 0; b < S; b++) {
-                        double fb = V[0][a] * V[1][b];
-                        int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
-#pragma unroll
-                        for (int c = 0; c < S; c++) {
-                            unsafeAtomicAdd(&lds[rowoff + c], fb * V[2][c]);
-                        }
-                    }
-            }
-        }
+        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -615,7 +674,6 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
                                                               DVec pos, DVec out, const uint32_t *list,
                                                               const int64_t *offsets, const uint32_t *counts)
 {
-    constexpr bool sorted = SORTED;
     // SORTED: `pos` is the plan's copy of the positions in list order and `out` its buffer of
     // results in list order (unsort_kernel pulls them back): nothing is gathered or scattered
     constexpr int S = Tuned<KIND>::S;
@@ -624,7 +682,8 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
     __shared__ T lds[Rg::CELLS];
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t start = offsets[tile];
-        const int count = (int)counts[tile];
+        // (what a crowded tile holds beyond g.chunk entries is read out by readout_heavy_kernel)
+        const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
         if (count == 0) continue;
         int t[3];
         tile_coords(g, tile, t);
@@ -637,40 +696,90 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
             lds[q] = in ? *(const T *)(canvas + goff) : (T)0;   // outside the block reads as 0
         }
         __syncthreads();
-        for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
-            int64_t idx[UNROLL];
-            double x[UNROLL][3];
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                int j = j0 + u * TTHREADS;
-                idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                if (idx[u] >= 0) {
-                    x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                if (idx[u] < 0) continue;
-                int lb[3];
-                double V[3][S];
-                particle_setup<KIND>(p, g, t, x[u], V, lb);
-                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
-                double value = 0;
-#pragma unroll
-                for (int a = 0; a < S; a++)
-#pragma unroll
-                    for (int b = 0; b < S; b++) {
-                        double fb = V[0][a] * V[1][b];
-                        int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
-#pragma unroll
-                        for (int c = 0; c < S; c++) value += (double)lds[rowoff + c] * (fb * V[2][c]);
-                    }
-                out.set(idx[u], 0, value);
-            }
+        tile_gather<KIND, T, TTHREADS, SORTED>(p, g, t, pos, out, list, start, count, lds);
+        __syncthreads();
+    }
+}
+
+// ---- crowded tiles ------------------------------------------------------------------------
+// work items (tile, piece >= 1) for what the tiles hold beyond `chunk` list entries
+__global__ void __launch_bounds__(TBLOCK) heavy_items_kernel(const uint32_t *counts, int64_t ntiles, int chunk,
+                                                             uint64_t *items, uint32_t *nitems, uint32_t cap)
+{
+    for (int64_t tile = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * TBLOCK) {
+        const uint32_t c = counts[tile];
+        if (c > (uint32_t)chunk) {
+            const uint32_t extra = (c - 1) / (uint32_t)chunk;
+            const uint32_t base = atomicAdd(nitems, extra);
+            for (uint32_t k = 1; k <= extra; k++)
+                if (base + k - 1 < cap) items[base + k - 1] = ((uint64_t)tile << 20) | k;
         }
+    }
+}
+
+// one workgroup per work item: the piece is accumulated in LDS like a tile of its own and the whole
+// region, box and halo, is added to the canvas with atomics (after the tile kernel and halo_merge)
+template <int KIND, typename T, int TTHREADS, bool SORTED>
+__global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
+                                                             DVec mass, double mass_scalar, const uint32_t *list,
+                                                             const int64_t *offsets, const uint32_t *counts,
+                                                             const uint64_t *items, const uint32_t *nitems, uint32_t cap)
+{
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    __shared__ double lds[Rg::CELLS];
+    const uint32_t n = *nitems < cap ? *nitems : cap;
+    for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        const int64_t tile = (int64_t)(items[item] >> 20);
+        const int64_t piece = (int64_t)(items[item] & 0xFFFFF);
+        int t[3];
+        tile_coords(g, tile, t);
+        const int64_t first = piece * g.chunk;
+        const int64_t left = (int64_t)counts[tile] - first;
+        const int count = left < g.chunk ? (int)left : g.chunk;
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) lds[q] = 0;
+        __syncthreads();
+        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds);
+        __syncthreads();
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
+            const double v = lds[q];
+            if (v == 0) continue;
+            const int c = q % R2, r = q / R2;
+            int64_t goff;
+            if (region_cell(p, g, t, r / R1, r % R1, c, &goff)) unsafeAtomicAdd((T *)(canvas + goff), (T)v);
+        }
+        __syncthreads();
+    }
+}
+
+template <int KIND, typename T, int TTHREADS, bool SORTED>
+__global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, BinGeom g, const char *canvas, DVec pos,
+                                                               DVec out, const uint32_t *list, const int64_t *offsets,
+                                                               const uint32_t *counts, const uint64_t *items,
+                                                               const uint32_t *nitems, uint32_t cap)
+{
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    __shared__ T lds[Rg::CELLS];
+    const uint32_t n = *nitems < cap ? *nitems : cap;
+    for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        const int64_t tile = (int64_t)(items[item] >> 20);
+        const int64_t piece = (int64_t)(items[item] & 0xFFFFF);
+        int t[3];
+        tile_coords(g, tile, t);
+        const int64_t first = piece * g.chunk;
+        const int64_t left = (int64_t)counts[tile] - first;
+        const int count = left < g.chunk ? (int)left : g.chunk;
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
+            const int c = q % R2, r = q / R2;
+            int64_t goff;
+            const bool in = region_cell(p, g, t, r / R1, r % R1, c, &goff);
+            lds[q] = in ? *(const T *)(canvas + goff) : (T)0;
+        }
+        __syncthreads();
+        tile_gather<KIND, T, TTHREADS, SORTED>(p, g, t, pos, out, list, offsets[tile] + first, count, lds);
         __syncthreads();
     }
 }
@@ -770,6 +879,8 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->inv) (void)hipFree(pl->inv);
     if (pl->out_sorted) (void)hipFree(pl->out_sorted);
     if (pl->host_groups) (void)hipHostFree(pl->host_groups);
+    if (pl->heavy_items) (void)hipFree(pl->heavy_items);
+    if (pl->nheavy) (void)hipFree(pl->nheavy);
     delete pl;
     return PMX_OK;
 }
@@ -835,7 +946,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         g.ntiles *= g.nt[d];
     }
     g.lseg = g.nseg = 0;
-    g._pad = 0;
+    g.chunk = 1 << 30;
     g.nunits = 0;
     if (walk) {
         // segments of the walk along axis 0: long (the S-1 trailing planes of a segment are staged
@@ -846,6 +957,13 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         g.lseg = lseg;
         g.nseg = (g.nt[0] + lseg - 1) / lseg;
         g.nunits = patches * g.nseg;
+    }
+    if (!walk) {
+        // list entries of a tile that its own workgroup takes: four times the mean population, at
+        // least 16384; what a crowded tile holds beyond that is cut into pieces of the same size
+        int64_t mean = g.ntiles > 0 ? npart / g.ntiles : 0;
+        int64_t ch = 4 * mean > 16384 ? 4 * mean : 16384;
+        g.chunk = (int32_t)(ch < (1 << 30) ? ch : (1 << 30));
     }
     PMX_REQUIRE(g.ntiles < 2147483647ll, PMX_EUNSUPPORTED, "more than 2^31 buckets");
     // The slot ranges of the previous build can be reused when it was for the same geometry
@@ -898,6 +1016,14 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         reuse = false;
     }
     if (!pl->flags) PMX_HIP_CHECK(hipMalloc((void **)&pl->flags, 16));
+    if (!pl->nheavy) PMX_HIP_CHECK(hipMalloc((void **)&pl->nheavy, 16));
+    {
+        size_t cb = pl->cap_heavy * 8;
+        rc = plan_ensure((void **)&pl->heavy_items, &cb, (np1 / (size_t)g.chunk + 16) * 8);
+        if (rc) return rc;
+        pl->cap_heavy = cb / 8;
+    }
+    PMX_HIP_CHECK(hipMemsetAsync(pl->nheavy, 0, 16, st));
     if (!pl->host_flag) {
         PMX_HIP_CHECK(hipHostMalloc((void **)&pl->host_flag, 64, hipHostMallocMapped));
         *pl->host_flag = 0;
@@ -1003,6 +1129,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     } else {
         bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nullptr);
     }
+    if (npart > 0 && !walk)
+        heavy_items_kernel<<<grid_for(g.ntiles, TBLOCK, 1024), TBLOCK, 0, st>>>(pl->counts, g.ntiles, g.chunk, pl->heavy_items,
+                                                                               pl->nheavy, (uint32_t)pl->cap_heavy);
     PMX_HIP_CHECK(hipGetLastError());
     pl->built = true;
     pl->have_history = npart > 0;
@@ -1040,6 +1169,17 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     }
 #undef PT
 #undef HM
+    // the pieces of crowded tiles (none for a uniform batch: the kernel then returns at once)
+    const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
+#define PH(K) do { if (sorted) paint_heavy_kernel<K, T, TileThreads<K, T>::paint, true><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); \
+                   else paint_heavy_kernel<K, T, TileThreads<K, T>::paint, false><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); } while (0)
+    switch (p.kind) {
+    case PMX_TUNED_NNB: PH(PMX_TUNED_NNB); break;
+    case PMX_TUNED_CIC: PH(PMX_TUNED_CIC); break;
+    case PMX_TUNED_TSC: PH(PMX_TUNED_TSC); break;
+    default: PH(PMX_TUNED_PCS); break;
+    }
+#undef PH
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }
@@ -1117,6 +1257,27 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         }
     }
 #undef RT
+    {
+        const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
+#define RH(K, T) do { if (sorted) readout_heavy_kernel<K, T, TileThreads<K, T>::readout, true><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); \
+                      else readout_heavy_kernel<K, T, TileThreads<K, T>::readout, false><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); } while (0)
+        if (p.canvas_elsize == 8) {
+            switch (p.kind) {
+            case PMX_TUNED_NNB: RH(PMX_TUNED_NNB, double); break;
+            case PMX_TUNED_CIC: RH(PMX_TUNED_CIC, double); break;
+            case PMX_TUNED_TSC: RH(PMX_TUNED_TSC, double); break;
+            default: RH(PMX_TUNED_PCS, double); break;
+            }
+        } else {
+            switch (p.kind) {
+            case PMX_TUNED_NNB: RH(PMX_TUNED_NNB, float); break;
+            case PMX_TUNED_CIC: RH(PMX_TUNED_CIC, float); break;
+            case PMX_TUNED_TSC: RH(PMX_TUNED_TSC, float); break;
+            default: RH(PMX_TUNED_PCS, float); break;
+            }
+        }
+#undef RH
+    }
     if (sorted)
         unsort_kernel<<<grid_for(pl->npart, TBLOCK), TBLOCK, 0, st>>>(pl->out_sorted, pl->inv, pl->npart, caller_out);
     PMX_HIP_CHECK(hipGetLastError());

@@ -55,7 +55,7 @@ struct BinGeom {
     int32_t walk;         // 0: tiles of T0 x T1 x T2 cells; 1: plane buckets of 1 x P1 x P2 cells
     int32_t lseg;         // walk form: planes per segment
     int32_t nseg;         // walk form: segments per patch column
-    int32_t _pad;
+    int32_t chunk;        // tile form: list entries of a tile that the tile kernels take themselves
     int64_t nunits;       // walk form: patches x segments (one workgroup each)
 };
 
@@ -125,6 +125,13 @@ struct pmx_binplan {
     double *out_sorted = nullptr;   // results of readout in list order
     size_t cap_out = 0;
     uint32_t *host_groups = nullptr;   // pinned: coherence counter of the count pass
+    // Crowded tiles (halos, blobs): the tile kernels take the first `chunk` list entries of a tile;
+    // what lies behind is cut into work items (tile, piece) for a second kernel, one workgroup each,
+    // so that a tile with 100 x the mean population does not keep one workgroup busy for milliseconds
+    uint64_t *heavy_items = nullptr;   // (tile << 20) | piece, piece >= 1
+    size_t cap_heavy = 0;
+    uint32_t *nheavy = nullptr;        // device: number of items of this build
+    int32_t chunk = 1 << 30;           // list entries per piece
     // history for the single-pass build: the slot ranges of the previous build of the same
     // geometry and particle count are reused (particles move little between time steps)
     bool have_history = false;

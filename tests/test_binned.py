@@ -158,6 +158,43 @@ def test_sparse_clusters_across_tile_faces(hip, form, oracle, name, period):
         check(c.cpu().numpy(), want - base)
 
 
+@pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs'])
+def test_crowded_tile_is_split(hip, oracle, name):
+    """A tile that holds many times the mean population (a halo) is cut into pieces for separate
+    workgroups (paint_heavy_kernel / readout_heavy_kernel: everything beyond the first 16384 list
+    entries): 70000 particles inside one tile and across its faces, 2000 elsewhere; dyadic positions
+    and masses, so CIC / TSC paint must equal the oracle bit for bit, accumulate and overwrite;
+    readout bit-identical."""
+    W = windows[name]
+    N = 64
+    rs = numpy.random.RandomState(12)
+    heavy = numpy.stack([rs.randint(8 * 16, 18 * 16, size=70000), rs.randint(16 * 16, 34 * 16, size=70000),
+                         rs.randint(30 * 16, 66 * 16, size=70000)], axis=1) / 16.0
+    pos_h = numpy.concatenate([heavy, rs.randint(0, N * 16, size=(2000, 3)) / 16.0])
+    mass_h = rs.randint(1, 5, size=len(pos_h)).astype('f8')
+    aff, oaff = Affine(3, period=N), oracle.Affine(3, period=N)
+    base = rs.randint(-3, 4, size=(N, N, N)).astype('f8')
+    want = base.copy()
+    oracle.Window(W.kind).paint(want, pos_h, mass=mass_h, transform=oaff)
+    window.BINNED, window.WALK = 'always', 'never'
+    check = assert_array_equal if name != 'pcs' else (lambda a, b: assert_allclose(a, b, rtol=0, atol=1e-10))
+    for srt in ('never', 'always'):
+        window.SORTED = srt
+        window.clear_bin_cache()
+        pos = torch.from_numpy(pos_h).to(hip.device)
+        mass = torch.from_numpy(mass_h).to(hip.device)
+        c = torch.from_numpy(base.copy()).to(hip.device)
+        W.paint(c, pos, mass=mass, transform=aff)
+        assert_binned_ran()
+        check(c.cpu().numpy(), want)
+        c = torch.full((N, N, N), 9.0, dtype=torch.float64, device=hip.device)
+        W.paint(c, pos, mass=mass, transform=aff, _overwrite=True)
+        check(c.cpu().numpy(), want - base)
+        field_h = rs.normal(size=(N, N, N))
+        got = W.readout(torch.from_numpy(field_h).to(hip.device), pos, transform=aff).cpu().numpy()
+        assert_array_equal(got, oracle.Window(W.kind).readout(field_h, pos_h, transform=oaff))
+
+
 @pytest.mark.parametrize('name', ['nnb', 'cic', 'tsc'])
 def test_binned_dyadic_bit_exact(hip, form, oracle, name):
     """positions on a 1/16-cell lattice, small integer masses: exact partial sums =>
