@@ -542,9 +542,10 @@ __global__ void __launch_bounds__(TBLOCK) halo_merge_walk_kernel(pmx_painter p, 
     }
 }
 
-// The same pipeline for readout: plane a+S of the mesh is requested (registers) while plane
-// a+S-1... — one step: records of plane k+2 gathered, plane k+1 sorted, the window of plane k
-// shifted by one mesh plane (staged in the ring during the previous step) and read out.
+// The same pipeline for readout.  One step: the records of plane k+2 are gathered, plane k+1 is
+// sorted, the register window of plane k takes mesh plane a+S-1 (staged in the ring during the
+// previous step) and the particles of plane k are read out; mesh plane a+S goes from registers
+// into the ring and plane a+S+1 is requested from the canvas.
 template <int KIND, typename T, typename PE>
 __global__ void __launch_bounds__(WTHREADS, walk_waves<KIND>()) readout_walk_kernel(pmx_painter p, BinGeom g, const char *canvas, DVec pos,
                                                                DVec out, const uint32_t *list, const int64_t *offsets,
