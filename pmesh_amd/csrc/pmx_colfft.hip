@@ -560,10 +560,11 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             Ns *= Rd::r[3];
         }
         if (!INV) {
-            // Z -> X for k = 0..M, consecutive lanes along the row
-            for (int q = tid; q < W * (M + 1); q += NT) {
-                int r = q / (M + 1), k = q % (M + 1);
-                if (r0 + r >= nrows) continue;
+            // Z -> X for k = 0..M, consecutive lanes along the row.  The Nyquist mode k = M starts a new
+            // 128-byte line of the row; where the row is padded (one rank: pitch = M + 8 in double) the
+            // rest of that line is written too (zeros): a whole line instead of a 16-byte piece that the
+            // memory side would have to merge into the old one.
+            auto mode = [&](int r, int k) __attribute__((always_inline)) {
                 cpx<T> zk = buf[lds_index<T, RB>(k == M ? 0 : k, r)];
                 cpx<T> zq = buf[lds_index<T, RB>(k == 0 ? 0 : M - k, r)];
                 cpx<T> E = {(T)0.5 * (zk.x + zq.x), (T)0.5 * (zk.y - zq.y)};       // (zk + conj zq)/2
@@ -573,7 +574,19 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 // X = E - i * w * D
                 cpx<T> X = {E.x + wd.y, E.y - wd.x};
                 X.x *= sc; X.y *= sc;
-                data[(r0 + r) * pitch + k] = X;
+                return X;
+            };
+#pragma unroll
+            for (int u = 0; u < LPT; u++) {
+                const int flat = tid + u * NT;
+                const int r = flat / M, k = flat % M;
+                if (r0 + r < nrows) data[(r0 + r) * pitch + k] = mode(r, k);
+            }
+            constexpr int LINE = 128 / (int)sizeof(cpx<T>);
+            const int tail = (pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
+            for (int q = tid; q < W * tail; q += NT) {
+                const int r = q / tail, j = q - r * tail;
+                if (r0 + r < nrows) data[(r0 + r) * pitch + M + j] = (j == 0) ? mode(r, M) : cpx<T>{(T)0, (T)0};
             }
         } else {
 #pragma unroll
