@@ -46,6 +46,30 @@ namespace pmx {
 // next build of slowly moving particles can reuse the ranges (single pass, see bin_onepass)
 __host__ __device__ __forceinline__ int64_t slot_capacity(int64_t c) { return c + (c >> 2) + 64; }
 
+// bucket of a particle at x: its tile (tile form: tiles in C order; walk form: the planes of a patch
+// column follow each other, a workgroup walks along axis 0), or g.ntiles if it touches no local cell
+template <int KIND, bool WALK>
+__device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const BinGeom &g, const double *x)
+{
+    constexpr int S = Tuned<KIND>::S;
+    bool ok = true;
+    int tt[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        double X = x[d] * p.scale[d] + p.translate[d];
+        ok = ok && (fabs(X) < 1073741824.0);   // NaN / out of int range: dropped
+        int I[S];
+        double V[S];
+        Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
+        int i0w = 0;
+        ok = ok && local_base<KIND>(p, d, I[0], &i0w);
+        tt[d] = (i0w + g.o[d]) / bucket_ext<WALK>(d);
+    }
+    const int64_t tb = WALK ? ((int64_t)tt[1] * g.nt[2] + tt[2]) * g.nt[0] + tt[0]
+                            : ((int64_t)tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+    return ok ? tb : g.ntiles;
+}
+
 // MODE 0: count pass of the two-pass build: tid[i] = tile, counts[tile]++.
 // MODE 1: single-pass build into the slot ranges of the previous build: the wave-aggregated
 //         atomic returns the first free slot of the group; particle i goes to
@@ -66,7 +90,6 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
     // noagg: the rows are known to be in no spatial order (the plan keeps a tile-ordered copy):
     // every lane then has a tile of its own and the search for equal tiles, up to 64 rounds of
     // ballots per chunk, finds nothing to merge — every lane adds for itself
-    constexpr int S = Tuned<KIND>::S;
     // particle chunks per trip: U independent load -> atomic chains per wave.  The single-pass
     // mode waits for its atomics to return: fewer registers / less LDS per block, more waves
     constexpr int U = MODE == 1 ? PMX_ONEPASS_U : 4;
@@ -124,26 +147,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
         for (int u = 0; u < U; u++) {
             int64_t i = base + u * TBLOCK + threadIdx.x;
             t[u] = -1;
-            if (i < n) {
-                bool ok = true;
-                int tt[3];
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    double X = xin[u][d] * p.scale[d] + p.translate[d];
-                    ok = ok && (fabs(X) < 1073741824.0);   // NaN / out of int range: dropped
-                    int I[S];
-                    double V[S];
-                    Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
-                    int i0w = 0;
-                    ok = ok && local_base<KIND>(p, d, I[0], &i0w);
-                    tt[d] = (i0w + g.o[d]) / bucket_ext<WALK>(d);
-                }
-                // tile form: tiles in C order; walk form: the planes of a patch column follow
-                // each other (a workgroup walks along axis 0)
-                const int64_t tb = WALK ? ((int64_t)tt[1] * g.nt[2] + tt[2]) * g.nt[0] + tt[0]
-                                        : ((int64_t)tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
-                t[u] = ok ? (int)tb : (int)g.ntiles;
-            }
+            if (i < n) t[u] = (int)particle_bucket<KIND, WALK>(p, g, xin[u]);
             // wave-aggregated counting: find the lanes that share my tile (ballots only)
             same[u] = 0;
             if (noagg) {
@@ -215,6 +219,193 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                         }
                     } else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
                 }
+            }
+        }
+    }
+    if (lane == 0 && nsampled) {
+        atomicAdd(&flags[1], nbreaks);
+        atomicAdd(&flags[2], nsampled);
+    }
+}
+
+// Single-pass build for rows in a coherent order (the common case: lattice order, tile order, the
+// order of the previous step), tile form without the tile-ordered copy.  bin_count_kernel<MODE 1> asks
+// the tile's global counter once per wave and chunk: a returning global atomic for every ~32 rows, and
+// a list piece of ~128 bytes written wherever the counter happened to stand — unaligned pieces from
+// different CUs cost the memory side twice what aligned ones do (scripts/partial_line_bench.hip).
+// Here a workgroup takes a BLOCK of BLOCK_ROWS consecutive rows, counts them per tile in an LDS table
+// (a few dozen distinct tiles at most when the order is coherent), asks every tile's global counter
+// ONCE, and then writes its rows of a tile as one contiguous piece (512 entries per tile in lattice
+// order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
+// Tiles that find no room in the table are handled per wave as in bin_count_kernel.
+#ifndef PMX_BLOCK_BUILD
+#define PMX_BLOCK_BUILD 1
+#endif
+#ifndef PMX_BLOCK_ITERS
+#define PMX_BLOCK_ITERS 16
+#endif
+constexpr int BLOCK_ITERS = PMX_BLOCK_ITERS;                     // trips of TBLOCK * PMX_ONEPASS_U rows
+constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
+constexpr int BLOCK_HT = 128;                       // entries of the LDS table (a power of two)
+// 16-byte pieces of the TBLOCK * U dense rows from `base` on, one per thread and q: -> bytes requested
+template <int NPRE, int U>
+__device__ __forceinline__ int request_rows(const DVec &pos, int64_t n, int64_t base, uint4 (&pre)[NPRE])
+{
+    const int rowb = 3 * pos.elsize;
+    const int64_t left = n - base;
+    const int bytes = left <= 0 ? 0 : ((int)((left < TBLOCK * U ? left : TBLOCK * U) * rowb) & ~15);
+    const char *src = pos.data + base * rowb;
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+        const int off = (threadIdx.x + q * TBLOCK) * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off < bytes) v = *(const uint4 *)(src + off);
+        pre[q] = v;
+    }
+    return bytes;
+}
+
+template <int KIND, bool DENSE>
+__global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
+                                                           uint32_t *counts, uint32_t *flags, const int64_t *offsets,
+                                                           uint32_t *list, uint32_t *host_flag)
+{
+    constexpr int U = PMX_ONEPASS_U;
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu, DIRECT = 0xFFu;
+    __shared__ __align__(16) unsigned char stage[DENSE ? U * TBLOCK * 24 : 16];
+    __shared__ uint32_t keys[BLOCK_HT], cnt[BLOCK_HT];
+    __shared__ int64_t first[BLOCK_HT], last[BLOCK_HT];
+    const int lane = threadIdx.x & 63;
+    uint32_t nbreaks = 0, nsampled = 0;
+    for (int64_t blk = blockIdx.x; blk * BLOCK_ROWS < n; blk += gridDim.x) {
+        const int64_t row0 = blk * BLOCK_ROWS;
+        __syncthreads();
+        for (int s = threadIdx.x; s < BLOCK_HT; s += TBLOCK) { keys[s] = EMPTY; cnt[s] = 0; }
+        __syncthreads();
+        // where row (it, u) of this thread goes: table entry (8 bits) | rank in the workgroup's piece (24 bits)
+        uint32_t where[BLOCK_ITERS][U];
+        // DENSE: 16-byte pieces of the next trip's rows, in flight while this trip computes
+        constexpr int NPRE = (U * TBLOCK * 24 + TBLOCK * 16 - 1) / (TBLOCK * 16);
+        uint4 pre[NPRE];
+        int pre_bytes = 0;
+        if (DENSE) pre_bytes = request_rows<NPRE, U>(pos, n, row0, pre);
+#pragma unroll
+        for (int it = 0; it < BLOCK_ITERS; it++) {
+            const int64_t base = row0 + (int64_t)it * (TBLOCK * U);
+            double xin[U][3];
+            if (base < n) {
+                if (DENSE) {
+                    // the rows of this trip were requested during the previous one (pre[]): they go to LDS,
+                    // the next trip's rows are requested, and only then does this trip compute
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < NPRE; q++) {
+                        const int off = (threadIdx.x + q * TBLOCK) * 16;
+                        if (off < pre_bytes) *(uint4 *)(stage + off) = pre[q];
+                    }
+                    {
+                        // (the last bytes of an array whose size is not a multiple of 16)
+                        const int rowb = 3 * pos.elsize;
+                        const int64_t left = n - base;
+                        const int nbytes = (int)((left < TBLOCK * U ? left : TBLOCK * U) * rowb);
+                        const char *src = pos.data + base * rowb;
+                        for (int off = (nbytes & ~15) + threadIdx.x * 4; off < nbytes; off += TBLOCK * 4)
+                            *(uint32_t *)(stage + off) = *(const uint32_t *)(src + off);
+                    }
+                    __syncthreads();
+                    if (it + 1 < BLOCK_ITERS) pre_bytes = request_rows<NPRE, U>(pos, n, base + TBLOCK * U, pre);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        int row = u * TBLOCK + threadIdx.x;
+                        if (base + row < n) {
+                            if (pos.elsize == 8) {
+                                const double *r = (const double *)stage + 3 * row;
+                                xin[u][0] = r[0]; xin[u][1] = r[1]; xin[u][2] = r[2];
+                            } else {
+                                const float *r = (const float *)stage + 3 * row;
+                                xin[u][0] = r[0]; xin[u][1] = r[1]; xin[u][2] = r[2];
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        int64_t i = base + u * TBLOCK + threadIdx.x;
+                        if (i < n) { xin[u][0] = pos.get(i, 0); xin[u][1] = pos.get(i, 1); xin[u][2] = pos.get(i, 2); }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = base + u * TBLOCK + threadIdx.x;
+                const int t = i < n ? (int)particle_bucket<KIND, false>(p, g, xin[u]) : -1;
+                // the lanes that share my tile (ballots only)
+                unsigned long long same = 0, active = __ballot(t >= 0);
+                while (active) {
+                    int leader = __ffsll((long long)active) - 1;
+                    int lt = __shfl(t, leader);
+                    unsigned long long m = __ballot(t == lt) & active;
+                    if (t == lt) same = m;
+                    active &= ~m;
+                }
+                if (u == 0 && ((((uint32_t)(base / (TBLOCK * U))) * 2654435761u) >> 27) == 0) {   // coherence sample, as in bin_count_kernel
+                    const int tprev = __shfl_up(t, 1);
+                    nbreaks += (uint32_t)__popcll(__ballot(lane > 0 && t >= 0 && t != tprev));
+                    nsampled += (uint32_t)__popcll(__ballot(t >= 0));
+                }
+                const int leader = t >= 0 ? __ffsll((long long)same) - 1 : lane;
+                uint32_t w = 0, bd = 0;
+                if (t >= 0 && lane == leader) {
+                    // the group's entry of the table and its first rank there
+                    uint32_t h = ((uint32_t)t * 2654435761u) >> 25;               // 7 bits: BLOCK_HT = 128
+                    uint32_t e = DIRECT;
+                    for (int probe = 0; probe < 8; probe++) {
+                        const uint32_t k = atomicCAS(&keys[h], EMPTY, (uint32_t)t);
+                        if (k == EMPTY || k == (uint32_t)t) { e = h; break; }
+                        h = (h + 1) & (BLOCK_HT - 1);
+                    }
+                    if (e != DIRECT) w = (e << 24) | atomicAdd(&cnt[e], (uint32_t)__popcll(same));
+                    else {
+                        // no room in the table: this group asks the global counter itself
+                        w = DIRECT << 24;
+                        bd = atomicAdd(&counts[t], (uint32_t)__popcll(same));
+                    }
+                }
+                w = __shfl(w, leader);
+                const uint32_t rank = (uint32_t)__popcll(same & (((unsigned long long)1 << lane) - 1));
+                if (t < 0) where[it][u] = EMPTY;
+                else if ((w >> 24) == DIRECT) {
+                    // written at once (rare): list[offsets[t] + b + rank]
+                    bd = __shfl(bd, leader);
+                    const int64_t slot = offsets[t] + (int64_t)bd + rank;
+                    if (slot < offsets[t + 1]) list[slot] = (uint32_t)i;
+                    else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
+                    where[it][u] = EMPTY;
+                } else where[it][u] = w + rank;       // (rank < 64, the count below 2^24: no carry into the entry bits)
+            }
+        }
+        __syncthreads();
+        // one request per tile of the block to its global counter
+        for (int s = threadIdx.x; s < BLOCK_HT; s += TBLOCK) {
+            if (keys[s] != EMPTY) {
+                const uint32_t t = keys[s];
+                const uint32_t b = atomicAdd(&counts[t], cnt[s]);
+                first[s] = offsets[t] + b;
+                last[s] = offsets[t + 1];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < BLOCK_ITERS; it++) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t w = where[it][u];
+                if (w == EMPTY) continue;
+                const int64_t i = row0 + (int64_t)it * (TBLOCK * U) + u * TBLOCK + threadIdx.x;
+                const uint32_t e = w >> 24;
+                const int64_t slot = first[e] + (w & 0xFFFFFFu);
+                if (slot < last[e]) list[slot] = (uint32_t)i;
+                else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
             }
         }
     }
@@ -818,6 +1009,14 @@ static double walk_min_density()
     return v;
 }
 
+// rows from which the single-pass rebuild of 8-byte positions takes the block form
+// (environment PMX_BLOCK_MIN_ROWS, read at every build: the tests force the form at small sizes)
+static int64_t block_min_rows()
+{
+    const char *e = getenv("PMX_BLOCK_MIN_ROWS");
+    return e ? atoll(e) : ((int64_t)1 << 25);
+}
+
 static int halo_cells(int S)
 {
     int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
@@ -1082,7 +1281,26 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             inv = pl->sorted ? pl->inv : nullptr;
             copyp = pl->sorted ? pl->pos_copy : nullptr;
             copy_gate = pl->sorted ? pl->flags : nullptr;
-            BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
+            // (measured, block against chunk form of the single pass: 512^3 f8 1.13 vs 1.20 ms, 768^3 3.33 vs 3.79,
+            // clustered 1.22 vs 1.33; but 12-byte rows 1.05 vs 0.98 and 256^3 0.23 vs 0.21: those stay with the chunks)
+            if (!walk && inv == nullptr && PMX_BLOCK_BUILD && pos->elsize == 8 && npart >= block_min_rows()) {
+                // rows in a coherent order, no tile-ordered copy: one request per tile and block of rows
+                const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
+                const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);
+#define BB(K)                                                                                                   \
+    do {                                                                                                        \
+        if (dense) bin_block_kernel<K, true><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag); \
+        else bin_block_kernel<K, false><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag); \
+    } while (0)
+                switch (p.kind) {
+                case PMX_TUNED_NNB: BB(PMX_TUNED_NNB); break;
+                case PMX_TUNED_CIC: BB(PMX_TUNED_CIC); break;
+                case PMX_TUNED_TSC: BB(PMX_TUNED_TSC); break;
+                default: BB(PMX_TUNED_PCS); break;
+                }
+#undef BB
+            } else
+                BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
             const uint32_t *gate = pl->flags;
             bin_zero_kernel<<<64, TBLOCK, 0, st>>>(pl->counts, nbuckets, gate);
             BCK(0, small_grid, gate);

@@ -37,15 +37,26 @@ def hip():
     backend.reset()
 
 
-@pytest.fixture(params=['tiles', 'walk', 'sorted'])
+@pytest.fixture(params=['tiles', 'walk', 'sorted', 'block'])
 def form(request, hip):
     """the forms of the binned kernels: the tile kernels through the index list
     (csrc/pmx_binned.hip), the walk kernels (csrc/pmx_walk.hip; TSC and PCS, the others stay on
-    the tiles) and the tile kernels on the plan's tile-ordered copy of the positions"""
+    the tiles), the tile kernels on the plan's tile-ordered copy of the positions, and the tile
+    kernels with the block form of the single-pass rebuild (bin_block_kernel, otherwise only
+    taken from 2^25 rows of 8-byte positions on)"""
+    import os
     window.WALK = 'always' if request.param == 'walk' else 'never'
     window.SORTED = 'always' if request.param == 'sorted' else 'never'
+    old = os.environ.get('PMX_BLOCK_MIN_ROWS')
+    if request.param == 'block':
+        os.environ['PMX_BLOCK_MIN_ROWS'] = '0'
     window.clear_bin_cache()
-    return request.param
+    yield request.param
+    if request.param == 'block':
+        if old is None:
+            del os.environ['PMX_BLOCK_MIN_ROWS']
+        else:
+            os.environ['PMX_BLOCK_MIN_ROWS'] = old
 
 
 def both(W, fn):
@@ -305,6 +316,36 @@ def test_rebuild_from_history_and_overflow(hip, form, oracle, name):
             serving = [e[1].value for e in window.bin_cache().entries if e[3]]
         # one plan (the pool keeps earlier ones) served every step
         assert [e[1].value for e in window.bin_cache().entries if e[3]] == serving
+
+
+@pytest.mark.parametrize('name', ['cic', 'pcs'])
+def test_block_rebuild_with_more_tiles_than_table_entries(hip, oracle, name, monkeypatch):
+    """the block form of the single-pass rebuild counts a block of 8192 rows per tile in an LDS table
+    of 128 entries; rows in random order over a 128^3 mesh (512 tiles) overflow it, and the groups
+    that find no entry go to the global counters themselves"""
+    monkeypatch.setenv('PMX_BLOCK_MIN_ROWS', '0')
+    W = windows[name]
+    N, n = 128, 100000
+    window.BINNED, window.WALK, window.SORTED = 'always', 'never', 'never'
+    window.clear_bin_cache()
+    aff = Affine(3, period=N)
+    oaff = oracle.Affine(3, period=N)
+    rs = numpy.random.RandomState(8)
+    field_h = rs.normal(size=(N, N, N))
+    field = torch.from_numpy(field_h).to(hip.device)
+    pos = torch.zeros((n, 3), dtype=torch.float64, device=hip.device)
+    ph = rs.uniform(0, N, size=(n, 3))
+    for k in range(3):
+        ph = ph + rs.normal(0, 0.2, size=(n, 3))
+        pos.copy_(torch.from_numpy(ph))
+        c = torch.zeros((N, N, N), dtype=torch.float64, device=hip.device)
+        W.paint(c, pos, transform=aff)
+        want = numpy.zeros((N, N, N))
+        oracle.Window(W.kind).paint(want, ph, transform=oaff)
+        assert_allclose(c.cpu().numpy(), want, rtol=0, atol=1e-12 * abs(want).max(), err_msg='step %d' % k)
+        got = W.readout(field, pos, transform=aff).cpu().numpy()
+        assert_array_equal(got, oracle.Window(W.kind).readout(field_h, ph, transform=oaff), err_msg='step %d' % k)
+    assert window.bin_cache().overflows(hip) >= 0
 
 
 def test_rebuild_drops_and_nonperiodic(hip, form, oracle):
