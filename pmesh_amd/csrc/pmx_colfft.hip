@@ -576,10 +576,8 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 X.x *= sc; X.y *= sc;
                 return X;
             };
-#pragma unroll
-            for (int u = 0; u < LPT; u++) {
-                const int flat = tid + u * NT;
-                const int r = flat / M, k = flat % M;
+            for (int q = tid; q < W * M; q += NT) {
+                const int r = q / M, k = q % M;
                 if (r0 + r < nrows) data[(r0 + r) * pitch + k] = mode(r, k);
             }
             constexpr int LINE = 128 / (int)sizeof(cpx<T>);
