@@ -318,14 +318,14 @@ def test_rebuild_from_history_and_overflow(hip, form, oracle, name):
         assert [e[1].value for e in window.bin_cache().entries if e[3]] == serving
 
 
-@pytest.mark.parametrize('name', ['cic', 'pcs'])
-def test_block_rebuild_with_more_tiles_than_table_entries(hip, oracle, name, monkeypatch):
+@pytest.mark.parametrize('name,strided,n', [('cic', False, 100000), ('pcs', False, 100000), ('tsc', True, 70001), ('cic', True, 5)])
+def test_block_rebuild_with_more_tiles_than_table_entries(hip, oracle, name, strided, n, monkeypatch):
     """the block form of the single-pass rebuild counts a block of 8192 rows per tile in an LDS table
     of 128 entries; rows in random order over a 128^3 mesh (512 tiles) overflow it, and the groups
     that find no entry go to the global counters themselves"""
     monkeypatch.setenv('PMX_BLOCK_MIN_ROWS', '0')
     W = windows[name]
-    N, n = 128, 100000
+    N = 128
     window.BINNED, window.WALK, window.SORTED = 'always', 'never', 'never'
     window.clear_bin_cache()
     aff = Affine(3, period=N)
@@ -333,7 +333,10 @@ def test_block_rebuild_with_more_tiles_than_table_entries(hip, oracle, name, mon
     rs = numpy.random.RandomState(8)
     field_h = rs.normal(size=(N, N, N))
     field = torch.from_numpy(field_h).to(hip.device)
-    pos = torch.zeros((n, 3), dtype=torch.float64, device=hip.device)
+    # strided: rows of a wider array (the kernel's path without the dense staging), a row count that
+    # is no multiple of anything, and a batch far smaller than one block
+    pos = (torch.zeros((n, 5), dtype=torch.float64, device=hip.device)[:, 1:4] if strided
+           else torch.zeros((n, 3), dtype=torch.float64, device=hip.device))
     ph = rs.uniform(0, N, size=(n, 3))
     for k in range(3):
         ph = ph + rs.normal(0, 0.2, size=(n, 3))
