@@ -233,16 +233,16 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // the tile's global counter once per wave and chunk: a returning global atomic for every ~32 rows, and
 // a list piece of ~128 bytes written wherever the counter happened to stand — unaligned pieces from
 // different CUs cost the memory side twice what aligned ones do (scripts/partial_line_bench.hip).
-// Here a workgroup takes a BLOCK of BLOCK_ROWS consecutive rows, counts them per tile in an LDS table
+// Here a workgroup takes a BLOCK of BLOCK_ROWS (4096) consecutive rows, counts them per tile in an LDS table
 // (a few dozen distinct tiles at most when the order is coherent), asks every tile's global counter
-// ONCE, and then writes its rows of a tile as one contiguous piece (512 entries per tile in lattice
+// ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
 #ifndef PMX_BLOCK_BUILD
 #define PMX_BLOCK_BUILD 1
 #endif
 #ifndef PMX_BLOCK_ITERS
-#define PMX_BLOCK_ITERS 16
+#define PMX_BLOCK_ITERS 8
 #endif
 constexpr int BLOCK_ITERS = PMX_BLOCK_ITERS;                     // trips of TBLOCK * PMX_ONEPASS_U rows
 constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
@@ -275,6 +275,10 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
     __shared__ __align__(16) unsigned char stage[DENSE ? U * TBLOCK * 24 : 16];
     __shared__ uint32_t keys[BLOCK_HT], cnt[BLOCK_HT];
     __shared__ int64_t first[BLOCK_HT], last[BLOCK_HT];
+    // where row (it, u) of thread tid goes: table entry (8 bits) | rank in the workgroup's piece (24 bits)
+    // (in LDS, and the trips as a real loop: unrolled, the kernel was 80 KB of code with its scalar
+    // registers spilled into vector lanes)
+    __shared__ uint32_t where[BLOCK_ITERS * U * TBLOCK];
     const int lane = threadIdx.x & 63;
     uint32_t nbreaks = 0, nsampled = 0;
     for (int64_t blk = blockIdx.x; blk * BLOCK_ROWS < n; blk += gridDim.x) {
@@ -282,14 +286,12 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
         __syncthreads();
         for (int s = threadIdx.x; s < BLOCK_HT; s += TBLOCK) { keys[s] = EMPTY; cnt[s] = 0; }
         __syncthreads();
-        // where row (it, u) of this thread goes: table entry (8 bits) | rank in the workgroup's piece (24 bits)
-        uint32_t where[BLOCK_ITERS][U];
         // DENSE: 16-byte pieces of the next trip's rows, in flight while this trip computes
         constexpr int NPRE = (U * TBLOCK * 24 + TBLOCK * 16 - 1) / (TBLOCK * 16);
         uint4 pre[NPRE];
         int pre_bytes = 0;
         if (DENSE) pre_bytes = request_rows<NPRE, U>(pos, n, row0, pre);
-#pragma unroll
+#pragma unroll 1
         for (int it = 0; it < BLOCK_ITERS; it++) {
             const int64_t base = row0 + (int64_t)it * (TBLOCK * U);
             double xin[U][3];
@@ -373,15 +375,15 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
                 }
                 w = __shfl(w, leader);
                 const uint32_t rank = (uint32_t)__popcll(same & (((unsigned long long)1 << lane) - 1));
-                if (t < 0) where[it][u] = EMPTY;
+                if (t < 0) where[(it * U + u) * TBLOCK + threadIdx.x] = EMPTY;
                 else if ((w >> 24) == DIRECT) {
                     // written at once (rare): list[offsets[t] + b + rank]
                     bd = __shfl(bd, leader);
                     const int64_t slot = offsets[t] + (int64_t)bd + rank;
                     if (slot < offsets[t + 1]) list[slot] = (uint32_t)i;
                     else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
-                    where[it][u] = EMPTY;
-                } else where[it][u] = w + rank;       // (rank < 64, the count below 2^24: no carry into the entry bits)
+                    where[(it * U + u) * TBLOCK + threadIdx.x] = EMPTY;
+                } else where[(it * U + u) * TBLOCK + threadIdx.x] = w + rank;       // (rank < 64, the count below 2^24: no carry into the entry bits)
             }
         }
         __syncthreads();
@@ -395,11 +397,11 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
             }
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 2
         for (int it = 0; it < BLOCK_ITERS; it++) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t w = where[it][u];
+                const uint32_t w = where[(it * U + u) * TBLOCK + threadIdx.x];
                 if (w == EMPTY) continue;
                 const int64_t i = row0 + (int64_t)it * (TBLOCK * U) + u * TBLOCK + threadIdx.x;
                 const uint32_t e = w >> 24;
@@ -587,9 +589,10 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
         double X = x[d] * p.scale[d] + p.translate[d];
         int I[S];
         Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
-        int w = wrap_fast(I[0], p.period[d]);
+        const int per = (int)p.period[d], siz = (int)p.size[d];      // (32-bit compares: see local_base32)
+        int w = wrap_fast(I[0], per);
         int i0w = w;
-        if (p.period[d] > 0 && w >= p.size[d]) i0w = w - (int)p.period[d];
+        if (per > 0 && w >= siz) i0w = w - per;
         lb[d] = i0w + g.o[d] - t[d] * tile_ext(d);
     }
 }

@@ -148,10 +148,10 @@ template <bool WALK> __device__ __forceinline__ int bucket_ext(int d)
 }
 
 // true modulo with a fast path for indices within one period of the box
-__device__ __forceinline__ int wrap_fast(int i, int64_t n)
+__device__ __forceinline__ int wrap_fast(int i, int n)
 {
     if (n <= 0) return i;
-    int m = (int)n;
+    int m = n;
     if (i < 0) { i += m; if (i < 0) { i %= m; if (i < 0) i += m; } }
     else if (i >= m) { i -= m; if (i >= m) i %= m; }
     return i;
@@ -170,20 +170,31 @@ __device__ __forceinline__ int wrap_near(int l, int64_t period)
 
 // first stencil index of a particle along axis d in the local frame (see header);
 // returns false if the particle touches no local cell along this axis
+// (period and size as 32-bit values: every mesh axis is far below 2^31 cells, and the 64-bit
+// compares of the painter's own fields cost several instructions each in the hot loops)
 template <int KIND>
-__device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, int *i0w)
+__device__ __forceinline__ bool local_base32(int period, int size, int I0, int *i0w)
 {
     constexpr int S = Tuned<KIND>::S;
-    int w = wrap_fast(I0, p.period[d]);
-    if (p.period[d] > 0) {
-        if (w < p.size[d]) *i0w = w;
-        else if (w >= p.period[d] - (S - 1)) *i0w = w - (int)p.period[d];
+    int w = I0;
+    if (period > 0) {
+        // true modulo with a fast path for indices within one period of the box
+        if (w < 0) { w += period; if (w < 0) { w %= period; if (w < 0) w += period; } }
+        else if (w >= period) { w -= period; if (w >= period) w %= period; }
+        if (w < size) *i0w = w;
+        else if (w >= period - (S - 1)) *i0w = w - period;
         else return false;
     } else {
-        if (w < -(S - 1) || w >= p.size[d]) return false;
+        if (w < -(S - 1) || w >= size) return false;
         *i0w = w;
     }
     return true;
+}
+
+template <int KIND>
+__device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, int *i0w)
+{
+    return local_base32<KIND>((int)p.period[d], (int)p.size[d], I0, i0w);
 }
 
 // launchers of pmx_walk.hip
