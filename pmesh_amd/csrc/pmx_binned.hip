@@ -1012,12 +1012,12 @@ static double walk_min_density()
     return v;
 }
 
-// rows from which the single-pass rebuild of 8-byte positions takes the block form
-// (environment PMX_BLOCK_MIN_ROWS, read at every build: the tests force the form at small sizes)
+// rows from which the single-pass rebuild takes the block form (environment PMX_BLOCK_MIN_ROWS, read
+// at every build; default: always.  The tests also run the chunk form, which walk and sorted plans use)
 static int64_t block_min_rows()
 {
     const char *e = getenv("PMX_BLOCK_MIN_ROWS");
-    return e ? atoll(e) : ((int64_t)1 << 25);
+    return e ? atoll(e) : 0;
 }
 
 static int halo_cells(int S)
@@ -1284,9 +1284,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             inv = pl->sorted ? pl->inv : nullptr;
             copyp = pl->sorted ? pl->pos_copy : nullptr;
             copy_gate = pl->sorted ? pl->flags : nullptr;
-            // (measured, block against chunk form of the single pass: 512^3 f8 1.13 vs 1.20 ms, 768^3 3.33 vs 3.79,
-            // clustered 1.22 vs 1.33; but 12-byte rows 1.05 vs 0.98 and 256^3 0.23 vs 0.21: those stay with the chunks)
-            if (!walk && inv == nullptr && PMX_BLOCK_BUILD && pos->elsize == 8 && npart >= block_min_rows()) {
+            // (measured, block against chunk form of the single pass, same box: 512^3 f8 1.01 vs 1.17 ms, 768^3 3.22 vs
+            // 3.76, clustered 0.96 vs 1.27, 12-byte rows 0.90 vs 0.96, config 3 0.86 vs 1.08, 256^3 0.17 vs 0.20)
+            if (!walk && inv == nullptr && PMX_BLOCK_BUILD && npart >= block_min_rows()) {
                 // rows in a coherent order, no tile-ordered copy: one request per tile and block of rows
                 const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
                 const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);

@@ -37,22 +37,22 @@ def hip():
     backend.reset()
 
 
-@pytest.fixture(params=['tiles', 'walk', 'sorted', 'block'])
+@pytest.fixture(params=['tiles', 'walk', 'sorted', 'chunks'])
 def form(request, hip):
     """the forms of the binned kernels: the tile kernels through the index list
     (csrc/pmx_binned.hip), the walk kernels (csrc/pmx_walk.hip; TSC and PCS, the others stay on
     the tiles), the tile kernels on the plan's tile-ordered copy of the positions, and the tile
-    kernels with the block form of the single-pass rebuild (bin_block_kernel, otherwise only
-    taken from 2^25 rows of 8-byte positions on)"""
+    kernels with the chunk form of the single-pass rebuild (bin_count_kernel<MODE 1> instead of
+    bin_block_kernel, which 'tiles' takes)"""
     import os
     window.WALK = 'always' if request.param == 'walk' else 'never'
     window.SORTED = 'always' if request.param == 'sorted' else 'never'
     old = os.environ.get('PMX_BLOCK_MIN_ROWS')
-    if request.param == 'block':
-        os.environ['PMX_BLOCK_MIN_ROWS'] = '0'
+    if request.param == 'chunks':
+        os.environ['PMX_BLOCK_MIN_ROWS'] = str(1 << 60)
     window.clear_bin_cache()
     yield request.param
-    if request.param == 'block':
+    if request.param == 'chunks':
         if old is None:
             del os.environ['PMX_BLOCK_MIN_ROWS']
         else:
@@ -320,10 +320,10 @@ def test_rebuild_from_history_and_overflow(hip, form, oracle, name):
 
 @pytest.mark.parametrize('name,strided,n', [('cic', False, 100000), ('pcs', False, 100000), ('tsc', True, 70001), ('cic', True, 5)])
 def test_block_rebuild_with_more_tiles_than_table_entries(hip, oracle, name, strided, n, monkeypatch):
-    """the block form of the single-pass rebuild counts a block of 8192 rows per tile in an LDS table
+    """the block form of the single-pass rebuild counts a block of 4096 rows per tile in an LDS table
     of 128 entries; rows in random order over a 128^3 mesh (512 tiles) overflow it, and the groups
     that find no entry go to the global counters themselves"""
-    monkeypatch.setenv('PMX_BLOCK_MIN_ROWS', '0')
+    monkeypatch.delenv('PMX_BLOCK_MIN_ROWS', raising=False)
     W = windows[name]
     N = 128
     window.BINNED, window.WALK, window.SORTED = 'always', 'never', 'never'
