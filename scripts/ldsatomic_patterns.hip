@@ -18,14 +18,14 @@ template <int PATTERN> __device__ __forceinline__ int base_cell(int tid, int it)
     if (PATTERN == 1) { int c = h & 31, b = (h >> 5) & 15, a = (h >> 9) & 7; return (a * R1 + b) * R2 + c; }
     int c = 10 + (h % 5), b = 6 + ((h >> 8) % 5), a = 2 + ((h >> 16) % 5); return (a * R1 + b) * R2 + c;
 }
-// OP 0: ds_add_f64, 1: ds_write_b64, 2: ds_read_b64
-template <int PATTERN, int OP>
+// OP 0: ds_add_f64 / ds_add_f32, 1: ds_write, 2: ds_read;  T: the element type of the region
+template <int PATTERN, int OP, typename T>
 __global__ void __launch_bounds__(512) k(double *out, int iters)
 {
-    __shared__ double lds[CELLS];
+    __shared__ T lds[CELLS];
     for (int q = threadIdx.x; q < CELLS; q += 512) lds[q] = 0;
     __syncthreads();
-    double v = (double)(threadIdx.x + 1), acc = 0;
+    T v = (T)(threadIdx.x + 1), acc = 0;
     for (int it = 0; it < iters; it++) {
         const int base = base_cell<PATTERN>(threadIdx.x, it);
 #pragma unroll
@@ -34,26 +34,26 @@ __global__ void __launch_bounds__(512) k(double *out, int iters)
             for (int b = 0; b < 3; b++)
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    double *p = &lds[base + (a * R1 + b) * R2 + c];
+                    T *p = &lds[base + (a * R1 + b) * R2 + c];
                     if (OP == 0) unsafeAtomicAdd(p, v);
-                    else if (OP == 1) *(volatile double *)p = v;
-                    else acc += *(volatile double *)p;
+                    else if (OP == 1) *(volatile T *)p = v;
+                    else acc += *(volatile T *)p;
                 }
     }
     __syncthreads();
-    double s = acc;
+    double s = (double)acc;
     for (int q = threadIdx.x; q < CELLS; q += 512) s += lds[q];
     if (s == 12345.0) out[blockIdx.x] = s;
 }
-template <int PATTERN, int OP> void run(const char *name)
+template <int PATTERN, int OP, typename T = double> void run(const char *name)
 {
     double *out; hipMalloc(&out, 1 << 20);
     int blocks = 256 * 3 * 4, iters = 200;       // 3 workgroups of 512 per CU resident (49 KB each), 4 rounds
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    k<PATTERN, OP><<<blocks, 512>>>(out, 10);
+    k<PATTERN, OP, T><<<blocks, 512>>>(out, 10);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    k<PATTERN, OP><<<blocks, 512>>>(out, iters);
+    k<PATTERN, OP, T><<<blocks, 512>>>(out, iters);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     double n = (double)blocks * 512 * iters * 27;
@@ -72,5 +72,11 @@ int main()
     run<0, 2>("ds_read_b64 lane-linear");
     run<1, 2>("ds_read_b64 random in the tile");
     run<3, 2>("ds_read_b64 random in a 5^3 blob");
+    run<0, 0, float>("ds_add_f32  lane-linear");
+    run<1, 0, float>("ds_add_f32  random in the tile");
+    run<2, 0, float>("ds_add_f32  lane-linear, same-cell pairs");
+    run<3, 0, float>("ds_add_f32  random in a 5^3 blob");
+    run<0, 1, float>("ds_write_b32 lane-linear");
+    run<1, 2, float>("ds_read_b32 random in the tile");
     return 0;
 }
