@@ -111,16 +111,24 @@ class _BinCache(object):
         shape = key[2:] + (n,)
         # free: invalidated entries and those built for an older version of this very tensor
         free = [e for e in self.entries if not e[3] or (e[0] is not None and e[0][0] == key[0])]
-        like = [e for e in free if e[5] == shape]
+        same = [e for e in self.entries if e[5] == shape]
+        like = [e for e in same if any(e is q for q in free)]
         if like:
-            e = min(like, key=lambda q: q[4])
+            # the one used last: its lists are the closest to these positions
+            e = max(like, key=lambda q: q[4])
+        elif same:
+            # another tensor of the same shape on the same geometry: a time-stepping caller that makes a
+            # new position tensor every step.  It takes over the plan (and its history; the previous
+            # tensor is released) rather than a second one that would start from nothing — a caller that
+            # alternates between two live particle sets of equal size rebuilds every time instead
+            e = max(same, key=lambda q: q[4])
         elif len(self.entries) < self.SLOTS:
             plan = C.c_void_p()
             be.call('binplan_create', C.byref(plan))
             e = [None, plan, None, False, 0, None]
             self.entries.append(e)
         else:
-            e = min(free or [q for q in self.entries if q[5] == shape] or self.entries, key=lambda q: q[4])
+            e = min(free or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape
         be.call('binplan_configure', e[1], _FORMS[WALK])
         be.call('binplan_sorted', e[1], _FORMS[SORTED], None)

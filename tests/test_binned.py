@@ -459,3 +459,39 @@ def test_baseline_cycle_equals_oracle(hip, oracle, N, name, dtype, gradient, tol
     err = abs(got - want).max() / abs(want).max()
     print('full-size cycle N=%d %s %s %s: max |error| / max |value| = %.3e' % (N, name, dtype, data, err))
     assert err <= tol
+
+@pytest.mark.parametrize('N,name,dtype,tol', [(256, 'cic', 'f8', 1e-11), (256, 'tsc', 'f4', 2e-5)])
+def test_time_stepping_cycles_equal_oracle(hip, oracle, N, name, dtype, tol):
+    """What bench.py times: consecutive cycles on positions that moved by a fraction of a cell, so
+    that every cycle after the first REBUILDS the bin plan in a single pass from the slot ranges
+    of the previous one (bin_block_kernel at full size).  Three steps of a 0.1-cell random walk
+    at config 2's size, every particle of every step against the CPU oracle."""
+    import ctypes as C
+    from pmesh_amd._arrays import vec
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    window.BINNED = 'auto'
+    window.clear_bin_cache()
+    L = 1000.0
+    tdt = torch.float64 if dtype == 'f8' else torch.float32
+    pos = torch.empty((N ** 3, 3), dtype=tdt, device=hip.device)
+    pv = vec(pos)
+    hip.call('synth_uniform', C.byref(pv), N, L, 42, 0, N ** 3, hip.stream())
+    pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype=dtype, resampler=name)
+    gen = torch.Generator(device=hip.device)
+    gen.manual_seed(99)
+    t = oracle.make_transfer(laplace_pow=-1, grad_dir=0, grad_kind=0)
+    served = []
+    for step in range(3):
+        if step:
+            pos = pos + torch.randn(pos.shape, dtype=tdt, device=hip.device, generator=gen) * (0.1 * L / N)
+        rho = pm.paint(pos)
+        assert_binned_ran()
+        served += [e[1].value for e in window.bin_cache().entries if e[3] and e[2] is pos]
+        f = rho.r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=Transfer.dx1(0)).readout(pos)
+        real, ck, back, want = oracle.pm_cycle(N, L, pos.cpu().numpy(), kind='tuned' + name, transfer=t, dtype=dtype)
+        err = abs(f.cpu().numpy() - want).max() / abs(want).max()
+        print('step %d N=%d %s %s: max |error| / max |value| = %.3e' % (step, N, name, dtype, err))
+        assert err <= tol
+    # one pooled plan served all three position tensors (the rebuilds had the previous slot ranges)
+    assert len(set(served)) == 1, served
