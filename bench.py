@@ -482,6 +482,12 @@ def main():
             'host_arrays': bool(args.host_arrays),
             'bin_overflows': _window.bin_cache().overflows(be),
             'tile_order_ms': round(1e3 * t_order, 3),
+            # every stage against the same roofline: its algorithmic bytes (the fused apply is
+            # charged to c2r) over its measured time, as a fraction of the HBM peak
+            'stage_roofline_frac': {k: round((algorithmic_bytes(k, e, pe, nu, me if k == 'paint' else 0) +
+                                              (algorithmic_bytes('apply', e, pe, nu) if k == 'c2r' and args.fuse_apply else 0)) *
+                                             units / (max(stage_ms[k], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                    for k in ('paint', 'r2c', 'c2r', 'readout')},
             'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu, me) for s in
                                         ('paint', 'r2c', 'apply', 'c2r', 'readout')) * units /
                                     (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
