@@ -238,6 +238,9 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
+#ifndef PMX_FULL_AXIS_FAST
+#define PMX_FULL_AXIS_FAST 1
+#endif
 #ifndef PMX_BLOCK_BUILD
 #define PMX_BLOCK_BUILD 1
 #endif
@@ -615,6 +618,15 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
         int I[S];
         Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
         const int per = (int)p.period[d], siz = (int)p.size[d];      // (32-bit compares: see local_base32)
+        if (PMX_FULL_AXIS_FAST && g.o[d] == 0 && per == siz) {
+            // the axis is the whole periodic mesh, a multiple of the (power of two) tile extent
+            // (pmx_binplan_supported): the base cell relative to the particle's tile is I0 mod T, whatever
+            // period the coordinate is in — two instructions instead of the wrap, the shift into the block
+            // and the subtraction of the tile origin.  (The list says which tile that is; a plan that no
+            // longer matches the positions then deposits into the wrong cells of the region, never outside it.)
+            lb[d] = I[0] & (tile_ext(d) - 1);
+            continue;
+        }
         int w = wrap_fast(I[0], per);
         int i0w = w;
         if (per > 0 && w >= siz) i0w = w - per;
