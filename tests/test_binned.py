@@ -351,6 +351,57 @@ def test_block_rebuild_with_more_tiles_than_table_entries(hip, oracle, name, str
     assert window.bin_cache().overflows(hip) >= 0
 
 
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('PMESH_AMD_FUZZ_SEEDS', '10'))))
+def test_random_geometries_over_moving_particles(hip, seed):
+    """Randomly drawn block geometries — extents that are and are not multiples of the tile, every axis
+    the whole periodic mesh / a block of a bigger periodic mesh / not periodic, scales and translations,
+    particles partly outside — over three steps of moving particles (first build, then single-pass
+    rebuilds): binned paint equals direct paint within the fp64 tolerance, binned readout equals direct
+    readout bit for bit."""
+    rs = numpy.random.RandomState(1000 + seed)
+    name = TUNED[seed % 4]
+    W = windows[name]
+    S = {'nnb': 1, 'cic': 2, 'tsc': 3, 'pcs': 4}[name]
+    T = (8, 16, 32)
+    shape, period = [], []
+    for d in range(3):
+        kind = rs.randint(3)
+        if kind == 0:                                   # the whole periodic mesh: a multiple of the tile
+            n = T[d] * rs.randint(2, 5)
+            shape.append(n); period.append(n)
+        elif kind == 1:                                 # a block of a bigger periodic mesh
+            n = rs.randint(T[d] + S, 3 * T[d] + 5)
+            shape.append(n); period.append(n + rs.randint(S, 40))
+        else:                                           # not periodic
+            shape.append(rs.randint(T[d] + S, 3 * T[d] + 5)); period.append(0)
+    scale = rs.uniform(0.5, 2.0, size=3)
+    translate = rs.uniform(-10, 10, size=3)
+    aff = Affine(3, scale=list(scale), translate=list(translate), period=period)
+    n = int(rs.randint(1, 40000))
+    lo = (-0.2 * numpy.array(shape) - translate) / scale
+    hi = (1.2 * numpy.array(shape) - translate) / scale
+    pos_h = rs.uniform(lo, hi, size=(n, 3))
+    mass = torch.from_numpy(rs.uniform(0.5, 1.5, size=n)).to(hip.device)
+    field = torch.from_numpy(rs.normal(size=shape)).to(hip.device)
+    pos = torch.zeros((n, 3), dtype=torch.float64, device=hip.device)
+    window.clear_bin_cache()
+    for step in range(3):
+        pos_h = pos_h + rs.normal(0, 0.3, size=(n, 3)) / scale
+        pos.copy_(torch.from_numpy(pos_h))
+        out = {}
+        for mode in ('always', 'never'):
+            window.BINNED = mode
+            c = torch.zeros(shape, dtype=torch.float64, device=hip.device)
+            W.paint(c, pos, mass=mass, transform=aff)
+            out[mode] = (c.cpu().numpy(), W.readout(field, pos, transform=aff).cpu().numpy())
+            if mode == 'always':
+                assert_binned_ran()
+        ref = max(1.0, abs(out['never'][0]).max())
+        assert_allclose(out['always'][0], out['never'][0], rtol=0, atol=1e-12 * ref,
+                        err_msg='%s shape %s period %s step %d' % (name, shape, period, step))
+        assert_array_equal(out['always'][1], out['never'][1], err_msg='%s shape %s period %s step %d' % (name, shape, period, step))
+
+
 def test_rebuild_drops_and_nonperiodic(hip, form, oracle):
     """history rebuilds with particles that touch no local cell (their own bucket) on a
     non-periodic sub-block: dropped particles read 0 and paint nothing"""
