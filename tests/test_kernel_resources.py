@@ -79,3 +79,9 @@ def test_tile_kernel_budgets():
     for k, v in t.items():
         if 'bin_count_kernel' in k:
             assert v['ScratchSize'] == 0, k
+    # the block form of the single-pass rebuild: a real loop (its first, fully unrolled version had 122
+    # VGPRs and 80 KB of code and was no faster than the chunk form), five workgroups per CU by its LDS
+    blocks = {k: v for k, v in t.items() if 'bin_block_kernel' in k}
+    assert len(blocks) == 8
+    for k, v in blocks.items():
+        assert v['ScratchSize'] == 0 and v['VGPRs'] <= 96 and v['LDS'] <= 32768, (k, v)
