@@ -643,7 +643,7 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     constexpr bool sorted = SORTED;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
-    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    constexpr int R1 = Rg::R1;
     // UNROLL particles per thread and trip: all index and position loads are issued before
     // the first use, so several dependent gathers are in flight per lane
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
@@ -678,7 +678,7 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
 #pragma unroll
                 for (int b = 0; b < S; b++) {
                     double fb = V[0][a] * V[1][b];
-                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
+                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * Rg::P2 + lb[2];
 #pragma unroll
                     for (int c = 0; c < S; c++) {
                         unsafeAtomicAdd(&lds[rowoff + c], fb * V[2][c]);
@@ -697,7 +697,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
     constexpr bool sorted = SORTED;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
-    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    constexpr int R1 = Rg::R1;
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];
         double x[UNROLL][3];
@@ -725,7 +725,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
 #pragma unroll
                 for (int b = 0; b < S; b++) {
                     double fb = V[0][a] * V[1][b];
-                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * R2 + lb[2];
+                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * Rg::template gpitch<T>() + lb[2];
 #pragma unroll
                     for (int c = 0; c < S; c++) value += (double)lds[rowoff + c] * (fb * V[2][c]);
                 }
@@ -764,11 +764,11 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
     // the list itself is then only read for a per-particle mass
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
-    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    constexpr int R1 = Rg::R1;
     // The tile is accumulated in double whatever the canvas type: ds_add_f32 measured ~5x
     // slower than ds_add_f64 on gfx950 (CIC f4 paint 5.3 ms vs 1.0 ms at 512^3), and the sum
     // is rounded to the canvas type once, at the flush.
-    __shared__ double lds[Rg::CELLS];
+    __shared__ double lds[Rg::LDS];
     // A workgroup walks a SEGMENT of up to ZSEG tiles that follow each other along z (the tile
     // index runs fastest along z) and keeps the z-halo — the planes c >= T2 of the region — in
     // LDS, where it becomes the first S-1 planes of the next tile's region.  Only the last tile of
@@ -801,12 +801,12 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int q = threadIdx.x + u * TTHREADS;
                 if (q < NCARRY) {
                     int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
-                    carry[u] = lds[r * R2 + T2 + c];
+                    carry[u] = lds[r * Rg::P2 + T2 + c];
                 }
             }
             __syncthreads();
         }
-        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) lds[q] = 0;
+        for (int q = threadIdx.x; q < Rg::LDS; q += TTHREADS) lds[q] = 0;
         __syncthreads();
         if (S > 1 && live) {
 #pragma unroll
@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int q = threadIdx.x + u * TTHREADS;
                 if (q < NCARRY) {
                     int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
-                    lds[r * R2 + c] = carry[u];
+                    lds[r * Rg::P2 + c] = carry[u];
                 }
             }
             __syncthreads();
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 in = in && l >= 0 && l < p.size[d];
             }
             if (in && region_cell(p, g, t, a, b, c, &goff)) {
-                T v = (T)lds[(a * R1 + b) * R2 + c];
+                T v = (T)lds[(a * R1 + b) * Rg::P2 + c];
                 T *dst = (T *)(canvas + goff);
                 if (overwrite) *dst = v;
                 else *dst += v;
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int a, b, c;
                 Rg::halo_decode(h, &a, &b, &c);
                 if (!last && c >= T2) continue;           // carried to the next tile instead
-                hbase[h] = (T)lds[(a * R1 + b) * R2 + c];
+                hbase[h] = (T)lds[(a * R1 + b) * Rg::P2 + c];
             }
         }
         live = !last;
@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
-    __shared__ T lds[Rg::CELLS];
+    __shared__ T lds[Rg::template glds<T>()];
     __shared__ int64_t tab[Rg::R0 + Rg::R1 + Rg::R2];
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t start = offsets[tile];
@@ -926,7 +926,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
             int c = q % R2, r = q / R2;
             int b = r % R1, a = r / R1;
             const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
-            lds[q] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;   // outside the block reads as 0
+            lds[r * Rg::template gpitch<T>() + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;   // outside the block reads as 0
         }
         __syncthreads();
         tile_gather<KIND, T, TTHREADS, SORTED>(p, g, t, pos, out, list, start, count, lds);
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
-    __shared__ double lds[Rg::CELLS];
+    __shared__ double lds[Rg::LDS];
     const uint32_t n = *nitems < cap ? *nitems : cap;
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
         const int64_t tile = (int64_t)(items[item] >> 20);
@@ -971,14 +971,14 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
         const int64_t first = piece * g.chunk;
         const int64_t left = (int64_t)counts[tile] - first;
         const int count = left < g.chunk ? (int)left : g.chunk;
-        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) lds[q] = 0;
+        for (int q = threadIdx.x; q < Rg::LDS; q += TTHREADS) lds[q] = 0;
         __syncthreads();
         tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
-            const double v = lds[q];
-            if (v == 0) continue;
             const int c = q % R2, r = q / R2;
+            const double v = lds[r * Rg::P2 + c];
+            if (v == 0) continue;
             int64_t goff;
             if (region_cell(p, g, t, r / R1, r % R1, c, &goff)) unsafeAtomicAdd((T *)(canvas + goff), (T)v);
         }
@@ -995,7 +995,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, 
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
-    __shared__ T lds[Rg::CELLS];
+    __shared__ T lds[Rg::template glds<T>()];
     const uint32_t n = *nitems < cap ? *nitems : cap;
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
         const int64_t tile = (int64_t)(items[item] >> 20);
@@ -1009,7 +1009,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, 
             const int c = q % R2, r = q / R2;
             int64_t goff;
             const bool in = region_cell(p, g, t, r / R1, r % R1, c, &goff);
-            lds[q] = in ? *(const T *)(canvas + goff) : (T)0;
+            lds[r * Rg::template gpitch<T>() + c] = in ? *(const T *)(canvas + goff) : (T)0;
         }
         __syncthreads();
         tile_gather<KIND, T, TTHREADS, SORTED>(p, g, t, pos, out, list, offsets[tile] + first, count, lds);

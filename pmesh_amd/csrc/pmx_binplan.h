@@ -62,6 +62,23 @@ struct BinGeom {
 template <int S> struct Region {
     static constexpr int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
     static constexpr int CELLS = R0 * R1 * R2;
+    // Row pitch of the region in LDS (cells).  For S >= 3 rows are 48 cells = 384 bytes = three whole
+    // bank rows instead of T2 + S - 1 = 34 / 35 cells: a particle whose base cell differs from its
+    // neighbour's along x or y (half of them on the benchmark's jittered lattice under TSC, whose rounding
+    // boundary the lattice straddles; any real distribution) then still hits the banks its z cell names, and
+    // lanes that walk along z stay conflict free: scripts/ldsatomic_patterns.hip 27 -> 19 clocks per ds_add_f64
+    // instruction.  It costs TSC its third workgroup per CU (69 KB regions), PCS nothing (80 KB: still two).
+#ifndef PMX_ROW_PITCH3
+#define PMX_ROW_PITCH3 48
+#endif
+    static constexpr int P2 = (S >= 3 && PMX_ROW_PITCH3 > R2) ? PMX_ROW_PITCH3 : R2;
+    static constexpr int LDS = R0 * R1 * P2;      // elements to allocate
+    // The readout's copy of the region: the same pitch where it costs no workgroup (PCS: paint 4.36 -> 3.90,
+    // readout 2.59 -> 2.44 ms at 512^3), the dense one for TSC, whose readout loses more by running two
+    // workgroups per CU instead of three than its LDS reads gain (1.64 -> 1.89 ms; paint 3.26 -> 2.75)
+    // (and only for 8-byte regions: 48 floats are 192 bytes, no multiple of a bank row — PCS fp32 readout 2.48 -> 2.60)
+    template <typename T> static constexpr int gpitch() { return (S >= 4 && sizeof(T) == 8) ? P2 : R2; }
+    template <typename T> static constexpr int glds() { return R0 * R1 * gpitch<T>(); }
     // compact numbering of the halo (region minus the T0 x T1 x T2 box)
     static constexpr int NA = (S - 1) * R1 * R2;     // a >= T0
     static constexpr int NB = T0 * (S - 1) * R2;     // a < T0, b >= T1
