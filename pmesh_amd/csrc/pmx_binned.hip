@@ -687,10 +687,10 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
 #pragma unroll
                 for (int b = 0; b < S; b++) {
                     double fb = V[0][a] * V[1][b];
-                    int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * Rg::P2 + lb[2];
+                    const int row = (lb[0] + a) * R1 + (lb[1] + b);
 #pragma unroll
                     for (int c = 0; c < S; c++) {
-                        unsafeAtomicAdd(&lds[rowoff + c], fb * V[2][c]);
+                        unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], fb * V[2][c]);
                     }
                 }
         }
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
     // The tile is accumulated in double whatever the canvas type: ds_add_f32 measured ~5x
     // slower than ds_add_f64 on gfx950 (CIC f4 paint 5.3 ms vs 1.0 ms at 512^3), and the sum
     // is rounded to the canvas type once, at the flush.
-    __shared__ double lds[Rg::LDS];
+    __shared__ double lds[Rg::DLDS];
     // A workgroup walks a SEGMENT of up to ZSEG tiles that follow each other along z (the tile
     // index runs fastest along z) and keeps the z-halo — the planes c >= T2 of the region — in
     // LDS, where it becomes the first S-1 planes of the next tile's region.  Only the last tile of
@@ -810,12 +810,12 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int q = threadIdx.x + u * TTHREADS;
                 if (q < NCARRY) {
                     int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
-                    carry[u] = lds[r * Rg::P2 + T2 + c];
+                    carry[u] = lds[Rg::dat(r, T2 + c)];
                 }
             }
             __syncthreads();
         }
-        for (int q = threadIdx.x; q < Rg::LDS; q += TTHREADS) lds[q] = 0;
+        for (int q = threadIdx.x; q < Rg::DLDS; q += TTHREADS) lds[q] = 0;
         __syncthreads();
         if (S > 1 && live) {
 #pragma unroll
@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int q = threadIdx.x + u * TTHREADS;
                 if (q < NCARRY) {
                     int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
-                    lds[r * Rg::P2 + c] = carry[u];
+                    lds[Rg::dat(r, c)] = carry[u];
                 }
             }
             __syncthreads();
@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 in = in && l >= 0 && l < p.size[d];
             }
             if (in && region_cell(p, g, t, a, b, c, &goff)) {
-                T v = (T)lds[(a * R1 + b) * Rg::P2 + c];
+                T v = (T)lds[Rg::dat(a * R1 + b, c)];
                 T *dst = (T *)(canvas + goff);
                 if (overwrite) *dst = v;
                 else *dst += v;
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int a, b, c;
                 Rg::halo_decode(h, &a, &b, &c);
                 if (!last && c >= T2) continue;           // carried to the next tile instead
-                hbase[h] = (T)lds[(a * R1 + b) * Rg::P2 + c];
+                hbase[h] = (T)lds[Rg::dat(a * R1 + b, c)];
             }
         }
         live = !last;
@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
-    __shared__ double lds[Rg::LDS];
+    __shared__ double lds[Rg::DLDS];
     const uint32_t n = *nitems < cap ? *nitems : cap;
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
         const int64_t tile = (int64_t)(items[item] >> 20);
@@ -980,13 +980,13 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
         const int64_t first = piece * g.chunk;
         const int64_t left = (int64_t)counts[tile] - first;
         const int count = left < g.chunk ? (int)left : g.chunk;
-        for (int q = threadIdx.x; q < Rg::LDS; q += TTHREADS) lds[q] = 0;
+        for (int q = threadIdx.x; q < Rg::DLDS; q += TTHREADS) lds[q] = 0;
         __syncthreads();
         tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             const int c = q % R2, r = q / R2;
-            const double v = lds[r * Rg::P2 + c];
+            const double v = lds[Rg::dat(r, c)];
             if (v == 0) continue;
             int64_t goff;
             if (region_cell(p, g, t, r / R1, r % R1, c, &goff)) unsafeAtomicAdd((T *)(canvas + goff), (T)v);

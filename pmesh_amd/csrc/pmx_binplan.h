@@ -73,6 +73,21 @@ template <int S> struct Region {
 #endif
     static constexpr int P2 = (S >= 3 && PMX_ROW_PITCH3 > R2) ? PMX_ROW_PITCH3 : R2;
     static constexpr int LDS = R0 * R1 * P2;      // elements to allocate
+    // TSC paint: the split layout.  Rows of exactly T2 = 32 cells (two bank rows: every row starts on bank 0) and
+    // the S - 1 halo columns of all rows in an array of their own behind them: bank-neutral like the 48-cell
+    // rows, but in the 49 KB of the dense region — three workgroups per CU instead of two.
+#ifndef PMX_SPLIT_TSC
+#define PMX_SPLIT_TSC 1
+#endif
+    static constexpr bool SPLIT = PMX_SPLIT_TSC && S == 3;
+    static constexpr int DMAIN = R0 * R1 * T2;
+    static constexpr int DLDS = SPLIT ? DMAIN + R0 * R1 * (S - 1) : LDS;     // elements of the deposit region
+    // element of row `row` (= a * R1 + b), column c of the deposit region
+    __device__ static __forceinline__ int dat(int row, int c)
+    {
+        if (SPLIT) return c < T2 ? row * T2 + c : DMAIN + row * (S - 1) + (c - T2);
+        return row * P2 + c;
+    }
     // The readout's copy of the region: the same pitch where it costs no workgroup (PCS: paint 4.36 -> 3.90,
     // readout 2.59 -> 2.44 ms at 512^3), the dense one for TSC, whose readout loses more by running two
     // workgroups per CU instead of three than its LDS reads gain (1.64 -> 1.89 ms; paint 3.26 -> 2.75)
