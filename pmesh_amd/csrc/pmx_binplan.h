@@ -73,13 +73,15 @@ template <int S> struct Region {
 #endif
     static constexpr int P2 = (S >= 3 && PMX_ROW_PITCH3 > R2) ? PMX_ROW_PITCH3 : R2;
     static constexpr int LDS = R0 * R1 * P2;      // elements to allocate
-    // TSC paint: the split layout.  Rows of exactly T2 = 32 cells (two bank rows: every row starts on bank 0) and
+    // CIC / TSC paint: the split layout.  Rows of exactly T2 = 32 cells (two bank rows: every row starts on bank 0) and
     // the S - 1 halo columns of all rows in an array of their own behind them: bank-neutral like the 48-cell
-    // rows, but in the 49 KB of the dense region — three workgroups per CU instead of two.
+    // rows, but in the 49 KB of the dense TSC region — three workgroups per CU instead of two (TSC paint 2.64 -> 2.53 ms);
+    // for CIC the same 40 KB as before and nothing on the lattice, where its base cells never leave their row, but
+    // -3.5 % on the clustered set (paint 1.395 -> 1.345 ms).
 #ifndef PMX_SPLIT_TSC
 #define PMX_SPLIT_TSC 1
 #endif
-    static constexpr bool SPLIT = PMX_SPLIT_TSC && S == 3;
+    static constexpr bool SPLIT = PMX_SPLIT_TSC && (S == 3 || S == 2);
     static constexpr int DMAIN = R0 * R1 * T2;
     static constexpr int DLDS = SPLIT ? DMAIN + R0 * R1 * (S - 1) : LDS;     // elements of the deposit region
     // element of row `row` (= a * R1 + b), column c of the deposit region
