@@ -238,8 +238,11 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
-#ifndef PMX_PAIR_TSC
-#define PMX_PAIR_TSC 1
+#ifndef PMX_SWAP_PCS
+#define PMX_SWAP_PCS 0
+#endif
+#ifndef PMX_SWAP_TSC
+#define PMX_SWAP_TSC 1
 #endif
 #ifndef PMX_FULL_AXIS_FAST
 #define PMX_FULL_AXIS_FAST 1
@@ -649,18 +652,14 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     constexpr int R1 = Rg::R1;
     // UNROLL particles per thread and trip: all index and position loads are issued before
     // the first use, so several dependent gathers are in flight per lane
-    // PAIR: a lane takes two CONSECUTIVE list entries in its two slots instead of entries TTHREADS apart.
-    // Consecutive entries are neighbours along z (rows arrive in runs along the contiguous axis) and under
-    // TSC every fourth such pair has the same z base cell: in different instructions they cannot collide.
-    // (Same box, with the 48-cell rows: TSC paint 2.83 -> 2.64 ms, config 3 2.74 -> 2.57, clustered 3.08 -> 2.95.  The
-    // same for CIC: 1.27 -> 1.31, uniform PCS 3.90 -> 4.90, clustered PCS 6.25 -> 5.87: TSC only.)
-    constexpr bool PAIR = PMX_PAIR_TSC && S == 3 && UNROLL == 2;
-    for (int j0 = PAIR ? (int)threadIdx.x * UNROLL : (int)threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+    // SWAP (TSC): odd lanes deposit their second particle first, see below
+    constexpr bool SWAP = PMX_SWAP_TSC && (S == 3 || (PMX_SWAP_PCS && S == 4)) && UNROLL == 2;
+    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            int j = PAIR ? j0 + u : j0 + u * TTHREADS;
+            int j = j0 + u * TTHREADS;
             idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
         }
 #pragma unroll
@@ -670,6 +669,18 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
                 // (sorted: idx is the list slot; a per-particle mass lives at the row the list names)
                 m[u] = mass.data ? mass.get(sorted ? (int64_t)list[idx[u]] : idx[u], 0) : mass_scalar;
             }
+        }
+        if (SWAP && (threadIdx.x & 1)) {
+            // odd lanes deposit their second particle first: neighbouring list entries — neighbours along z, every
+            // fourth pair on the same cell under TSC — then sit in different instructions, while the loads stay dense
+            // and every instruction still reaches all banks (even cells of one run, odd cells of another).  Same box,
+            // with the bank-neutral rows: TSC paint 2.70 -> 2.53 ms on the jittered lattice, 1.53 -> 1.56 on a perfect
+            // one.  (A lane taking two CONSECUTIVE entries instead did the same for the jittered lattice, 2.58, but its
+            // stride-2 loads cost the perfect one 0.7 ms; for CIC and uniform PCS that form measured +3 % and +25 %.)
+#pragma unroll
+            for (int d = 0; d < 3; d++) { const double tmp = x[0][d]; x[0][d] = x[1][d]; x[1][d] = tmp; }
+            const double tm = m[0]; m[0] = m[1]; m[1] = tm;
+            const int64_t ti = idx[0]; idx[0] = idx[1]; idx[1] = ti;
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
