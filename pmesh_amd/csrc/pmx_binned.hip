@@ -238,9 +238,6 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
-#ifndef PMX_SWAP_PCS
-#define PMX_SWAP_PCS 0
-#endif
 #ifndef PMX_SWAP_TSC
 #define PMX_SWAP_TSC 1
 #endif
@@ -652,8 +649,8 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     constexpr int R1 = Rg::R1;
     // UNROLL particles per thread and trip: all index and position loads are issued before
     // the first use, so several dependent gathers are in flight per lane
-    // SWAP (TSC): odd lanes deposit their second particle first, see below
-    constexpr bool SWAP = PMX_SWAP_TSC && (S == 3 || (PMX_SWAP_PCS && S == 4)) && UNROLL == 2;
+    // SWAP (TSC, PCS): odd lanes deposit their second particle first, see below
+    constexpr bool SWAP = PMX_SWAP_TSC && S >= 3 && UNROLL == 2;
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
@@ -676,7 +673,9 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
             // and every instruction still reaches all banks (even cells of one run, odd cells of another).  Same box,
             // with the bank-neutral rows: TSC paint 2.70 -> 2.53 ms on the jittered lattice, 1.53 -> 1.56 on a perfect
             // one.  (A lane taking two CONSECUTIVE entries instead did the same for the jittered lattice, 2.58, but its
-            // stride-2 loads cost the perfect one 0.7 ms; for CIC and uniform PCS that form measured +3 % and +25 %.)
+            // stride-2 loads cost the perfect one 0.7 ms.)  PCS: the clustered set gains — config 5's per-GPU load 98 -> 87 ms of
+            // paint, 256^3 1.12 -> 0.96 — the lattice, on which PCS base cells have no jitter to begin with, pays 6 %
+            // (3.92 -> 4.16 ms).  CIC: +3 % either way, not used.
 #pragma unroll
             for (int d = 0; d < 3; d++) { const double tmp = x[0][d]; x[0][d] = x[1][d]; x[1][d] = tmp; }
             const double tm = m[0]; m[0] = m[1]; m[1] = tm;
