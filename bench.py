@@ -34,6 +34,11 @@ import os
 import sys
 import time
 
+# Runtime switches of the HSA / HIP layer are read when the runtime initialises, i.e. at the first
+# torch.cuda call: set them before anything imports torch.  (dmabuf IPC is the only form the host
+# driver of this pool supports; without it RCCL fails with `hipIpcGetMemHandle: invalid argument`.)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -93,7 +98,27 @@ def parse():
                          'the reported rate then is PCIe inclusive and is NOT the headline metric)')
     ap.add_argument('--fuse-apply', type=int, default=1,
                     help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
-    return ap.parse_args()
+    ap.add_argument('--migrate', type=int, default=1,
+                    help='1 (--gpus N > 1): move every particle to the rank that owns its cell once, before the '
+                         'timed cycles; 0: the particles stay on the rank that generated them')
+    ap.add_argument('--np', default='slab', choices=['slab', 'pencil'],
+                    help="process mesh for --gpus N > 1: slab = [N] (one transpose per transform), pencil = "
+                         "pfft's split_size_2d(N), e.g. [2, 4] on 8 ranks (the reference's default for 3-d)")
+    ap.add_argument('--config', default=None, choices=['c2', 'c3', 'c4', 'c5'],
+                    help="BASELINE.json's other configurations as presets (the default run is the headline metric's "
+                         "512^3 workload): c2 = 256^3 CIC fp64; c3 = 512^3 TSC fp32, gradient readout; c4 = 1024^3 "
+                         "mesh / 1024^3 particles CIC fp64 on slabs; c5 = 2048^3 mesh / 2 x 2048^3 clustered particles, "
+                         "PCS, per-particle mass, pencils (needs 8 GPUs: 52 GB of particles per GPU)")
+    args = ap.parse_args()
+    presets = {
+        'c2': dict(mesh=256),
+        'c3': dict(mesh=512, window='tsc', dtype='f4', gradient=0),
+        'c4': dict(mesh=1024, np='slab'),
+        'c5': dict(mesh=2048, window='pcs', data='clustered', double=1, mass='array', np='pencil'),
+    }
+    for k, v in presets.get(args.config, {}).items():
+        setattr(args, k, v)
+    return args
 
 
 def cpu_baseline(args):
@@ -245,7 +270,6 @@ def main():
     launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ      # under torch.distributed.run
     if world > 1 or launched:
         import torch.distributed as dist
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group(os.environ.get('PMESH_AMD_DIST_BACKEND', 'nccl'))
 
     from pmesh_amd import backend
@@ -293,8 +317,24 @@ def main():
         mass = 0.5 + (torch.arange(nloc, device=be.device, dtype=torch.int64) % 1024).to(torch.float64) / 1024.0
         mtot = float(comm.allreduce(float(mass.sum()))) if world > 1 else float(mass.sum())
 
+    if args.np == 'pencil' and world > 1:
+        from pmesh_amd.fft import split_size_2d
+        np_ = [int(x) for x in split_size_2d(world)]
+    else:
+        np_ = [world]
     pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype=args.dtype, resampler=args.window,
-                      np=[world])
+                      np=np_)
+    if world > 1 and args.migrate:
+        # every particle moves to the rank that owns its cell, once and untimed: what a time-stepping code
+        # does after its first decompose.  (The ranks generate slabs of lattice ids; on a pencil mesh, or with
+        # the Zel'dovich displacements, most rows would otherwise travel as "ghosts" in every cycle.)
+        home = pm.domain.decompose(pos, smoothing=0, _scale=pm.affine.scale)
+        if args.mass == 'array':
+            pos, mass = home.exchange(pos, mass)
+        else:
+            pos = home.exchange(pos)
+        nloc = int(pos.shape[0])
+        del home
     transfer = Transfer.dx1(0)             # T(k) = i k_x / k^2
     rho = pm.create('real')
     t_order = 0.0
@@ -307,11 +347,16 @@ def main():
         t_order = time.perf_counter() - t0
 
     # a time-stepping caller: the positions of consecutive cycles differ by a small random step
+    # (three position sets; two when a third would not leave room for the mesh and the bin lists)
     psets = [pos]
     if args.drift > 0:
         gen = torch.Generator(device=be.device)
         gen.manual_seed(4321 + rank)
-        for k in range(2):
+        free_b, _ = torch.cuda.mem_get_info()
+        set_b = pos.numel() * pos.element_size()
+        work_b = 14 * nloc + 6 * e * N ** 3 // world          # bin lists + mesh, work buffers, halo staging
+        nextra = 2 if free_b > 3 * set_b + work_b else 1      # (+1: the temporary of the random step)
+        for k in range(nextra):
             step = torch.randn(pos.shape, dtype=tdt, device=be.device, generator=gen) * (args.drift * L / N)
             psets.append(psets[-1] + step)
             del step
@@ -444,13 +489,16 @@ def main():
         else:
             kname = {'paint': 'paint_tuned_kernel', 'readout': 'readout_tuned_kernel',
                      'apply': 'transfer_kernel'}[dom]
+        # HBM bytes per launch of the dominant stage's kernels from the PMC passes of this configuration
+        # (profiles/traffic.json, regenerated by scripts/make_traffic.py from scripts/profile_round.sh output)
         traffic = None
+        traffic_key = '%d/%s/%s/%s%s%s' % (N, args.window, args.dtype, args.data, '/x2' if args.double else '',
+                                           '/mass' if args.mass == 'array' else '')
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = '%s/%d/%s/%s/%s' % (dom, N, args.window, args.dtype, args.data)
-                traffic = tj.get(key)
+                traffic = tj.get('%s/%s' % (dom, traffic_key))
             except Exception:
                 traffic = None
         line = {
@@ -468,8 +516,9 @@ def main():
                                       ('' if args.gradient is None else ' (gradient %d)' % args.gradient) +
                                       (', per-particle fp64 mass' if args.mass == 'array' else '')),
                        'decomposition': ('single GPU' if world == 1 else
-                                         'slab np=[%d], particle exchange included (%s)'
-                                         % (world, 'ghosts only' if args.ghosts_only else 'all particles')),
+                                         '%s np=%s, particle exchange included (%s)'
+                                         % ('slab' if len(np_) == 1 else 'pencil', np_,
+                                            'ghosts only' if args.ghosts_only else 'all particles')),
                        'particles': ntot, 'apply': 'fused into c2r' if args.fuse_apply else 'separate kernel',
                        'fft': 'LDS row + column FFT kernels' if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
@@ -488,11 +537,14 @@ def main():
                                               (algorithmic_bytes('apply', e, pe, nu) if k == 'c2r' and args.fuse_apply else 0)) *
                                              units / (max(stage_ms[k], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                     for k in ('paint', 'r2c', 'c2r', 'readout')},
+            # the same without the bytes of the fused apply (the pass itself moves 2 e per cell, whatever rides on it)
+            'c2r_alone_roofline_frac': round(algorithmic_bytes('c2r', e, pe, nu) * units /
+                                             (max(stage_ms['c2r'], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             'cycle_roofline_frac': (sum(algorithmic_bytes(s, e, pe, nu, me) for s in
                                         ('paint', 'r2c', 'apply', 'c2r', 'readout')) * units /
                                     (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_key': traffic_key,
                          # the bin pass exists only to feed paint and readout and has no algorithmic
                          # bytes of its own: their bytes over the time of all three
                          'with_bin_frac': ((algorithmic_bytes('paint', e, pe, nu, me) +

@@ -43,8 +43,9 @@ typedef enum pmx_status {
     PMX_ENOMEM = 5
 } pmx_status;
 
-/* Window kinds on the path (pmesh/_window_imp.h:4-28; window.py:230-255).
- * The wavelet kinds (db/sym) are not built. */
+/* Window kinds on the path (pmesh/_window_imp.h:4-28; window.py:230-255): every kind of the
+ * reference's registry, the table-driven ones (lanczos, acg, db / sym wavelets) after
+ * pmx_window_set_table. */
 typedef enum pmx_window_kind {
     PMX_NEAREST = 0,   /* PMESH_PAINTER_NEAREST   */
     PMX_LINEAR = 1,    /* PMESH_PAINTER_LINEAR    */
@@ -134,19 +135,20 @@ typedef struct pmx_binplan pmx_binplan;
 int pmx_binplan_create(pmx_binplan **plan);
 int pmx_binplan_destroy(pmx_binplan *plan);
 /* Which kernels the next builds of this plan serve: 0 = tile form (one workgroup accumulates a
- * tile of 8 x 16 x 32 cells in LDS, S^3 LDS operations per particle), 1 = walk form (a workgroup
- * walks a patch of 16 x 32 columns plane by plane with the stencil of every cell in registers,
- * S^2 LDS operations per cell: csrc/pmx_walk.hip; TSC and PCS, rows of `pos` contiguous),
- * -1 (default) = the library's choice, today always the tiles (the walk form measured no faster
- * on MI355X: DESIGN.md).  Same results either way (readout bit-identical, paint up to the order
- * of the additions into a cell). */
+ * tile of 8 x 16 x 32 cells in LDS), -1 (default) = the library's choice (the tiles), 2 = tiles
+ * with the chunk form of the single-pass rebuild (what plans with a tile-ordered copy use; a test
+ * hook), 1 = walk form (a workgroup walks a patch of 16 x 32 columns plane by plane with the
+ * stencil of every cell in registers: csrc/pmx_walk.hip, TSC and PCS) — a measured alternative that
+ * is no faster on MI355X and only part of a `make WALK=1` build: PMX_EUNSUPPORTED
+ * otherwise.  Same results in every form (readout bit-identical, paint up to the order of the
+ * additions into a cell). */
 int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
 /* Rows without spatial coherence (catalogues in file order, shuffled sets) make every access
  * through the index list a sector of its own.  A plan can instead carry a copy of the positions
  * in tile order (one gather per build): paint and readout stream it, readout writes its results
  * in tile order and pulls them back through the inverse list.  pref: -1 (default) = decided by
- * the first build of a geometry from the measured coherence of the row order (more than 16
- * distinct tiles per 64 consecutive rows), 0 = never, 1 = always, -2 = leave unchanged.
+ * the first build of a geometry from the measured coherence of the row order (more than 24
+ * changes of tile per 64 consecutive rows), 0 = never, 1 = always, -2 = leave unchanged.
  * is_sorted (optional): whether the plan as built carries the copy.  Results do not depend on it
  * (readout bit-identical, paint up to the order of the additions). */
 int pmx_binplan_sorted(pmx_binplan *plan, int32_t pref, int32_t *is_sorted);

@@ -26,8 +26,20 @@ def touched(*tensors):
     cache (window._BinCache) and the Layout memos key on (data_ptr, _version): without the bump
     a tensor rewritten by readout(out=), gather or an FFT would be served a stale plan."""
     for t in tensors:
-        if isinstance(t, torch.Tensor):
+        if isinstance(t, torch.Tensor) and not t.is_inference():
             torch.autograd.graph.increment_version(t)
+
+
+_unversioned = [0]
+
+
+def version_of(t):
+    """the version counter of a tensor for cache keys; tensors made under torch.inference_mode() have
+    none: they get a fresh value every time, i.e. they are never found in a cache"""
+    if t.is_inference():
+        _unversioned[0] -= 1
+        return _unversioned[0]
+    return t._version
 
 
 # ---- host <-> device staging for numpy callers -------------------------------------------

@@ -238,19 +238,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
-#ifndef PMX_SWAP_TSC
-#define PMX_SWAP_TSC 1
-#endif
-#ifndef PMX_FULL_AXIS_FAST
-#define PMX_FULL_AXIS_FAST 1
-#endif
-#ifndef PMX_BLOCK_BUILD
-#define PMX_BLOCK_BUILD 1
-#endif
-#ifndef PMX_BLOCK_ITERS
-#define PMX_BLOCK_ITERS 8
-#endif
-constexpr int BLOCK_ITERS = PMX_BLOCK_ITERS;                     // trips of TBLOCK * PMX_ONEPASS_U rows
+constexpr int BLOCK_ITERS = 8;                     // trips of TBLOCK * PMX_ONEPASS_U rows
 constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
 constexpr int BLOCK_HT = 128;                       // entries of the LDS table (a power of two)
 // 16-byte pieces of the TBLOCK * U dense rows from `base` on, one per thread and q: -> bytes requested
@@ -621,7 +609,7 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
         int I[S];
         Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
         const int per = (int)p.period[d], siz = (int)p.size[d];      // (32-bit compares: see local_base32)
-        if (PMX_FULL_AXIS_FAST && g.o[d] == 0 && per == siz) {
+        if (g.o[d] == 0 && per == siz) {
             // the axis is the whole periodic mesh, a multiple of the (power of two) tile extent
             // (pmx_binplan_supported): the base cell relative to the particle's tile is I0 mod T, whatever
             // period the coordinate is in — two instructions instead of the wrap, the shift into the block
@@ -650,7 +638,7 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     // UNROLL particles per thread and trip: all index and position loads are issued before
     // the first use, so several dependent gathers are in flight per lane
     // SWAP (TSC, PCS): odd lanes deposit their second particle first, see below
-    constexpr bool SWAP = PMX_SWAP_TSC && S >= 3 && UNROLL == 2;
+    constexpr bool SWAP = S >= 3 && UNROLL == 2;
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
@@ -1057,27 +1045,6 @@ static bool same_geometry(const pmx_painter &a, const pmx_painter &b)
     return true;
 }
 
-// mean particles per cell from which form -1 chooses the walk kernels for S >= 3
-// (environment PMX_WALK_MIN_DENSITY; default 0 = never)
-static double walk_min_density()
-{
-    static double v = -1;
-    if (v < 0) {
-        const char *e = getenv("PMX_WALK_MIN_DENSITY");
-        v = e ? atof(e) : 0.0;         // 0: never chosen automatically
-        if (!(v >= 0)) v = 0.0;
-    }
-    return v;
-}
-
-// rows from which the single-pass rebuild takes the block form (environment PMX_BLOCK_MIN_ROWS, read
-// at every build; default: always.  The tests also run the chunk form, which walk and sorted plans use)
-static int64_t block_min_rows()
-{
-    const char *e = getenv("PMX_BLOCK_MIN_ROWS");
-    return e ? atoll(e) : 0;
-}
-
 static int halo_cells(int S)
 {
     int R0 = T0 + S - 1, R1 = T1 + S - 1, R2 = T2 + S - 1;
@@ -1098,7 +1065,10 @@ extern "C" int pmx_binplan_create(pmx_binplan **plan)
 extern "C" int pmx_binplan_configure(pmx_binplan *pl, int32_t form)
 {
     PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
-    PMX_REQUIRE(form >= -1 && form <= 1, PMX_EINVAL, "form must be -1 (auto), 0 (tiles) or 1 (walk)");
+    PMX_REQUIRE(form >= -1 && form <= 2, PMX_EINVAL, "form must be -1 (auto), 0 (tiles), 1 (walk) or 2 (tiles, chunk rebuild)");
+#ifndef PMX_WITH_WALK
+    PMX_REQUIRE(form != 1, PMX_EUNSUPPORTED, "the walk kernels are not part of this build (make WALK=1)");
+#endif
     if (pl->form != form) pl->have_history = false;
     pl->form = form;
     return PMX_OK;
@@ -1187,15 +1157,15 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     BinGeom g;
     g.kind = p.kind;
     g.S = native_support(p.kind);
-    // Which form: the walk kernels (pmx_walk.hip) pay per mesh plane and per particle with S^2
-    // instead of S^3 LDS operations: TSC / PCS at a density of the order of one particle per
-    // cell; the tile kernels otherwise (sparse batches, CIC / NNB).
-    double cells = (double)p.size[0] * (double)p.size[1] * (double)p.size[2];
-    // (form -1, "auto", stays with the tiles: on MI355X the walk kernels measured no faster —
-    // DESIGN.md "walk form" — unless PMX_WALK_MIN_DENSITY asks for them)
-    bool walk = pl->form == 1 || (pl->form < 0 && g.S >= 3 && walk_min_density() > 0 &&
-                                   (double)npart >= walk_min_density() * cells);
+    // Which form: the tile kernels.  (The walk kernels of pmx_walk.hip — S^2 instead of S^3 LDS
+    // operations per particle for TSC / PCS — measured no faster on MI355X, DESIGN.md "walk form":
+    // they are only part of a `make WALK=1` build and only chosen by form 1.)
+#ifdef PMX_WITH_WALK
+    bool walk = pl->form == 1;
     if (g.S < 3 || !walk_layout_ok(pos)) walk = false;      // built for TSC / PCS; rows gathered by LDS-DMA
+#else
+    constexpr bool walk = false;
+#endif
     g.walk = walk ? 1 : 0;
     const int T[3] = {walk ? 1 : T0, walk ? P1 : T1, walk ? P2 : T2};
     g.ntiles = 1;
@@ -1238,6 +1208,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             pl->seen_overflows = seen;
             pl->distrust = pl->distrust ? (pl->distrust < 64 ? 2 * pl->distrust : 64) : 1;
             pl->skip = pl->distrust;
+        } else if (pl->last_reuse && pl->distrust > 0) {
+            // the previous single-pass build raised no flag (as far as the host has seen): trust returns
+            // step by step, so that one overflow late in a long run does not cost 64 two-pass builds
+            pl->distrust /= 2;
         }
     }
     if (reuse && pl->skip > 0) {
@@ -1309,13 +1283,18 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         if (inv != nullptr && !W) BC2(K, MODE, GRID, GATE, false, true);                                        \
         else BC2(K, MODE, GRID, GATE, W, false);                                                                \
     } while (0)
+#ifdef PMX_WITH_WALK
+#define BCW(K, MODE, GRID, GATE) BC(K, MODE, GRID, GATE, true)
+#else
+#define BCW(K, MODE, GRID, GATE) do { } while (0)
+#endif
 #define BCK(MODE, GRID, GATE)                                                                                   \
     do {                                                                                                        \
         switch (p.kind) {                                                                                       \
         case PMX_TUNED_NNB: BC(PMX_TUNED_NNB, MODE, GRID, GATE, false); break;                                  \
-        case PMX_TUNED_CIC: if (walk) BC(PMX_TUNED_CIC, MODE, GRID, GATE, true); else BC(PMX_TUNED_CIC, MODE, GRID, GATE, false); break; \
-        case PMX_TUNED_TSC: if (walk) BC(PMX_TUNED_TSC, MODE, GRID, GATE, true); else BC(PMX_TUNED_TSC, MODE, GRID, GATE, false); break; \
-        default: if (walk) BC(PMX_TUNED_PCS, MODE, GRID, GATE, true); else BC(PMX_TUNED_PCS, MODE, GRID, GATE, false); break; \
+        case PMX_TUNED_CIC: BC(PMX_TUNED_CIC, MODE, GRID, GATE, false); break;                                  \
+        case PMX_TUNED_TSC: if (walk) BCW(PMX_TUNED_TSC, MODE, GRID, GATE); else BC(PMX_TUNED_TSC, MODE, GRID, GATE, false); break; \
+        default: if (walk) BCW(PMX_TUNED_PCS, MODE, GRID, GATE); else BC(PMX_TUNED_PCS, MODE, GRID, GATE, false); break; \
         }                                                                                                       \
     } while (0)
         const uint32_t *nogate = nullptr;
@@ -1335,16 +1314,18 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             incoherent(pl->host_groups[0], (double)pl->host_groups[1]) != pl->sorted)
             reuse = false;       // the order of the rows changed its character since the plan was built: start over
         if (!reuse) pl->sorted = false;
+        pl->last_reuse = reuse;
         if (reuse) {
             // single pass into the previous slot ranges; if a tile overflowed (flags[0]) the
             // exact two-pass build below runs, otherwise its kernels return at once.  Whether the
             // plan carries the tile-ordered copy was decided by its first build.
             inv = pl->sorted ? pl->inv : nullptr;
             copyp = pl->sorted ? pl->pos_copy : nullptr;
+            if (pl->sorted) pl->copy_elsize = pos->elsize;      // the single pass rewrites the copy
             copy_gate = pl->sorted ? pl->flags : nullptr;
             // (measured, block against chunk form of the single pass, same box: 512^3 f8 1.01 vs 1.17 ms, 768^3 3.22 vs
             // 3.76, clustered 0.96 vs 1.27, 12-byte rows 0.90 vs 0.96, config 3 0.86 vs 1.08, 256^3 0.17 vs 0.20)
-            if (!walk && inv == nullptr && PMX_BLOCK_BUILD && npart >= block_min_rows()) {
+            if (!walk && inv == nullptr && pl->form != 2) {
                 // rows in a coherent order, no tile-ordered copy: one request per tile and block of rows
                 const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
                 const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);
@@ -1369,13 +1350,22 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             bin_scatter_kernel<<<small_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, gate, inv);
         } else {
             BCK(0, full_grid, nogate);
-            // First build of a geometry: how coherent is the row order?  (the only host
-            // synchronisation of a plan's life; history rebuilds keep the answer)
+            // How coherent is the row order?  Every build leaves its measurement in host_groups
+            // (asynchronous copy, below); a two-pass build of about as many rows as that one (within an
+            // eighth: ghost batches change their size from step to step, overflow repairs, reallocations)
+            // decides from it without waiting.  Only a plan object that has never measured rows like these
+            // synchronises: once in its life for a time-stepping caller.
             bool want = pl->sort_pref == 1;
             if (pl->sort_pref < 0 && !walk && npart >= (1 << 16)) {
-                PMX_HIP_CHECK(hipMemcpyAsync(pl->host_groups, pl->flags + 1, 8, hipMemcpyDeviceToHost, st));
-                PMX_HIP_CHECK(hipStreamSynchronize(st));
-                pl->host_groups[2] = (uint32_t)npart;
+                const double was = (double)pl->host_groups[2];
+                const bool known = pl->have_measure && pl->host_groups[1] > 4096 &&
+                                   fabs((double)npart - was) * 8.0 <= (double)npart;
+                if (!known) {
+                    PMX_HIP_CHECK(hipMemcpyAsync(pl->host_groups, pl->flags + 1, 8, hipMemcpyDeviceToHost, st));
+                    PMX_HIP_CHECK(hipStreamSynchronize(st));
+                    pl->host_groups[2] = (uint32_t)npart;
+                    pl->have_measure = true;
+                }
                 want = pl->host_groups[1] > 0 && incoherent(pl->host_groups[0], (double)pl->host_groups[1]);
             }
             if (want && !walk) {
@@ -1385,18 +1375,21 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                 rc = plan_ensure((void **)&pl->inv, &ci, np1 * 4); if (rc) return rc;
                 pl->cap_inv = ci / 4;
                 pl->sorted = true;
+                pl->copy_elsize = (int)es;
                 inv = pl->inv;
             }
             bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate);
             bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate, inv);
         }
 #undef BCK
+#undef BCW
 #undef BC
 #undef BC2
-        if (reuse && pl->sort_pref < 0 && !walk) {
+        if (pl->sort_pref < 0 && !walk && npart >= (1 << 16)) {
             // what this build saw of the row order, read by the NEXT build (stale at worst: a hint)
             PMX_HIP_CHECK(hipMemcpyAsync(pl->host_groups, pl->flags + 1, 8, hipMemcpyDeviceToHost, st));
             pl->host_groups[2] = (uint32_t)npart;
+            pl->have_measure = true;
         }
         if (pl->sorted) {
             const unsigned cgrid = (unsigned)(nbuckets < 65535 * 8 ? nbuckets : 65535 * 8);
@@ -1432,6 +1425,7 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     const int sorted = pl->sorted ? 1 : 0;
     if (sorted) {
         // stream the plan's copy of the positions (dense rows of 3 elements, list order)
+        PMX_REQUIRE(pos.elsize == pl->copy_elsize, PMX_EINVAL, "positions changed their element type since pmx_binplan_build");
         const int es = pos.elsize;
         pos.data = (const char *)pl->pos_copy;
         pos.stride0 = 3 * es;
@@ -1473,6 +1467,7 @@ extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *ca
     PMX_REQUIRE(pl->npart == 0 || vec_ok(pos), PMX_EINVAL, "pos");
     pmx_painter p = *p_;
     hipStream_t st = (hipStream_t)stream;
+#ifdef PMX_WITH_WALK
     if (pl->g.walk) {
         PMX_REQUIRE(walk_layout_ok(pos), PMX_EINVAL, "positions are not laid out as at pmx_binplan_build");
         PMX_REQUIRE(!(mass && mass->data) || (mass->stride0 % 4 == 0 && ((uintptr_t)mass->data) % 4 == 0 &&
@@ -1480,6 +1475,7 @@ extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *ca
                     PMX_EINVAL, "mass must be float / double on 4-byte boundaries");
         return paint_walk(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
     }
+#endif
     if (p.canvas_elsize == 8) return paint_binned_t<double>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
     return paint_binned_t<float>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
 }
@@ -1505,6 +1501,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         int rc = plan_ensure((void **)&pl->out_sorted, &cb, pl->cap_list * 8);
         if (rc) return rc;
         pl->cap_out = cb / 8;
+        PMX_REQUIRE(dpos.elsize == pl->copy_elsize, PMX_EINVAL, "positions changed their element type since pmx_binplan_build");
         const int es = dpos.elsize;
         dpos.data = (const char *)pl->pos_copy;
         dpos.stride0 = 3 * es;
@@ -1513,10 +1510,12 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         dout.stride0 = 8; dout.stride1 = 0; dout.elsize = 8;
     }
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
+#ifdef PMX_WITH_WALK
     if (g.walk) {
         PMX_REQUIRE(walk_layout_ok(pos), PMX_EINVAL, "positions are not laid out as at pmx_binplan_build");
         return readout_walk(pl, p, canvas, dpos, dout, st);
     }
+#endif
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
 #define RT(K, T) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
                       else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)

@@ -159,6 +159,8 @@ struct pmx_binplan {
     double *out_sorted = nullptr;   // results of readout in list order
     size_t cap_out = 0;
     uint32_t *host_groups = nullptr;   // pinned: coherence counter of the count pass
+    bool have_measure = false;         // host_groups holds the coherence of some earlier build of this plan
+    int copy_elsize = 0;               // element size of the rows in pos_copy
     // Crowded tiles (halos, blobs): the tile kernels take the first `chunk` list entries of a tile;
     // what lies behind is cut into work items (tile, piece) for a second kernel, one workgroup each,
     // so that a tile with 100 x the mean population does not keep one workgroup busy for milliseconds
@@ -171,6 +173,7 @@ struct pmx_binplan {
     bool have_history = false;
     uint32_t seen_overflows = 0;
     int distrust = 0, skip = 0;  // back-off after an overflow
+    bool last_reuse = false;     // the previous build was a single-pass (history) build
 };
 
 namespace pmx {

@@ -23,7 +23,7 @@ import numpy
 import torch
 
 from . import _abi, backend
-from ._arrays import touched, to_device, vec, is_tensor, torch_dtype, to_numpy
+from ._arrays import touched, to_device, vec, is_tensor, torch_dtype, numpy_dtype, to_numpy, version_of
 from .comm import default_comm
 
 
@@ -69,10 +69,29 @@ def _scatter_add(be, values, indices, nout):
     return out
 
 
+#: 'collective' (the reference, domain.py:50-57): every Layout.exchange / gather first broadcasts the
+#: root's dtype and trailing shape (one small object broadcast instead of the reference's two);
+#: 'static': the caller guarantees that all ranks pass the same dtype and shape, nothing is sent.
+#: The ghosts-only routing of ParticleMesh.paint / readout (Layout.exchange_remote) never promotes:
+#: it ships the caller's position / mass tensors, whose types the ranks share by construction.
+PROMOTE = 'collective'
+
+
 def promote(data, comm):
-    """domain.py:50-57.  dtypes are agreed statically here: the two bcasts of the
-    reference are dropped on the single-process communicator and kept otherwise
-    only to validate the trailing shape."""
+    """domain.py:50-57: every rank adopts the dtype of the root's array (e.g. an empty rank whose
+    array came out with a default dtype); a trailing shape that differs from the root's raises
+    ValueError on the ranks where it differs."""
+    if getattr(comm, 'size', 1) == 1 or PROMOTE != 'collective':
+        return data
+    if not (is_tensor(data) or isinstance(data, numpy.ndarray)):
+        data = numpy.asarray(data)
+    name = numpy_dtype(data.dtype).str if is_tensor(data) else data.dtype.str
+    sig = (name, tuple(int(x) for x in data.shape[1:]))
+    root = comm.bcast(sig)
+    if root[0] != sig[0]:
+        data = data.to(torch_dtype(numpy.dtype(root[0]))) if is_tensor(data) else data.astype(root[0])
+    if tuple(root[1]) != sig[1]:
+        raise ValueError('the shape of the data does not match across ranks.')
     return data
 
 
@@ -80,7 +99,8 @@ def pack_arrays(seq):
     """
     Copy a sequence of host arrays of equal length into one structured array, one field per
     array, each field keeping the trailing shape of its column (domain.py:59-80; what
-    Layout.exchange(pack=True) ships in the reference — here every array travels on its own).
+    Layout.exchange(pack=True) ships in the reference; here the device rows are packed as bytes,
+    Layout._exchange_packed).
     """
     cols = [numpy.asarray(a) for a in seq]
     lengths = set(c.shape[0] for c in cols)
@@ -117,6 +137,24 @@ class Layout(object):
         self.sendlength = sendlength
         self.recvlength = int(self.recvcounts.sum())
         self.indices = indices     # device tensor, int32/int64
+        self._agreed = set()       # directions whose length check has been held collectively
+
+    def _wrong_length(self, n, expected, direction, message):
+        """The reference allgathers the verdict of the length check on every call, so that every
+        rank raises (domain.py:177-179, 240-242).  Here the ranks agree on it collectively the
+        first time a layout is used in a direction (one integer all-reduce) — a wrong array then
+        raises ValueError everywhere, as in the reference.  Later calls check locally and return
+        True on a mismatch: the caller then takes part in the exchange with rows of zeros before
+        it raises, so the other ranks are never left waiting in the all-to-all."""
+        bad = int(n) != int(expected)
+        if self.comm.size > 1 and direction not in self._agreed:
+            self._agreed.add(direction)
+            if int(self.comm.allreduce(int(bad), op='max')):
+                raise ValueError(message)
+            return False
+        if bad and self.comm.size == 1:
+            raise ValueError(message)
+        return bad
 
     def get_exchange_cost(self):
         """ exchange cost per rank: items sent to any other rank (domain.py:125-136). """
@@ -129,11 +167,14 @@ class Layout(object):
         Delievers data to the intersecting domains (domain.py:138-171).
 
         Every data item shall have the length and ordering of the positions that built the
-        layout.  Ghosts are created if a particle intersects multiple domains.  `pack` is
-        accepted for compatibility: every array is exchanged with its own all-to-all-v
-        (device buffers need no struct packing).
+        layout.  Ghosts are created if a particle intersects multiple domains.  pack=True (the
+        default, as in the reference): the rows of all arrays travel in ONE all-to-all-v, packed
+        side by side as bytes; pack=False: one exchange per array.
         """
-        r = tuple([self._exchange(arg) for arg in args])
+        if pack and len(args) > 1 and self.comm.size > 1:
+            r = self._exchange_packed(args)
+        else:
+            r = tuple([self._exchange(arg) for arg in args])
         if len(args) == 0:
             return None
         if len(args) == 1:
@@ -147,7 +188,7 @@ class Layout(object):
         # the source tensor is unchanged (same storage, same version counter).
         memo_key = None
         if is_tensor(data) and data.device == be.device:
-            memo_key = (data.data_ptr(), data._version, tuple(data.shape), data.stride(), data.dtype)
+            memo_key = (data.data_ptr(), version_of(data), tuple(data.shape), data.stride(), data.dtype)
             memo = getattr(self, '_memo', None)
             if memo is not None and memo[0] == memo_key:
                 return memo[2]
@@ -156,12 +197,71 @@ class Layout(object):
             self._memo = (memo_key, data, r)
         return r
 
+    def _exchange_packed(self, args):
+        """exchange(pack=True): the gathered rows of every array side by side in one byte row per
+        item, one all-to-all-v for all of them (domain.py:161-166, pack_arrays)."""
+        be = backend.get()
+        cols, hosts = [], []
+        message = 'the length of data does not match that used to build the layout'
+        for a in args:
+            a = promote(a, self.comm)
+            t, host = to_device(a, be.device, 'data', allow_int=True)
+            cols.append(t)
+            hosts.append(host)
+        if len(set(len(t) for t in cols)) > 1:
+            raise ValueError('the shape of the data does not match across different columns.')
+        wrong = self._wrong_length(len(cols[0]), self.sendlength, 'exchange', message)
+        nsend = int(self.sendcounts.sum())
+        parts, metas = [], []
+        for t in cols:
+            trailing = tuple(t.shape[1:])
+            if wrong:
+                t = torch.zeros((self.sendlength,) + trailing, dtype=t.dtype, device=be.device)
+            rb = t.element_size()
+            for s_ in trailing:
+                rb *= s_
+            if nsend:
+                rows = self._take(be, t, self.indices, nsend)
+                parts.append(rows.reshape(nsend, -1).view(torch.uint8).reshape(nsend, rb))
+            metas.append((t.dtype, trailing, rb))
+        packed = torch.cat(parts, dim=1) if nsend else torch.empty((0, sum(m[2] for m in metas)),
+                                                                   dtype=torch.uint8, device=be.device)
+        recv = torch.empty((self.recvlength, packed.shape[1]), dtype=torch.uint8, device=be.device)
+        self.comm.alltoallv(packed, self.sendcounts, recv, self.recvcounts)
+        if wrong:
+            raise ValueError(message)
+        out, off = [], 0
+        for (dt, trailing, rb), host in zip(metas, hosts):
+            r = recv[:, off:off + rb].contiguous().view(dt).reshape((self.recvlength,) + trailing)
+            off += rb
+            out.append(to_numpy(r) if host else r)
+        return tuple(out)
+
+    @staticmethod
+    def _take(be, data, indices, nrows):
+        """rows `indices` of data, contiguous (data.take(indices, axis=0), domain.py:188)"""
+        trailing = tuple(data.shape[1:])
+        row_bytes = data.element_size()
+        for s in trailing:
+            row_bytes *= s
+        if data.dim() > 1 and not data[0:1].is_contiguous() and data.shape[0] > 0:
+            data = data.contiguous()
+        buffer = torch.empty((nrows,) + trailing, dtype=data.dtype, device=be.device)
+        if nrows:
+            if row_bytes % 4:
+                raise TypeError('rows must be a multiple of 4 bytes')
+            stride0 = data.stride(0) * data.element_size() if data.shape[0] > 1 else row_bytes
+            be.call('take_rows', data.data_ptr(), stride0, row_bytes, indices.data_ptr(),
+                    indices.element_size(), nrows, buffer.data_ptr(), be.stream())
+        return buffer
+
     def _exchange_impl(self, be, data):
+        data = promote(data, self.comm)
         data, host = to_device(data, be.device, 'data', allow_int=True)
-        # the reference allgathers this check (domain.py:177-179); a local raise is enough here
-        # and keeps a host-side object collective out of every exchange
-        if len(data) != self.sendlength:
-            raise ValueError('the length of data does not match that used to build the layout')
+        message = 'the length of data does not match that used to build the layout'
+        wrong = self._wrong_length(len(data), self.sendlength, 'exchange', message)
+        if wrong:
+            data = torch.zeros((self.sendlength,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         trailing = tuple(data.shape[1:])
         row_bytes = data.element_size()
         for s in trailing:
@@ -181,6 +281,8 @@ class Layout(object):
         else:
             recvbuffer = torch.empty((self.recvlength,) + trailing, dtype=data.dtype, device=be.device)
             self.comm.alltoallv(buffer, self.sendcounts, recvbuffer, self.recvcounts)
+        if wrong:
+            raise ValueError(message)
         return to_numpy(recvbuffer) if host else recvbuffer
 
     # ---- ghosts-only routing --------------------------------------------------------
@@ -212,12 +314,14 @@ class Layout(object):
         be = backend.get()
         idx, sc, rc, nsend, nrecv = self._remote(be)
         data, host = to_device(data, be.device, 'data', allow_int=True)
-        if len(data) != self.sendlength:
-            raise ValueError('the length of data does not match that used to build the layout')
-        memo_key = (data.data_ptr(), data._version, tuple(data.shape), data.stride(), data.dtype)
+        memo_key = (data.data_ptr(), version_of(data), tuple(data.shape), data.stride(), data.dtype)
         memo = getattr(self, '_memo_remote', None)
         if memo is not None and memo[0] == memo_key:
             return memo[2]
+        message = 'the length of data does not match that used to build the layout'
+        wrong = self._wrong_length(len(data), self.sendlength, 'exchange', message)
+        if wrong:
+            data = torch.zeros((self.sendlength,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         trailing = tuple(data.shape[1:])
         row_bytes = data.element_size()
         for s in trailing:
@@ -234,6 +338,8 @@ class Layout(object):
         recvbuffer = torch.empty((nrecv,) + trailing, dtype=data.dtype, device=be.device)
         if self.comm.size > 1:
             self.comm.alltoallv(buffer, sc, recvbuffer, rc)
+        if wrong:
+            raise ValueError(message)
         self._memo_remote = (memo_key, data, recvbuffer)
         return recvbuffer
 
@@ -242,13 +348,17 @@ class Layout(object):
         their owners and add them into `out` (one row per original item) in place """
         be = backend.get()
         idx, sc, rc, nsend, nrecv = self._remote(be)
-        if len(data) != nrecv:
-            raise ValueError('the length of data does not match result of exchange_remote')
+        message = 'the length of data does not match result of exchange_remote'
+        wrong = self._wrong_length(len(data), nrecv, 'gather_remote', message)
         if self.comm.size == 1:
             return out
+        if wrong:
+            data = torch.zeros((nrecv,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         data = data.contiguous()
         back = torch.empty((nsend,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         self.comm.alltoallv(data, rc, back, sc)
+        if wrong:
+            raise ValueError(message)
         if nsend:
             if back.dtype != out.dtype:
                 back = back.to(out.dtype)
@@ -274,9 +384,14 @@ class Layout(object):
             copy; 'any' uses any one of local or ghost; 'mean' the mean over copies.
         """
         be = backend.get()
+        data = promote(data, self.comm)
         data, host = to_device(data, be.device, 'data', allow_int=True)
-        if len(data) != self.recvlength:
-            raise ValueError('the length of data does not match result of a domain.exchange')
+        message = 'the length of data does not match result of a domain.exchange'
+        wrong = self._wrong_length(len(data), self.recvlength, 'gather', message)
+        if wrong:
+            if mode == 'local':
+                raise ValueError(message)              # no communication in this mode
+            data = torch.zeros((self.recvlength,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         trailing = tuple(data.shape[1:])
 
         def finish(r):
@@ -304,6 +419,8 @@ class Layout(object):
         else:
             recvbuffer = torch.empty((len(self.indices),) + trailing, dtype=data.dtype, device=be.device)
             self.comm.alltoallv(data, self.recvcounts, recvbuffer, self.sendcounts)
+        if wrong:
+            raise ValueError(message)
 
         if self.sendlength == 0:
             return finish(torch.empty((0,) + trailing, dtype=data.dtype, device=be.device))

@@ -11,6 +11,7 @@ of pmesh/_window.pyx:128-205.
 """
 import ctypes as C
 import os
+import sys
 
 import threading
 
@@ -18,7 +19,7 @@ import numpy
 import torch
 
 from . import _abi, backend
-from ._arrays import to_device, vec, vec_ref, real_view, is_tensor, touched, upload, to_numpy
+from ._arrays import to_device, vec, vec_ref, real_view, is_tensor, touched, upload, to_numpy, version_of
 
 
 def _mkarr(var, shape, dtype):
@@ -73,11 +74,13 @@ BINNED_MIN_PARTICLES = 1 << 17
 # point).  Measured break-even on a 64 x 512 x 512 block (scripts/thresh_probe.py):
 # CIC 2^20 particles, PCS 2^17; thin ghost bands at a slab face sit well below both.
 BINNED_MIN_DENSITY = {1: 0.06, 2: 0.06, 3: 0.02, 4: 0.008}
-# Which binned kernels: 'auto' (the library decides per batch: the walk form of
-# csrc/pmx_walk.hip for TSC / PCS at ~1 particle per cell, the tile form otherwise),
-# 'never' (tile form only), 'always' (walk form for every window of support >= 2).
+# Which binned kernels: 'auto' / 'never': the tile kernels (csrc/pmx_binned.hip); 'always': the walk
+# form of csrc/pmx_walk.hip for TSC / PCS — a measured alternative that is no faster on MI355X and only
+# exists in a `make WALK=1` build of the library (PmxError otherwise); 'chunks': the tile kernels with
+# the chunk form of the single-pass rebuild (a test hook: what plans with a tile-ordered copy use).
 WALK = os.environ.get('PMESH_AMD_WALK', 'auto')
-_FORMS = {'auto': -1, 'never': 0, 'always': 1}
+_FORMS = {'auto': -1, 'never': 0, 'always': 1, 'chunks': 2}
+_SORTS = {'auto': -1, 'never': 0, 'always': 1}
 # A tile-ordered copy of the positions inside the plan, for rows without spatial coherence
 # (include/pmesh_amd.h: pmx_binplan_sorted): 'auto' (measured by the first build), 'never', 'always'.
 SORTED = os.environ.get('PMESH_AMD_SORTED', 'auto')
@@ -96,7 +99,7 @@ class _BinCache(object):
         self.clock = 0
 
     def _key(self, pos, painter):
-        return (pos.data_ptr(), pos._version, tuple(pos.shape), pos.stride(), pos.dtype, WALK, SORTED,
+        return (pos.data_ptr(), version_of(pos), tuple(pos.shape), pos.stride(), pos.dtype, WALK, SORTED,
                 painter.kind, tuple(painter.scale), tuple(painter.translate),
                 tuple(painter.period), tuple(painter.size))
 
@@ -113,25 +116,30 @@ class _BinCache(object):
         free = [e for e in self.entries if not e[3] or (e[0] is not None and e[0][0] == key[0])]
         same = [e for e in self.entries if e[5] == shape]
         like = [e for e in same if any(e is q for q in free)]
+        # entries of the same shape whose tensor nobody else holds any more: a time-stepping caller that
+        # makes a new position tensor every step and dropped the old one.  The new tensor takes over that
+        # plan and its history (single-pass rebuild) rather than opening a second one from nothing.  A
+        # tensor that is still alive elsewhere — a second particle set of equal size (two species; probes
+        # at as many points as there are particles) — keeps its plan while a slot is free.
+        dead = [e for e in same if e[2] is not None and sys.getrefcount(e[2]) <= 2]
         if like:
             # the one used last: its lists are the closest to these positions
             e = max(like, key=lambda q: q[4])
-        elif same:
-            # another tensor of the same shape on the same geometry: a time-stepping caller that makes a
-            # new position tensor every step.  It takes over the plan (and its history; the previous
-            # tensor is released) rather than a second one that would start from nothing — a caller that
-            # alternates between two live particle sets of equal size rebuilds every time instead
-            e = max(same, key=lambda q: q[4])
+        elif dead:
+            e = max(dead, key=lambda q: q[4])
         elif len(self.entries) < self.SLOTS:
             plan = C.c_void_p()
             be.call('binplan_create', C.byref(plan))
             e = [None, plan, None, False, 0, None]
             self.entries.append(e)
+        elif same and not free:
+            # every slot is taken by a live tensor: the plan of the same shape used last has the closest lists
+            e = max(same, key=lambda q: q[4])
         else:
             e = min(free or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape
         be.call('binplan_configure', e[1], _FORMS[WALK])
-        be.call('binplan_sorted', e[1], _FORMS[SORTED], None)
+        be.call('binplan_sorted', e[1], _SORTS[SORTED], None)
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
         e[3] = True
         e[4] = self._tick()

@@ -6,6 +6,9 @@ library + RCCL.  Every assert runs on every rank; a failure exits non-zero.
 import os
 import sys
 
+# read by the HSA runtime when it initialises (the first torch.cuda call): before importing torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -499,6 +502,68 @@ def case_pencil(be, comm):
     assert abs(f - out[share]).max() <= 1e-11 * abs(out).max()
 
 
+def case_length_check_is_collective(be, comm):
+    """domain.py:177-179, 240-242: a wrong array on ONE rank raises ValueError on EVERY rank the first
+    time a layout is used (the verdict is all-reduced); afterwards the offending rank raises alone,
+    after taking part in the exchange, so nobody is left waiting in the all-to-all"""
+    import pytest
+    from pmesh_amd import domain
+    P = comm.size
+    dcop = domain.GridND([numpy.linspace(0, 1, P + 1)], comm=comm, periodic=True)
+    rng = numpy.random.RandomState(100 + comm.rank)
+    pos = rng.uniform(0, 1, size=(40, 1))
+    layout = dcop.decompose(pos, smoothing=0.01)
+    bad = numpy.ones(41 if comm.rank == P - 1 else 40)
+    with pytest.raises(ValueError):
+        layout.exchange(bad)                       # first use: every rank raises
+    good = layout.exchange(numpy.ones(40))         # the check of this direction has been held
+    assert len(good) == layout.recvlength
+    with pytest.raises(ValueError):
+        layout.gather(numpy.ones(layout.recvlength + (1 if comm.rank == 0 else 0)))
+    assert_array_equal(layout.gather(good, mode='any'), numpy.ones(40))
+    # later mistakes: the offending rank raises, the others complete the exchange
+    if comm.rank == P - 1:
+        with pytest.raises(ValueError):
+            layout.exchange(bad)
+    else:
+        layout.exchange(numpy.ones(40))
+    comm.Barrier()
+
+
+def case_promote_and_pack(be, comm):
+    """domain.py:50-57 (an empty rank adopts the root's dtype; a trailing shape that differs raises)
+    and domain.py:161-166 (pack=True: one all-to-all-v for all arrays, same rows as one by one)"""
+    import pytest
+    from pmesh_amd import domain, comm as C
+    P = comm.size
+    a = numpy.zeros((3, 2), dtype='f4') if comm.rank == 0 else numpy.zeros((0, 2), dtype='f8')
+    assert domain.promote(a, comm).dtype == numpy.dtype('f4')
+    b = numpy.zeros((3, 2)) if comm.rank == 0 else numpy.zeros((3, 3))
+    if comm.rank == 0:
+        domain.promote(b, comm)
+    else:
+        with pytest.raises(ValueError):
+            domain.promote(b, comm)
+    dcop = domain.GridND([numpy.linspace(0, 1, P + 1)], comm=comm, periodic=True)
+    rng = numpy.random.RandomState(7 + comm.rank)
+    pos = rng.uniform(0, 1, size=(50, 3))
+    mass = rng.uniform(size=50)
+    ident = numpy.arange(50, dtype='i4') + 1000 * comm.rank
+    layout = dcop.decompose(pos[:, :1], smoothing=0.05)
+    one = [layout.exchange(pos), layout.exchange(mass), layout.exchange(ident)]
+    rec = C.trace(True) if hasattr(comm, '_dist') else None
+    packed = layout.exchange(pos, mass, ident)
+    if rec is not None:
+        C.trace(False)
+        assert len(rec) == 1, rec                   # ONE collective for the three arrays
+    for x, y in zip(one, packed):
+        assert x.dtype == y.dtype and x.shape == y.shape
+        assert_array_equal(x, y)
+    unpacked = layout.exchange(pos, mass, ident, pack=False)
+    for x, y in zip(one, unpacked):
+        assert_array_equal(x, y)
+
+
 def case_comm_trace(be, comm):
     """the record of the data-path collectives that bench.py --gpus N reports (pmesh_amd.comm.trace):
     a slab FFT round trip moves the whole half spectrum twice, (P-1)/P of it off rank"""
@@ -523,7 +588,7 @@ def case_comm_trace(be, comm):
     assert 0.7 * full <= total <= 1.3 * full, (total, full)
 
 
-CASES = [case_comm_trace, case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+CASES = [case_comm_trace, case_length_check_is_collective, case_promote_and_pack, case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 

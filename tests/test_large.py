@@ -73,6 +73,39 @@ def test_rocfft_refuses_spans_it_gets_wrong():
     backend.reset()
 
 
+@pytest.mark.parametrize('config', ['C4', 'C5'])
+def test_multi_gpu_configs_decomposed_on_thread_ranks(config):
+    """BASELINE.json configs 4 and 5 in their DECOMPOSED form, at the largest size one GPU holds, with the
+    8 ranks as threads of one process driving the real kernels (tests/distributed_cycle.py):
+      C4: 1024^3 mesh, 1024^3 uniform particles, CIC fp64, slab np=[8], ghosts-only routing, pipelined
+          transposes, fused transfer — config 4 exactly, minus the wire;
+      C5: 2 x 4 pencils, PCS, 2 x 1024^3 Zel'dovich-displaced particles with a per-particle fp64 mass on a
+          1024^3 mesh (config 5 is 2048^3 / 2 x 2048^3: 8x this; positions in fp32 so that the distributed
+          set, its one-rank copy and both sets of bin lists fit the 288 GB together).
+    Every rank's readout equals the one-rank cycle (pinned to the oracle at this size by the test above) to
+    1e-11 of the result's scale, and the first planes of rank 0's painted block equal the oracle's paint of
+    every particle of every rank that touches them to 1e-12."""
+    import os
+    import subprocess
+    import sys
+    free, _ = torch.cuda.mem_get_info()
+    need = 110e9 if config == 'C4' else 200e9
+    if free < need:
+        pytest.skip('needs %.0f GB of free HBM' % (need / 1e9))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'tests', 'distributed_cycle.py'), '--ranks', '8', '--mesh', '1024',
+           '--steps', '1', '--warmup', '1', '--check', '1', '--oracle-planes', '2']
+    if config == 'C4':
+        cmd += ['--window', 'cic']
+    else:
+        cmd += ['--np', '2x4', '--window', 'pcs', '--data', 'clustered', '--double', '1', '--mass', 'array',
+                '--pos-dtype', 'f4']
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500)
+    print(out.stdout[-2000:])
+    assert out.returncode == 0, out.stdout[-2000:] + '\n' + out.stderr[-4000:]
+    assert 'vs one rank' in out.stdout and 'vs oracle' in out.stdout
+
+
 def _slab_subset(pos, N, L, k0, nplanes, margin):
     """rows of `pos` whose x grid coordinate lies within `margin` cells of planes [k0, k0 + nplanes)"""
     out = []
