@@ -95,7 +95,8 @@ def parse():
     ap.add_argument('--host-arrays', type=int, default=0,
                     help='1: positions and results are numpy arrays in host memory, as an unmodified nbodykit / '
                          'fastpm caller passes them: every paint / readout stages them over PCIe (diagnostic: '
-                         'the reported rate then is PCIe inclusive and is NOT the headline metric)')
+                         'the reported rate then is PCIe inclusive and is NOT the headline metric); 2: the same with '
+                         'the position arrays registered once (ParticleMesh.stage) and refreshed once per cycle')
     ap.add_argument('--fuse-apply', type=int, default=1,
                     help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
     ap.add_argument('--migrate', type=int, default=1,
@@ -364,6 +365,10 @@ def main():
         if world > 1 or args.exchange:
             raise SystemExit('--host-arrays is a single-GPU diagnostic')
         psets = [q.cpu().numpy() for q in psets]
+        if args.host_arrays == 2:
+            # the caller registers its arrays (ParticleMesh.stage): one upload per cycle instead of one per
+            # paint / readout call
+            psets = [pm.stage(q) for q in psets]
     layouts = [None] * len(psets)
     layout = None
     t_decompose = 0.0
@@ -412,8 +417,10 @@ def main():
             layout._memo = None
             layout._memo_remote = None
         mark(0)
-        if (layout is None or args.ghosts_only) and not args.host_arrays:
-            pm.resampler.prebin(rho.value, pos, pm.affine)      # tile binning, shared by paint+readout
+        if args.host_arrays == 2:
+            pos.refresh()                                       # this step's positions cross the link once
+        if (layout is None or args.ghosts_only) and args.host_arrays != 1:
+            pm.resampler.prebin(rho.value, getattr(pos, 'tensor', pos), pm.affine)      # tile binning, shared by paint+readout
         mark(1)
         pm.paint(pos, mass=mass, hold=False, layout=layout, out=rho)   # includes the zero fill
         mark(2)

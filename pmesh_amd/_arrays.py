@@ -72,8 +72,79 @@ def numpy_dtype_of(t):
         return None
 
 
+class Staged(object):
+    """A host array registered for repeated use (`ParticleMesh.stage(X)` / `pmesh_amd.stage(X)`): its
+    device copy is made once and every later paint / readout / decompose that is handed this object
+    works on that copy — examples/nbody.py's force() uploads the same positions for the paint and for
+    each of its three readouts, 3.2 GB each at 512^3 particles.  Results still come back as numpy arrays:
+    to the library it is a host array whose upload has already happened.  The caller promises not to
+    change the host array while the handle is in use (`refresh()` after an update in place)."""
+
+    def __init__(self, host, device):
+        self.host = numpy.asarray(host)
+        self.tensor = None
+        self.device = device
+        self.refresh()
+
+    def refresh(self):
+        """upload the host array again (after it was changed in place)"""
+        t, _ = to_device(self.host, self.device, 'staged array', allow_int=True)
+        if self.tensor is not None and self.tensor.shape == t.shape and self.tensor.dtype == t.dtype:
+            self.tensor.copy_(t)                 # same storage: plans and layouts keyed on it see a new version
+        else:
+            self.tensor = t
+        return self
+
+    # enough of the array protocol for callers that go on using the handle like the array it wraps
+    def __len__(self):
+        return len(self.host)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.host if dtype is None else self.host.astype(dtype)
+
+    @property
+    def shape(self):
+        return self.host.shape
+
+    @property
+    def dtype(self):
+        return self.host.dtype
+
+    @property
+    def ndim(self):
+        return self.host.ndim
+
+
+# device copies of READ-ONLY host arrays (flags.writeable == False: the caller cannot have changed them
+# between two calls) found again by their buffer: [key, array (kept alive: the address stays taken), tensor]
+_READONLY_SLOTS = 4
+_readonly = []
+
+
+def _readonly_copy(a, device):
+    key = (a.__array_interface__['data'][0], a.shape, a.strides, a.dtype.str, str(device))
+    for e in _readonly:
+        if e[0] == key:
+            _readonly.remove(e)
+            _readonly.append(e)
+            return e[2]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')          # torch warns that the array is not writable; it is only read
+        src = a if all(s >= 0 for s in a.strides) else numpy.ascontiguousarray(a)
+        t = upload(torch.from_numpy(src), device)
+    _readonly.append([key, a, t])
+    del _readonly[:-_READONLY_SLOTS]
+    return t
+
+
 def to_device(x, device, what='array', allow_int=False):
     """-> (tensor on `device`, came_from_host).  Lists become float64."""
+    if isinstance(x, Staged):
+        t = x.tensor
+        if not allow_int and t.dtype not in _FLOATS:
+            raise TypeError('%s must be float32 or float64, got %s' % (what, t.dtype))
+        return t, True
     if is_tensor(x):
         t = x
         host = False
@@ -81,6 +152,10 @@ def to_device(x, device, what='array', allow_int=False):
         a = numpy.asarray(x)
         if a.dtype == object:
             raise TypeError('%s: unsupported dtype object' % what)
+        if (not a.flags.writeable and a.ndim and a.nbytes >= (1 << 20) and a.dtype.byteorder in ('=', '|', '<')
+                and device.type == 'cuda' and (allow_int or a.dtype.str[1:] in ('f4', 'f8'))):
+            # a large read-only array: its device copy is remembered (same buffer -> same contents)
+            return _readonly_copy(a, device), True
         if not a.flags.writeable:
             a = a.copy()
         if a.dtype.byteorder not in ('=', '|', '<'):

@@ -101,6 +101,10 @@ class SelfComm(object):
         recv.copy_(send)
         return _Done() if async_op else None
 
+    def alltoall_views(self, send_views, recv_views, async_op=False):
+        recv_views[0].copy_(send_views[0])
+        return _Done() if async_op else None
+
     def subgroups(self, rank_lists):
         return [self for _ in rank_lists]
 
@@ -203,6 +207,54 @@ class TorchComm(object):
                 return _Traced(w, rec, send)
             rec[4] = _stamp(send)
         return w if async_op else None
+
+
+class _Staged(object):
+    """an exchange through one staging buffer (backends without the list form of all-to-all): the
+    pieces are copied to their places when the exchange is waited for"""
+    def __init__(self, work, staging, recv_views):
+        self.work, self.staging, self.recv_views = work, staging, recv_views
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        o = 0
+        for v in self.recv_views:
+            n = v.numel()
+            v.copy_(self.staging[o:o + n].view(v.shape))
+            o += n
+        return True
+
+
+def _torch_alltoall_views(self, send_views, recv_views, async_op=False):
+    """all-to-all of one contiguous tensor per peer on either side (views into larger arrays: row
+    ranges that are contiguous by themselves but not next to each other — the pieces of a chunked
+    pencil transpose).  RCCL takes the lists as they are (grouped send / recv); gloo has no list
+    form: the pieces travel through one staging buffer on either side."""
+    rec = None
+    if _trace is not None:
+        away = sum(v.numel() * v.element_size() for i, v in enumerate(send_views) if i != self.rank)
+        rec = ['alltoall', away, self.size - 1, _stamp(send_views[0]), None, bool(async_op)]
+        _trace.append(rec)
+    if self._dist.get_backend(self.group) == 'nccl':
+        w = self._dist.all_to_all(list(recv_views), list(send_views), group=self.group, async_op=async_op)
+    else:
+        send = torch.cat([v.reshape(-1) for v in send_views])
+        staging = torch.empty(sum(v.numel() for v in recv_views), dtype=send.dtype, device=send.device)
+        work = self._dist.all_to_all_single(staging, send, output_split_sizes=[v.numel() for v in recv_views],
+                                            input_split_sizes=[v.numel() for v in send_views], group=self.group,
+                                            async_op=async_op)
+        w = _Staged(work if async_op else None, staging, recv_views)
+        if not async_op:
+            w.wait()
+    if rec is not None:
+        if async_op:
+            return _Traced(w, rec, send_views[0])
+        rec[4] = _stamp(send_views[0])
+    return w if async_op else None
+
+
+TorchComm.alltoall_views = _torch_alltoall_views
 
 
 def _torch_subgroups(self, rank_lists):

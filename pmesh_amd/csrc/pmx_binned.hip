@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
+constexpr int ZSCR = 72;                           // words of a wave's table in the z sort of tile_deposit
 constexpr int BLOCK_ITERS = 8;                     // trips of TBLOCK * PMX_ONEPASS_U rows
 constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
 constexpr int BLOCK_HT = 128;                       // entries of the LDS table (a power of two)
@@ -625,21 +626,68 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
     }
 }
 
+// ---- experiments on the deposit of S >= 3 windows (compile-time, A/B'd with EXTRA=-D...) ----
+// PMX_ZSORT: the two list entries every lane of a wave holds (128 per wave and trip) are re-dealt among the
+//   lanes in the order of their z cell, even sorted positions to the first particle slot and odd ones to the
+//   second: an atomic instruction then finds ~2 lanes on every bank pair (rows are whole bank rows) whatever
+//   the jitter of the particles did to the natural order.
+// PMX_ZMERGE: neighbouring lanes whose particles sit in the same (x, y) row with z cells 1 .. DMAX apart pass
+//   the overlapping part of their z runs down the wave in registers (DPP shifts), and only the last lane of a
+//   chain issues the atomic for a cell: S^2 instead of S^3 lane-atomics along an intact chain.
+#ifndef PMX_ZSORT
+#define PMX_ZSORT 0
+#endif
+#ifndef PMX_ZMERGE
+#define PMX_ZMERGE 0
+#endif
+#ifndef PMX_ZMERGE_DMAX
+#define PMX_ZMERGE_DMAX 3
+#endif
+#ifndef PMX_ZMERGE_MINS
+#define PMX_ZMERGE_MINS 3
+#endif
+#ifndef PMX_ZSORT_MINS
+#define PMX_ZSORT_MINS 3
+#endif
+
+// lane i <- lane i - 1 (wave_shr:1) / lane i + 1 (wave_shl:1) of a 32-bit value; lanes without a source read `fill`
+__device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+// the neighbour's double, ANDed with a lane mask (all ones: take it, zero: +0.0)
+__device__ __forceinline__ double wave_shr1_masked(double v, int mask)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = wave_shr1((int)b, 0) & mask, hi = wave_shr1((int)(b >> 32), 0) & mask;
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double pull_double(int srcbytes, double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(srcbytes, (int)b), hi = __builtin_amdgcn_ds_bpermute(srcbytes, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // The particles [start, start + count) of a tile's list are deposited into its LDS region.
 template <int KIND, int TTHREADS, bool SORTED>
 __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                              const DVec &mass, double mass_scalar, const uint32_t *list,
-                                             int64_t start, int count, double *lds)
+                                             int64_t start, int count, double *lds, uint32_t *zscratch)
 {
     constexpr bool sorted = SORTED;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1;
+    constexpr bool ZSORT = PMX_ZSORT && S >= PMX_ZSORT_MINS && UNROLL == 2;
+    constexpr bool ZMERGE = PMX_ZMERGE && S >= PMX_ZMERGE_MINS;
+    constexpr int DMAX = PMX_ZMERGE_DMAX < S - 1 ? PMX_ZMERGE_DMAX : S - 1;
     // UNROLL particles per thread and trip: all index and position loads are issued before
     // the first use, so several dependent gathers are in flight per lane
     // SWAP (TSC, PCS): odd lanes deposit their second particle first, see below
-    constexpr bool SWAP = S >= 3 && UNROLL == 2;
-    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+    constexpr bool SWAP = S >= 3 && UNROLL == 2 && !ZSORT && !ZMERGE;
+    const int lane = threadIdx.x & 63;
+    // (ZSORT / ZMERGE: the lanes of a wave work together, so the trip count is the wave's, not the lane's)
+    for (int jw = threadIdx.x - lane; jw < count; jw += TTHREADS * UNROLL) {
+        const int j0 = jw + lane;
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
 #pragma unroll
@@ -649,6 +697,7 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
+            x[u][0] = x[u][1] = x[u][2] = 0; m[u] = 0;
             if (idx[u] >= 0) {
                 x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
                 // (sorted: idx is the list slot; a per-particle mass lives at the row the list names)
@@ -669,28 +718,134 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
             const double tm = m[0]; m[0] = m[1]; m[1] = tm;
             const int64_t ti = idx[0]; idx[0] = idx[1]; idx[1] = ti;
         }
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) ok[u] = idx[u] >= 0;
+        if (ZSORT) {
+            // counting sort of the wave's 2 x 64 entries by z cell (T2 bins + one for the empty slots) in a small
+            // table of the wave's own; LDS operations of one wave execute in order, the fences keep the compiler
+            // from moving them across each other
+            uint32_t *zh = zscratch + (threadIdx.x >> 6) * ZSCR;             // [0, 40): bins; [40, 72): sources, 4 per word
+            unsigned char *zsrc = (unsigned char *)(zh + 40);
+            if (lane < 40) zh[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            int key[UNROLL];
+            uint32_t rank[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                key[u] = T2;
+                if (ok[u]) {
+                    const double X = x[u][2] * p.scale[2] + p.translate[2];
+                    const int I0 = Tuned<KIND>::first(X);
+                    const int per = (int)p.period[2], siz = (int)p.size[2];
+                    int lb2;
+                    if (g.o[2] == 0 && per == siz) lb2 = I0 & (T2 - 1);
+                    else {
+                        int w = wrap_fast(I0, per);
+                        if (per > 0 && w >= siz) w -= per;
+                        lb2 = w + g.o[2] - t[2] * T2;
+                    }
+                    key[u] = (unsigned)lb2 < (unsigned)T2 ? lb2 : T2;
+                }
+                rank[u] = atomicAdd(&zh[key[u]], 1u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // exclusive prefix over the T2 + 1 bins (lanes 0 .. T2)
+            uint32_t c = lane <= T2 ? zh[lane] : 0u, incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= off) incl += up;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane <= T2) zh[lane] = incl - c;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint32_t ppos = zh[key[u]] + rank[u];                  // sorted position, 0 .. 127
+                zsrc[ppos] = (unsigned char)(lane | (u << 6));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // sorted positions 2 l and 2 l + 1 become the first and the second particle of lane l
+            const uint32_t two = ((const unsigned short *)zsrc)[lane];
+            double nx[UNROLL][3], nm[UNROLL];
+            bool nok[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const int src = (int)((two >> (8 * u)) & 0xFF);
+                const int sl = (src & 63) << 2;
+                const bool second = (src & 64) != 0;
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double a0 = pull_double(sl, x[0][d]), a1 = pull_double(sl, x[1][d]);
+                    nx[u][d] = second ? a1 : a0;
+                }
+                const double m0 = pull_double(sl, m[0]), m1 = pull_double(sl, m[1]);
+                nm[u] = second ? m1 : m0;
+                const int o0 = __builtin_amdgcn_ds_bpermute(sl, (int)ok[0]), o1 = __builtin_amdgcn_ds_bpermute(sl, (int)ok[1]);
+                nok[u] = (second ? o1 : o0) != 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                x[u][0] = nx[u][0]; x[u][1] = nx[u][1]; x[u][2] = nx[u][2]; m[u] = nm[u]; ok[u] = nok[u];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            if (idx[u] < 0) continue;
+            if (!ZMERGE && !ok[u]) continue;
             int lb[3];
             double V[3][S];
             particle_setup<KIND>(p, g, t, x[u], V, lb);
             // a plan that no longer matches the positions (rewritten behind the cache's back)
             // must not index outside the LDS region
-            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            const bool inside = !((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2);
+            if (!ZMERGE && !inside) continue;
 #pragma unroll
             for (int a = 0; a < S; a++) V[0][a] *= m[u];
+            if (!ZMERGE) {
 #pragma unroll
-            for (int a = 0; a < S; a++)
+                for (int a = 0; a < S; a++)
 #pragma unroll
-                for (int b = 0; b < S; b++) {
-                    double fb = V[0][a] * V[1][b];
-                    const int row = (lb[0] + a) * R1 + (lb[1] + b);
+                    for (int b = 0; b < S; b++) {
+                        double fb = V[0][a] * V[1][b];
+                        const int row = (lb[0] + a) * R1 + (lb[1] + b);
 #pragma unroll
-                    for (int c = 0; c < S; c++) {
-                        unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], fb * V[2][c]);
+                        for (int c = 0; c < S; c++) {
+                            unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], fb * V[2][c]);
+                        }
                     }
-                }
+            } else {
+                // all 64 lanes stay in step; a lane without a particle breaks the chain
+                const bool live = ok[u] && inside;
+                if (!live) { lb[0] = lb[1] = lb[2] = 0; }
+                const int rowkey = live ? lb[0] * R1 + lb[1] : -1;
+                const int prow = wave_shr1(rowkey, -2), pz = wave_shr1(lb[2], 0);
+                const int dz = lb[2] - pz;
+                const int take = (live && prow == rowkey && dz >= 1 && dz <= DMAX) ? dz : 0;   // my slot c gets its slot c + take
+                const int give = wave_shl1(take, 0);                                            // my successor takes my slots >= give
+                int mask[S];
+#pragma unroll
+                for (int q = 1; q < S; q++) mask[q] = take == q ? -1 : 0;
+#pragma unroll
+                for (int a = 0; a < S; a++)
+#pragma unroll
+                    for (int b = 0; b < S; b++) {
+                        const double fb = V[0][a] * V[1][b];
+                        const int row = (lb[0] + a) * R1 + (lb[1] + b);
+                        double tv[S];
+#pragma unroll
+                        for (int c = S - 1; c >= 0; c--) {
+                            double acc = fb * V[2][c];
+#pragma unroll
+                            for (int q = 1; q <= DMAX; q++)
+                                if (c + q < S) acc += wave_shr1_masked(tv[c + q], mask[q]);
+                            tv[c] = live ? acc : 0.0;
+                        }
+#pragma unroll
+                        for (int c = 0; c < S; c++)
+                            if (live && (give == 0 || c < give)) unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], tv[c]);
+                    }
+            }
         }
     }
 }
@@ -776,6 +931,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
     // slower than ds_add_f64 on gfx950 (CIC f4 paint 5.3 ms vs 1.0 ms at 512^3), and the sum
     // is rounded to the canvas type once, at the flush.
     __shared__ double lds[Rg::DLDS];
+    __shared__ uint32_t zscratch[(PMX_ZSORT && S >= PMX_ZSORT_MINS) ? (TTHREADS / 64) * ZSCR : 1];
     // A workgroup walks a SEGMENT of up to ZSEG tiles that follow each other along z (the tile
     // index runs fastest along z) and keeps the z-halo — the planes c >= T2 of the region — in
     // LDS, where it becomes the first S-1 planes of the next tile's region.  Only the last tile of
@@ -826,7 +982,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
             }
             __syncthreads();
         }
-        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds);
+        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, zscratch);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -969,6 +1125,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
     __shared__ double lds[Rg::DLDS];
+    __shared__ uint32_t zscratch[(PMX_ZSORT && S >= PMX_ZSORT_MINS) ? (TTHREADS / 64) * ZSCR : 1];
     const uint32_t n = *nitems < cap ? *nitems : cap;
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
         const int64_t tile = (int64_t)(items[item] >> 20);
@@ -980,7 +1137,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
         const int count = left < g.chunk ? (int)left : g.chunk;
         for (int q = threadIdx.x; q < Rg::DLDS; q += TTHREADS) lds[q] = 0;
         __syncthreads();
-        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds);
+        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, zscratch);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             const int c = q % R2, r = q / R2;

@@ -461,6 +461,10 @@ class Plan(object):
                  n1l * P1 == N1 and m1 * P0 == N1 and n1l & (n1l - 1) == 0 and m1 & (m1 - 1) == 0 and
                  all(e1i[q + 1] - e1i[q] == n1l for q in range(P1)) and
                  all(e1o[q + 1] - e1o[q] == m1 for q in range(P0)))
+        planes = self._plane_chunks(p, rowc, colc, fuse1, n0l, N0, P0)
+        if planes:
+            return self._execute_pencil_pipelined(be, bufin, bufout, transfer, planes, same, rowc, colc,
+                                                  N0, N1, N2, N2c, n0l, n1l, m1, m2, e2o, e0i, norm, W0, W1, W2)
         if self.forward:
             X = bufin.storage
             if not same:
@@ -511,6 +515,118 @@ class Plan(object):
             out = bufout.storage
             be.slab_pack(Z, out, n0l * n1l, N2c, 1, e2o, elb, inverse=True)
             self._row(be, out, n0l * n1l, N2, N2c, True)
+
+    def _plane_chunks(self, p, rowc, colc, fuse1, n0l, N0, P0):
+        """[(first plane, planes)] of the local axis-0 range if both transposes of the pencil transform
+        can be pipelined over chunks of planes: the fused axis-1 pass, equal plane ranges on all ranks
+        (the chunk boundaries must agree) and asynchronous exchanges on both sub-communicators"""
+        C = int(OVERLAP_CHUNKS)
+        if C < 2 or not fuse1 or n0l * P0 != N0 or n0l < 2 * C:
+            return None
+        if not (hasattr(rowc, 'alltoall_views') and hasattr(colc, 'alltoall_views')):
+            return None
+        if not (_async_exchange_works(rowc) and _async_exchange_works(colc)):
+            return None
+        w = -(-n0l // C)
+        out, a = [], 0
+        while a < n0l:
+            out.append((a, min(w, n0l - a)))
+            a += w
+        return out if len(out) > 1 else None
+
+    def _execute_pencil_pipelined(self, be, bufin, bufout, transfer, planes, same, rowc, colc,
+                                  N0, N1, N2, N2c, n0l, n1l, m1, m2, e2o, e0i, norm, W0, W1, W2):
+        """The pencil transform with BOTH global transposes cut into chunks of the local planes (axis 0 of
+        the real side, which neither the row transform, nor the first transpose, nor the axis-1 pass mixes):
+        chunk c is row-transformed and packed while the first transpose of chunk c - 1 is on the wire
+        (RCCL's stream), its axis-1 pass (pmx_colfft_resplit: unpack, transform, pack in one kernel) runs
+        under the first transpose of chunk c + 1, and its second transpose under the axis-1 pass of
+        chunk c + 1.  The second transpose delivers chunk c of rank s as the planes [e0i[s] + a, e0i[s] + b)
+        of the (N0, m1, m2) block: row ranges that are contiguous one by one (comm.alltoall_views), so nothing
+        is copied; the axis-0 pass runs once everything has arrived.  PFFT (pm.py:1417-1434) has no such
+        overlap.  c2r mirrors it.  Same numbers as the single exchanges
+        (tests/mp_cases.py::case_pencil_pipelined_equals_single_exchange)."""
+        es = self.elsize
+        elb = 2 * es
+        P0, P1 = len(e0i) - 1, len(e2o) - 1
+        # per chunk: where its pieces live in the work buffers (reals)
+        o1, o2, acc1, acc2 = [], [], 0, 0
+        for a, n in planes:
+            o1.append(acc1)
+            o2.append(acc2)
+            acc1 += 2 * n * n1l * N2c          # row side: (n, n1l, N2c) = the sum of its P1 last-axis blocks
+            acc2 += 2 * n * N1 * m2            # between the transposes: (n, N1, m2)
+        t1s = lambda n: [2 * n * n1l * (e2o[q + 1] - e2o[q]) for q in range(P1)]
+        t1r = lambda n: [2 * n * n1l * m2] * P1
+        out = bufout.storage
+        if self.forward:
+            X = bufin.storage
+            if not same:
+                nreal = n0l * n1l * 2 * N2c
+                W0[:nreal].copy_(bufin.storage[:nreal])
+                X = W0
+            w1 = []
+            for (a, n), q1, q2 in zip(planes, o1, o2):
+                rows = X[2 * a * n1l * N2c:]
+                self._row(be, rows, n * n1l, N2, N2c, False)
+                be.slab_pack(rows, W1[q1:], n * n1l, N2c, 1, e2o, elb)          # split the last axis
+                w1.append(rowc.alltoall(W1[q1:q1 + 2 * n * n1l * N2c], W2[q2:q2 + 2 * n * N1 * m2], t1s(n), t1r(n),
+                                        async_op=True))
+            w2 = []
+            # the packed output of the axis-1 pass goes to W0: the row side (X, which may be W0) is only read by
+            # the packs above, and those are all enqueued — hence executed — before the first of these passes
+            Y = W0
+            for (a, n), q2, w in zip(planes, o2, w1):
+                w.wait()
+                if m2:
+                    be.colfft_resplit(es, False, W2[q2:], Y[q2:], n, N1, m2, n1l, m1)
+                blk = 2 * n * m1 * m2
+                send = [Y[q2 + s * blk:q2 + (s + 1) * blk] for s in range(P0)]
+                recv = [out[2 * (e0i[s] + a) * m1 * m2:2 * (e0i[s] + a + n) * m1 * m2] for s in range(P0)]
+                w2.append(colc.alltoall_views(send, recv, async_op=True))
+            for w in w2:
+                w.wait()
+            self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
+        else:
+            S = bufin.storage
+            if not same:
+                ncplx = 2 * N0 * m1 * m2
+                W0[:ncplx].copy_(bufin.storage[:ncplx])
+                S = W0
+            if transfer is not None and m1 * m2:
+                t, start, nmesh, boxsize = transfer
+                be.colfft(es, True, S, 1, N0, m1 * m2, transfer=t, n1=m1, n2=m2, start=start, nmesh=nmesh,
+                          boxsize=boxsize)
+            else:
+                self._col(be, S, 1, N0, m1 * m2, True)
+            w2 = []
+            for (a, n), q2 in zip(planes, o2):
+                blk = 2 * n * m1 * m2
+                send = [S[2 * (e0i[s] + a) * m1 * m2:2 * (e0i[s] + a + n) * m1 * m2] for s in range(P0)]
+                recv = [W1[q2 + s * blk:q2 + (s + 1) * blk] for s in range(P0)]
+                w2.append(colc.alltoall_views(send, recv, async_op=True))
+            # where the first transpose (row group) delivers: W0 when the transform works in place (S is the
+            # caller's buffer), else — S is W0 — a buffer of this plan's own
+            if S is W0:
+                if getattr(self, '_work_z', None) is None or self._work_z.numel() < acc1 or self._work_z.dtype != W0.dtype:
+                    self._work_z = torch.empty(acc1, dtype=W0.dtype, device=W0.device)
+                Z = self._work_z
+            else:
+                Z = W0
+            w1 = []
+            for (a, n), q1, q2, w in zip(planes, o1, o2, w2):
+                w.wait()
+                if m2:
+                    be.colfft_resplit(es, True, W1[q2:], W2[q2:], n, N1, m2, m1, n1l)
+                w1.append(rowc.alltoall(W2[q2:q2 + 2 * n * N1 * m2], Z[q1:q1 + 2 * n * n1l * N2c], t1r(n), t1s(n),
+                                        async_op=True))
+            # (every second transpose has been waited for by now: `out`, which is S when the transform works
+            # in place, may be overwritten)
+            for (a, n), q1, w in zip(planes, o1, w1):
+                w.wait()
+                rows = out[2 * a * n1l * N2c:]
+                be.slab_pack(Z[q1:], rows, n * n1l, N2c, 1, e2o, elb, inverse=True)
+                self._row(be, rows, n * n1l, N2, N2c, True)
 
     def can_fuse(self):
         """True if execute(..., transfer=) can fold a transfer function into the transform"""

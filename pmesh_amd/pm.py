@@ -1322,6 +1322,18 @@ class ParticleMesh(object):
             id += isource[:, i]
         return source, id
 
+    def stage(self, array):
+        """Register a host (numpy) array for repeated use: returns a handle to pass wherever the array
+        would go (`paint`, `readout`, `decompose`, `Layout.exchange`).  The array is uploaded once; the
+        calls that follow find its device copy — and the bin plan and layout memos keyed on it — instead
+        of moving it over PCIe again.  `force()` of examples/nbody.py:199-218 hands the same positions to
+        one paint and three readouts: with `X = pm.stage(X)` they cross the link once.  Results still
+        come back as numpy arrays.  After changing the host array in place call `handle.refresh()`."""
+        from ._arrays import Staged
+        if isinstance(array, Staged) or is_tensor(array):
+            return array
+        return Staged(array, backend.get().device)
+
     def tile_order(self, pos, transform=None):
         """ A permutation of the rows of `pos` that makes them spatially coherent (an extension;
             the reference has no counterpart).

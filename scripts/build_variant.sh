@@ -1,11 +1,11 @@
 #!/bin/bash
 # scripts/build_variant.sh <name> "<EXTRA flags>" [file.hip ...]: builds pmesh_amd/libpmesh_amd_<name>.so with the
-# given files recompiled under EXTRA (default: pmx_walk.hip), the other objects as they are.
+# given files recompiled under EXTRA (default: pmx_binned.hip), the other objects of the product build as they are.
 name=$1; flags=$2; shift 2
-files=${@:-pmx_walk.hip}
+files=${@:-pmx_binned.hip}
 cd pmesh_amd/csrc
 objs=""
-for f in pmx_core pmx_window pmx_binned pmx_walk pmx_domain pmx_transfer pmx_synth pmx_fft pmx_colfft pmx_whitenoise; do
+for f in pmx_core pmx_window pmx_binned pmx_domain pmx_transfer pmx_synth pmx_fft pmx_colfft pmx_whitenoise; do
   if echo " $files " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -I../../include $flags -c $f.hip -o /tmp/${f}_$name.o || exit 1
     objs="$objs /tmp/${f}_$name.o"

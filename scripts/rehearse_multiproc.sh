@@ -16,3 +16,12 @@ for n in 2 4 8; do
     echo "n=$n mesh=$mesh rc=$?"; tail -c 600 "$out/n${n}_mesh${mesh}.json"; echo
   done
 done
+# the pencil mesh (2 x 4 at n = 8, pipelined transposes) with PCS on the clustered set, per-particle mass
+for n in 4 8; do
+  port=$((port + 1))
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
+      --master-port $port bench.py --gpus $n --steps 3 --warmup 1 --mesh 256 --np pencil --window pcs \
+      --data clustered --double 1 --mass array --no-cpu-baseline \
+      > "$out/n${n}_pencil.json" 2> "$out/n${n}_pencil.err"
+  echo "n=$n pencil rc=$?"; tail -c 400 "$out/n${n}_pencil.json"; echo
+done

@@ -4,7 +4,7 @@ vars=$1; shift
 for cfg in "$@"; do
   for v in $vars; do
     lib=$PWD/pmesh_amd/libpmesh_amd_$v.so; [ "$v" = "base" ] && lib=$PWD/pmesh_amd/libpmesh_amd.so
-    PMESH_AMD_LIBRARY=$lib PMESH_AMD_WALK=${WALK:-always} timeout 300 python bench.py $cfg --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/v.json 2>gpurun_out/v.err
+    PMESH_AMD_LIBRARY=$lib timeout 300 python bench.py $cfg --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/v.json 2>gpurun_out/v.err
     python - "$v" "$cfg" <<'PY'
 import json, sys
 try:

@@ -502,6 +502,49 @@ def case_pencil(be, comm):
     assert abs(f - out[share]).max() <= 1e-11 * abs(out).max()
 
 
+def case_pencil_pipelined_equals_single_exchange(be, comm):
+    """fft.OVERLAP_CHUNKS: both transposes of the pencil transform cut into chunks of the local planes,
+    exchanged asynchronously (the second one into row ranges of the output: comm.alltoall_views), give
+    the numbers of the single exchanges bit for bit; r2c / c2r in place and out of place, with the fused
+    transfer, equal and uneven last-axis blocks"""
+    from pmesh_amd import fft as F, comm as C
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    shapes = {4: [2, 2], 8: [2, 4]}
+    if comm.size not in shapes:
+        return
+    np_ = shapes[comm.size]
+    saved = F.OVERLAP_CHUNKS
+    try:
+        for Nmesh in ([64, 64, 128], [64, 128, 128]):
+            res = {}
+            for chunks in (1, 2, 3):
+                F.OVERLAP_CHUNKS = chunks
+                pm = ParticleMesh(BoxSize=[3.0, 2.0, 5.0], Nmesh=Nmesh, comm=comm, dtype='f8', np=np_)
+                data = numpy.random.RandomState(31).normal(size=Nmesh)
+                real = pm.create('real', value=data[pm.create('real').slices])
+                real.r2c()                       # (first use: the probes of the asynchronous exchange)
+                rec = C.trace(True) if hasattr(comm, '_dist') else None
+                ck = real.r2c()
+                if rec is not None:
+                    C.trace(False)
+                    over = [r for r in rec if r[5]]
+                    # pipelined: every data exchange is asynchronous, 2 transposes x chunks of them
+                    assert len(over) == (2 * chunks if chunks > 1 else 0), (chunks, len(rec), len(over))
+                back = ck.c2r()
+                T = Transfer.dx1(1)
+                f = ck.c2r(transfer=T)
+                ck2 = real.copy().r2c(out=Ellipsis)
+                back2 = ck2.copy().c2r(out=Ellipsis)
+                res[chunks] = [numpy.asarray(x.value.cpu()).copy() for x in (ck, back, f, ck2, back2)]
+                assert_allclose(res[chunks][1], data[back.slices], rtol=0, atol=1e-12)
+            for chunks in (2, 3):
+                for x, y in zip(res[1], res[chunks]):
+                    assert_array_equal(x, y)
+    finally:
+        F.OVERLAP_CHUNKS = saved
+
+
 def case_length_check_is_collective(be, comm):
     """domain.py:177-179, 240-242: a wrong array on ONE rank raises ValueError on EVERY rank the first
     time a layout is used (the verdict is all-reduced); afterwards the offending rank raises alone,
@@ -588,7 +631,8 @@ def case_comm_trace(be, comm):
     assert 0.7 * full <= total <= 1.3 * full, (total, full)
 
 
-CASES = [case_comm_trace, case_length_check_is_collective, case_promote_and_pack, case_pencil, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+CASES = [case_comm_trace, case_length_check_is_collective, case_promote_and_pack, case_pencil,
+         case_pencil_pipelined_equals_single_exchange, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 

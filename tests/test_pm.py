@@ -688,6 +688,32 @@ def test_default_process_mesh_and_plan_cache(be):
     assert abs(float(t.r2c().c2r().value.mean()) - 2.0) < 1e-12
 
 
+def test_staged_host_arrays(be):
+    """ParticleMesh.stage: a numpy array registered once is uploaded once; paint / readout / decompose take
+    the handle wherever the array would go, return numpy like for the array itself, and share one device
+    copy (one bin plan, one layout memo); refresh() after an update in place"""
+    from pmesh_amd._arrays import Staged
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='f8', resampler='cic')
+    rs = numpy.random.RandomState(3)
+    X = rs.uniform(0, 8, size=(500, 3))
+    h = pm.stage(X)
+    assert isinstance(h, Staged) and pm.stage(h) is h and len(h) == 500 and h.shape == (500, 3)
+    a = pm.paint(X)
+    b = pm.paint(h)
+    assert_array_equal(numpy.asarray(a), numpy.asarray(b))
+    layout = pm.decompose(h)
+    c = pm.paint(h, layout=layout)
+    assert_allclose(numpy.asarray(c), numpy.asarray(a), rtol=0, atol=1e-13)
+    f = a.readout(h)
+    assert isinstance(f, numpy.ndarray)
+    assert_array_equal(f, a.readout(X))
+    t0 = h.tensor
+    X += 0.25
+    assert_array_equal(a.readout(h.refresh()), a.readout(X))
+    assert h.tensor is t0                                   # the same device storage, a new version
+    assert_array_equal(numpy.asarray(pm.paint(h)), numpy.asarray(pm.paint(X)))
+
+
 def test_pack_arrays():
     from pmesh_amd.domain import pack_arrays          # domain.py:59-80
     a = numpy.arange(12.0).reshape(4, 3)

@@ -68,6 +68,20 @@ class ThreadComm(object):
             from pmesh_amd.comm import _Done
             return _Done()
 
+    def alltoall_views(self, send_views, recv_views, async_op=False):
+        """one contiguous tensor per peer on either side (pmesh_amd.comm.TorchComm.alltoall_views)"""
+        if send_views[0].is_cuda:
+            torch.cuda.synchronize()
+        allv = self._exchange(list(send_views))
+        for s in range(self.size):
+            recv_views[s].copy_(allv[s][self.rank].view(recv_views[s].shape))
+        if send_views[0].is_cuda:
+            torch.cuda.synchronize()
+        self.shared.barrier.wait()
+        if async_op:
+            from pmesh_amd.comm import _Done
+            return _Done()
+
     def _alltoall(self, send, recv, send_splits=None, recv_splits=None, rows=False):
         if send_splits is None:
             n = send.shape[0] // self.size
