@@ -238,7 +238,6 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
-constexpr int ZSCR = 72;                           // words of a wave's table in the z sort of tile_deposit
 constexpr int BLOCK_ITERS = 8;                     // trips of TBLOCK * PMX_ONEPASS_U rows
 constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
 constexpr int BLOCK_HT = 128;                       // entries of the LDS table (a power of two)
@@ -626,68 +625,71 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
     }
 }
 
-// ---- experiments on the deposit of S >= 3 windows (compile-time, A/B'd with EXTRA=-D...) ----
-// PMX_ZSORT: the two list entries every lane of a wave holds (128 per wave and trip) are re-dealt among the
-//   lanes in the order of their z cell, even sorted positions to the first particle slot and odd ones to the
-//   second: an atomic instruction then finds ~2 lanes on every bank pair (rows are whole bank rows) whatever
-//   the jitter of the particles did to the natural order.
-// PMX_ZMERGE: neighbouring lanes whose particles sit in the same (x, y) row with z cells 1 .. DMAX apart pass
-//   the overlapping part of their z runs down the wave in registers (DPP shifts), and only the last lane of a
-//   chain issues the atomic for a cell: S^2 instead of S^3 lane-atomics along an intact chain.
-#ifndef PMX_ZSORT
-#define PMX_ZSORT 0
+// timing experiments (wrong results; bench with PMESH_AMD_BENCH_NOCHECK=1): where does the deposit spend its time?
+//   PMX_EXP_NOATOM: the weights are computed and folded into one register, nothing goes to LDS
+//   PMX_EXP_NOWEIGHT: the LDS atomics with a constant instead of the weight products
+#ifndef PMX_FIXED_POINT
+#define PMX_FIXED_POINT 1
 #endif
-#ifndef PMX_ZMERGE
-#define PMX_ZMERGE 0
+#ifndef PMX_FIXED_MIN_S
+#define PMX_FIXED_MIN_S 3
 #endif
-#ifndef PMX_ZMERGE_DMAX
-#define PMX_ZMERGE_DMAX 3
+#ifndef PMX_EXP_NOATOM
+#define PMX_EXP_NOATOM 0
 #endif
-#ifndef PMX_ZMERGE_MINS
-#define PMX_ZMERGE_MINS 3
-#endif
-#ifndef PMX_ZSORT_MINS
-#define PMX_ZSORT_MINS 3
+#ifndef PMX_EXP_NOWEIGHT
+#define PMX_EXP_NOWEIGHT 0
 #endif
 
-// lane i <- lane i - 1 (wave_shr:1) / lane i + 1 (wave_shl:1) of a 32-bit value; lanes without a source read `fill`
-__device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
-// the neighbour's double, ANDed with a lane mask (all ones: take it, zero: +0.0)
-__device__ __forceinline__ double wave_shr1_masked(double v, int mask)
+// ---- fixed-point accumulation (FIXED) -------------------------------------------------------------------
+// The region is accumulated as 64-bit integers: every contribution v is rounded once to a multiple of 2^-f
+// (v 2^f + 1.5 2^52 in ONE fma, whose mantissa then holds the integer) and added with ds_add_u64.  Why: on
+// gfx950 a ds_add_f64 instruction whose lanes meet on a cell or a bank costs far more than an integer one
+// (scripts/deposit_model.hip, the benchmark's jittered lattice under TSC: 19.0 against 11.5 clocks per wave
+// instruction; a perfect lattice 11.9 against 10.5) and the S >= 3 paint kernels are bound by exactly that
+// (with the atomics compiled out TSC paints in 1.10 instead of 2.10 ms, PCS in 1.78 instead of 3.49).  The sum of
+// a region no longer depends on the order of arrival: it is bit-reproducible.  f comes from what can meet in a
+// cell: at most n particles (those of the z segment's tiles) of mass <= mb with a weight product <= wb:
+// every contribution below 2^50 units, every sum below 2^61.  The reference adds doubles (relative error
+// 2^-53 per add); here the absolute error per add is 2^-f-1 with 2^f >= 2^50 / (mb wb) unless a segment holds
+// more than 2^11 particles per unit... in numbers: a uniform 512^3 set (16384 particles per segment) is
+// accumulated in steps of 2^-47 = 7e-15 of the particle mass.
+constexpr double FIXED_MAGIC = 6755399441055744.0;                    // 1.5 * 2^52
+constexpr long long FIXED_MAGIC_BITS = 0x4338000000000000ll;          // its bit pattern (low word 0)
+
+// scale 2^f for a region that at most n particles of |mass| <= mb deposit into (weights of painter p)
+__device__ __forceinline__ int fixed_exponent(const pmx_painter &p, double mb, int64_t n)
 {
-    const long long b = __double_as_longlong(v);
-    const int lo = wave_shr1((int)b, 0) & mask, hi = wave_shr1((int)(b >> 32), 0) & mask;
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    double wb = 1.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+        if (p.order[d]) wb *= 2.0 * fabs(p.scale[d]) + 2.0;           // bound of the derivative weights
+    const double b = mb * wb;
+    int e = (b > 0 && b < 1e300) ? ilogb(b) + 1 : 0;                   // b < 2^e
+    int lg = 0;
+    while (((int64_t)1 << lg) < n && lg < 40) lg++;                    // n <= 2^lg
+    int f = 50 - e;
+    if (61 - e - lg < f) f = 61 - e - lg;
+    return f < -900 ? -900 : (f > 900 ? 900 : f);
 }
-__device__ __forceinline__ double pull_double(int srcbytes, double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_ds_bpermute(srcbytes, (int)b), hi = __builtin_amdgcn_ds_bpermute(srcbytes, (int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+__device__ __forceinline__ double pow2(int f) { return __longlong_as_double((long long)(1023 + f) << 52); }
 
 // The particles [start, start + count) of a tile's list are deposited into its LDS region.
-template <int KIND, int TTHREADS, bool SORTED>
+template <int KIND, int TTHREADS, bool SORTED, bool FIXED = false>
 __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                              const DVec &mass, double mass_scalar, const uint32_t *list,
-                                             int64_t start, int count, double *lds, uint32_t *zscratch)
+                                             int64_t start, int count, double *lds, double scale = 1.0)
 {
     constexpr bool sorted = SORTED;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1;
-    constexpr bool ZSORT = PMX_ZSORT && S >= PMX_ZSORT_MINS && UNROLL == 2;
-    constexpr bool ZMERGE = PMX_ZMERGE && S >= PMX_ZMERGE_MINS;
-    constexpr int DMAX = PMX_ZMERGE_DMAX < S - 1 ? PMX_ZMERGE_DMAX : S - 1;
     // UNROLL particles per thread and trip: all index and position loads are issued before
     // the first use, so several dependent gathers are in flight per lane
     // SWAP (TSC, PCS): odd lanes deposit their second particle first, see below
-    constexpr bool SWAP = S >= 3 && UNROLL == 2 && !ZSORT && !ZMERGE;
-    const int lane = threadIdx.x & 63;
-    // (ZSORT / ZMERGE: the lanes of a wave work together, so the trip count is the wave's, not the lane's)
-    for (int jw = threadIdx.x - lane; jw < count; jw += TTHREADS * UNROLL) {
-        const int j0 = jw + lane;
+    constexpr bool SWAP = S >= 3 && UNROLL == 2;
+    double sink = 0;
+    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
 #pragma unroll
@@ -697,7 +699,6 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            x[u][0] = x[u][1] = x[u][2] = 0; m[u] = 0;
             if (idx[u] >= 0) {
                 x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
                 // (sorted: idx is the list slot; a per-particle mass lives at the row the list names)
@@ -718,136 +719,39 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
             const double tm = m[0]; m[0] = m[1]; m[1] = tm;
             const int64_t ti = idx[0]; idx[0] = idx[1]; idx[1] = ti;
         }
-        bool ok[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) ok[u] = idx[u] >= 0;
-        if (ZSORT) {
-            // counting sort of the wave's 2 x 64 entries by z cell (T2 bins + one for the empty slots) in a small
-            // table of the wave's own; LDS operations of one wave execute in order, the fences keep the compiler
-            // from moving them across each other
-            uint32_t *zh = zscratch + (threadIdx.x >> 6) * ZSCR;             // [0, 40): bins; [40, 72): sources, 4 per word
-            unsigned char *zsrc = (unsigned char *)(zh + 40);
-            if (lane < 40) zh[lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            int key[UNROLL];
-            uint32_t rank[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                key[u] = T2;
-                if (ok[u]) {
-                    const double X = x[u][2] * p.scale[2] + p.translate[2];
-                    const int I0 = Tuned<KIND>::first(X);
-                    const int per = (int)p.period[2], siz = (int)p.size[2];
-                    int lb2;
-                    if (g.o[2] == 0 && per == siz) lb2 = I0 & (T2 - 1);
-                    else {
-                        int w = wrap_fast(I0, per);
-                        if (per > 0 && w >= siz) w -= per;
-                        lb2 = w + g.o[2] - t[2] * T2;
-                    }
-                    key[u] = (unsigned)lb2 < (unsigned)T2 ? lb2 : T2;
-                }
-                rank[u] = atomicAdd(&zh[key[u]], 1u);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            // exclusive prefix over the T2 + 1 bins (lanes 0 .. T2)
-            uint32_t c = lane <= T2 ? zh[lane] : 0u, incl = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= off) incl += up;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane <= T2) zh[lane] = incl - c;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const uint32_t ppos = zh[key[u]] + rank[u];                  // sorted position, 0 .. 127
-                zsrc[ppos] = (unsigned char)(lane | (u << 6));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            // sorted positions 2 l and 2 l + 1 become the first and the second particle of lane l
-            const uint32_t two = ((const unsigned short *)zsrc)[lane];
-            double nx[UNROLL][3], nm[UNROLL];
-            bool nok[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const int src = (int)((two >> (8 * u)) & 0xFF);
-                const int sl = (src & 63) << 2;
-                const bool second = (src & 64) != 0;
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const double a0 = pull_double(sl, x[0][d]), a1 = pull_double(sl, x[1][d]);
-                    nx[u][d] = second ? a1 : a0;
-                }
-                const double m0 = pull_double(sl, m[0]), m1 = pull_double(sl, m[1]);
-                nm[u] = second ? m1 : m0;
-                const int o0 = __builtin_amdgcn_ds_bpermute(sl, (int)ok[0]), o1 = __builtin_amdgcn_ds_bpermute(sl, (int)ok[1]);
-                nok[u] = (second ? o1 : o0) != 0;
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                x[u][0] = nx[u][0]; x[u][1] = nx[u][1]; x[u][2] = nx[u][2]; m[u] = nm[u]; ok[u] = nok[u];
-            }
-        }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            if (!ZMERGE && !ok[u]) continue;
+            if (idx[u] < 0) continue;
             int lb[3];
             double V[3][S];
             particle_setup<KIND>(p, g, t, x[u], V, lb);
             // a plan that no longer matches the positions (rewritten behind the cache's back)
             // must not index outside the LDS region
-            const bool inside = !((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2);
-            if (!ZMERGE && !inside) continue;
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            // (FIXED: the mass carries the 2^f — a power of two, so the products are those of the reference times 2^f)
+            const double mu = FIXED ? m[u] * scale : m[u];
 #pragma unroll
-            for (int a = 0; a < S; a++) V[0][a] *= m[u];
-            if (!ZMERGE) {
+            for (int a = 0; a < S; a++) V[0][a] *= mu;
 #pragma unroll
-                for (int a = 0; a < S; a++)
+            for (int a = 0; a < S; a++)
 #pragma unroll
-                    for (int b = 0; b < S; b++) {
-                        double fb = V[0][a] * V[1][b];
-                        const int row = (lb[0] + a) * R1 + (lb[1] + b);
+                for (int b = 0; b < S; b++) {
+                    double fb = V[0][a] * V[1][b];
+                    const int row = (lb[0] + a) * R1 + (lb[1] + b);
 #pragma unroll
-                        for (int c = 0; c < S; c++) {
-                            unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], fb * V[2][c]);
-                        }
+                    for (int c = 0; c < S; c++) {
+                        if (PMX_EXP_NOATOM) sink += fb * V[2][c];
+                        else if (PMX_EXP_NOWEIGHT) unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], m[u]);
+                        else if (FIXED) {
+                            const double r = __builtin_fma(fb, V[2][c], FIXED_MAGIC);
+                            atomicAdd((unsigned long long *)&lds[Rg::dat(row, lb[2] + c)],
+                                      (unsigned long long)(__double_as_longlong(r) - FIXED_MAGIC_BITS));
+                        } else unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], fb * V[2][c]);
                     }
-            } else {
-                // all 64 lanes stay in step; a lane without a particle breaks the chain
-                const bool live = ok[u] && inside;
-                if (!live) { lb[0] = lb[1] = lb[2] = 0; }
-                const int rowkey = live ? lb[0] * R1 + lb[1] : -1;
-                const int prow = wave_shr1(rowkey, -2), pz = wave_shr1(lb[2], 0);
-                const int dz = lb[2] - pz;
-                const int take = (live && prow == rowkey && dz >= 1 && dz <= DMAX) ? dz : 0;   // my slot c gets its slot c + take
-                const int give = wave_shl1(take, 0);                                            // my successor takes my slots >= give
-                int mask[S];
-#pragma unroll
-                for (int q = 1; q < S; q++) mask[q] = take == q ? -1 : 0;
-#pragma unroll
-                for (int a = 0; a < S; a++)
-#pragma unroll
-                    for (int b = 0; b < S; b++) {
-                        const double fb = V[0][a] * V[1][b];
-                        const int row = (lb[0] + a) * R1 + (lb[1] + b);
-                        double tv[S];
-#pragma unroll
-                        for (int c = S - 1; c >= 0; c--) {
-                            double acc = fb * V[2][c];
-#pragma unroll
-                            for (int q = 1; q <= DMAX; q++)
-                                if (c + q < S) acc += wave_shr1_masked(tv[c + q], mask[q]);
-                            tv[c] = live ? acc : 0.0;
-                        }
-#pragma unroll
-                        for (int c = 0; c < S; c++)
-                            if (live && (give == 0 || c < give)) unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], tv[c]);
-                    }
-            }
+                }
         }
     }
+    if (PMX_EXP_NOATOM && sink == 12345.678) lds[0] = sink;
 }
 
 // The particles [start, start + count) of a tile's list read their values from its LDS region.
@@ -916,12 +820,28 @@ template <int KIND> struct TileThreads<KIND, float> {
     static constexpr int readout = PMX_TILE_THREADS_RF4;
 };
 
-template <int KIND, typename T, int TTHREADS, bool SORTED>
+// what a cell of the region holds as a double (FIXED: the integer sum times 2^-f)
+template <bool FIXED> __device__ __forceinline__ double cell_value(double raw, double inv)
+{
+    return FIXED ? (double)__double_as_longlong(raw) * inv : raw;
+}
+// mstats (per-particle masses only): [0] = max |m| over the finite masses, [1] = number of non-finite ones.
+// The FIXED kernel serves a batch whose masses are all finite, its floating-point twin (launched behind it,
+// want_odd = 1) the others: each returns at once when the batch is not its own.
+__device__ __forceinline__ bool batch_is_mine(const double *mstats, int want_odd)
+{
+    const bool odd = mstats != nullptr && mstats[1] != 0.0;
+    return odd == (want_odd != 0);
+}
+
+template <int KIND, typename T, int TTHREADS, bool SORTED, bool FIXED>
 __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
-                                                            const uint32_t *counts, T *halo, int overwrite)
+                                                            const uint32_t *counts, T *halo, int overwrite,
+                                                            const double *mstats, int want_odd)
 {
+    if (!batch_is_mine(mstats, want_odd)) return;
     // SORTED: `pos` is the plan's copy of the positions in list order (row = list slot);
     // the list itself is then only read for a per-particle mass
     constexpr int S = Tuned<KIND>::S;
@@ -931,7 +851,6 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
     // slower than ds_add_f64 on gfx950 (CIC f4 paint 5.3 ms vs 1.0 ms at 512^3), and the sum
     // is rounded to the canvas type once, at the flush.
     __shared__ double lds[Rg::DLDS];
-    __shared__ uint32_t zscratch[(PMX_ZSORT && S >= PMX_ZSORT_MINS) ? (TTHREADS / 64) * ZSCR : 1];
     // A workgroup walks a SEGMENT of up to ZSEG tiles that follow each other along z (the tile
     // index runs fastest along z) and keeps the z-halo — the planes c >= T2 of the region — in
     // LDS, where it becomes the first S-1 planes of the next tile's region.  Only the last tile of
@@ -948,6 +867,18 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
       const int seg = (int)(w - column * nseg);
       const int t2a = seg * ZSEG, t2b = (t2a + ZSEG < nt2) ? t2a + ZSEG : nt2;
       bool live = false;                        // the region holds the z-halo of the previous tile
+      double scale = 1.0, inv = 1.0;
+      if (FIXED) {
+          // one scale for the segment: the z-halo carried from tile to tile keeps its meaning
+          int64_t nseg_part = 0;
+          for (int t2 = t2a; t2 < t2b; t2++) {
+              const uint32_t c = counts[column * nt2 + t2];
+              nseg_part += c < (uint32_t)g.chunk ? c : (uint32_t)g.chunk;
+          }
+          const int f = fixed_exponent(p, mstats ? mstats[0] : fabs(mass_scalar), nseg_part);
+          scale = pow2(f);
+          inv = pow2(-f);
+      }
       for (int t2 = t2a; t2 < t2b; t2++) {
         const int64_t tile = column * nt2 + t2;
         const bool last = (t2 == t2b - 1);
@@ -982,7 +913,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
             }
             __syncthreads();
         }
-        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, zscratch);
+        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -998,7 +929,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 in = in && l >= 0 && l < p.size[d];
             }
             if (in && region_cell(p, g, t, a, b, c, &goff)) {
-                T v = (T)lds[Rg::dat(a * R1 + b, c)];
+                T v = (T)cell_value<FIXED>(lds[Rg::dat(a * R1 + b, c)], inv);
                 T *dst = (T *)(canvas + goff);
                 if (overwrite) *dst = v;
                 else *dst += v;
@@ -1011,7 +942,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int a, b, c;
                 Rg::halo_decode(h, &a, &b, &c);
                 if (!last && c >= T2) continue;           // carried to the next tile instead
-                hbase[h] = (T)lds[Rg::dat(a * R1 + b, c)];
+                hbase[h] = (T)cell_value<FIXED>(lds[Rg::dat(a * R1 + b, c)], inv);
             }
         }
         live = !last;
@@ -1115,17 +1046,18 @@ __global__ void __launch_bounds__(TBLOCK) heavy_items_kernel(const uint32_t *cou
 
 // one workgroup per work item: the piece is accumulated in LDS like a tile of its own and the whole
 // region, box and halo, is added to the canvas with atomics (after the tile kernel and halo_merge)
-template <int KIND, typename T, int TTHREADS, bool SORTED>
+template <int KIND, typename T, int TTHREADS, bool SORTED, bool FIXED>
 __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                              DVec mass, double mass_scalar, const uint32_t *list,
                                                              const int64_t *offsets, const uint32_t *counts,
-                                                             const uint64_t *items, const uint32_t *nitems, uint32_t cap)
+                                                             const uint64_t *items, const uint32_t *nitems, uint32_t cap,
+                                                             const double *mstats, int want_odd)
 {
+    if (!batch_is_mine(mstats, want_odd)) return;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
     __shared__ double lds[Rg::DLDS];
-    __shared__ uint32_t zscratch[(PMX_ZSORT && S >= PMX_ZSORT_MINS) ? (TTHREADS / 64) * ZSCR : 1];
     const uint32_t n = *nitems < cap ? *nitems : cap;
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
         const int64_t tile = (int64_t)(items[item] >> 20);
@@ -1137,11 +1069,17 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
         const int count = left < g.chunk ? (int)left : g.chunk;
         for (int q = threadIdx.x; q < Rg::DLDS; q += TTHREADS) lds[q] = 0;
         __syncthreads();
-        tile_deposit<KIND, TTHREADS, SORTED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, zscratch);
+        double scale = 1.0, inv = 1.0;
+        if (FIXED) {
+            const int f = fixed_exponent(p, mstats ? mstats[0] : fabs(mass_scalar), count);
+            scale = pow2(f);
+            inv = pow2(-f);
+        }
+        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             const int c = q % R2, r = q / R2;
-            const double v = lds[Rg::dat(r, c)];
+            const double v = cell_value<FIXED>(lds[Rg::dat(r, c)], inv);
             if (v == 0) continue;
             int64_t goff;
             if (region_cell(p, g, t, r / R1, r % R1, c, &goff)) unsafeAtomicAdd((T *)(canvas + goff), (T)v);
@@ -1179,6 +1117,34 @@ __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, 
         tile_gather<KIND, T, TTHREADS, SORTED>(p, g, t, pos, out, list, offsets[tile] + first, count, lds);
         __syncthreads();
     }
+}
+
+// stats[0] = max |m| over the finite masses (as the bit pattern of a non-negative double, which orders like an
+// integer), stats[1] = how many are not finite
+__global__ void __launch_bounds__(TBLOCK) mass_stats_kernel(DVec mass, int64_t n, unsigned long long *stats)
+{
+    double mx = 0;
+    unsigned long long odd = 0;
+    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * TBLOCK) {
+        const double m = fabs(mass.get(i, 0));
+        if (m <= 1.7e308) mx = m > mx ? m : mx;
+        else odd++;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+        odd += __shfl_down(odd, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&stats[0], (unsigned long long)__double_as_longlong(mx));
+        if (odd) atomicAdd(&stats[2], odd);
+    }
+}
+// stats[1] (double) = stats[2] (integer count)
+__global__ void mass_stats_finish_kernel(unsigned long long *stats)
+{
+    ((double *)stats)[1] = (double)stats[2];
 }
 
 int plan_ensure(void **ptr, size_t *cap, size_t need)
@@ -1266,6 +1232,7 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->inv) (void)hipFree(pl->inv);
     if (pl->out_sorted) (void)hipFree(pl->out_sorted);
     if (pl->host_groups) (void)hipHostFree(pl->host_groups);
+    if (pl->mstats) (void)hipFree(pl->mstats);
     if (pl->heavy_items) (void)hipFree(pl->heavy_items);
     if (pl->nheavy) (void)hipFree(pl->nheavy);
     delete pl;
@@ -1588,8 +1555,30 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
         pos.stride0 = 3 * es;
         pos.stride1 = es;
     }
-#define PT(K) do { if (sorted) paint_tile_kernel<K, T, TileThreads<K, T>::paint, true><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite); \
-                   else paint_tile_kernel<K, T, TileThreads<K, T>::paint, false><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite); } while (0)
+    // Fixed-point regions for the windows whose deposit is bound by the LDS atomics (S >= 3); NNB / CIC are
+    // bound by memory and keep their doubles.  Per-particle masses: their largest finite magnitude, and whether
+    // all of them are finite, are found on the device; a batch with a NaN / Inf mass is served by the
+    // floating-point kernels, launched behind the fixed-point ones (each returns at once when the batch is not
+    // its own).  A scalar mass decides on the host.
+    const bool fixed_kind = PMX_FIXED_POINT && g.S >= PMX_FIXED_MIN_S;
+    const double *mstats = nullptr;
+    bool run_fixed = fixed_kind, run_float = !fixed_kind;
+    if (fixed_kind) {
+        if (mass.data) {
+            if (!pl->mstats) PMX_HIP_CHECK(hipMalloc((void **)&pl->mstats, 32));
+            PMX_HIP_CHECK(hipMemsetAsync(pl->mstats, 0, 32, st));
+            mass_stats_kernel<<<grid_for(pl->npart, TBLOCK, 2048), TBLOCK, 0, st>>>(mass, pl->npart, (unsigned long long *)pl->mstats);
+            mass_stats_finish_kernel<<<1, 1, 0, st>>>((unsigned long long *)pl->mstats);
+            mstats = pl->mstats;
+            run_float = true;
+        } else if (!(fabs(ms) <= 1.7e308)) {
+            run_fixed = false;
+            run_float = true;
+        }
+    }
+#define PT2(K, FX, ODD) do { if (sorted) paint_tile_kernel<K, T, TileThreads<K, T>::paint, true, FX><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite, mstats, ODD); \
+                   else paint_tile_kernel<K, T, TileThreads<K, T>::paint, false, FX><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite, mstats, ODD); } while (0)
+#define PT(K) do { if (run_fixed) PT2(K, true, 0); if (run_float) PT2(K, false, (run_fixed ? 1 : 0)); } while (0)
 #define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
@@ -1598,11 +1587,13 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     default: PT(PMX_TUNED_PCS); HM(4); break;
     }
 #undef PT
+#undef PT2
 #undef HM
     // the pieces of crowded tiles (none for a uniform batch: the kernel then returns at once)
     const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
-#define PH(K) do { if (sorted) paint_heavy_kernel<K, T, TileThreads<K, T>::paint, true><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); \
-                   else paint_heavy_kernel<K, T, TileThreads<K, T>::paint, false><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); } while (0)
+#define PH2(K, FX, ODD) do { if (sorted) paint_heavy_kernel<K, T, TileThreads<K, T>::paint, true, FX><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, mstats, ODD); \
+                   else paint_heavy_kernel<K, T, TileThreads<K, T>::paint, false, FX><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, mstats, ODD); } while (0)
+#define PH(K) do { if (run_fixed) PH2(K, true, 0); if (run_float) PH2(K, false, (run_fixed ? 1 : 0)); } while (0)
     switch (p.kind) {
     case PMX_TUNED_NNB: PH(PMX_TUNED_NNB); break;
     case PMX_TUNED_CIC: PH(PMX_TUNED_CIC); break;
@@ -1610,6 +1601,7 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     default: PH(PMX_TUNED_PCS); break;
     }
 #undef PH
+#undef PH2
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }

@@ -167,6 +167,7 @@ struct pmx_binplan {
     uint64_t *heavy_items = nullptr;   // (tile << 20) | piece, piece >= 1
     size_t cap_heavy = 0;
     uint32_t *nheavy = nullptr;        // device: number of items of this build
+    double *mstats = nullptr;          // device: [0] max |m| of the finite per-particle masses, [1] non-finite ones
     int32_t chunk = 1 << 30;           // list entries per piece
     // history for the single-pass build: the slot ranges of the previous build of the same
     // geometry and particle count are reused (particles move little between time steps)
