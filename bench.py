@@ -99,6 +99,8 @@ def parse():
                          'the position arrays registered once (ParticleMesh.stage) and refreshed once per cycle')
     ap.add_argument('--fuse-apply', type=int, default=1,
                     help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
+    ap.add_argument('--deterministic', type=int, default=0,
+                    help='1: window.DETERMINISTIC — bit-reproducible paint (integer sums, one more sweep of the block)')
     ap.add_argument('--migrate', type=int, default=1,
                     help='1 (--gpus N > 1): move every particle to the rank that owns its cell once, before the '
                          'timed cycles; 0: the particles stay on the rank that generated them')
@@ -387,6 +389,8 @@ def main():
         layouts = [layout] + [pm.decompose(q) for q in psets[1:]]
 
     from pmesh_amd import window as _window
+    if args.deterministic:
+        _window.DETERMINISTIC = True
     if args.binned == 0:
         _window.BINNED = 'never'
     elif args.binned == 1:
@@ -535,7 +539,7 @@ def main():
             'value_with_decompose': ntot / (elapsed / args.steps + t_decompose),
             'comm': comm_line,
             'drift_cells': args.drift,
-            'host_arrays': bool(args.host_arrays),
+            'host_arrays': bool(args.host_arrays), 'deterministic_paint': bool(args.deterministic),
             'bin_overflows': _window.bin_cache().overflows(be),
             'tile_order_ms': round(1e3 * t_order, 3),
             # every stage against the same roofline: its algorithmic bytes (the fused apply is

@@ -143,6 +143,15 @@ int pmx_binplan_destroy(pmx_binplan *plan);
  * otherwise.  Same results in every form (readout bit-identical, paint up to the order of the
  * additions into a cell). */
 int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
+/* Deterministic paint (the reference's scatter is a serial loop, pmesh/_window.pyx:157-165: the same call gives
+ * the same bits).  on = 1: pmx_paint_binned accumulates every cell as a 64-bit integer in units of 2^-f — the
+ * LDS regions, the halos between tiles (integer atomics on a dense int64 copy of the block) and the pieces of
+ * crowded tiles — with one f for the batch (from the largest tile population and the largest |mass|), and
+ * rounds once into the caller's canvas: independent of the order in which anything arrives, run to run and
+ * whatever the order of the rows.  Within 2^-f (<= 2^-50 x the largest |mass| x tile population / 2^11) per
+ * contribution of the reference's sum.  Default 0: S >= 3 windows still accumulate their LDS regions in fixed
+ * point (it is the faster form), the halos are merged with floating-point atomics. */
+int pmx_binplan_deterministic(pmx_binplan *plan, int32_t on);
 /* Rows without spatial coherence (catalogues in file order, shuffled sets) make every access
  * through the index list a sector of its own.  A plan can instead carry a copy of the positions
  * in tile order (one gather per build): paint and readout stream it, readout writes its results

@@ -820,10 +820,15 @@ template <int KIND> struct TileThreads<KIND, float> {
     static constexpr int readout = PMX_TILE_THREADS_RF4;
 };
 
-// what a cell of the region holds as a double (FIXED: the integer sum times 2^-f)
-template <bool FIXED> __device__ __forceinline__ double cell_value(double raw, double inv)
+// MODE of the paint kernels: 0 = the region accumulates doubles; 1 = 64-bit fixed point, one scale per z segment,
+// converted when the region is flushed; 2 = DETERMINISTIC: fixed point with ONE scale for the whole batch
+// (*dexp), and the region is flushed AS INTEGERS into a dense int64 copy of the block (`canvas` is that copy, the
+// painter describes its dense layout): owned cells stored, halos and crowded pieces added with integer atomics —
+// exact, so the result does not depend on any order — and det_finish_kernel converts once into the caller's canvas.
+// what a cell of the region holds as a double (fixed point: the integer sum times 2^-f)
+template <int MODE> __device__ __forceinline__ double cell_value(double raw, double inv)
 {
-    return FIXED ? (double)__double_as_longlong(raw) * inv : raw;
+    return MODE == 1 ? (double)__double_as_longlong(raw) * inv : raw;      // (MODE 2: the raw integer travels on)
 }
 // mstats (per-particle masses only): [0] = max |m| over the finite masses, [1] = number of non-finite ones.
 // The FIXED kernel serves a batch whose masses are all finite, its floating-point twin (launched behind it,
@@ -834,13 +839,17 @@ __device__ __forceinline__ bool batch_is_mine(const double *mstats, int want_odd
     return odd == (want_odd != 0);
 }
 
-template <int KIND, typename T, int TTHREADS, bool SORTED, bool FIXED>
+template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE>
 __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
                                                             const uint32_t *counts, T *halo, int overwrite,
-                                                            const double *mstats, int want_odd)
+                                                            const double *mstats, int want_odd, const int32_t *dexp,
+                                                            pmx_painter pw)
 {
+    // pw: the painter of the particles (weights, scale bound); p: the layout that is written (MODE 2: the dense
+    // integer copy of the block, else the same as pw)
+    constexpr bool FIXED = MODE != 0;
     if (!batch_is_mine(mstats, want_odd)) return;
     // SORTED: `pos` is the plan's copy of the positions in list order (row = list slot);
     // the list itself is then only read for a per-particle mass
@@ -875,7 +884,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
               const uint32_t c = counts[column * nt2 + t2];
               nseg_part += c < (uint32_t)g.chunk ? c : (uint32_t)g.chunk;
           }
-          const int f = fixed_exponent(p, mstats ? mstats[0] : fabs(mass_scalar), nseg_part);
+          const int f = MODE == 2 ? *dexp : fixed_exponent(pw, mstats ? mstats[0] : fabs(mass_scalar), nseg_part);
           scale = pow2(f);
           inv = pow2(-f);
       }
@@ -913,7 +922,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
             }
             __syncthreads();
         }
-        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pw, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -929,7 +938,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 in = in && l >= 0 && l < p.size[d];
             }
             if (in && region_cell(p, g, t, a, b, c, &goff)) {
-                T v = (T)cell_value<FIXED>(lds[Rg::dat(a * R1 + b, c)], inv);
+                T v = (T)cell_value<MODE>(lds[Rg::dat(a * R1 + b, c)], inv);
                 T *dst = (T *)(canvas + goff);
                 if (overwrite) *dst = v;
                 else *dst += v;
@@ -942,7 +951,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
                 int a, b, c;
                 Rg::halo_decode(h, &a, &b, &c);
                 if (!last && c >= T2) continue;           // carried to the next tile instead
-                hbase[h] = (T)cell_value<FIXED>(lds[Rg::dat(a * R1 + b, c)], inv);
+                hbase[h] = (T)cell_value<MODE>(lds[Rg::dat(a * R1 + b, c)], inv);
             }
         }
         live = !last;
@@ -956,10 +965,13 @@ __global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, Bin
 // (Measured alternative: the owner tile pulling its neighbours' halos with plain
 // loads/stores — deterministic, no atomics — took 690 us against 398 us for this kernel
 // at 512^3: the strided single-cell faces cost a read-modify-write of a whole sector each.)
-template <int S, typename T>
+__device__ __forceinline__ bool batch_is_mine(const double *mstats, int want_odd);
+template <int S, typename T, bool INTEGER = false>
 __global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGeom g, char *canvas, const T *halo,
-                                                            const uint32_t *counts, int overwrite)
+                                                            const uint32_t *counts, int overwrite,
+                                                            const double *mstats = nullptr, int want_odd = 0)
 {
+    if (!batch_is_mine(mstats, want_odd)) return;      // (only the deterministic path has two staging buffers)
     using Rg = Region<S>;
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         int t[3];
@@ -977,8 +989,14 @@ __global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGe
             Rg::halo_decode(h, &a, &b, &c);
             if (!last && c >= T2) continue;     // not staged: carried to the next tile in LDS
             T v = hbase[h];
-            if (v == (T)0) continue;
             int64_t goff;
+            if (INTEGER) {
+                // (deterministic paint: T is double, its bits a 64-bit integer: an exact, order-independent add)
+                const unsigned long long bits = (unsigned long long)__double_as_longlong((double)v);
+                if (bits != 0 && region_cell(p, g, t, a, b, c, &goff)) atomicAdd((unsigned long long *)(canvas + goff), bits);
+                continue;
+            }
+            if (v == (T)0) continue;
             if (region_cell(p, g, t, a, b, c, &goff)) unsafeAtomicAdd((T *)(canvas + goff), v);
         }
     }
@@ -1046,13 +1064,15 @@ __global__ void __launch_bounds__(TBLOCK) heavy_items_kernel(const uint32_t *cou
 
 // one workgroup per work item: the piece is accumulated in LDS like a tile of its own and the whole
 // region, box and halo, is added to the canvas with atomics (after the tile kernel and halo_merge)
-template <int KIND, typename T, int TTHREADS, bool SORTED, bool FIXED>
+template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE>
 __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                              DVec mass, double mass_scalar, const uint32_t *list,
                                                              const int64_t *offsets, const uint32_t *counts,
                                                              const uint64_t *items, const uint32_t *nitems, uint32_t cap,
-                                                             const double *mstats, int want_odd)
+                                                             const double *mstats, int want_odd, const int32_t *dexp,
+                                                             pmx_painter pw)
 {
+    constexpr bool FIXED = MODE != 0;
     if (!batch_is_mine(mstats, want_odd)) return;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
@@ -1071,17 +1091,22 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
         __syncthreads();
         double scale = 1.0, inv = 1.0;
         if (FIXED) {
-            const int f = fixed_exponent(p, mstats ? mstats[0] : fabs(mass_scalar), count);
+            const int f = MODE == 2 ? *dexp : fixed_exponent(pw, mstats ? mstats[0] : fabs(mass_scalar), count);
             scale = pow2(f);
             inv = pow2(-f);
         }
-        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(p, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
+        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pw, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             const int c = q % R2, r = q / R2;
-            const double v = cell_value<FIXED>(lds[Rg::dat(r, c)], inv);
-            if (v == 0) continue;
             int64_t goff;
+            if (MODE == 2) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(lds[Rg::dat(r, c)]);
+                if (bits != 0 && region_cell(p, g, t, r / R1, r % R1, c, &goff)) atomicAdd((unsigned long long *)(canvas + goff), bits);
+                continue;
+            }
+            const double v = cell_value<MODE>(lds[Rg::dat(r, c)], inv);
+            if (v == 0) continue;
             if (region_cell(p, g, t, r / R1, r % R1, c, &goff)) unsafeAtomicAdd((T *)(canvas + goff), (T)v);
         }
         __syncthreads();
@@ -1147,6 +1172,40 @@ __global__ void mass_stats_finish_kernel(unsigned long long *stats)
     ((double *)stats)[1] = (double)stats[2];
 }
 
+// deterministic paint: the one scale of the batch.  A cell can receive from the particles of the (at most) 8 tiles
+// whose regions contain it: n = 8 max(counts).
+__global__ void __launch_bounds__(1024) det_scale_kernel(pmx_painter p, const uint32_t *counts, int64_t ntiles,
+                                                         const double *mstats, double mass_scalar, int32_t *dexp)
+{
+    __shared__ uint32_t mx[1024];
+    uint32_t m = 0;
+    for (int64_t i = threadIdx.x; i < ntiles; i += 1024) m = counts[i] > m ? counts[i] : m;
+    mx[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off && mx[threadIdx.x + off] > mx[threadIdx.x]) mx[threadIdx.x] = mx[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dexp[0] = fixed_exponent(p, mstats ? mstats[0] : fabs(mass_scalar), 8 * (int64_t)mx[0] + 1);
+}
+
+// canvas (+)= scratch 2^-f, cell by cell of the block: the one rounding of a deterministic paint
+template <typename T>
+__global__ void __launch_bounds__(TBLOCK) det_finish_kernel(pmx_painter p, char *canvas, const long long *scratch,
+                                                            const int32_t *dexp, int overwrite, const double *mstats)
+{
+    if (mstats != nullptr && mstats[1] != 0.0) return;       // the floating-point kernels served this batch
+    const double inv = pow2(-dexp[0]);
+    const int64_t n1 = p.size[1], n2 = p.size[2], total = p.size[0] * n1 * n2;
+    for (int64_t q = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; q < total; q += (int64_t)gridDim.x * TBLOCK) {
+        const int64_t i2 = q % n2, r = q / n2, i1 = r % n1, i0 = r / n1;
+        T *dst = (T *)(canvas + i0 * p.strides[0] + i1 * p.strides[1] + i2 * p.strides[2]);
+        const T v = (T)((double)scratch[q] * inv);
+        if (overwrite) *dst = v;
+        else *dst += v;
+    }
+}
+
 int plan_ensure(void **ptr, size_t *cap, size_t need)
 {
     if (need <= *cap) return PMX_OK;
@@ -1197,6 +1256,13 @@ extern "C" int pmx_binplan_configure(pmx_binplan *pl, int32_t form)
     return PMX_OK;
 }
 
+extern "C" int pmx_binplan_deterministic(pmx_binplan *pl, int32_t on)
+{
+    PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
+    pl->deterministic = on ? 1 : 0;
+    return PMX_OK;
+}
+
 extern "C" int pmx_binplan_sorted(pmx_binplan *pl, int32_t pref, int32_t *is_sorted)
 {
     PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
@@ -1233,6 +1299,8 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->out_sorted) (void)hipFree(pl->out_sorted);
     if (pl->host_groups) (void)hipHostFree(pl->host_groups);
     if (pl->mstats) (void)hipFree(pl->mstats);
+    if (pl->dscratch) (void)hipFree(pl->dscratch);
+    if (pl->dhalo) (void)hipFree(pl->dhalo);
     if (pl->heavy_items) (void)hipFree(pl->heavy_items);
     if (pl->nheavy) (void)hipFree(pl->nheavy);
     delete pl;
@@ -1560,7 +1628,8 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     // all of them are finite, are found on the device; a batch with a NaN / Inf mass is served by the
     // floating-point kernels, launched behind the fixed-point ones (each returns at once when the batch is not
     // its own).  A scalar mass decides on the host.
-    const bool fixed_kind = PMX_FIXED_POINT && g.S >= PMX_FIXED_MIN_S;
+    const bool det = pl->deterministic != 0;
+    const bool fixed_kind = det || (PMX_FIXED_POINT && g.S >= PMX_FIXED_MIN_S);
     const double *mstats = nullptr;
     bool run_fixed = fixed_kind, run_float = !fixed_kind;
     if (fixed_kind) {
@@ -1576,10 +1645,31 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
             run_float = true;
         }
     }
-#define PT2(K, FX, ODD) do { if (sorted) paint_tile_kernel<K, T, TileThreads<K, T>::paint, true, FX><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite, mstats, ODD); \
-                   else paint_tile_kernel<K, T, TileThreads<K, T>::paint, false, FX><<<pgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, halo, overwrite, mstats, ODD); } while (0)
-#define PT(K) do { if (run_fixed) PT2(K, true, 0); if (run_float) PT2(K, false, (run_fixed ? 1 : 0)); } while (0)
-#define HM(S_) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite)
+    // deterministic: the fixed-point kernels write a dense int64 copy of the block (pd: its layout) with the
+    // batch's one scale; det_finish_kernel converts into the caller's canvas
+    pmx_painter pd = p;
+    int32_t *dexp = nullptr;
+    double *dhalo = nullptr;
+    if (det && run_fixed) {
+        const size_t cells = (size_t)p.size[0] * (size_t)p.size[1] * (size_t)p.size[2];
+        rc = plan_ensure(&pl->dscratch, &pl->cap_dscratch, cells * 8 + 64); if (rc) return rc;
+        rc = plan_ensure(&pl->dhalo, &pl->cap_dhalo, (size_t)g.ntiles * (size_t)halo_cells(g.S) * 8 + 16); if (rc) return rc;
+        dexp = (int32_t *)((char *)pl->dscratch + cells * 8);
+        dhalo = (double *)pl->dhalo;
+        pd.canvas_elsize = 8;
+        pd.strides[2] = 8; pd.strides[1] = 8 * p.size[2]; pd.strides[0] = 8 * p.size[2] * p.size[1];
+        det_scale_kernel<<<1, 1024, 0, st>>>(p, pl->counts, g.ntiles, mstats, ms, dexp);
+    }
+#define PT3(K, TT, MD, ODD, PP, CV, HL, OW) do { if (sorted) paint_tile_kernel<K, TT, TileThreads<K, TT>::paint, true, MD><<<pgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, HL, OW, mstats, ODD, dexp, p); \
+                   else paint_tile_kernel<K, TT, TileThreads<K, TT>::paint, false, MD><<<pgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, HL, OW, mstats, ODD, dexp, p); } while (0)
+#define PT(K) do { if (run_fixed && det) PT3(K, double, 2, 0, pd, pl->dscratch, dhalo, 1); \
+                   else if (run_fixed) PT3(K, T, 1, 0, p, canvas, halo, overwrite); \
+                   if (run_float) PT3(K, T, 0, (run_fixed ? 1 : 0), p, canvas, halo, overwrite); } while (0)
+    // (a batch is served either by the fixed-point or by the floating-point kernels: the merge of the other
+    // finds only zeros in its staging buffer... the deterministic one has a staging buffer of its own)
+#define HM(S_) do { if (run_fixed && det) { halo_merge_kernel<S_, double, true><<<grid, TBLOCK, 0, st>>>(pd, g, (char *)pl->dscratch, dhalo, pl->counts, 1, mstats, 0); \
+                                            if (run_float) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite, mstats, 1); } \
+                    else halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite); } while (0)
     switch (p.kind) {
     case PMX_TUNED_NNB: PT(PMX_TUNED_NNB); break;
     case PMX_TUNED_CIC: PT(PMX_TUNED_CIC); HM(2); break;
@@ -1587,13 +1677,15 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     default: PT(PMX_TUNED_PCS); HM(4); break;
     }
 #undef PT
-#undef PT2
+#undef PT3
 #undef HM
     // the pieces of crowded tiles (none for a uniform batch: the kernel then returns at once)
     const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
-#define PH2(K, FX, ODD) do { if (sorted) paint_heavy_kernel<K, T, TileThreads<K, T>::paint, true, FX><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, mstats, ODD); \
-                   else paint_heavy_kernel<K, T, TileThreads<K, T>::paint, false, FX><<<hgrid, TileThreads<K, T>::paint, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, mstats, ODD); } while (0)
-#define PH(K) do { if (run_fixed) PH2(K, true, 0); if (run_float) PH2(K, false, (run_fixed ? 1 : 0)); } while (0)
+#define PH3(K, TT, MD, ODD, PP, CV) do { if (sorted) paint_heavy_kernel<K, TT, TileThreads<K, TT>::paint, true, MD><<<hgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, mstats, ODD, dexp, p); \
+                   else paint_heavy_kernel<K, TT, TileThreads<K, TT>::paint, false, MD><<<hgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, mstats, ODD, dexp, p); } while (0)
+#define PH(K) do { if (run_fixed && det) PH3(K, double, 2, 0, pd, pl->dscratch); \
+                   else if (run_fixed) PH3(K, T, 1, 0, p, canvas); \
+                   if (run_float) PH3(K, T, 0, (run_fixed ? 1 : 0), p, canvas); } while (0)
     switch (p.kind) {
     case PMX_TUNED_NNB: PH(PMX_TUNED_NNB); break;
     case PMX_TUNED_CIC: PH(PMX_TUNED_CIC); break;
@@ -1601,7 +1693,11 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     default: PH(PMX_TUNED_PCS); break;
     }
 #undef PH
-#undef PH2
+#undef PH3
+    if (run_fixed && det) {
+        const int64_t cells = p.size[0] * p.size[1] * p.size[2];
+        det_finish_kernel<T><<<grid_for(cells, TBLOCK, 8192), TBLOCK, 0, st>>>(p, (char *)canvas, (const long long *)pl->dscratch, dexp, overwrite, mstats);
+    }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }

@@ -168,6 +168,11 @@ struct pmx_binplan {
     size_t cap_heavy = 0;
     uint32_t *nheavy = nullptr;        // device: number of items of this build
     double *mstats = nullptr;          // device: [0] max |m| of the finite per-particle masses, [1] non-finite ones
+    int deterministic = 0;             // paint through a dense int64 copy of the block: bit-reproducible
+    void *dscratch = nullptr;          // that copy (+ the batch's exponent behind it)
+    size_t cap_dscratch = 0;
+    void *dhalo = nullptr;             // its halo staging (8 bytes per cell whatever the canvas type)
+    size_t cap_dhalo = 0;
     int32_t chunk = 1 << 30;           // list entries per piece
     // history for the single-pass build: the slot ranges of the previous build of the same
     // geometry and particle count are reused (particles move little between time steps)

@@ -84,6 +84,13 @@ _SORTS = {'auto': -1, 'never': 0, 'always': 1}
 # A tile-ordered copy of the positions inside the plan, for rows without spatial coherence
 # (include/pmesh_amd.h: pmx_binplan_sorted): 'auto' (measured by the first build), 'never', 'always'.
 SORTED = os.environ.get('PMESH_AMD_SORTED', 'auto')
+# Deterministic paint: True makes every paint that the tile kernels can serve (3-d, tuned window, native support,
+# no hsml) bit-reproducible — independent of the order of arrival of anything and of the order of the rows: all
+# sums are 64-bit integers in units of 2^-f (include/pmesh_amd.h: pmx_binplan_deterministic), rounded once into the
+# canvas.  The reference's scatter is a serial loop (pmesh/_window.pyx:157-165) and reproducible for that reason.
+# Costs one more sweep over the block (measured at 512^3: bench.py --deterministic 1).  Batches the tile kernels cannot
+# take (2-d meshes, hsml, tables) still use floating-point atomics.
+DETERMINISTIC = os.environ.get('PMESH_AMD_DETERMINISTIC', '0') not in ('0', '', 'false', 'False')
 
 
 class _BinCache(object):
@@ -108,6 +115,7 @@ class _BinCache(object):
         for e in self.entries:
             if e[0] == key and e[3]:
                 e[4] = self._tick()
+                be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
                 return e[1]
         # a plan that last served the same geometry and particle count rebuilds in a single
         # pass over the positions (csrc/pmx_binned.hip: slot ranges of the previous build)
@@ -138,6 +146,7 @@ class _BinCache(object):
         else:
             e = min(free or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape
+        be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
         be.call('binplan_configure', e[1], _FORMS[WALK])
         be.call('binplan_sorted', e[1], _SORTS[SORTED], None)
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
@@ -204,7 +213,7 @@ def clear_bin_cache():
 def _binned_ok(be, painter, pos, n, hs):
     if BINNED == 'never' or be.name != 'hip' or hs is not None:
         return False
-    if BINNED == 'auto':
+    if BINNED == 'auto' and not DETERMINISTIC:
         if n < BINNED_MIN_PARTICLES:
             return False
         cells = 1

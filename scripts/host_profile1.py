@@ -1,0 +1,35 @@
+"""cProfile of the host side of the one-rank cycle with a layout (device idle: small mesh)"""
+import cProfile, io, pstats, sys, time
+sys.path.insert(0, '.')
+import torch
+from pmesh_amd.pm import ParticleMesh
+from pmesh_amd.transfer import Transfer
+from pmesh_amd import window
+dev = torch.device('cuda')
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+pm = ParticleMesh(BoxSize=1000.0, Nmesh=[N, N, N], dtype='f8')
+pos = torch.rand((N ** 3, 3), dtype=torch.float64, device=dev) * 1000.0
+rho = pm.create('real')
+layout = pm.decompose(pos)
+T = Transfer.dx1(0)
+res = torch.empty(len(pos), dtype=torch.float64, device=dev)
+def cycle():
+    window.clear_bin_cache()
+    layout._memo = None; layout._memo_remote = None
+    pm.paint(pos, hold=False, layout=layout, out=rho)
+    rhok = rho.r2c(out=Ellipsis)
+    back = rhok.c2r(out=Ellipsis, transfer=T)
+    return back.readout(pos, layout=layout, out=res)
+for _ in range(5): cycle()
+torch.cuda.synchronize()
+K = 50
+t = time.perf_counter()
+for _ in range(K): cycle()
+ti = (time.perf_counter() - t) / K
+torch.cuda.synchronize()
+print('host issue %.3f ms / cycle' % (ti * 1e3))
+pr = cProfile.Profile(); pr.enable()
+for _ in range(K): cycle()
+pr.disable()
+torch.cuda.synchronize()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(25); print(s.getvalue()[:4500])

@@ -281,6 +281,62 @@ def test_plan_is_shared_and_invalidated(hip):
     assert_allclose(c2.cpu().numpy(), c3.cpu().numpy(), rtol=0, atol=1e-12 * float(c3.abs().max()))
 
 
+@pytest.mark.parametrize('name,dt', [('cic', 'f8'), ('tsc', 'f4'), ('pcs', 'f8'), ('nnb', 'f8')])
+def test_deterministic_paint(hip, oracle, name, dt):
+    """window.DETERMINISTIC (the reference's scatter is a serial loop, _window.pyx:157-165: same call, same bits):
+    every sum of the paint is a 64-bit integer, so the result is the same bit for bit run after run AND for any
+    order of the rows; hold / overwrite, per-particle masses of both signs, crowded cells, slab-local blocks;
+    within 1e-12 (f8) of the oracle; a NaN mass falls back to the floating-point kernels and poisons only its cells"""
+    W = windows[name]
+    tdt = torch.float64 if dt == 'f8' else torch.float32
+    saved = window.DETERMINISTIC
+    try:
+        for shape, period, scale, translate in (((64, 64, 64), (64, 64, 64), 1.0, 0.0), ((24, 48, 64), (96, 48, 64), 1.0, (-32.0, 0.0, 0.0))):
+            rs = numpy.random.RandomState(17)
+            n = 120000
+            pos_h = numpy.concatenate([rs.uniform(-10, 100, size=(n - 30000, 3)), rs.normal(40.0, 0.7, size=(30000, 3))])
+            mass_h = rs.uniform(-1.0, 3.0, size=n)
+            aff = Affine(3, scale=scale, translate=translate, period=period)
+            oaff = oracle.Affine(3, scale=scale, translate=translate, period=period)
+            pos = torch.from_numpy(pos_h).to(hip.device)
+            mass = torch.from_numpy(mass_h).to(hip.device)
+            perm = torch.randperm(n, device=hip.device)
+            pos2, mass2 = pos[perm].contiguous(), mass[perm].contiguous()
+            window.BINNED = 'always'
+            for hold in (False, True):
+                outs = []
+                for P, M in ((pos, mass), (pos, mass), (pos2, mass2)):
+                    window.DETERMINISTIC = True
+                    window.clear_bin_cache()
+                    c = torch.full(shape, 0.5 if hold else 7.0, dtype=tdt, device=hip.device)
+                    W.paint(c, P, mass=M, transform=aff, _overwrite=not hold)
+                    outs.append(c)
+                assert torch.equal(outs[0], outs[1]), 'two runs differ'
+                assert torch.equal(outs[0], outs[2]), 'the order of the rows matters'
+                want = numpy.full(shape, 0.5 if hold else 0.0)
+                oracle.Window(W.kind).paint(want, pos_h, mass=mass_h, transform=oaff)
+                tol = 1e-12 if dt == 'f8' else 2e-6
+                assert_allclose(outs[0].cpu().numpy().astype('f8'), want, rtol=0, atol=tol * max(1.0, abs(want).max()))
+            # scalar mass
+            window.clear_bin_cache()
+            a = torch.zeros(shape, dtype=tdt, device=hip.device)
+            b = torch.zeros(shape, dtype=tdt, device=hip.device)
+            W.paint(a, pos, mass=2.5, transform=aff)
+            W.paint(b, pos2, mass=2.5, transform=aff)
+            assert torch.equal(a, b)
+        # a NaN mass: the floating-point kernels serve the batch, the NaN stays in its own cells
+        window.clear_bin_cache()
+        mass_bad = mass.clone()
+        mass_bad[5] = float('nan')
+        c = torch.zeros((64, 64, 64), dtype=tdt, device=hip.device)
+        W.paint(c, pos, mass=mass_bad, transform=Affine(3, period=64))
+        nbad = int(torch.isnan(c).sum())
+        assert 1 <= nbad <= W.support ** 3, nbad
+    finally:
+        window.DETERMINISTIC = saved
+        window.clear_bin_cache()
+
+
 def test_two_live_particle_sets_keep_their_plans(hip):
     """two live position tensors of equal shape on one geometry (two species; probes at as many points
     as there are particles) each keep a plan slot: alternating between them finds both plans again
