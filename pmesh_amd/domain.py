@@ -309,39 +309,62 @@ class Layout(object):
     def remote_recvlength(self):
         return self._remote(backend.get())[4]
 
-    def exchange_remote(self, data):
-        """ rows of `data` received from the other ranks (ordered by source rank) """
+    def exchange_remote(self, data, *more):
+        """ rows of `data` received from the other ranks (ordered by source rank).  Several arrays
+        (positions and per-particle masses of a paint) travel side by side in ONE all-to-all-v, as
+        Layout.exchange(pack=True) sends them; results are remembered per source tensor, so the
+        readouts that follow a paint find the positions already exchanged. """
         be = backend.get()
         idx, sc, rc, nsend, nrecv = self._remote(be)
-        data, host = to_device(data, be.device, 'data', allow_int=True)
-        memo_key = (data.data_ptr(), version_of(data), tuple(data.shape), data.stride(), data.dtype)
+        arrays = [to_device(a, be.device, 'data', allow_int=True)[0] for a in (data,) + more]
+        keys = [(a.data_ptr(), version_of(a), tuple(a.shape), a.stride(), a.dtype) for a in arrays]
         memo = getattr(self, '_memo_remote', None)
-        if memo is not None and memo[0] == memo_key:
-            return memo[2]
-        message = 'the length of data does not match that used to build the layout'
-        wrong = self._wrong_length(len(data), self.sendlength, 'exchange', message)
-        if wrong:
-            data = torch.zeros((self.sendlength,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
-        trailing = tuple(data.shape[1:])
-        row_bytes = data.element_size()
-        for s in trailing:
-            row_bytes *= s
-        if data.dim() > 1 and not data[0:1].is_contiguous() and data.shape[0] > 0:
-            data = data.contiguous()
-        buffer = torch.empty((nsend,) + trailing, dtype=data.dtype, device=be.device)
-        if nsend:
-            if row_bytes % 4:
-                raise TypeError('rows must be a multiple of 4 bytes')
-            stride0 = data.stride(0) * data.element_size() if data.shape[0] > 1 else row_bytes
-            be.call('take_rows', data.data_ptr(), stride0, row_bytes, idx.data_ptr(),
-                    idx.element_size(), nsend, buffer.data_ptr(), be.stream())
-        recvbuffer = torch.empty((nrecv,) + trailing, dtype=data.dtype, device=be.device)
-        if self.comm.size > 1:
-            self.comm.alltoallv(buffer, sc, recvbuffer, rc)
-        if wrong:
-            raise ValueError(message)
-        self._memo_remote = (memo_key, data, recvbuffer)
-        return recvbuffer
+        if not isinstance(memo, dict):
+            memo = self._memo_remote = {}
+        missing = [i for i, k in enumerate(keys) if k not in memo]
+        if missing:
+            message = 'the length of data does not match that used to build the layout'
+            wrong = False
+            for i in missing:
+                wrong = self._wrong_length(len(arrays[i]), self.sendlength, 'exchange', message) or wrong
+            parts, metas = [], []
+            for i in missing:
+                a = arrays[i]
+                trailing = tuple(a.shape[1:])
+                if wrong:
+                    a = torch.zeros((self.sendlength,) + trailing, dtype=a.dtype, device=be.device)
+                rb = a.element_size()
+                for s_ in trailing:
+                    rb *= s_
+                metas.append((a.dtype, trailing, rb))
+                if nsend:
+                    parts.append(self._take(be, a, idx, nsend))
+            if len(missing) == 1:
+                dt, trailing, rb = metas[0]
+                recv = torch.empty((nrecv,) + trailing, dtype=dt, device=be.device)
+                if self.comm.size > 1:
+                    send = parts[0] if nsend else torch.empty((0,) + trailing, dtype=dt, device=be.device)
+                    self.comm.alltoallv(send, sc, recv, rc)
+                got = [recv]
+            else:
+                width = sum(m[2] for m in metas)
+                packed = (torch.cat([q.reshape(nsend, -1).view(torch.uint8).reshape(nsend, m[2]) for q, m in zip(parts, metas)],
+                                    dim=1) if nsend else torch.empty((0, width), dtype=torch.uint8, device=be.device))
+                recv = torch.empty((nrecv, width), dtype=torch.uint8, device=be.device)
+                if self.comm.size > 1:
+                    self.comm.alltoallv(packed, sc, recv, rc)
+                got, off = [], 0
+                for dt, trailing, rb in metas:
+                    got.append(recv[:, off:off + rb].contiguous().view(dt).reshape((nrecv,) + trailing))
+                    off += rb
+            if wrong:
+                raise ValueError(message)
+            for i, r in zip(missing, got):
+                memo[keys[i]] = (arrays[i], r)            # (the source tensor is kept alive: its address stays taken)
+            while len(memo) > 4:
+                memo.pop(next(iter(memo)))
+        res = [memo[k][1] for k in keys]
+        return res[0] if not more else tuple(res)
 
     def gather_remote_add(self, data, out):
         """ send the per-ghost results `data` (rows as exchange_remote delivered them) back to

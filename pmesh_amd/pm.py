@@ -1428,8 +1428,10 @@ class ParticleMesh(object):
             resampler.paint(out.value, dpos, mass=dmass, transform=transform, diffdir=gradient,
                             _overwrite=not hold)
             if layout.remote_recvlength or layout.comm.size > 1:
-                rpos = layout.exchange_remote(dpos)
-                rmass = dmass if _is_scalar(mass) else layout.exchange_remote(dmass)
+                if _is_scalar(mass):
+                    rpos, rmass = layout.exchange_remote(dpos), dmass
+                else:
+                    rpos, rmass = layout.exchange_remote(dpos, dmass)     # one all-to-all-v for both
                 if len(rpos):
                     resampler.paint(out.value, rpos, mass=rmass, transform=transform, diffdir=gradient)
             return out
