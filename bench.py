@@ -104,7 +104,7 @@ def parse():
     ap.add_argument('--migrate', type=int, default=1,
                     help='1 (--gpus N > 1): move every particle to the rank that owns its cell once, before the '
                          'timed cycles; 0: the particles stay on the rank that generated them')
-    ap.add_argument('--np', default='slab', choices=['slab', 'pencil'],
+    ap.add_argument('--decomp', default='slab', choices=['slab', 'pencil'],
                     help="process mesh for --gpus N > 1: slab = [N] (one transpose per transform), pencil = "
                          "pfft's split_size_2d(N), e.g. [2, 4] on 8 ranks (the reference's default for 3-d)")
     ap.add_argument('--config', default=None, choices=['c2', 'c3', 'c4', 'c5'],
@@ -116,8 +116,8 @@ def parse():
     presets = {
         'c2': dict(mesh=256),
         'c3': dict(mesh=512, window='tsc', dtype='f4', gradient=0),
-        'c4': dict(mesh=1024, np='slab'),
-        'c5': dict(mesh=2048, window='pcs', data='clustered', double=1, mass='array', np='pencil'),
+        'c4': dict(mesh=1024, decomp='slab'),
+        'c5': dict(mesh=2048, window='pcs', data='clustered', double=1, mass='array', decomp='pencil'),
     }
     for k, v in presets.get(args.config, {}).items():
         setattr(args, k, v)
@@ -320,7 +320,7 @@ def main():
         mass = 0.5 + (torch.arange(nloc, device=be.device, dtype=torch.int64) % 1024).to(torch.float64) / 1024.0
         mtot = float(comm.allreduce(float(mass.sum()))) if world > 1 else float(mass.sum())
 
-    if args.np == 'pencil' and world > 1:
+    if args.decomp == 'pencil' and world > 1:
         from pmesh_amd.fft import split_size_2d
         np_ = [int(x) for x in split_size_2d(world)]
     else:

@@ -20,7 +20,7 @@ done
 for n in 4 8; do
   port=$((port + 1))
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
-      --master-port $port bench.py --gpus $n --steps 3 --warmup 1 --mesh 256 --np pencil --window pcs \
+      --master-port $port bench.py --gpus $n --steps 3 --warmup 1 --mesh 256 --decomp pencil --window pcs \
       --data clustered --double 1 --mass array --no-cpu-baseline \
       > "$out/n${n}_pencil.json" 2> "$out/n${n}_pencil.err"
   echo "n=$n pencil rc=$?"; tail -c 400 "$out/n${n}_pencil.json"; echo
