@@ -839,8 +839,22 @@ __device__ __forceinline__ bool batch_is_mine(const double *mstats, int want_odd
     return odd == (want_odd != 0);
 }
 
+// waves per SIMD the compiler must leave room for (the register budget): the regions allow 4 / 3 / 2 workgroups of
+// 512 threads per CU for CIC / TSC / PCS, i.e. 8 / 6 / 4 waves per SIMD; the fixed-point TSC kernel came out at 84-90
+// VGPRs, one over the 80 that six waves per SIMD leave: two workgroups per CU instead of three
+#ifndef PMX_PAINT_WAVES_TSC
+#define PMX_PAINT_WAVES_TSC 6
+#endif
+#ifndef PMX_PAINT_WAVES_CIC
+#define PMX_PAINT_WAVES_CIC 1
+#endif
+template <int KIND> constexpr int paint_min_waves()
+{
+    return KIND == PMX_TUNED_TSC ? PMX_PAINT_WAVES_TSC : (KIND == PMX_TUNED_CIC ? PMX_PAINT_WAVES_CIC : 1);
+}
+
 template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE>
-__global__ void __launch_bounds__(TTHREADS) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
+__global__ void __launch_bounds__(TTHREADS, paint_min_waves<KIND>()) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
                                                             const uint32_t *counts, T *halo, int overwrite,
