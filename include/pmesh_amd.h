@@ -152,6 +152,11 @@ int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
  * contribution of the reference's sum.  Default 0: S >= 3 windows still accumulate their LDS regions in fixed
  * point (it is the faster form), the halos are merged with floating-point atomics. */
 int pmx_binplan_deterministic(pmx_binplan *plan, int32_t on);
+/* The fixed-point regions of pmx_paint_binned need the largest |mass| of a per-particle mass array and must know
+ * that every mass is finite; by default a reduction kernel in front of every paint finds out (one read of the
+ * masses).  A caller that knows (masses that do not change between time steps) says so once per paint: bound >= 0
+ * and finite = all masses are finite and |mass| <= bound; anything else (negative, NaN, Inf) = unknown. */
+int pmx_binplan_mass_bound(pmx_binplan *plan, double bound);
 /* Rows without spatial coherence (catalogues in file order, shuffled sets) make every access
  * through the index list a sector of its own.  A plan can instead carry a copy of the positions
  * in tile order (one gather per build): paint and readout stream it, readout writes its results

@@ -90,6 +90,7 @@ DEVICE_ONLY = {
     'binplan_destroy': (C.c_int, [_vp]),
     'binplan_configure': (C.c_int, [_vp, _i32]),
     'binplan_deterministic': (C.c_int, [_vp, _i32]),
+    'binplan_mass_bound': (C.c_int, [_vp, _f64]),
     'binplan_overflows': (C.c_int, [_vp, _P(C.c_uint32)]),
     'binplan_sorted': (C.c_int, [_vp, _i32, _P(_i32)]),
     'binplan_supported': (C.c_int, [_P(Painter), _i64]),

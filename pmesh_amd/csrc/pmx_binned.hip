@@ -1277,6 +1277,13 @@ extern "C" int pmx_binplan_deterministic(pmx_binplan *pl, int32_t on)
     return PMX_OK;
 }
 
+extern "C" int pmx_binplan_mass_bound(pmx_binplan *pl, double bound)
+{
+    PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
+    pl->mass_bound = bound;          // < 0, NaN or Inf: unknown, found on the device by every paint
+    return PMX_OK;
+}
+
 extern "C" int pmx_binplan_sorted(pmx_binplan *pl, int32_t pref, int32_t *is_sorted)
 {
     PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
@@ -1647,7 +1654,11 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     const double *mstats = nullptr;
     bool run_fixed = fixed_kind, run_float = !fixed_kind;
     if (fixed_kind) {
-        if (mass.data) {
+        if (mass.data && pl->mass_bound >= 0 && pl->mass_bound <= 1.7e308) {
+            // the caller knows the largest |mass| (pmx_binplan_mass_bound) and that all masses are finite: no pass over
+            // them; the kernels read the bound where a scalar mass would stand (unused with a mass array)
+            ms = pl->mass_bound;
+        } else if (mass.data) {
             if (!pl->mstats) PMX_HIP_CHECK(hipMalloc((void **)&pl->mstats, 32));
             PMX_HIP_CHECK(hipMemsetAsync(pl->mstats, 0, 32, st));
             mass_stats_kernel<<<grid_for(pl->npart, TBLOCK, 2048), TBLOCK, 0, st>>>(mass, pl->npart, (unsigned long long *)pl->mstats);

@@ -168,6 +168,7 @@ struct pmx_binplan {
     size_t cap_heavy = 0;
     uint32_t *nheavy = nullptr;        // device: number of items of this build
     double *mstats = nullptr;          // device: [0] max |m| of the finite per-particle masses, [1] non-finite ones
+    double mass_bound = -1.0;          // largest |mass| of the per-particle masses of the next paint, if the caller knows it
     int deterministic = 0;             // paint through a dense int64 copy of the block: bit-reproducible
     void *dscratch = nullptr;          // that copy (+ the batch's exponent behind it)
     size_t cap_dscratch = 0;

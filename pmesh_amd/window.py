@@ -210,6 +210,20 @@ def clear_bin_cache():
     bin_cache().clear()
 
 
+_mass_bounds = []          # [(data_ptr, version, shape, dtype), tensor (kept alive), bound]
+
+
+def _mass_bound(m):
+    key = (m.data_ptr(), version_of(m), tuple(m.shape), m.stride(), m.dtype)
+    for e in _mass_bounds:
+        if e[0] == key:
+            return e[2]
+    b = float(m.abs().max()) if m.numel() else 0.0          # NaN if any mass is NaN: "unknown" to the library
+    _mass_bounds.append((key, m, b))
+    del _mass_bounds[:-4]
+    return b
+
+
 def _binned_ok(be, painter, pos, n, hs):
     if BINNED == 'never' or be.name != 'hip' or hs is not None:
         return False
@@ -420,6 +434,9 @@ class ResampleWindow(object):
         hv = vec(hs) if hs is not None else None
         if n and _binned_ok(be, p, pos, n, hs):
             plan = bin_cache().lookup(be, pos, p, pv, n)
+            # the largest |mass| of a mass array, found once per tensor and version (a time-stepping caller's
+            # masses do not change): the kernels then need no pass over the masses in front of every paint
+            be.call('binplan_mass_bound', plan, _mass_bound(m) if mv is not None else -1.0)
             be.call('paint_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv),
                     mass_scalar, int(bool(_overwrite)), be.stream())
         else:
