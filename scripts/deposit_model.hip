@@ -100,6 +100,20 @@ int main()
     run(Cfg{3, 0, 1, 0, 1, 1, 0}, "TSC split, random order in the tile, rotated z order");
     run(Cfg{3, 0, 1, 1, 0, 0, 1}, "TSC split, jittered lattice, swap, ds_add_u64");
     run(Cfg{3, 0, 0, 0, 0, 0, 1}, "TSC split, perfect lattice, ds_add_u64");
+    for (int p : {34, 35, 36, 37, 38, 40}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "TSC pitch %d, jittered lattice, swap, ds_add_u64", p);
+        run(Cfg{3, p, 1, 1, 0, 0, 1}, nm);
+        snprintf(nm, sizeof nm, "TSC pitch %d, jittered lattice, no swap, ds_add_u64", p);
+        run(Cfg{3, p, 1, 0, 0, 0, 1}, nm);
+    }
+    run(Cfg{3, 0, 1, 0, 0, 0, 1}, "TSC split, jittered lattice, no swap, ds_add_u64");
+    run(Cfg{3, 0, 1, 0, 0, 1, 1}, "TSC split, random order in the tile, ds_add_u64");
+    run(Cfg{4, 48, 1, 1, 0, 0, 1}, "PCS pitch 48, jittered base cells, swap, ds_add_u64");
+    run(Cfg{4, 48, 1, 0, 0, 0, 1}, "PCS pitch 48, jittered base cells, no swap, ds_add_u64");
+    run(Cfg{4, 35, 1, 0, 0, 0, 1}, "PCS pitch 35, jittered base cells, no swap, ds_add_u64");
+    run(Cfg{4, 35, 0, 0, 0, 0, 1}, "PCS pitch 35, lattice, ds_add_u64");
+    run(Cfg{4, 48, 1, 0, 0, 1, 1}, "PCS pitch 48, random order in the tile, ds_add_u64");
     for (int p : {34, 35, 36, 37, 40, 48}) {
         char nm[128];
         snprintf(nm, sizeof nm, "TSC pitch %d, jittered lattice, swap", p);
