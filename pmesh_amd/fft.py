@@ -105,13 +105,8 @@ class Partition(object):
         self.nproc = P
         self.pencil = len(np_) == 2 and P > 1 and min(np_) > 1
         if self.pencil:
-            if is_c2c:
-                raise NotImplementedError('complex-to-complex meshes on a pencil decomposition')
             if nd != 3:
                 raise ValueError('a 2-d process mesh needs a 3-d mesh')
-            if not transposed:
-                # built lazily: only the transposed ("ComplexField") layout exists for pencils
-                self._unsupported = 'untransposed complex fields on a pencil decomposition'
             self._init_pencil(np_, itemsize)
             return
         r = procmesh.comm.rank
@@ -280,7 +275,8 @@ def _pencil_init(self, np_, itemsize):
     P0, P1 = int(np_[0]), int(np_[1])
     p0, p1 = [int(x) for x in self.procmesh.this]
     N0, N1, N2 = [int(x) for x in self.Nmesh]
-    N2c = N2 // 2 + 1
+    # complex-to-complex meshes (pm.py:1270): configuration space is complex too, the whole last axis is kept
+    N2c = N2 if self.is_c2c else N2 // 2 + 1
     self.P0, self.P1, self.p0, self.p1 = P0, P1, p0, p1
     self.cshape_o = numpy.array([N0, N1, N2c], dtype='intp')
     self.i_edges = [block_edges(N0, P0), block_edges(N1, P1), numpy.array([0, N2], dtype='intp')]
@@ -292,16 +288,29 @@ def _pencil_init(self, np_, itemsize):
     self.local_o_start = numpy.array([0, self.o_edges[1][p0], self.o_edges[2][p1]], dtype='intp')
     self.local_o_shape = numpy.array([N0, self.o_edges[1][p0 + 1] - self.o_edges[1][p0],
                                       self.o_edges[2][p1 + 1] - self.o_edges[2][p1]], dtype='intp')
-    self.pitch_c = N2c
+    self.pitch_c = self.pitch_i = N2c
     n0l, n1l = int(self.local_i_shape[0]), int(self.local_i_shape[1])
-    padded = [n0l, n1l, 2 * N2c]
-    self.i_strides = _c_strides(padded)
-    self.i_alloc = n0l * n1l * 2 * N2c
+    if self.is_c2c:
+        self.i_strides = _c_strides([n0l, n1l, N2c])           # in complex elements
+        self.i_alloc = n0l * n1l * N2c
+    else:
+        padded = [n0l, n1l, 2 * N2c]
+        self.i_strides = _c_strides(padded)
+        self.i_alloc = n0l * n1l * 2 * N2c
+    tshape = [int(x) for x in self.local_o_shape]          # the transposed block (N0, m1, m2)
+    mid = n0l * N1 * tshape[2]                             # (n0loc, N1, n2cloc) between the transposes
+    self.t_alloc = int(numpy.prod(tshape, dtype='i8'))
+    if not self.transposed:
+        # the untransposed complex field is distributed like the real one (PFFT without
+        # PFFT_TRANSPOSED_OUT on a 2-d process mesh): (N0 / P0, N1 / P1, N2c), dense
+        self.o_edges = [self.i_edges[0], self.i_edges[1], numpy.array([0, N2c], dtype='intp')]
+        self.local_o_start = numpy.array([self.i_edges[0][p0], self.i_edges[1][p1], 0], dtype='intp')
+        self.local_o_shape = numpy.array([n0l, n1l, N2c], dtype='intp')
     oshape = [int(x) for x in self.local_o_shape]
     self.o_strides = _c_strides(oshape)
     self.o_alloc = int(numpy.prod(oshape, dtype='i8'))
-    mid = n0l * N1 * oshape[2]                         # (n0loc, N1, n2cloc) between the transposes
-    self.alloc_reals = max(self.i_alloc, 2 * self.o_alloc, 2 * mid, 2)
+    ireals = 2 * self.i_alloc if self.is_c2c else self.i_alloc
+    self.alloc_reals = max(ireals, 2 * self.o_alloc, 2 * self.t_alloc, 2 * mid, 2)
 
 
 Partition._init_pencil = _pencil_init
@@ -375,9 +384,15 @@ class Plan(object):
 
     def execute(self, bufin, bufout, transfer=None):
         p = self.partition
+        if getattr(p, 'pencil', False) and not p.transposed:
+            if transfer is not None:
+                raise NotImplementedError('fused transfer needs the transposed complex field')
+            return self._execute_pencil_untransposed(bufin, bufout)
         if getattr(p, 'is_c2c', False):
             if transfer is not None:
                 raise NotImplementedError('fused transfer on a complex-to-complex mesh')
+            if getattr(p, 'pencil', False):
+                return self._execute_pencil(bufin, bufout, None)
             if p.nproc > 1 and not p.transposed:
                 return self._execute_slab_untransposed(bufin, bufout)
             return self._execute_c2c(bufin, bufout)
@@ -434,9 +449,22 @@ class Plan(object):
         rowc, colc = p.procmesh.subcomms()
         P0, P1 = p.P0, p.P1
         N0, N1, N2 = [int(x) for x in p.Nmesh]
-        N2c = N2 // 2 + 1
+        c2c = bool(getattr(p, 'is_c2c', False))
+        N2c = N2 if c2c else N2 // 2 + 1
         n0l, n1l = int(p.local_i_shape[0]), int(p.local_i_shape[1])
         m1, m2 = int(p.local_o_shape[1]), int(p.local_o_shape[2])      # complex local extents
+        if c2c:
+            # the row stage of a complex-to-complex mesh: C2C along the contiguous axis (rocFFT), in place
+            def row(buf, nrows, inverse):
+                if nrows == 0:
+                    return
+                kind = _abi.PMX_FFT_C2C_BWD if inverse else _abi.PMX_FFT_C2C_FWD
+                plan = self._native(('crow', inverse, nrows, N2),
+                                    lambda: be.fft_create(kind, self.elsize, [N2], [1], N2, [1], N2, nrows, 1.0, True))
+                be.fft_execute(plan, buf, buf)
+        else:
+            def row(buf, nrows, inverse):
+                self._row(be, buf, nrows, N2, N2c, inverse)
         e1i = [int(x) for x in p.i_edges[1]]      # axis 1 by P1 (real side)
         e0i = [int(x) for x in p.i_edges[0]]      # axis 0 by P0
         e1o = [int(x) for x in p.o_edges[1]]      # axis 1 by P0 (complex side)
@@ -461,7 +489,7 @@ class Plan(object):
                  n1l * P1 == N1 and m1 * P0 == N1 and n1l & (n1l - 1) == 0 and m1 & (m1 - 1) == 0 and
                  all(e1i[q + 1] - e1i[q] == n1l for q in range(P1)) and
                  all(e1o[q + 1] - e1o[q] == m1 for q in range(P0)))
-        planes = self._plane_chunks(p, rowc, colc, fuse1, n0l, N0, P0)
+        planes = None if c2c else self._plane_chunks(p, rowc, colc, fuse1, n0l, N0, P0)
         if planes:
             return self._execute_pencil_pipelined(be, bufin, bufout, transfer, planes, same, rowc, colc,
                                                   N0, N1, N2, N2c, n0l, n1l, m1, m2, e2o, e0i, norm, W0, W1, W2)
@@ -471,7 +499,7 @@ class Plan(object):
                 nreal = n0l * n1l * 2 * N2c
                 W0[:nreal].copy_(bufin.storage[:nreal])
                 X = W0
-            self._row(be, X, n0l * n1l, N2, N2c, False)
+            row(X, n0l * n1l, False)
             be.slab_pack(X, W1, n0l * n1l, N2c, 1, e2o, elb)                 # split the last axis
             rowc.alltoall(W1[:sum(s1)], W2[:sum(r1)], s1, r1)
             if fuse1:
@@ -514,7 +542,68 @@ class Plan(object):
             rowc.alltoall(W1[:sum(r1)], Z[:sum(s1)], r1, s1)
             out = bufout.storage
             be.slab_pack(Z, out, n0l * n1l, N2c, 1, e2o, elb, inverse=True)
-            self._row(be, out, n0l * n1l, N2, N2c, True)
+            row(out, n0l * n1l, True)
+
+    def _execute_pencil_untransposed(self, bufin, bufout, mode=None):
+        """The untransposed complex layout on a 2-d process mesh — (N0 / P0, N1 / P1, N2c), distributed like
+        the real field: what PFFT delivers without PFFT_TRANSPOSED_OUT, and what the reference builds next
+        to the transposed plans on any process mesh (pm.py:1332-1349).  It is the transposed transform
+        (self.sibling) plus the two global transposes back, without the FFT stages in between:
+        (N0, m1, m2) <-> column group <-> (n0l, N1, m2) <-> row group <-> (n0l, n1l, N2c).
+        mode 'T->U' / 'U->T': the layout change alone (Field.cast)."""
+        be = backend.get()
+        p = self.partition
+        t = self.sibling
+        if t is None:
+            raise NotImplementedError('untransposed plan without its transposed sibling')
+        pt = t.partition
+        rowc, colc = p.procmesh.subcomms()
+        P0, P1 = p.P0, p.P1
+        N0, N1 = int(p.Nmesh[0]), int(p.Nmesh[1])
+        N2c = int(p.pitch_c)
+        n0l, n1l = int(p.local_i_shape[0]), int(p.local_i_shape[1])
+        m1, m2 = int(pt.local_o_shape[1]), int(pt.local_o_shape[2])
+        e1i = [int(x) for x in pt.i_edges[1]]
+        e0i = [int(x) for x in pt.i_edges[0]]
+        e1o = [int(x) for x in pt.o_edges[1]]
+        e2o = [int(x) for x in pt.o_edges[2]]
+        elb = 2 * self.elsize
+        rdt = bufin.storage.dtype
+        dev = bufin.storage.device
+        need = max(int(pt.alloc_reals), 2 * n0l * N1 * m2, 2 * n0l * n1l * N2c, 2 * N0 * m1 * m2, 2)
+        if self._work is None or self._work[0].numel() < need or self._work[0].dtype != rdt:
+            self._work = [torch.empty(need, dtype=rdt, device=dev) for _ in range(3)]
+        TB, WA, WB = self._work
+        tb = _Storage(TB)
+        s1 = [2 * n0l * n1l * (e2o[q + 1] - e2o[q]) for q in range(P1)]       # row group, by last-axis range
+        r1 = [2 * n0l * (e1i[q + 1] - e1i[q]) * m2 for q in range(P1)]        # ... by axis-1 range
+        s2 = [2 * n0l * (e1o[q + 1] - e1o[q]) * m2 for q in range(P0)]        # column group, by axis-1 range
+        r2 = [2 * (e0i[q + 1] - e0i[q]) * m1 * m2 for q in range(P0)]         # ... by row range (contiguous)
+
+        def t_to_u(src, dst):
+            colc.alltoall(src[:sum(r2)], WA[:sum(s2)], r2, s2)
+            be.slab_pack(WA, WB, n0l, N1, m2, e1o, elb, inverse=True)          # blocks -> (n0l, N1, m2)
+            be.slab_pack(WB, WA, n0l, N1, m2, e1i, elb)                        # split axis 1 by P1
+            rowc.alltoall(WA[:sum(r1)], WB[:sum(s1)], r1, s1)
+            be.slab_pack(WB, dst, n0l * n1l, N2c, 1, e2o, elb, inverse=True)   # blocks -> (n0l n1l, N2c)
+
+        def u_to_t(src, dst):
+            be.slab_pack(src, WA, n0l * n1l, N2c, 1, e2o, elb)
+            rowc.alltoall(WA[:sum(s1)], WB[:sum(r1)], s1, r1)
+            be.slab_pack(WB, WA, n0l, N1, m2, e1i, elb, inverse=True)
+            be.slab_pack(WA, WB, n0l, N1, m2, e1o, elb)
+            colc.alltoall(WB[:sum(s2)], dst[:sum(r2)], s2, r2)
+
+        if mode == 'T->U':
+            t_to_u(bufin.storage, bufout.storage)
+        elif mode == 'U->T':
+            u_to_t(bufin.storage, bufout.storage)
+        elif self.forward:
+            t.execute(bufin, tb)
+            t_to_u(TB, bufout.storage)
+        else:
+            u_to_t(bufin.storage, TB)
+            t.execute(tb, bufout)
 
     def _plane_chunks(self, p, rowc, colc, fuse1, n0l, N0, P0):
         """[(first plane, planes)] of the local axis-0 range if both transposes of the pencil transform
@@ -1099,8 +1188,10 @@ class Plan(object):
         """(N0, n1_local, N2c) <-> (n0_local, N1, N2c): the layout change between the transposed
         and the untransposed complex field of a slab decomposition (Field.cast); out of place"""
         p = self.partition
-        if p.nproc == 1 or getattr(p, 'pencil', False) or p.transposed:
-            raise NotImplementedError('retranspose is a method of untransposed slab plans')
+        if p.nproc == 1 or p.transposed:
+            raise NotImplementedError('retranspose is a method of the untransposed plans of several ranks')
+        if getattr(p, 'pencil', False):
+            return self._execute_pencil_untransposed(bufin, bufout, mode='T->U' if to_untransposed else 'U->T')
         self._execute_slab_untransposed(bufin, bufout, mode='T->U' if to_untransposed else 'U->T')
 
     def destroy(self):

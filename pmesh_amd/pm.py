@@ -501,9 +501,6 @@ class Field(NDArrayLike):
             if self.pm.comm.size == 1:
                 out.value[...] = self.value
                 return out
-            if len(self.pm.np) != 1:
-                raise NotImplementedError('casting between transposed and untransposed complex '
-                                          'fields on a pencil decomposition')
             if out._base in self._base:
                 raise ValueError('the layouts differ: this cast cannot be done in place')
             to_u = isinstance(out, UntransposedComplexField)

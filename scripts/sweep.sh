@@ -26,6 +26,3 @@ run m1024 --mesh 1024 --steps 5
 run c5_shard --mesh 1024 --double 1 --mass array --window pcs --data clustered --steps 3 --warmup 1
 run shuffled --data shuffled --steps 5
 run host_arrays --host-arrays 1 --steps 5
-PMESH_AMD_WALK=always run walk_tsc_f8 --window tsc
-PMESH_AMD_WALK=always run walk_pcs_f8 --window pcs
-PMESH_AMD_WALK=always run walk_config3 --window tsc --dtype f4 --gradient 0

@@ -545,6 +545,53 @@ def case_pencil_pipelined_equals_single_exchange(be, comm):
         F.OVERLAP_CHUNKS = saved
 
 
+def case_pencil_untransposed_and_c2c(be, comm):
+    """every plan of the reference on a 2-d process mesh (pm.py:1332-1349 builds all eight): the untransposed
+    complex layout — distributed like the real field, (N0 / P0, N1 / P1, N2c) — r2c / c2r through it and casts both
+    ways; complex-to-complex meshes (pm.py:1270) transposed and untransposed; even and uneven blocks"""
+    from pmesh_amd.pm import ParticleMesh, UntransposedComplexField, TransposedComplexField
+    shapes = {4: [2, 2], 6: [2, 3], 8: [2, 4]}
+    if comm.size not in shapes:
+        return
+    np_ = shapes[comm.size]
+    for Nmesh, dtype, tol in (([8, 12, 10], 'f8', 1e-13), ([10, 9, 14], 'f8', 1e-13), ([64, 64, 128], 'f8', 1e-13)):
+        pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, comm=comm, dtype=dtype, np=np_)
+        data = numpy.random.RandomState(37).normal(size=Nmesh).astype(dtype)
+        real = pm.create('real', value=data[pm.create('real').slices])
+        Nc = list(Nmesh[:-1]) + [Nmesh[-1] // 2 + 1]
+        ref = numpy.fft.rfftn(data.astype('f8')) / numpy.prod(Nmesh)
+        cu = real.r2c(out=UntransposedComplexField(pm))
+        assert isinstance(cu, UntransposedComplexField)
+        assert tuple(cu.start[:2]) == tuple(real.start[:2]) and int(cu.start[2]) == 0    # distributed like the real field
+        assert tuple(cu.shape) == (real.shape[0], real.shape[1], Nc[2])
+        full = gather_field(comm, cu, Nc)
+        assert numpy.sqrt((abs(full - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < tol, Nmesh
+        assert_array_equal(numpy.asarray(real), data[real.slices])                       # input preserved
+        back = cu.c2r()
+        assert numpy.sqrt(((numpy.asarray(back) - data[back.slices]) ** 2).sum() /
+                          max((data[back.slices] ** 2).sum(), 1e-300)) < 4 * tol
+        ct = real.r2c()
+        as_u = ct.cast(type='untransposedcomplex')
+        assert_array_equal(gather_field(comm, as_u, Nc), gather_field(comm, ct, Nc))
+        as_t = cu.cast(type='transposedcomplex')
+        assert_array_equal(gather_field(comm, as_t, Nc), gather_field(comm, cu, Nc))
+        assert isinstance(as_t, TransposedComplexField)
+    for Nmesh in ([8, 12, 10], [16, 8, 12]):
+        pm = ParticleMesh(BoxSize=4.0, Nmesh=Nmesh, comm=comm, dtype='c16', np=np_)
+        rs = numpy.random.RandomState(43)
+        data = rs.normal(size=Nmesh) + 1j * rs.normal(size=Nmesh)
+        real = pm.create('real', value=data[pm.create('real').slices])
+        ref = numpy.fft.fftn(data) / numpy.prod(Nmesh)
+        ck = real.r2c()
+        assert tuple(ck.cshape) == tuple(Nmesh)
+        assert numpy.sqrt((abs(gather_field(comm, ck, Nmesh) - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < 1e-13
+        back = ck.c2r()
+        assert_allclose(numpy.asarray(back), data[back.slices], rtol=0, atol=1e-12)
+        cu = real.r2c(out=UntransposedComplexField(pm))
+        assert numpy.sqrt((abs(gather_field(comm, cu, Nmesh) - ref) ** 2).sum() / (abs(ref) ** 2).sum()) < 1e-13
+        assert_allclose(numpy.asarray(cu.c2r()), data[back.slices], rtol=0, atol=1e-12)
+
+
 def case_length_check_is_collective(be, comm):
     """domain.py:177-179, 240-242: a wrong array on ONE rank raises ValueError on EVERY rank the first
     time a layout is used (the verdict is all-reduced); afterwards the offending rank raises alone,
@@ -632,7 +679,7 @@ def case_comm_trace(be, comm):
 
 
 CASES = [case_comm_trace, case_length_check_is_collective, case_promote_and_pack, case_pencil,
-         case_pencil_pipelined_equals_single_exchange, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+         case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 
