@@ -267,6 +267,17 @@ int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N
 int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N,
                      int64_t B, int64_t nsplit, double scale, int64_t plain_pitch, void *stream);
 
+/* r2c -> transfer -> c2r back to back (what a PM force step does with every density field): the last forward
+ * pass and the first inverse pass run along the same axis and are one kernel — forward column transform, times
+ * `scale` (the forward normalisation), times the transfer function (t != NULL, as in pmx_colfft), inverse column
+ * transform, the column resident in LDS — one sweep of the array instead of two, bit-identical to
+ * pmx_colfft(inverse = 0, scale) followed by pmx_colfft(inverse = 1, t).  In place on the (N, B) block at
+ * n_stride elements per line (0 = B).  PFFT has no such fusion (pm.py:689, 1017 are two separate executes). */
+int pmx_colfft_roundtrip_supported(int64_t n, int32_t elsize);
+int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64_t B, double scale,
+                         const pmx_transfer *transfer, int64_t n1, int64_t n2, const int64_t *start,
+                         const int64_t *nmesh, const double *boxsize, int64_t n_stride, void *stream);
+
 /* The axis-1 pass of a pencil transform (PFFT's 2-d process mesh, pm.py:1417-1434) between its two
  * global transposes: src is the (A, N, B) array cut into ranges of nsplit_in lines (the receive
  * buffer of one all-to-all), dst the same array cut into ranges of nsplit_out lines (the send

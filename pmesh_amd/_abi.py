@@ -104,6 +104,9 @@ DEVICE_ONLY = {
     'colfft_supported': (C.c_int, [_i64, _i32]),
     'colfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
                          _P(_i64), _P(_f64), _i64, _i64, _vp]),
+    'colfft_roundtrip_supported': (C.c_int, [_i64, _i32]),
+    'colfft_roundtrip': (C.c_int, [_i32, _vp, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64), _P(_i64), _P(_f64),
+                                   _i64, _vp]),
     'colfft_split': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _i64, _vp]),
     'colfft_resplit': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f64, _vp]),
     'colfft_chunk': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f64, _P(Transfer),

@@ -102,6 +102,16 @@ class HipBackend(object):
                   _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3),
                   int(a_stride), int(n_stride), self.stream())
 
+    def colfft_roundtrip_supported(self, n, elsize):
+        return self.lib.pmx_colfft_roundtrip_supported(int(n), int(elsize)) == 0
+
+    def colfft_roundtrip(self, elsize, data, N, B, scale=1.0, transfer=None, n1=1, n2=1,
+                         start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0), n_stride=0):
+        """forward column FFT x scale [x transfer] x inverse column FFT in one kernel, in place on (N, B)"""
+        self.call('colfft_roundtrip', elsize, data.data_ptr(), N, B, float(scale),
+                  C.byref(transfer) if transfer is not None else None, n1, n2,
+                  _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3), int(n_stride), self.stream())
+
     def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0, plain_pitch=0):
         """column FFT fused with the slab pack (forward: plain -> split) / unpack (inverse);
         plain_pitch: elements per line of the plain side (0 = B)"""

@@ -352,6 +352,39 @@ template <typename T, int LOGN, int RB> struct HalfTw {
     static constexpr bool value = (LOGN < 16) && (full > 150 * 1024 || (full > 76 * 1024 && full <= 80 * 1024));
 };
 
+// the Stockham passes of an N-point transform over the LDS-resident tile (compile-time radices)
+template <typename T, int LOGN, bool INV, int RB, bool HT>
+__device__ __forceinline__ void run_passes(cpx<T> *buf, const cpx<T> *tw, int col, int tj)
+{
+    constexpr int N = Len<LOGN>::N;
+    constexpr int TPC = N / Rpt<T, LOGN>::value;
+    int Ns = 1;
+    using Rd = Radices<LOGN>;
+    if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+    Ns *= Rd::r[0];
+    if (Rd::n > 1) {
+        if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[1] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        Ns *= Rd::r[1];
+    }
+    if (Rd::n > 2) {
+        if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[2] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        Ns *= Rd::r[2];
+    }
+    if (Rd::n > 3) {
+        if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[3] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        Ns *= Rd::r[3];
+    }
+}
+
 // REMAP: the columns go through col_offset (chunks of a pipelined transpose).  A template
 // parameter because the per-lane column offsets cost the plain passes 34 VGPRs (156 instead of
 // 122 at N = 512: one workgroup per CU instead of two, 541 instead of 476 us per pass).
@@ -405,32 +438,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
             buf[lds_index<T, RB>(n, col)] = v;
         }
         __syncthreads();
-        int Ns = 1;
-        using Rd = Radices<LOGN>;
-        // passes (compile-time radices)
-        if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        Ns *= Rd::r[0];
-        if (Rd::n > 1) {
-            if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[1] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            Ns *= Rd::r[1];
-        }
-        if (Rd::n > 2) {
-            if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[2] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            Ns *= Rd::r[2];
-        }
-        if (Rd::n > 3) {
-            if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            else if (Rd::r[3] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-            Ns *= Rd::r[3];
-        }
+        run_passes<T, LOGN, INV, RB, HT>(buf, tw, col, tj);
         // store
         const T sc = (T)g.scale;
 #pragma unroll
@@ -443,6 +451,68 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
                 obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn + lcol] = v;
             }
         }
+    }
+}
+
+// The last pass of r2c and the first pass of c2r run along the same axis: for a caller that goes r2c -> transfer ->
+// c2r back to back they are ONE kernel — forward transform of the column, times the forward scale, times the
+// transfer function, inverse transform, with the column in LDS throughout: the spectrum is neither written nor read
+// (one sweep of the array instead of two; pmx_colfft_roundtrip).  Every value takes exactly the roundings of the
+// two separate passes (the scaled mode is rounded to T before the transfer multiplies it), so the result is
+// bit-identical to them.  Plain layout, A = 1 (the axis-0 pass of one block), in place.
+template <typename T, int LOGN, bool APPLY, int RB>
+__global__ void __launch_bounds__((Len<LOGN>::N / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))))
+colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
+{
+    constexpr int N = Len<LOGN>::N;
+    constexpr int W = RB / (int)sizeof(cpx<T>);
+    constexpr int RPT = Rpt<T, LOGN>::value;
+    constexpr int TPC = N / RPT;
+    constexpr int NT = TPC * W;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
+    cpx<T> *tw = buf + N * W;
+    constexpr bool HT = HalfTw<T, LOGN, RB>::value;
+    const int tid = threadIdx.x;
+    for (int n = tid; n < (HT ? N / 2 : N); n += NT) tw[n] = twiddle[n];
+    const int64_t tilesB = (g.B + W - 1) / W;
+    const int col = tid % W, tj = tid / W;
+    const int64_t tile = blockIdx.x;
+    if (tile >= tilesB) return;
+    const int64_t b0 = tile * W;
+    const bool colok = b0 + col < g.B;
+    cpx<T> *base = data + b0;
+    ColK ck = {0, 0, 0};
+    if (APPLY && colok) ck = column_k(g, b0 + col);
+    __syncthreads();
+    cpx<T> ld[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        int n = tj + u * TPC;
+        ld[u] = colok ? base[(int64_t)n * g.in.sn + col] : cpx<T>{0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; u++) buf[lds_index<T, RB>(tj + u * TPC, col)] = ld[u];
+    __syncthreads();
+    run_passes<T, LOGN, false, RB, HT>(buf, tw, col, tj);
+    // what the forward pass would have stored and the inverse pass loaded: the mode times the forward scale,
+    // then the transfer function
+    const T sc = (T)g.scale;
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        int n = tj + u * TPC;
+        cpx<T> v = buf[lds_index<T, RB>(n, col)];
+        v.x *= sc;
+        v.y *= sc;
+        if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
+        buf[lds_index<T, RB>(n, col)] = v;
+    }
+    __syncthreads();
+    run_passes<T, LOGN, true, RB, HT>(buf, tw, col, tj);
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        int n = tj + u * TPC;
+        if (colok) base[(int64_t)n * g.out.sn + col] = buf[lds_index<T, RB>(n, col)];
     }
 }
 
@@ -862,6 +932,92 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     if (elsize == 8) return dispatch_logn<double>(g, data, data, tw, inverse != 0, apply, st);
     // float: 16 columns x 8 B = 128-byte rows, 16 lines per thread: 1024 threads at N = 1024
     return dispatch_logn<float>(g, data, data, tw, inverse != 0, apply, st);
+}
+
+template <typename T, int LOGN, int RB>
+static int launch_round(const ColGeom &g, void *data, const void *tw, bool apply, hipStream_t st)
+{
+    constexpr int N = Len<LOGN>::N;
+    constexpr int W = RB / (int)sizeof(cpx<T>);
+    constexpr int NT = N / Rpt<T, LOGN>::value * W;
+    size_t lds = (size_t)(N * W + (HalfTw<T, LOGN, RB>::value ? N / 2 : N)) * sizeof(cpx<T>);
+    int64_t tiles = (g.B + W - 1) / W;
+    PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
+#define LAUNCH(AP)                                                                                             \
+    do {                                                                                                       \
+        auto k = colfft_round_kernel<T, LOGN, AP, RB>;                                                         \
+        PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        k<<<(unsigned)tiles, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                              \
+    } while (0)
+    if (apply) LAUNCH(true); else LAUNCH(false);
+#undef LAUNCH
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+template <typename T>
+static int dispatch_round(const ColGeom &g, void *data, const void *tw, bool apply, hipStream_t st)
+{
+    switch (g.logN) {
+    case 6: return launch_round<T, 6, 128>(g, data, tw, apply, st);
+    case 7: return launch_round<T, 7, 128>(g, data, tw, apply, st);
+    case 8: return launch_round<T, 8, 128>(g, data, tw, apply, st);
+    case 9: return launch_round<T, 9, 128>(g, data, tw, apply, st);
+    case 10: return launch_round<T, 10, (sizeof(T) == 8 ? PMX_RB_D1024 : 128)>(g, data, tw, apply, st);
+    case 11: return launch_round<T, 11, 64>(g, data, tw, apply, st);
+    case 22: return launch_round<T, 22, 128>(g, data, tw, apply, st);
+    case 23: return launch_round<T, 23, 128>(g, data, tw, apply, st);
+    case 24: return launch_round<T, 24, PMX_RB768>(g, data, tw, apply, st);
+    case 38: return launch_round<T, 38, 128>(g, data, tw, apply, st);
+    case 39: return launch_round<T, 39, (sizeof(T) == 4 ? 64 : 128)>(g, data, tw, apply, st);
+    }
+    set_error("pmx_colfft_roundtrip: length code %d is not built", g.logN);
+    return PMX_EUNSUPPORTED;
+}
+
+extern "C" int pmx_colfft_roundtrip_supported(int64_t n, int32_t elsize)
+{
+    int rc = pmx_colfft_supported(n, elsize);
+    if (rc) return rc;
+    const int code = length_code(n);
+    return (code == 25 || code == 40) ? PMX_EUNSUPPORTED : PMX_OK;      // 1536 / 1280: one-precision kernels, not built here
+}
+
+extern "C" int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64_t B, double scale,
+                                    const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
+                                    const int64_t *nmesh, const double *boxsize, int64_t n_stride, void *stream)
+{
+    int rc = pmx_colfft_roundtrip_supported(N, elsize);
+    if (rc) { set_error("pmx_colfft_roundtrip: unsupported length %lld", (long long)N); return rc; }
+    PMX_REQUIRE(data != nullptr && B >= 0, PMX_EINVAL, "bad arguments");
+    if (B == 0) return PMX_OK;
+    ColGeom g;
+    g.A = 1; g.B = B; g.N = (int32_t)N; g.scale = scale;
+    g.logN = length_code(N);
+    g.n1 = 1; g.n2 = 1;
+    g.in = g.out = plain_addr(N, B);
+    PMX_REQUIRE(n_stride == 0 || n_stride >= B, PMX_EINVAL, "n_stride smaller than B");
+    if (n_stride) g.in.sn = g.out.sn = n_stride;
+    const bool apply = t != nullptr;
+    if (apply) {
+        PMX_REQUIRE(n1 * n2 == B && B < (1ll << 31), PMX_EINVAL, "fused transfer needs the axis-0 pass of one block");
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
+                    t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
+                    PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
+        g.t = *t;
+        g.n1 = (int32_t)n1; g.n2 = (int32_t)n2;
+        for (int d = 0; d < 3; d++) {
+            g.start[d] = start[d]; g.nmesh[d] = nmesh[d];
+            g.dw[d] = 2 * M_PI / nmesh[d];
+            g.nl[d] = nmesh[d] / boxsize[d];
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)N, elsize, &tw, st);
+    if (rc) return rc;
+    if (elsize == 8) return dispatch_round<double>(g, data, tw, apply, st);
+    return dispatch_round<float>(g, data, tw, apply, st);
 }
 
 // The axis-1 pass of a slab-decomposed transform fused with the pack / unpack around the

@@ -323,6 +323,37 @@ def _c_strides(shape):
     return s
 
 
+#: r2c -> [transfer] -> c2r back to back: the last pass of the forward transform (axis 0) is DEFERRED — the plan
+#: leaves a note on the buffer's storage instead of running it — and an in-place c2r that finds the note runs ONE
+#: kernel for both axis-0 passes (pmx_colfft_roundtrip: forward, scale, transfer, inverse with the column in LDS):
+#: one sweep of the array less per cycle.  Whoever else looks at the spectrum first (Field.value, any other plan,
+#: cast, apply with a callable ...) runs the deferred pass then (`settle`): the values are those of the eager
+#: transform either way, bit for bit.  One rank, the LDS column kernels (Plan._execute_local_hybrid).
+DEFER_LAST_PASS = os.environ.get('PMESH_AMD_DEFER_LAST_PASS', '1') not in ('0', '', 'false')
+
+
+class _Pending(object):
+    """the deferred axis-0 pass of a forward transform"""
+    __slots__ = ('partition', 'run', 'fused')
+
+    def __init__(self, partition, run, fused):
+        self.partition, self.run, self.fused = partition, run, fused
+
+
+def settle(storage):
+    """run a deferred pass on this storage now (no-op if there is none)"""
+    pend = getattr(storage, '_pmx_pending', None)
+    if pend is not None:
+        storage._pmx_pending = None
+        pend.run()
+
+
+def forget(storage):
+    """the storage is about to be overwritten as a whole: a deferred pass on it is moot"""
+    if getattr(storage, '_pmx_pending', None) is not None:
+        storage._pmx_pending = None
+
+
 class LocalBuffer(object):
     """pfft.LocalBuffer(partition, base=None): device storage with a real
     ("input") and a complex ("output") view (pm.py:226, 236, 240).  `a in b` tests
@@ -341,6 +372,9 @@ class LocalBuffer(object):
 
     def __contains__(self, other):
         return isinstance(other, LocalBuffer) and other.storage.data_ptr() == self.storage.data_ptr()
+
+    def settle(self):
+        settle(self.storage)
 
     def view_input(self):
         p = self.partition
@@ -384,6 +418,16 @@ class Plan(object):
 
     def execute(self, bufin, bufout, transfer=None):
         p = self.partition
+        pend = getattr(bufin.storage, '_pmx_pending', None)
+        if pend is not None:
+            # a deferred forward pass on the input: an in-place inverse transform of the same partition on one
+            # rank takes it over (see _execute_local_hybrid); anything else needs the finished spectrum first
+            mine = (not self.forward and pend.partition is p and p.nproc == 1 and
+                    bufin.storage is bufout.storage and not getattr(p, 'is_c2c', False))
+            if not mine:
+                settle(bufin.storage)
+        if bufout.storage is not bufin.storage:
+            forget(bufout.storage)
         if getattr(p, 'pencil', False) and not p.transposed:
             if transfer is not None:
                 raise NotImplementedError('fused transfer needs the transposed complex field')
@@ -801,9 +845,11 @@ class Plan(object):
                     blk = st[i0 * plane * es:]
                     be.rowfft(self.elsize, False, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
                     be.colfft(self.elsize, False, blk, i1 - i0, N1, N2c, a_stride=sa)
-                be.colfft(self.elsize, False, st, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
+                self._last_forward_pass(be, st, N0, N1, N2c, norm, sn)
             else:
-                if transfer is not None:
+                if self._take_over_forward_pass(be, st, transfer, N0, N1, N2c, sn):
+                    pass
+                elif transfer is not None:
                     t, start, nmesh, boxsize = transfer
                     be.colfft(self.elsize, True, st, 1, N0, N1 * N2c, transfer=t, n1=N1, n2=N2c,
                               start=start, nmesh=nmesh, boxsize=boxsize, n_stride=sn)
@@ -825,11 +871,13 @@ class Plan(object):
                 be.fft_execute(self._native(('z', inplace), make), bufin.storage, bufout.storage)
             out = bufout.storage
             be.colfft(self.elsize, False, out, N0, N1, N2c, a_stride=sa)
-            be.colfft(self.elsize, False, out, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
+            self._last_forward_pass(be, out, N0, N1, N2c, norm, sn)
         else:
             # in place on the complex data (c2r(out=...) made `bufin` a copy when needed)
             src = bufin.storage
-            if transfer is not None:
+            if self._take_over_forward_pass(be, src, transfer, N0, N1, N2c, sn):
+                pass
+            elif transfer is not None:
                 t, start, nmesh, boxsize = transfer
                 be.colfft(self.elsize, True, src, 1, N0, N1 * N2c, transfer=t, n1=N1, n2=N2c,
                           start=start, nmesh=nmesh, boxsize=boxsize, n_stride=sn)
@@ -843,6 +891,38 @@ class Plan(object):
                     return be.fft_create(_abi.PMX_FFT_C2R, self.elsize, [N2], [1], N2c, [1], 2 * N2c,
                                          rows, 1.0, inplace)
                 be.fft_execute(self._native(('z', inplace), make), src, bufout.storage)
+
+    def _last_forward_pass(self, be, st, N0, N1, N2c, norm, sn):
+        """the axis-0 pass that ends r2c on one rank — run now, or left as a note on the storage for the inverse
+        transform that may follow at once (DEFER_LAST_PASS)"""
+        es = self.elsize
+
+        def run():
+            be.colfft(es, False, st, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
+        if not (DEFER_LAST_PASS and hasattr(be, 'colfft_roundtrip') and be.colfft_roundtrip_supported(N0, es)):
+            return run()
+
+        def fused(transfer):
+            if transfer is not None:
+                t, start, nmesh, boxsize = transfer
+                be.colfft_roundtrip(es, st, N0, N1 * N2c, scale=norm, transfer=t, n1=N1, n2=N2c, start=start,
+                                    nmesh=nmesh, boxsize=boxsize, n_stride=sn)
+            else:
+                be.colfft_roundtrip(es, st, N0, N1 * N2c, scale=norm, n_stride=sn)
+        st._pmx_pending = _Pending(self.partition, run, fused)
+
+    def _take_over_forward_pass(self, be, st, transfer, N0, N1, N2c, sn):
+        """first stage of c2r on one rank: if the forward transform left its last pass for us, both axis-0 passes
+        (and the transfer) are one kernel; returns False when there is nothing to take over"""
+        pend = getattr(st, '_pmx_pending', None)
+        if pend is None:
+            return False
+        st._pmx_pending = None
+        if pend.partition is not self.partition:
+            pend.run()
+            return False
+        pend.fused(transfer)
+        return True
 
     def _execute_slab(self, bufin, bufout, transfer=None):
         """Slab-decomposed 3-D (or 2-D) transform with one global transpose."""

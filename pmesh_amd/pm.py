@@ -199,19 +199,41 @@ class Field(NDArrayLike):
         part = self._partition = pm._get_partition(type(self))
         buf = self._base = _fft.LocalBuffer(part, pm._rdtype, base=base)
         if isinstance(self, RealField):
-            self.value, self.start, edges = buf.view_input(), part.local_i_start, part.i_edges
+            self._value, self.start, edges = buf.view_input(), part.local_i_start, part.i_edges
         else:
-            self.value, self.start, edges = buf.view_output(), part.local_o_start, part.o_edges
-            # views of the same memory: the components and the (…, 2) real layout
-            self.real, self.imag = self.value.real, self.value.imag
-            self.plain = torch.view_as_real(self.value)
+            self._value, self.start, edges = buf.view_output(), part.local_o_start, part.o_edges
         self.cshape = numpy.array([e[-1] for e in edges], dtype='intp')       # the collective shape
         self.csize = int(numpy.prod(self.cshape, dtype='i8'))
-        self.shape = tuple(self.value.shape)
+        self.shape = tuple(self._value.shape)
         self.size = int(numpy.prod(self.shape, dtype='i8'))
-        self.dtype = numpy_dtype(self.value.dtype)
+        self.dtype = numpy_dtype(self._value.dtype)
         # where the local block sits in the collective array
         self.slices = tuple(slice(int(a), int(a) + int(n)) for a, n in zip(self.start, self.shape))
+
+    # `value` is the view of the local block (pm.py:234-242).  A forward transform on one rank may have left its
+    # last pass for the inverse transform that usually follows at once (fft.DEFER_LAST_PASS): whoever looks at
+    # the values first makes it happen.
+    @property
+    def value(self):
+        _fft.settle(self._base.storage)
+        return self._value
+
+    @value.setter
+    def value(self, v):
+        self._value = v
+
+    # views of the same memory: the components and the (..., 2) real layout of a complex field
+    @property
+    def real(self):
+        return self.value.real
+
+    @property
+    def imag(self):
+        return self.value.imag
+
+    @property
+    def plain(self):
+        return torch.view_as_real(self.value)
 
     # coordinates are built lazily: the fused kernels never read them
     @property

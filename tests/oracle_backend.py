@@ -125,6 +125,15 @@ class OracleBackend(object):
         y = numpy.fft.ifft(x, axis=1) * N if inverse else numpy.fft.fft(x, axis=1)
         arr[...] = y * scale
 
+    def colfft_roundtrip_supported(self, n, elsize):
+        return self.colfft_supported(n, elsize)
+
+    def colfft_roundtrip(self, elsize, data, N, B, scale=1.0, transfer=None, n1=1, n2=1,
+                         start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0), n_stride=0):
+        self.colfft(elsize, False, data, 1, N, B, scale=scale, n_stride=n_stride)
+        self.colfft(elsize, True, data, 1, N, B, transfer=transfer, n1=n1, n2=n2, start=start, nmesh=nmesh,
+                    boxsize=boxsize, n_stride=n_stride)
+
     def colfft_split(self, elsize, inverse, src, dst, A, N, B, nsplit, scale=1.0, plain_pitch=0):
         cdt = 'c8' if elsize == 4 else 'c16'
         pp = plain_pitch or B

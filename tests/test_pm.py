@@ -688,6 +688,54 @@ def test_default_process_mesh_and_plan_cache(be):
     assert abs(float(t.r2c().c2r().value.mean()) - 2.0) < 1e-12
 
 
+@pytest.mark.parametrize('Nmesh,dtype', [([64, 64, 128], 'f8'), ([128, 64, 128], 'f4'), ([192, 64, 128], 'f8')])
+def test_deferred_last_pass_is_invisible(be, Nmesh, dtype):
+    """fft.DEFER_LAST_PASS: on one rank r2c leaves its last (axis-0) pass for an in-place c2r that follows at once —
+    one kernel then does forward pass, scale, transfer and inverse pass with the column in LDS — and whoever looks
+    at the spectrum first (value, apply with a callable, an out-of-place c2r, a second r2c into the buffer, paint)
+    makes the deferred pass happen.  Same bits as the eager transforms in every case."""
+    from pmesh_amd import fft as F
+    pm = ParticleMesh(BoxSize=[3.0, 2.0, 5.0], Nmesh=Nmesh, dtype=dtype)
+    data = numpy.random.RandomState(11).normal(size=Nmesh).astype(dtype)
+    T = Transfer.dx1(0)
+    saved = F.DEFER_LAST_PASS
+
+    def run(defer, scenario):
+        F.DEFER_LAST_PASS = defer
+        real = pm.create('real', value=data)
+        ck = real.r2c(out=Ellipsis)
+        if scenario == 'fused':
+            return numpy.asarray(ck.c2r(out=Ellipsis, transfer=T))
+        if scenario == 'plain':
+            return numpy.asarray(ck.c2r(out=Ellipsis))
+        if scenario == 'peek':
+            spec = numpy.asarray(ck).copy()
+            return spec, numpy.asarray(ck.c2r(out=Ellipsis, transfer=T))
+        if scenario == 'callable':
+            ck.apply(lambda k, v: v * 2.0, out=Ellipsis)
+            return numpy.asarray(ck.c2r(out=Ellipsis))
+        if scenario == 'outofplace':
+            back = ck.c2r(transfer=T)
+            return numpy.asarray(back), numpy.asarray(ck).copy()
+        if scenario == 'abandon':
+            # the spectrum is never looked at: the buffer is painted over / transformed again
+            real2 = pm.create('real', base=ck._base, value=data * 2)
+            return numpy.asarray(real2.r2c(out=Ellipsis))
+    try:
+        for scenario in ('fused', 'plain', 'peek', 'callable', 'outofplace', 'abandon'):
+            a, b = run(False, scenario), run(True, scenario)
+            if isinstance(a, tuple):
+                for x, y in zip(a, b):
+                    assert_array_equal(x, y, err_msg=scenario)
+            else:
+                assert_array_equal(a, b, err_msg=scenario)
+        ref = numpy.fft.irfftn(numpy.fft.rfftn(data.astype("f8")), s=Nmesh, axes=(0, 1, 2))
+        tol = 1e-12 if dtype == 'f8' else 5e-5
+        assert abs(run(True, 'plain') - ref).max() < tol * abs(ref).max()
+    finally:
+        F.DEFER_LAST_PASS = saved
+
+
 def test_staged_host_arrays(be):
     """ParticleMesh.stage: a numpy array registered once is uploaded once; paint / readout / decompose take
     the handle wherever the array would go, return numpy like for the array itself, and share one device
