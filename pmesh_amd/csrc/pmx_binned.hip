@@ -63,7 +63,7 @@ __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const B
         Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
         int i0w = 0;
         ok = ok && local_base<KIND>(p, d, I[0], &i0w);
-        tt[d] = (i0w + g.o[d]) / bucket_ext<WALK>(d);
+        tt[d] = (int)((unsigned)(i0w + g.o[d]) / (unsigned)bucket_ext<WALK>(d));      // (never negative for a particle that counts)
     }
     const int64_t tb = WALK ? ((int64_t)tt[1] * g.nt[2] + tt[2]) * g.nt[0] + tt[0]
                             : ((int64_t)tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
@@ -238,7 +238,10 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 // ONCE, and then writes its rows of a tile as one contiguous piece (256 entries per tile in lattice
 // order at 512^3), from one CU, so that the pieces meet in its L2 as whole lines.
 // Tiles that find no room in the table are handled per wave as in bin_count_kernel.
-constexpr int BLOCK_ITERS = 8;                     // trips of TBLOCK * PMX_ONEPASS_U rows
+#ifndef PMX_BLOCK_ITERS
+#define PMX_BLOCK_ITERS 8
+#endif
+constexpr int BLOCK_ITERS = PMX_BLOCK_ITERS;                     // trips of TBLOCK * PMX_ONEPASS_U rows
 constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
 constexpr int BLOCK_HT = 128;                       // entries of the LDS table (a power of two)
 // 16-byte pieces of the TBLOCK * U dense rows from `base` on, one per thread and q: -> bytes requested

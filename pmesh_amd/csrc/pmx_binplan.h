@@ -222,17 +222,18 @@ __device__ __forceinline__ bool local_base32(int period, int size, int I0, int *
     constexpr int S = Tuned<KIND>::S;
     int w = I0;
     if (period > 0) {
-        // true modulo with a fast path for indices within one period of the box
-        if (w < 0) { w += period; if (w < 0) { w %= period; if (w < 0) w += period; } }
-        else if (w >= period) { w -= period; if (w >= period) w %= period; }
-        if (w < size) *i0w = w;
-        else if (w >= period - (S - 1)) *i0w = w - period;
-        else return false;
-    } else {
-        if (w < -(S - 1) || w >= size) return false;
-        *i0w = w;
+        // true modulo.  Indices within one period of the box — all but stray particles — take two selects; the
+        // division sits behind ONE branch that a wave only enters if some lane is further out (the nested
+        // branches this replaces cost the bin pass a dozen exec-mask instructions per axis whether taken or not)
+        w += (w < 0) ? period : 0;
+        w -= (w >= period) ? period : 0;
+        if ((unsigned)w >= (unsigned)period) { w %= period; if (w < 0) w += period; }
+        const bool in = w < size;
+        *i0w = in ? w : w - period;
+        return in || w >= period - (S - 1);
     }
-    return true;
+    *i0w = w;
+    return !(w < -(S - 1) || w >= size);
 }
 
 template <int KIND>
