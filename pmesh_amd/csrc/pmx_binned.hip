@@ -851,13 +851,14 @@ __device__ __forceinline__ bool batch_is_mine(const double *mstats, int want_odd
 #ifndef PMX_PAINT_WAVES_CIC
 #define PMX_PAINT_WAVES_CIC 1
 #endif
-template <int KIND> constexpr int paint_min_waves()
+// (the variants on the tile-ordered copy would spill a few bytes under that budget: they keep the default)
+template <int KIND, bool SORTED> constexpr int paint_min_waves()
 {
-    return KIND == PMX_TUNED_TSC ? PMX_PAINT_WAVES_TSC : (KIND == PMX_TUNED_CIC ? PMX_PAINT_WAVES_CIC : 1);
+    return (KIND == PMX_TUNED_TSC && !SORTED) ? PMX_PAINT_WAVES_TSC : (KIND == PMX_TUNED_CIC ? PMX_PAINT_WAVES_CIC : 1);
 }
 
 template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE>
-__global__ void __launch_bounds__(TTHREADS, paint_min_waves<KIND>()) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
+__global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
                                                             const uint32_t *counts, T *halo, int overwrite,

@@ -76,6 +76,11 @@ def test_tile_kernel_budgets():
     for k, v in tiles.items():
         if 'ILi5Ed' in k:
             assert v['LDS'] <= 40960 and v['Occupancy'] >= 4, (k, v)
+    # TSC (kind 6) through the index list, fixed-point regions (MODE 1): 49 KB regions allow three workgroups of
+    # 512 threads per CU only if six waves per SIMD fit the registers (80 VGPRs); at 84-90 it ran two (paint 2.23
+    # instead of 1.85 ms on config 3)
+    tsc = [v for k, v in tiles.items() if 'paint_tile_kernelILi6E' in k and 'ELb0ELi1E' in k]
+    assert len(tsc) == 2 and all(v['VGPRs'] <= 80 and v['Occupancy'] >= 6 for v in tsc), tsc
     for k, v in t.items():
         if 'bin_count_kernel' in k:
             assert v['ScratchSize'] == 0, k
