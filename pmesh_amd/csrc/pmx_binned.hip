@@ -667,13 +667,13 @@ __device__ __forceinline__ int fixed_exponent(const pmx_painter &p, double mb, i
 #pragma unroll
     for (int d = 0; d < 3; d++)
         if (p.order[d]) wb *= 2.0 * fabs(p.scale[d]) + 2.0;           // bound of the derivative weights
-    const double b = mb * wb;
-    int e = (b > 0 && b < 1e300) ? ilogb(b) + 1 : 0;                   // b < 2^e
+    // mb wb < 2^e, from the two exponents (their product may not be representable)
+    const int e = ((mb > 0) ? ilogb(mb) + 1 : -1000) + (wb > 1.0 ? ilogb(wb) + 1 : 0);
     int lg = 0;
     while (((int64_t)1 << lg) < n && lg < 40) lg++;                    // n <= 2^lg
     int f = 50 - e;
     if (61 - e - lg < f) f = 61 - e - lg;
-    return f < -900 ? -900 : (f > 900 ? 900 : f);
+    return f < -1020 ? -1020 : (f > 1020 ? 1020 : f);                  // (2^f and 2^-f stay normal doubles)
 }
 __device__ __forceinline__ double pow2(int f) { return __longlong_as_double((long long)(1023 + f) << 52); }
 

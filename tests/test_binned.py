@@ -337,6 +337,33 @@ def test_deterministic_paint(hip, oracle, name, dt):
         window.clear_bin_cache()
 
 
+@pytest.mark.parametrize('name', ['tsc', 'pcs'])
+@pytest.mark.parametrize('scale_m', [1e-290, 1.0, 1e250])
+def test_fixed_point_regions_over_the_range_of_masses(hip, oracle, name, scale_m):
+    """the S >= 3 paint accumulates 64-bit integers in units of 2^-f chosen from the largest |mass|: masses of
+    1e-290 and of 1e250, scalar and per particle, gradient paint (derivative weights carry the scale), against the
+    oracle to 1e-12 of the largest cell"""
+    W = windows[name]
+    N = 64
+    rs = numpy.random.RandomState(23)
+    pos_h = rs.uniform(0, 64, size=(50000, 3))
+    mass_h = rs.uniform(0.1, 1.0, size=50000) * scale_m
+    aff = Affine(3, scale=3.0, period=N * 3)
+    oaff = oracle.Affine(3, scale=3.0, period=N * 3)
+    shape = (3 * N, 3 * N, 3 * N)
+    pos = torch.from_numpy(pos_h).to(hip.device)
+    window.BINNED = 'always'
+    for mass, mh in ((torch.from_numpy(mass_h).to(hip.device), mass_h), (0.7 * scale_m, 0.7 * scale_m)):
+        for diffdir in (None, 2):
+            window.clear_bin_cache()
+            c = torch.zeros(shape, dtype=torch.float64, device=hip.device)
+            W.paint(c, pos, mass=mass, diffdir=diffdir, transform=aff)
+            assert_binned_ran()
+            want = numpy.zeros(shape)
+            oracle.Window(W.kind).paint(want, pos_h, mass=mh, diffdir=diffdir, transform=oaff)
+            assert_allclose(c.cpu().numpy(), want, rtol=0, atol=1e-12 * abs(want).max())
+
+
 def test_two_live_particle_sets_keep_their_plans(hip):
     """two live position tensors of equal shape on one geometry (two species; probes at as many points
     as there are particles) each keep a plan slot: alternating between them finds both plans again
