@@ -531,7 +531,10 @@ def main():
                                          % ('slab' if len(np_) == 1 else 'pencil', np_,
                                             'ghosts only' if args.ghosts_only else 'all particles')),
                        'particles': ntot, 'apply': 'fused into c2r' if args.fuse_apply else 'separate kernel',
-                       'fft': 'LDS row + column FFT kernels' if args.colfft else 'rocFFT 3-d'},
+                       'fft': ('LDS row + column FFT kernels' + (
+                           ', the last pass of r2c deferred into the first of c2r (one kernel for both and the transfer; '
+                           'its time shows under c2r)' if world == 1 and _fft.DEFER_LAST_PASS and args.fuse_apply else ''))
+                       if args.colfft else 'rocFFT 3-d'},
             'stages_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'decompose_ms': round(1e3 * t_decompose, 3),
             # the exchange reported both ways — `value` has decompose outside the cycle
