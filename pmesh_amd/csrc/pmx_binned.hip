@@ -735,21 +735,32 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
             const double mu = FIXED ? m[u] * scale : m[u];
 #pragma unroll
             for (int a = 0; a < S; a++) V[0][a] *= mu;
+            // Split layout: whether stencil point c of this particle lies in the halo columns depends on its z cell
+            // alone, so the choice between the two bases of a row — its 32 cells and its halo columns — is one select
+            // per point with the masks of the particle, and c rides on the instruction's immediate offset (written
+            // out by hand: left to itself the compiler compares and selects per atomic, a quarter of the kernel's
+            // vector instructions)
+            bool inhalo[S];
+#pragma unroll
+            for (int c = 0; c < S; c++) inhalo[c] = Rg::SPLIT && c > 0 && lb[2] + c >= T2;
 #pragma unroll
             for (int a = 0; a < S; a++)
 #pragma unroll
                 for (int b = 0; b < S; b++) {
                     double fb = V[0][a] * V[1][b];
                     const int row = (lb[0] + a) * R1 + (lb[1] + b);
+                    const int imain = Rg::SPLIT ? row * T2 + lb[2] : row * Rg::P2 + lb[2];
+                    const int ihalo = Rg::DMAIN + row * (S - 1) + lb[2] - T2;
 #pragma unroll
                     for (int c = 0; c < S; c++) {
+                        const int cell = (inhalo[c] ? ihalo : imain) + c;
                         if (PMX_EXP_NOATOM) sink += fb * V[2][c];
-                        else if (PMX_EXP_NOWEIGHT) unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], m[u]);
+                        else if (PMX_EXP_NOWEIGHT) unsafeAtomicAdd(&lds[cell], m[u]);
                         else if (FIXED) {
                             const double r = __builtin_fma(fb, V[2][c], FIXED_MAGIC);
-                            atomicAdd((unsigned long long *)&lds[Rg::dat(row, lb[2] + c)],
+                            atomicAdd((unsigned long long *)&lds[cell],
                                       (unsigned long long)(__double_as_longlong(r) - FIXED_MAGIC_BITS));
-                        } else unsafeAtomicAdd(&lds[Rg::dat(row, lb[2] + c)], fb * V[2][c]);
+                        } else unsafeAtomicAdd(&lds[cell], fb * V[2][c]);
                     }
                 }
         }
@@ -869,6 +880,9 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
     // integer copy of the block, else the same as pw)
     constexpr bool FIXED = MODE != 0;
     if (!batch_is_mine(mstats, want_odd)) return;
+    // (only the deterministic mode has two layouts; elsewhere the second painter is never read, which keeps its 38
+    // scalar registers out of the kernel — with both live the scalar file spilled into vector lanes)
+    const pmx_painter &pwr = MODE == 2 ? pw : p;
     // SORTED: `pos` is the plan's copy of the positions in list order (row = list slot);
     // the list itself is then only read for a per-particle mass
     constexpr int S = Tuned<KIND>::S;
@@ -902,7 +916,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
               const uint32_t c = counts[column * nt2 + t2];
               nseg_part += c < (uint32_t)g.chunk ? c : (uint32_t)g.chunk;
           }
-          const int f = MODE == 2 ? *dexp : fixed_exponent(pw, mstats ? mstats[0] : fabs(mass_scalar), nseg_part);
+          const int f = MODE == 2 ? *dexp : fixed_exponent(pwr, mstats ? mstats[0] : fabs(mass_scalar), nseg_part);
           scale = pow2(f);
           inv = pow2(-f);
       }
@@ -940,7 +954,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             }
             __syncthreads();
         }
-        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pw, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -1092,6 +1106,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
 {
     constexpr bool FIXED = MODE != 0;
     if (!batch_is_mine(mstats, want_odd)) return;
+    const pmx_painter &pwr = MODE == 2 ? pw : p;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
@@ -1109,11 +1124,11 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
         __syncthreads();
         double scale = 1.0, inv = 1.0;
         if (FIXED) {
-            const int f = MODE == 2 ? *dexp : fixed_exponent(pw, mstats ? mstats[0] : fabs(mass_scalar), count);
+            const int f = MODE == 2 ? *dexp : fixed_exponent(pwr, mstats ? mstats[0] : fabs(mass_scalar), count);
             scale = pow2(f);
             inv = pow2(-f);
         }
-        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pw, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
+        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pwr, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             const int c = q % R2, r = q / R2;

@@ -460,8 +460,13 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 // (one sweep of the array instead of two; pmx_colfft_roundtrip).  Every value takes exactly the roundings of the
 // two separate passes (the scaled mode is rounded to T before the transfer multiplies it), so the result is
 // bit-identical to them.  Plain layout, A = 1 (the axis-0 pass of one block), in place.
+// (register budget: two workgroups per CU, as the plain passes run — unconstrained, the float kernel of N = 512 took
+// 162 VGPRs and ran one: 0.50 ms for the 1.07 GB it moves)
+#ifndef PMX_ROUND_WAVES
+#define PMX_ROUND_WAVES 4
+#endif
 template <typename T, int LOGN, bool APPLY, int RB>
-__global__ void __launch_bounds__((Len<LOGN>::N / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))))
+__global__ void __launch_bounds__((Len<LOGN>::N / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))), PMX_ROUND_WAVES)
 colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 {
     constexpr int N = Len<LOGN>::N;
