@@ -333,11 +333,13 @@ DEFER_LAST_PASS = os.environ.get('PMESH_AMD_DEFER_LAST_PASS', '1') not in ('0', 
 
 
 class _Pending(object):
-    """the deferred axis-0 pass of a forward transform"""
-    __slots__ = ('partition', 'run', 'fused')
+    """the deferred axis-0 pass of a forward transform.  kind: 'local' (one rank), 'slab' (several ranks, one
+    exchange: the pass is due on the received block), 'slabpipe' (pipelined exchange: `data` holds the chunk
+    buffers the all-to-alls deliver into and their handles)"""
+    __slots__ = ('partition', 'run', 'fused', 'kind', 'data')
 
-    def __init__(self, partition, run, fused):
-        self.partition, self.run, self.fused = partition, run, fused
+    def __init__(self, partition, run, fused, kind='local', data=None):
+        self.partition, self.run, self.fused, self.kind, self.data = partition, run, fused, kind, data
 
 
 def settle(storage):
@@ -418,12 +420,19 @@ class Plan(object):
 
     def execute(self, bufin, bufout, transfer=None):
         p = self.partition
+        # a forward plan whose last pass is still deferred has its work buffers lent out (pipelined slabs)
+        owed = getattr(self, '_deferred_on', None)
+        if owed is not None:
+            self._deferred_on = None
+            settle(owed)
         pend = getattr(bufin.storage, '_pmx_pending', None)
         if pend is not None:
-            # a deferred forward pass on the input: an in-place inverse transform of the same partition on one
-            # rank takes it over (see _execute_local_hybrid); anything else needs the finished spectrum first
-            mine = (not self.forward and pend.partition is p and p.nproc == 1 and
-                    bufin.storage is bufout.storage and not getattr(p, 'is_c2c', False))
+            # a deferred forward pass on the input: an in-place inverse transform of the same partition takes it
+            # over (one rank: _execute_local_hybrid; slabs: _execute_slab); anything else needs the finished
+            # spectrum first
+            mine = (not self.forward and pend.partition is p and bufin.storage is bufout.storage and
+                    not getattr(p, 'is_c2c', False) and
+                    (pend.kind == 'local') == (p.nproc == 1))
             if not mine:
                 settle(bufin.storage)
         if bufout.storage is not bufin.storage:
@@ -909,7 +918,25 @@ class Plan(object):
                                     nmesh=nmesh, boxsize=boxsize, n_stride=sn)
             else:
                 be.colfft_roundtrip(es, st, N0, N1 * N2c, scale=norm, n_stride=sn)
-        st._pmx_pending = _Pending(self.partition, run, fused)
+        st._pmx_pending = _Pending(self.partition, run, fused, 'local')
+
+    def _last_slab_pass(self, be, out, N0, n1loc, N2c, nb):
+        """the axis-0 pass on the block a slab transpose delivered (one exchange) — now, or deferred"""
+        es = self.elsize
+
+        def run():
+            be.colfft(es, False, out, 1, N0, nb)
+        if not (DEFER_LAST_PASS and hasattr(be, 'colfft_roundtrip') and be.colfft_roundtrip_supported(N0, es)):
+            return run()
+
+        def fused(transfer):
+            if transfer is not None:
+                t, start, nmesh, boxsize = transfer
+                be.colfft_roundtrip(es, out, N0, nb, transfer=t, n1=n1loc, n2=N2c, start=start, nmesh=nmesh,
+                                    boxsize=boxsize)
+            else:
+                be.colfft_roundtrip(es, out, N0, nb)
+        out._pmx_pending = _Pending(self.partition, run, fused, 'slab')
 
     def _take_over_forward_pass(self, be, st, transfer, N0, N1, N2c, sn):
         """first stage of c2r on one rank: if the forward transform left its last pass for us, both axis-0 passes
@@ -972,6 +999,10 @@ class Plan(object):
             nb = n1loc * N2c
             pi = int(getattr(p, 'pitch_i', N2c))                # complex elements per real-side row
             chunks = self._chunks(be, p, P, N0, N1, N2c, n0loc, n1loc, e0, e1)
+            pend = getattr(bufin.storage, '_pmx_pending', None)
+            if pend is not None and not (same and ((chunks and pend.kind == 'slabpipe' and pend.data['chunks'] == chunks) or
+                                                    (not chunks and pend.kind == 'slab'))):
+                settle(bufin.storage)                          # a deferred pass this transform cannot take over
             if chunks:
                 return self._execute_slab_pipelined(be, comm, bufin, bufout, transfer, chunks, same,
                                                     N0, N1, N2, N2c, n0loc, n1loc, pi, norm, W0, W1, W2)
@@ -997,14 +1028,24 @@ class Plan(object):
                 out = bufout.storage
                 comm.alltoall(W1[:nsend], out[:nrecv], send_splits, recv_splits)
                 if nb:
-                    be.colfft(self.elsize, False, out, 1, N0, nb)
+                    self._last_slab_pass(be, out, N0, n1loc, N2c, nb)
             else:
                 S = bufin.storage
+                pend = getattr(S, '_pmx_pending', None)
+                if pend is not None:
+                    S._pmx_pending = None
+                    if pend.kind == 'slab' and same:
+                        pend.fused(transfer)                    # both axis-0 passes and the transfer: one kernel
+                    else:
+                        pend.run()
+                        pend = None
                 if not same:
                     ncplx = 2 * n1loc * N0 * n2
                     W0[:ncplx].copy_(bufin.storage[:ncplx])     # c2r preserves its input
                     S = W0
-                if nb and transfer is not None:
+                if pend is not None:
+                    pass
+                elif nb and transfer is not None:
                     # the local block is (N0, n1loc, N2c) at global start (0, o_start[1], 0)
                     t, start, nmesh, boxsize = transfer
                     be.colfft(self.elsize, True, S, 1, N0, nb, transfer=t, n1=n1loc, n2=N2c,
@@ -1197,13 +1238,40 @@ class Plan(object):
                 be.colfft_split(es, False, X[2 * b0:], W1[o:o + n], n0loc, N1, cw, n1loc, scale=norm, plain_pitch=pi)
                 works.append(comm.alltoall(W1[o:o + n], W2[o:o + n], async_op=True))
             out = bufout.storage
-            for (b0, cw), o, w in zip(chunks, offs, works):
-                w.wait()
-                be.colfft_chunk(es, False, W2[o:], out, N0, n1loc, cw, N2c, b0, True)
+
+            def run():
+                for (b0, cw), o, w in zip(chunks, offs, works):
+                    w.wait()
+                    be.colfft_chunk(es, False, W2[o:], out, N0, n1loc, cw, N2c, b0, True)
+            if DEFER_LAST_PASS and hasattr(be, 'colfft_roundtrip') and be.colfft_roundtrip_supported(N0, es):
+                # the chunks stay where the all-to-alls deliver them: an in-place c2r that follows at once runs
+                # both axis-0 passes and the transfer on them as one kernel and sends them straight back
+                out._pmx_pending = _Pending(self.partition, run, None, 'slabpipe',
+                                            dict(chunks=chunks, offs=offs, works=works, W2=W2))
+                self._deferred_on = out
+            else:
+                run()
         else:
             S = bufin.storage                              # read only: c2r preserves its input
             t = transfer
+            pend = getattr(S, '_pmx_pending', None)
+            if pend is not None:
+                # (checked by _execute_slab: same chunks, in place) the forward transform left its chunks for us
+                S._pmx_pending = None
+                F2 = pend.data['W2']
+                for (b0, cw), o, fw in zip(chunks, offs, pend.data['works']):
+                    n = 2 * N0 * n1loc * cw
+                    fw.wait()
+                    if t is not None:
+                        st = [int(t[1][0]), int(t[1][1]), int(t[1][2]) + b0]
+                        be.colfft_roundtrip(es, F2[o:], N0, n1loc * cw, transfer=t[0], n1=n1loc, n2=cw, start=st,
+                                            nmesh=t[2], boxsize=t[3])
+                    else:
+                        be.colfft_roundtrip(es, F2[o:], N0, n1loc * cw)
+                    works.append(comm.alltoall(F2[o:o + n], W1[o:o + n], async_op=True))
             for (b0, cw), o in zip(chunks, offs):
+                if pend is not None:
+                    break
                 n = 2 * N0 * n1loc * cw
                 if t is not None:
                     be.colfft_chunk(es, True, W2[o:], S, N0, n1loc, cw, N2c, b0, False, transfer=t[0],
@@ -1257,6 +1325,7 @@ class Plan(object):
             comm.alltoall(W[:sum(col_splits)], bufout.storage[:sum(rows_splits)], col_splits, rows_splits)
         elif self.forward:
             t.execute(bufin, tb)                                        # -> (N0, n1loc, n2) in TB
+            settle(TB)                                                  # (the sibling may have deferred its last pass)
             comm.alltoall(TB[:sum(rows_splits)], W[:sum(col_splits)], rows_splits, col_splits)
             be.slab_pack(W, bufout.storage, n0loc, N1c, n2, e1, elb, inverse=True)
         else:
@@ -1270,6 +1339,8 @@ class Plan(object):
         p = self.partition
         if p.nproc == 1 or p.transposed:
             raise NotImplementedError('retranspose is a method of the untransposed plans of several ranks')
+        settle(bufin.storage)
+        forget(bufout.storage)
         if getattr(p, 'pencil', False):
             return self._execute_pencil_untransposed(bufin, bufout, mode='T->U' if to_untransposed else 'U->T')
         self._execute_slab_untransposed(bufin, bufout, mode='T->U' if to_untransposed else 'U->T')
