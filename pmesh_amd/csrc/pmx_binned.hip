@@ -244,6 +244,9 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 constexpr int BLOCK_ITERS = PMX_BLOCK_ITERS;                     // trips of TBLOCK * PMX_ONEPASS_U rows
 constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
 constexpr int BLOCK_HT = 128;                       // entries of the LDS table (a power of two)
+#ifndef PMX_EXP_BINFLOOR
+#define PMX_EXP_BINFLOOR 0                          // timing experiment, see bin_block_kernel
+#endif
 // 16-byte pieces of the TBLOCK * U dense rows from `base` on, one per thread and q: -> bytes requested
 template <int NPRE, int U>
 __device__ __forceinline__ int request_rows(const DVec &pos, int64_t n, int64_t base, uint4 (&pre)[NPRE])
@@ -354,6 +357,11 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
                 }
                 const int leader = t >= 0 ? __ffsll((long long)same) - 1 : lane;
                 uint32_t w = 0, bd = 0;
+#if PMX_EXP_BINFLOOR
+                // timing experiment (wrong lists): no table, no counters — what positions -> tile ids -> list costs
+                where[(it * U + u) * TBLOCK + threadIdx.x] = t >= 0 ? (uint32_t)(t & 0xFFFFFF) : EMPTY;
+                if (PMX_EXP_BINFLOOR > 1) continue;
+#endif
                 if (t >= 0 && lane == leader) {
                     // the group's entry of the table and its first rank there
                     uint32_t h = ((uint32_t)t * 2654435761u) >> 25;               // 7 bits: BLOCK_HT = 128
@@ -401,6 +409,10 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
                 const uint32_t w = where[(it * U + u) * TBLOCK + threadIdx.x];
                 if (w == EMPTY) continue;
                 const int64_t i = row0 + (int64_t)it * (TBLOCK * U) + u * TBLOCK + threadIdx.x;
+#if PMX_EXP_BINFLOOR > 1
+                list[i] = (uint32_t)i + (w & 1);      // sequential: the floor of reading rows and writing a list
+                continue;
+#endif
                 const uint32_t e = w >> 24;
                 const int64_t slot = first[e] + (w & 0xFFFFFFu);
                 if (slot < last[e]) list[slot] = (uint32_t)i;
@@ -640,6 +652,7 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
 #ifndef PMX_EXP_NOATOM
 #define PMX_EXP_NOATOM 0
 #endif
+
 #ifndef PMX_EXP_NOWEIGHT
 #define PMX_EXP_NOWEIGHT 0
 #endif
