@@ -65,9 +65,10 @@ __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const B
         ok = ok && local_base<KIND>(p, d, I[0], &i0w);
         tt[d] = (int)((unsigned)(i0w + g.o[d]) / (unsigned)bucket_ext<WALK>(d));      // (never negative for a particle that counts)
     }
-    const int64_t tb = WALK ? ((int64_t)tt[1] * g.nt[2] + tt[2]) * g.nt[0] + tt[0]
-                            : ((int64_t)tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
-    return ok ? tb : g.ntiles;
+    // (32-bit: pmx_binplan_build refuses more than 2^31 buckets; the 64-bit multiplies cost four issue slots each)
+    const int tb = WALK ? (tt[1] * g.nt[2] + tt[2]) * g.nt[0] + tt[0]
+                        : (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+    return ok ? (int64_t)tb : g.ntiles;
 }
 
 // MODE 0: count pass of the two-pass build: tid[i] = tile, counts[tile]++.
