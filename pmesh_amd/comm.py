@@ -46,14 +46,16 @@ def _stamp(t):
 def trace_summary(records):
     """-> dict of totals over `records` (call after a device synchronisation)"""
     out = {'collectives': len(records), 'bytes_sent': 0, 'sync_ms': 0.0, 'overlapped_window_ms': 0.0,
-           'max_link_GBs': 0.0}
+           'max_link_GBs': 0.0, 'max_link_GBs_overlapped': 0.0}
     for kind, nbytes, peers, a, b, overlapped in records:
         ms = a.elapsed_time(b) if hasattr(a, 'elapsed_time') else 1e3 * (b - a)
         out['bytes_sent'] += nbytes
         out['overlapped_window_ms' if overlapped else 'sync_ms'] += ms
-        if not overlapped and peers and ms > 0:
-            # xGMI is point to point: one link per peer carries this rank's share for that peer
-            out['max_link_GBs'] = max(out['max_link_GBs'], nbytes / peers / (ms * 1e-3) / 1e9)
+        if peers and ms > 0:
+            # xGMI is point to point: one link per peer carries this rank's share for that peer.  (An overlapped
+            # exchange's window also holds the kernels that ran underneath: its rate is a lower bound.)
+            key = 'max_link_GBs_overlapped' if overlapped else 'max_link_GBs'
+            out[key] = max(out[key], nbytes / peers / (ms * 1e-3) / 1e9)
     return out
 
 
@@ -94,8 +96,9 @@ class SelfComm(object):
     def alltoall_counts(self, sendcounts):
         return numpy.array(sendcounts, copy=True)
 
-    def alltoallv(self, send, sendcounts, recv, recvcounts):
+    def alltoallv(self, send, sendcounts, recv, recvcounts, async_op=False):
         recv.copy_(send)
+        return _Done() if async_op else None
 
     def alltoall(self, send, recv, send_splits=None, recv_splits=None, async_op=False):
         recv.copy_(send)
@@ -168,20 +171,25 @@ class TorchComm(object):
         self._dist.all_to_all_single(r, s, group=self.group)
         return r.cpu().numpy()
 
-    def alltoallv(self, send, sendcounts, recv, recvcounts):
-        """rows of `send` (first axis) split by sendcounts -> rows of `recv`."""
+    def alltoallv(self, send, sendcounts, recv, recvcounts, async_op=False):
+        """rows of `send` (first axis) split by sendcounts -> rows of `recv`.  async_op: returns a handle whose
+        wait() orders the current stream (RCCL) / the host (gloo) after the exchange — the particle exchanges of
+        paint / readout run under the kernels of the caller's own particles"""
         rec = None
         if _trace is not None:
             row = send.element_size() * (send.numel() // max(1, send.shape[0])) if send.dim() else send.element_size()
             away = (int(numpy.sum(sendcounts)) - int(sendcounts[self.rank])) * row
-            rec = ['alltoallv', away, self.size - 1, _stamp(send), None, False]
-        self._dist.all_to_all_single(recv, send,
-                                     output_split_sizes=[int(c) for c in recvcounts],
-                                     input_split_sizes=[int(c) for c in sendcounts],
-                                     group=self.group)
+            rec = ['alltoallv', away, self.size - 1, _stamp(send), None, bool(async_op)]
+        w = self._dist.all_to_all_single(recv, send,
+                                         output_split_sizes=[int(c) for c in recvcounts],
+                                         input_split_sizes=[int(c) for c in sendcounts],
+                                         group=self.group, async_op=async_op)
         if rec is not None:
-            rec[4] = _stamp(send)
             _trace.append(rec)
+            if async_op:
+                return _Traced(w, rec, send)
+            rec[4] = _stamp(send)
+        return w if async_op else None
 
     def alltoall(self, send, recv, send_splits=None, recv_splits=None, async_op=False):
         """async_op: returns a handle whose wait() orders the *current stream* (RCCL) / the host

@@ -309,93 +309,120 @@ class Layout(object):
     def remote_recvlength(self):
         return self._remote(backend.get())[4]
 
-    def exchange_remote(self, data, *more):
+    def exchange_remote(self, data, *more, async_op=False):
         """ rows of `data` received from the other ranks (ordered by source rank).  Several arrays
         (positions and per-particle masses of a paint) travel side by side in ONE all-to-all-v, as
         Layout.exchange(pack=True) sends them; results are remembered per source tensor, so the
-        readouts that follow a paint find the positions already exchanged. """
+        readouts that follow a paint find the positions already exchanged.  async_op: returns a handle
+        whose wait() gives the arrays — the exchange then runs (on RCCL's stream) under whatever the
+        caller enqueues in between: the paint of its own particles. """
+        state = self._exchange_remote_begin((data,) + more, async_op)
+        if async_op:
+            return _RemoteExchange(self, state)
+        return self._exchange_remote_end(state)
+
+    def _exchange_remote_begin(self, arrays_in, async_op):
         be = backend.get()
         idx, sc, rc, nsend, nrecv = self._remote(be)
-        arrays = [to_device(a, be.device, 'data', allow_int=True)[0] for a in (data,) + more]
+        arrays = [to_device(a, be.device, 'data', allow_int=True)[0] for a in arrays_in]
         keys = [(a.data_ptr(), version_of(a), tuple(a.shape), a.stride(), a.dtype) for a in arrays]
         memo = getattr(self, '_memo_remote', None)
         if not isinstance(memo, dict):
             memo = self._memo_remote = {}
         missing = [i for i, k in enumerate(keys) if k not in memo]
-        if missing:
-            message = 'the length of data does not match that used to build the layout'
-            wrong = False
-            for i in missing:
-                wrong = self._wrong_length(len(arrays[i]), self.sendlength, 'exchange', message) or wrong
-            parts, metas = [], []
-            for i in missing:
-                a = arrays[i]
-                trailing = tuple(a.shape[1:])
-                if wrong:
-                    a = torch.zeros((self.sendlength,) + trailing, dtype=a.dtype, device=be.device)
-                rb = a.element_size()
-                for s_ in trailing:
-                    rb *= s_
-                metas.append((a.dtype, trailing, rb))
-                if nsend:
-                    parts.append(self._take(be, a, idx, nsend))
-            if len(missing) == 1:
-                dt, trailing, rb = metas[0]
-                recv = torch.empty((nrecv,) + trailing, dtype=dt, device=be.device)
-                if self.comm.size > 1:
-                    send = parts[0] if nsend else torch.empty((0,) + trailing, dtype=dt, device=be.device)
-                    self.comm.alltoallv(send, sc, recv, rc)
+        st = dict(arrays=arrays, keys=keys, memo=memo, missing=missing, many=len(arrays_in) > 1, work=None, wrong=False)
+        if not missing:
+            return st
+        message = 'the length of data does not match that used to build the layout'
+        wrong = False
+        for i in missing:
+            wrong = self._wrong_length(len(arrays[i]), self.sendlength, 'exchange', message) or wrong
+        parts, metas = [], []
+        for i in missing:
+            a = arrays[i]
+            trailing = tuple(a.shape[1:])
+            if wrong:
+                a = torch.zeros((self.sendlength,) + trailing, dtype=a.dtype, device=be.device)
+            rb = a.element_size()
+            for s_ in trailing:
+                rb *= s_
+            metas.append((a.dtype, trailing, rb))
+            if nsend:
+                parts.append(self._take(be, a, idx, nsend))
+        if len(missing) == 1:
+            dt, trailing, rb = metas[0]
+            recv = torch.empty((nrecv,) + trailing, dtype=dt, device=be.device)
+            send = parts[0] if nsend else torch.empty((0,) + trailing, dtype=dt, device=be.device)
+        else:
+            width = sum(m[2] for m in metas)
+            send = (torch.cat([q.reshape(nsend, -1).view(torch.uint8).reshape(nsend, m[2]) for q, m in zip(parts, metas)],
+                              dim=1) if nsend else torch.empty((0, width), dtype=torch.uint8, device=be.device))
+            recv = torch.empty((nrecv, width), dtype=torch.uint8, device=be.device)
+        if self.comm.size > 1:
+            st['work'] = self.comm.alltoallv(send, sc, recv, rc, async_op=async_op)
+        st.update(wrong=wrong, message=message, metas=metas, recv=recv, send=send, nrecv=nrecv)
+        return st
+
+    def _exchange_remote_end(self, st):
+        memo, keys = st['memo'], st['keys']
+        if st['missing']:
+            if st['work'] is not None:
+                st['work'].wait()
+            if st['wrong']:
+                raise ValueError(st['message'])
+            recv, metas, nrecv = st['recv'], st['metas'], st['nrecv']
+            if len(st['missing']) == 1:
                 got = [recv]
             else:
-                width = sum(m[2] for m in metas)
-                packed = (torch.cat([q.reshape(nsend, -1).view(torch.uint8).reshape(nsend, m[2]) for q, m in zip(parts, metas)],
-                                    dim=1) if nsend else torch.empty((0, width), dtype=torch.uint8, device=be.device))
-                recv = torch.empty((nrecv, width), dtype=torch.uint8, device=be.device)
-                if self.comm.size > 1:
-                    self.comm.alltoallv(packed, sc, recv, rc)
                 got, off = [], 0
                 for dt, trailing, rb in metas:
                     got.append(recv[:, off:off + rb].contiguous().view(dt).reshape((nrecv,) + trailing))
                     off += rb
-            if wrong:
-                raise ValueError(message)
-            for i, r in zip(missing, got):
-                memo[keys[i]] = (arrays[i], r)            # (the source tensor is kept alive: its address stays taken)
+            for i, r in zip(st['missing'], got):
+                memo[keys[i]] = (st['arrays'][i], r)      # (the source tensor is kept alive: its address stays taken)
             while len(memo) > 4:
                 memo.pop(next(iter(memo)))
+            st['missing'] = []
         res = [memo[k][1] for k in keys]
-        return res[0] if not more else tuple(res)
+        return tuple(res) if st['many'] else res[0]
 
-    def gather_remote_add(self, data, out):
+    def gather_remote_add(self, data, out, async_op=False):
         """ send the per-ghost results `data` (rows as exchange_remote delivered them) back to
-        their owners and add them into `out` (one row per original item) in place """
+        their owners and add them into `out` (one row per original item) in place.  async_op: returns a
+        handle; the results travel while the caller reads out its own particles, wait() adds them. """
         be = backend.get()
         idx, sc, rc, nsend, nrecv = self._remote(be)
         message = 'the length of data does not match result of exchange_remote'
         wrong = self._wrong_length(len(data), nrecv, 'gather_remote', message)
         if self.comm.size == 1:
-            return out
+            return _Finished(out) if async_op else out
         if wrong:
             data = torch.zeros((nrecv,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         data = data.contiguous()
         back = torch.empty((nsend,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
-        self.comm.alltoallv(data, rc, back, sc)
-        if wrong:
-            raise ValueError(message)
-        if nsend:
-            if back.dtype != out.dtype:
-                back = back.to(out.dtype)
-            ncol = 1
-            for s in back.shape[1:]:
-                ncol *= s
-            # nout = 0: accumulate into `out` without clearing it (include/pmesh_amd.h)
-            if out.dtype not in (torch.float32, torch.float64):
-                out.index_add_(0, idx.to(torch.int64), back)
-                return out
-            be.call('scatter_add', back.data_ptr(), back.element_size(), ncol, idx.data_ptr(),
-                    idx.element_size(), nsend, out.data_ptr(), 0, be.stream())
-            touched(out)
-        return out
+        work = self.comm.alltoallv(data, rc, back, sc, async_op=async_op)
+
+        def finish(target):
+            if work is not None:
+                work.wait()
+            if wrong:
+                raise ValueError(message)
+            if nsend:
+                b = back if back.dtype == target.dtype else back.to(target.dtype)
+                ncol = 1
+                for s in b.shape[1:]:
+                    ncol *= s
+                # nout = 0: accumulate into `out` without clearing it (include/pmesh_amd.h)
+                if target.dtype not in (torch.float32, torch.float64):
+                    target.index_add_(0, idx.to(torch.int64), b)
+                    return target
+                be.call('scatter_add', b.data_ptr(), b.element_size(), ncol, idx.data_ptr(),
+                        idx.element_size(), nsend, target.data_ptr(), 0, be.stream())
+                touched(target)
+            return target
+        if async_op:
+            return _Pending2(finish, data)
+        return finish(out)
 
     def gather(self, data, mode='sum', out=None):
         """
@@ -473,6 +500,32 @@ class Layout(object):
             r = mode.reduceat(rb, offset)
             return finish(torch.from_numpy(r).to(be.device))
         raise NotImplementedError
+
+
+class _RemoteExchange(object):
+    """handle of Layout.exchange_remote(async_op=True)"""
+    def __init__(self, layout, state):
+        self.layout, self.state = layout, state
+
+    def wait(self):
+        return self.layout._exchange_remote_end(self.state)
+
+
+class _Pending2(object):
+    """handle of Layout.gather_remote_add(async_op=True): wait(out) adds what came back into `out`"""
+    def __init__(self, finish, keepalive):
+        self.finish, self.keepalive = finish, keepalive
+
+    def wait(self, out):
+        return self.finish(out)
+
+
+class _Finished(object):
+    def __init__(self, out):
+        self.out = out
+
+    def wait(self, out):
+        return out
 
 
 class GridND(object):

@@ -679,12 +679,17 @@ class RealField(Field):
             # a caller's device buffer takes the result directly (no fresh tensor per call)
             direct = (is_tensor(out) and out.device == be.device and out.dtype == torch.float64 and
                       out.dim() == 1 and out.shape[0] == dpos.shape[0] and out.is_contiguous())
-            res = resampler.readout(self.value, dpos, out=out if direct else None, transform=transform,
-                                    diffdir=gradient)
+            pending = None
             if layout.comm.size > 1:
+                # the ghosts first: their partial sums travel back to their owners (on RCCL's stream) while the
+                # caller's own particles — almost all of the work — are read out
                 rpos = layout.exchange_remote(dpos)
                 rres = resampler.readout(self.value, rpos, transform=transform, diffdir=gradient)
-                layout.gather_remote_add(rres, res)
+                pending = layout.gather_remote_add(rres, None, async_op=True)
+            res = resampler.readout(self.value, dpos, out=out if direct else None, transform=transform,
+                                    diffdir=gradient)
+            if pending is not None:
+                pending.wait(res)
             if direct:
                 return out
             if out is not None:
@@ -1444,13 +1449,22 @@ class ParticleMesh(object):
             dmass = mass
             if not _is_scalar(mass):
                 dmass, _ = to_device(mass, be.device, 'mass')
+            remote = layout.remote_recvlength or layout.comm.size > 1
+            handle = None
+            if remote:
+                # the rows bound for other ranks leave first (one all-to-all-v for positions and masses, on
+                # RCCL's stream) and travel while the caller's own particles are painted
+                if _is_scalar(mass):
+                    handle = layout.exchange_remote(dpos, async_op=True)
+                else:
+                    handle = layout.exchange_remote(dpos, dmass, async_op=True)
             resampler.paint(out.value, dpos, mass=dmass, transform=transform, diffdir=gradient,
                             _overwrite=not hold)
-            if layout.remote_recvlength or layout.comm.size > 1:
+            if remote:
                 if _is_scalar(mass):
-                    rpos, rmass = layout.exchange_remote(dpos), dmass
+                    rpos, rmass = handle.wait(), dmass
                 else:
-                    rpos, rmass = layout.exchange_remote(dpos, dmass)     # one all-to-all-v for both
+                    rpos, rmass = handle.wait()
                 if len(rpos):
                     resampler.paint(out.value, rpos, mass=rmass, transform=transform, diffdir=gradient)
             return out

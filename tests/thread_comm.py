@@ -59,8 +59,11 @@ class ThreadComm(object):
         allc = self._exchange(numpy.array(sendcounts))
         return numpy.array([allc[s][self.rank] for s in range(self.size)])
 
-    def alltoallv(self, send, sendcounts, recv, recvcounts):
+    def alltoallv(self, send, sendcounts, recv, recvcounts, async_op=False):
         self.alltoall(send, recv, [int(c) for c in sendcounts], [int(c) for c in recvcounts], rows=True)
+        if async_op:
+            from pmesh_amd.comm import _Done
+            return _Done()
 
     def alltoall(self, send, recv, send_splits=None, recv_splits=None, rows=False, async_op=False):
         self._alltoall(send, recv, send_splits, recv_splits, rows)
