@@ -700,6 +700,30 @@ def case_promote_and_pack(be, comm):
         assert_array_equal(x, y)
 
 
+def case_async_ghost_exchange(be, comm):
+    """Layout.exchange_remote / gather_remote_add with async_op=True (what paint / readout use to run the
+    particle exchange under their local work) give what the blocking calls give, packed or not"""
+    from pmesh_amd import domain
+    P = comm.size
+    dcop = domain.GridND([numpy.linspace(0, 1, P + 1)], comm=comm, periodic=True)
+    rng = numpy.random.RandomState(50 + comm.rank)
+    pos = torch.from_numpy(rng.uniform(0, 1, size=(200, 3))).to(be.device)
+    mass = torch.from_numpy(rng.uniform(size=200)).to(be.device)
+    a = dcop.decompose(pos[:, :1], smoothing=0.08)
+    b = dcop.decompose(pos[:, :1], smoothing=0.08)
+    rp, rm = a.exchange_remote(pos, mass)
+    h = b.exchange_remote(pos, mass, async_op=True)
+    rp2, rm2 = h.wait()
+    assert torch.equal(rp, rp2) and torch.equal(rm, rm2)
+    assert torch.equal(b.exchange_remote(pos), rp)                      # remembered per source tensor
+    vals = rp[:, 0] * 2 + rm
+    out1 = torch.zeros(200, dtype=torch.float64, device=be.device)
+    out2 = torch.zeros(200, dtype=torch.float64, device=be.device)
+    a.gather_remote_add(vals, out1)
+    b.gather_remote_add(vals.clone(), None, async_op=True).wait(out2)
+    assert torch.allclose(out1, out2, rtol=0, atol=1e-15)
+
+
 def case_comm_trace(be, comm):
     """the record of the data-path collectives that bench.py --gpus N reports (pmesh_amd.comm.trace):
     a slab FFT round trip moves the whole half spectrum twice, (P-1)/P of it off rank"""
@@ -724,7 +748,7 @@ def case_comm_trace(be, comm):
     assert 0.7 * full <= total <= 1.3 * full, (total, full)
 
 
-CASES = [case_comm_trace, case_length_check_is_collective, case_promote_and_pack, case_pencil,
+CASES = [case_comm_trace, case_async_ghost_exchange, case_length_check_is_collective, case_promote_and_pack, case_pencil,
          case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
