@@ -169,6 +169,15 @@ __device__ __forceinline__ int64_t col_offset(const ColAddr &a, int64_t b)
     return q * a.cpitch + (b - q * a.cw);
 }
 
+// offset of line n of a column.  With n = tj + c, tj < TPC, c a multiple of TPC and TPC, 1 << sh powers
+// of two it splits into line_offset(tj) + line_offset(c) — a per-thread part computed once and a part
+// that is the same for the whole workgroup (scalar unit); the kernels of the power-of-two lengths
+// address their lines that way instead of four 64-bit multiply-adds per element.
+__device__ __forceinline__ int64_t line_offset(const ColAddr &a, int n)
+{
+    return (int64_t)(n >> a.sh) * a.shi + (int64_t)(n & a.mask) * a.sn;
+}
+
 struct ColGeom {
     int64_t A, B;          // outer and inner batch extents
     int32_t N, logN;
@@ -198,6 +207,47 @@ template <typename T, int RB = 128> __device__ __forceinline__ int lds_index(int
     // the column slot is rotated by the row number: a wave that walks along a column
     // (the transposing load/store of the row kernel) then also spreads over all banks
     return ((row >> 1) * 2 + half) * W + ((col + row) & (W - 1));
+}
+
+// The same index in two steps, for rows of the form `row + c` with c a compile-time constant whose set
+// bits are clear in `row` (row + c == row | c: no carries).  Every term of lds_index is then additive or
+// XOR-linear in the two parts, so the per-thread part is computed once (RowBase) and every access costs
+// a constant that the compiler folds into the offset field of the ds_read / ds_write:
+//   (row + c) & ~1 = (row & ~1) + (c & ~1),   half(row + c) = half(row) ^ half(c),
+//   rotation (col + row + c) & (W - 1): independent of c when c is a multiple of W.
+// The power-of-two lengths address every line this way (rows tj + u * TPC, butterfly legs j + r * N/R,
+// outputs base + r * Ns); before, the swizzle was recomputed for every element — 8 integer operations
+// against the 6 floating-point ones of the butterfly itself.
+// ROT = false: without the rotation of the column slot.  The rotation only matters to accesses that walk
+// along a column of the tile with consecutive lanes (the transposing load / store of the row kernel); the
+// column kernels never do — their lanes always cover whole 128-byte tile rows, and permuting the slots
+// inside a row changes nothing for the banks — so their tiles are laid out without it and the column slot
+// costs no instruction at all.
+template <typename T, int RB> struct RowBase { int e[2]; int cr; };
+
+template <typename T, int RB, bool ROT = true> __device__ __forceinline__ RowBase<T, RB> row_base(int row, int col)
+{
+    constexpr int W = RB / (int)sizeof(cpx<T>);
+    RowBase<T, RB> b;
+    b.cr = ROT ? col + row : col;
+    if (RB == 256) {
+        b.e[0] = b.e[1] = row * W;
+    } else {
+        const int half = (row ^ (row >> 3) ^ (row >> 6) ^ (row >> 9)) & 1;
+        b.e[0] = ((row & ~1) + half) * W;
+        b.e[1] = ((row & ~1) + (half ^ 1)) * W;
+    }
+    if (!ROT) { b.e[0] += col; b.e[1] += col; }
+    return b;
+}
+
+template <typename T, int RB, bool ROT = true> __device__ __forceinline__ int lds_at(const RowBase<T, RB> &b, int c)
+{
+    constexpr int W = RB / (int)sizeof(cpx<T>);
+    const int rot = ROT ? (b.cr + c) & (W - 1) : 0;
+    if (RB == 256) return b.e[0] + c * W + rot;
+    const int hc = (c ^ (c >> 3) ^ (c >> 6) ^ (c >> 9)) & 1;
+    return b.e[hc] + (c & ~1) * W + rot;
 }
 
 // One pass of the Stockham autosort FFT over the LDS-resident tile.  Lane mapping: the W
@@ -253,15 +303,64 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
     __syncthreads();
 }
 
+// The pass for power-of-two lengths: everything but the lane's position is a compile-time constant.
+// tb = row_base(tj, col) of the calling kernel: the legs of butterfly j = tj + q * TPC are the rows
+// tj + (q * TPC + r * N/R) (tj < TPC <= N/R: disjoint bits).  The arithmetic is that of stockham_pass,
+// operation for operation: the results are bit-identical.
+template <typename T, bool INV, int R, int RB, bool HALFTW, int N, int NS, int TPC, int TWS, bool ROT>
+__device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj)
+{
+    constexpr int nb = N / R;
+    constexpr int per = nb / TPC;
+    static_assert((N & (N - 1)) == 0 && (TPC & (TPC - 1)) == 0 && nb % TPC == 0 && per >= 1 && per <= 4,
+                  "power-of-two pass: butterflies per thread");
+    cpx<T> v[per][R];
+#pragma unroll
+    for (int q = 0; q < per; q++) {
+        const int j = tj + q * TPC;
+        const int k = j & (NS - 1);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cpx<T> x = buf[lds_at<T, RB, ROT>(tb, q * TPC + r * nb)];
+            if (r > 0 && NS > 1) {
+                const int m = r * k * (N / (NS * R));
+                cpx<T> w;
+                if (HALFTW) {
+                    w = tw[m & (N / 2 - 1)];
+                    if (m & (N / 2)) { w.x = -w.x; w.y = -w.y; }
+                } else {
+                    w = tw[m * TWS];
+                }
+                if (INV) w.y = -w.y;
+                x = cmul(x, w);
+            }
+            v[q][r] = x;
+        }
+        fftR<T, INV, R>(v[q]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < per; q++) {
+        const int j = tj + q * TPC;
+        const int k = j & (NS - 1);
+        // outputs: rows (j - k) * R + k + r * NS — k in the low bits, r above them, j / NS on top
+        const RowBase<T, RB> wb = row_base<T, RB, ROT>((j - k) * R + k, col);
+#pragma unroll
+        for (int r = 0; r < R; r++) buf[lds_at<T, RB, ROT>(wb, r * NS)] = v[q][r];
+    }
+    __syncthreads();
+}
+
 // Fused transfer (SIMPLE forms).  The wavenumbers along axes 1 and 2 depend only on the
 // column, so they are computed once per tile and thread; per element only axis 0 remains.
 struct ColK { double k1, k2, k12sq; };
 
 __device__ __forceinline__ double kcoord(const ColGeom &g, int d, int64_t i)
 {
-    int64_t gi = i + g.start[d];
+    // (mesh sides are below 2^31: 32-bit integers convert to double in one instruction, 64-bit ones in four)
+    const int32_t gi = (int32_t)i + (int32_t)g.start[d];
     double wi = (double)gi;
-    if (gi >= g.nmesh[d] / 2) wi -= g.nmesh[d];
+    if (gi >= (int32_t)g.nmesh[d] / 2) wi -= (double)(int32_t)g.nmesh[d];
     wi *= g.dw[d];
     return wi * g.nl[d];
 }
@@ -353,11 +452,26 @@ template <typename T, int LOGN, int RB> struct HalfTw {
 };
 
 // the Stockham passes of an N-point transform over the LDS-resident tile (compile-time radices)
+template <typename T, int LOGN, bool INV, int RB, bool HT, int TPC, int TWS, bool ROT, int I, int NS>
+__device__ __forceinline__ void run_passes_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj)
+{
+    using Rd = Radices<LOGN>;
+    if constexpr (I < Rd::n) {
+        stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT>(buf, tw, tb, col, tj);
+        run_passes_p2<T, LOGN, INV, RB, HT, TPC, TWS, ROT, I + 1, NS * Rd::r[I]>(buf, tw, tb, col, tj);
+    }
+}
+
 template <typename T, int LOGN, bool INV, int RB, bool HT>
 __device__ __forceinline__ void run_passes(cpx<T> *buf, const cpx<T> *tw, int col, int tj)
 {
     constexpr int N = Len<LOGN>::N;
     constexpr int TPC = N / Rpt<T, LOGN>::value;
+    if constexpr (LOGN < 16) {
+        const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);      // column kernels: tiles without the rotation
+        run_passes_p2<T, LOGN, INV, RB, HT, TPC, 1, false, 0, 1>(buf, tw, tb, col, tj);
+        return;
+    }
     int Ns = 1;
     using Rd = Radices<LOGN>;
     if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
@@ -413,7 +527,10 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     // two (fused pass 680 -> 490 us at 512^3, float passes 343 -> 250 us).
     constexpr bool ONE_TILE = N < PMX_COL_STRIDE_FROM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += (ONE_TILE ? ntiles : (int64_t)gridDim.x)) {
-        const int64_t a = tile / tilesB, b0 = (tile - a * tilesB) * W;
+        // (the launcher keeps the tile count below 2^31: a 32-bit division, a dozen scalar instructions
+        // instead of the ~150 of the 64-bit one)
+        const uint32_t ua = (uint32_t)tile / (uint32_t)tilesB;
+        const int64_t a = ua, b0 = (int64_t)((uint32_t)tile - ua * (uint32_t)tilesB) * W;
         const bool colok = b0 + col < g.B;
         // plain: one base per tile, lanes add their column; REMAP: a base per lane
         const cpx<T> *ibase = src + a * g.in.sa + (REMAP ? (colok ? col_offset(g.in, b0 + col) : 0) : b0);
@@ -422,33 +539,42 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         ColK ck = {0, 0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         __syncthreads();
+        constexpr bool P2 = LOGN < 16;      // power-of-two length: additive addressing (line_offset, lds_at)
+        const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);
+        const cpx<T> *ithread = ibase + (line_offset(g.in, tj) + lcol);
+        cpx<T> *othread = obase + (line_offset(g.out, tj) + lcol);
         // load: RPT rows per thread, all loads issued before the first LDS store
         cpx<T> ld[RPT];
 #pragma unroll
-        for (int u = 0; u < RPT; u++) {
-            int n = tj + u * TPC;
-            ld[u] = colok ? ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + lcol]
-                          : cpx<T>{0, 0};
+        for (int u = 0; u < RPT; u++) ld[u] = cpx<T>{0, 0};
+        if (colok) {
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                int n = tj + u * TPC;
+                if (P2) ld[u] = ithread[line_offset(g.in, u * TPC)];
+                else ld[u] = ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + lcol];
+            }
         }
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
             int n = tj + u * TPC;
             cpx<T> v = ld[u];
             if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
-            buf[lds_index<T, RB>(n, col)] = v;
+            buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col)] = v;
         }
         __syncthreads();
         run_passes<T, LOGN, INV, RB, HT>(buf, tw, col, tj);
         // store
         const T sc = (T)g.scale;
+        if (colok) {
 #pragma unroll
-        for (int u = 0; u < RPT; u++) {
-            int n = tj + u * TPC;
-            if (colok) {
-                cpx<T> v = buf[lds_index<T, RB>(n, col)];
+            for (int u = 0; u < RPT; u++) {
+                int n = tj + u * TPC;
+                cpx<T> v = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
-                obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn + lcol] = v;
+                if (P2) othread[line_offset(g.out, u * TPC)] = v;
+                else obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn + lcol] = v;
             }
         }
     }
@@ -490,14 +616,19 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
     ColK ck = {0, 0, 0};
     if (APPLY && colok) ck = column_k(g, b0 + col);
     __syncthreads();
+    constexpr bool P2 = LOGN < 16;
+    const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);
+    cpx<T> *ithread = base + ((int64_t)tj * g.in.sn + col);
+    cpx<T> *othread = base + ((int64_t)tj * g.out.sn + col);
     cpx<T> ld[RPT];
 #pragma unroll
-    for (int u = 0; u < RPT; u++) {
-        int n = tj + u * TPC;
-        ld[u] = colok ? base[(int64_t)n * g.in.sn + col] : cpx<T>{0, 0};
+    for (int u = 0; u < RPT; u++) ld[u] = cpx<T>{0, 0};
+    if (colok) {
+#pragma unroll
+        for (int u = 0; u < RPT; u++) ld[u] = ithread[(int64_t)(u * TPC) * g.in.sn];
     }
 #pragma unroll
-    for (int u = 0; u < RPT; u++) buf[lds_index<T, RB>(tj + u * TPC, col)] = ld[u];
+    for (int u = 0; u < RPT; u++) buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)] = ld[u];
     __syncthreads();
     run_passes<T, LOGN, false, RB, HT>(buf, tw, col, tj);
     // what the forward pass would have stored and the inverse pass loaded: the mode times the forward scale,
@@ -506,18 +637,19 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 #pragma unroll
     for (int u = 0; u < RPT; u++) {
         int n = tj + u * TPC;
-        cpx<T> v = buf[lds_index<T, RB>(n, col)];
+        const int at = P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col);
+        cpx<T> v = buf[at];
         v.x *= sc;
         v.y *= sc;
         if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
-        buf[lds_index<T, RB>(n, col)] = v;
+        buf[at] = v;
     }
     __syncthreads();
     run_passes<T, LOGN, true, RB, HT>(buf, tw, col, tj);
+    if (colok) {
 #pragma unroll
-    for (int u = 0; u < RPT; u++) {
-        int n = tj + u * TPC;
-        if (colok) base[(int64_t)n * g.out.sn + col] = buf[lds_index<T, RB>(n, col)];
+        for (int u = 0; u < RPT; u++)
+            othread[(int64_t)(u * TPC) * g.out.sn] = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)];
     }
 }
 
@@ -566,6 +698,115 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
         // planes) whose stride exceeds rpp*pitch by plane_extra elements
         cpx<T> *data = data_ + (rpp > 0 ? (r0 / rpp) * plane_extra : 0);
         __syncthreads();
+        if constexpr (LOGM < 16 && NT % M == 0) {
+            // Power-of-two rows.  NT is a multiple of M (all but 2048 reals in double, whose tile has 4 rows), so a thread keeps ONE position along the row for all
+            // its LPT elements (n = tid % M) and steps through the rows of the tile (r = tid / M + u * NT / M):
+            // the swizzled LDS row and the global address are computed once per thread, the per-element part is
+            // a rotation of the column slot and a workgroup-uniform row stride.
+            constexpr int RSTEP = NT / M;                      // rows between successive elements of a thread
+            static_assert(NT % M == 0 && RSTEP * LPT == W, "row kernel: thread -> element mapping");
+            const int n = tid & (M - 1), rt = tid / M;
+            const bool full = r0 + W <= nrows;                 // all but (at most) the last tile
+            cpx<T> *gthread = data + ((r0 + rt) * pitch + n);
+            const RowBase<T, RB> nb_ = row_base<T, RB>(n, 0);
+            auto at = [&](const RowBase<T, RB> &b, int r) __attribute__((always_inline)) {
+                return b.e[0] + ((b.cr + r) & (W - 1));
+            };
+            cpx<T> ld[LPT];
+#pragma unroll
+            for (int u = 0; u < LPT; u++) ld[u] = cpx<T>{0, 0};
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < LPT; u++) ld[u] = gthread[(int64_t)(u * RSTEP) * pitch];
+            } else {
+#pragma unroll
+                for (int u = 0; u < LPT; u++)
+                    if (r0 + rt + u * RSTEP < nrows) ld[u] = gthread[(int64_t)(u * RSTEP) * pitch];
+            }
+            if (INV && tid < W) xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
+#pragma unroll
+            for (int u = 0; u < LPT; u++) buf[at(nb_, rt + u * RSTEP)] = ld[u];
+            __syncthreads();
+            if (INV) {
+                // X -> Z, pairs (k, M-k) handled together, in place: k in [1, M/2) by all threads (k fixed per
+                // thread), k = 0 (paired with the Nyquist mode kept in xm) and k = M/2 (its own partner) likewise
+                constexpr int H = M / 2;
+                constexpr int PSTEP = NT / H;
+                const int k = tid & (H - 1), rp = tid / H;
+                const int k2 = M - k;
+                const RowBase<T, RB> bk = row_base<T, RB>(k, 0), bq = row_base<T, RB>(k == 0 ? H : k2, 0);
+                cpx<T> w = tw[k];
+                w.y = -w.y;                                  // conj(w)^k = exp(+2 pi i k / N)
+#pragma unroll
+                for (int i = 0; i < W / PSTEP; i++) {
+                    const int r = rp + i * PSTEP;
+                    cpx<T> xk = buf[at(bk, r)];
+                    cpx<T> xq = (k == 0) ? xm[r] : buf[at(bq, r)];
+                    if (k == 0) { xk.y = 0; xq.y = 0; }
+                    cpx<T> A = {xk.x + xq.x, xk.y - xq.y}, D = {xk.x - xq.x, xk.y + xq.y};
+                    cpx<T> B = cmul(w, D);
+                    buf[at(bk, r)] = {A.x - B.y, A.y + B.x};            // A + i B
+                    if (k != 0) {
+                        cpx<T> Ac = {A.x, -A.y};
+                        cpx<T> Dc = {-D.x, D.y};
+                        cpx<T> wc = {-w.x, w.y};
+                        cpx<T> Bc = cmul(wc, Dc);
+                        buf[at(bq, r)] = {Ac.x - Bc.y, Ac.y + Bc.x};
+                    } else {
+                        // k = 0's thread also takes k = M/2, whose partner is itself (only Z[M/2] is written)
+                        cpx<T> xh = buf[at(bq, r)];
+                        cpx<T> Ah = {xh.x + xh.x, xh.y - xh.y}, Dh = {xh.x - xh.x, xh.y + xh.y};
+                        cpx<T> wh = tw[H];
+                        wh.y = -wh.y;
+                        cpx<T> Bh = cmul(wh, Dh);
+                        buf[at(bq, r)] = {Ah.x - Bh.y, Ah.y + Bh.x};
+                    }
+                }
+                __syncthreads();
+            }
+            {
+                const RowBase<T, RB> tb = row_base<T, RB>(tj, col);
+                run_passes_p2<T, LOGM, INV, RB, false, TPC, 2, true, 0, 1>(buf, tw, tb, col, tj);
+            }
+            if (!INV) {
+                // Z -> X for k = 0..M-1 (k = n: fixed per thread), then the Nyquist mode and the rest of its line
+                const RowBase<T, RB> bq = row_base<T, RB>(n == 0 ? 0 : M - n, 0);
+                const cpx<T> w = tw[n];
+                auto mode = [&](cpx<T> zk, cpx<T> zq, cpx<T> wk) __attribute__((always_inline)) {
+                    cpx<T> E = {(T)0.5 * (zk.x + zq.x), (T)0.5 * (zk.y - zq.y)};       // (zk + conj zq)/2
+                    cpx<T> D = {(T)0.5 * (zk.x - zq.x), (T)0.5 * (zk.y + zq.y)};       // (zk - conj zq)/2
+                    cpx<T> wd = cmul(wk, D);
+                    cpx<T> X = {E.x + wd.y, E.y - wd.x};                               // X = E - i * w * D
+                    X.x *= sc; X.y *= sc;
+                    return X;
+                };
+#pragma unroll
+                for (int u = 0; u < LPT; u++) {
+                    const int r = rt + u * RSTEP;
+                    cpx<T> X = mode(buf[at(nb_, r)], buf[at(bq, r)], w);
+                    if (full || r0 + r < nrows) gthread[(int64_t)(u * RSTEP) * pitch] = X;
+                }
+                constexpr int LINE = 128 / (int)sizeof(cpx<T>);
+                const int tail = (pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
+                const RowBase<T, RB> b0 = row_base<T, RB>(0, 0);
+                for (int q = tid; q < W * tail; q += NT) {
+                    const int r = q / tail, j = q - r * tail;
+                    if (r0 + r < nrows) {
+                        cpx<T> z0 = buf[at(b0, r)];
+                        data[(r0 + r) * pitch + M + j] = (j == 0) ? mode(z0, z0, cpx<T>{(T)-1, (T)0}) : cpx<T>{(T)0, (T)0};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < LPT; u++) {
+                    const int r = rt + u * RSTEP;
+                    cpx<T> v = buf[at(nb_, r)];
+                    v.x *= sc; v.y *= sc;
+                    if (full || r0 + r < nrows) gthread[(int64_t)(u * RSTEP) * pitch] = v;
+                }
+            }
+            continue;
+        }
         // load W rows, consecutive lanes along the row
         cpx<T> ld[LPT];
 #pragma unroll
@@ -611,6 +852,10 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             __syncthreads();
         }
         int Ns = 1;
+        if constexpr (LOGM < 16) {
+            const RowBase<T, RB> tb = row_base<T, RB>(tj, col);
+            run_passes_p2<T, LOGM, INV, RB, false, TPC, 2, true, 0, 1>(buf, tw, tb, col, tj);
+        } else {
         if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
         Ns *= Rd::r[0];
         if (Rd::n > 1) {
@@ -633,6 +878,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             else if (Rd::r[3] == 5) stockham_pass<T, INV, 5, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
             Ns *= Rd::r[3];
+        }
         }
         if (!INV) {
             // Z -> X for k = 0..M, consecutive lanes along the row.  The Nyquist mode k = M starts a new

@@ -9,7 +9,7 @@ for cfg in "$@"; do
 import json, sys
 try:
     d=json.loads(open("gpurun_out/v.json").read().strip().splitlines()[-1]); st=d["stages_ms"]
-    print("[%-6s] %-42s %.3f ms  bin %.2f paint %.2f readout %.2f" % (sys.argv[1], sys.argv[2], d["ms_per_step"], st["bin"], st["paint"], st["readout"]))
+    print("[%-6s] %-42s %.3f ms  bin %.2f paint %.2f r2c %.3f c2r %.3f readout %.2f" % (sys.argv[1], sys.argv[2], d["ms_per_step"], st["bin"], st["paint"], st["r2c"], st["c2r"], st["readout"]))
 except Exception as ex:
     print("[%s] %s FAILED" % (sys.argv[1], sys.argv[2]), open("gpurun_out/v.err").read()[-300:])
 PY
