@@ -178,6 +178,15 @@ __device__ __forceinline__ int64_t line_offset(const ColAddr &a, int n)
     return (int64_t)(n >> a.sh) * a.shi + (int64_t)(n & a.mask) * a.sn;
 }
 
+// a workgroup-uniform offset, pinned to scalar registers where it is used: in the loop of the pipelined
+// kernel the compiler otherwise hoists the RPT line offsets, parks them in VECTOR registers across the
+// passes and spills them
+template <bool PIN> __device__ __forceinline__ int64_t uniform_offset(int64_t off)
+{
+    if (PIN) asm volatile("" : "+s"(off));
+    return off;
+}
+
 struct ColGeom {
     int64_t A, B;          // outer and inner batch extents
     int32_t N, logN;
@@ -451,6 +460,25 @@ template <typename T, int LOGN, int RB> struct HalfTw {
     static constexpr bool value = (LOGN < 16) && (full > 150 * 1024 || (full > 76 * 1024 && full <= 80 * 1024));
 };
 
+// tiles of which only one fits a CU beside its twiddles: the column kernel pipelines them (see there)
+#ifndef PMX_COL_PIPE
+#define PMX_COL_PIPE 1
+#endif
+template <typename T, int LOGN, int RB> struct ColPipe {
+    static constexpr size_t bytes = (size_t)(Len<LOGN>::N * (RB / (int)sizeof(cpx<T>))
+                                             + (HalfTw<T, LOGN, RB>::value ? Len<LOGN>::N / 2 : Len<LOGN>::N)) * sizeof(cpx<T>);
+    static constexpr bool value = PMX_COL_PIPE && bytes > 80 * 1024;
+};
+
+// The round-trip kernel (colfft_round_kernel) has the same persistent form behind PMX_ROUND_PIPE, off by default: its
+// two transforms and the double-precision transfer arithmetic leave no room for the 32 registers of the prefetched
+// tile within 128 VGPRs (1024 threads), the compiler spills the prefetched lines themselves, and 1024^3 in double
+// went from 6.9 to 8.6 ms per launch; with 512 threads of 16 lines (256 VGPRs) 7.3 ms.
+#ifndef PMX_ROUND_PIPE
+#define PMX_ROUND_PIPE 0
+#endif
+template <typename T, int LOGN, int RB> struct RoundPipe { static constexpr bool value = PMX_ROUND_PIPE && ColPipe<T, LOGN, RB>::value; };
+
 // the Stockham passes of an N-point transform over the LDS-resident tile (compile-time radices)
 template <typename T, int LOGN, bool INV, int RB, bool HT, int TPC, int TWS, bool ROT, int I, int NS>
 __device__ __forceinline__ void run_passes_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj)
@@ -520,41 +548,70 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 
     const int64_t tilesB = (g.B + W - 1) / W;
     const int64_t ntiles = g.A * tilesB;
-    const int col = tid % W, tj = tid / W;   // W consecutive lanes = one 128-byte row segment
+    const int col_ = tid % W, tj_ = tid / W;   // W consecutive lanes = one 128-byte row segment
     // One workgroup per tile (grid = ntiles), and the loop says so: with a grid-stride loop the
     // optimiser keeps everything tile-invariant alive across the FFT passes — 156 / 166 / 212
     // VGPRs for the chunk, fused-transfer and float variants, i.e. one workgroup per CU instead of
     // two (fused pass 680 -> 490 us at 512^3, float passes 343 -> 250 us).
-    constexpr bool ONE_TILE = N < PMX_COL_STRIDE_FROM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += (ONE_TILE ? ntiles : (int64_t)gridDim.x)) {
-        // (the launcher keeps the tile count below 2^31: a 32-bit division, a dozen scalar instructions
-        // instead of the ~150 of the 64-bit one)
+    // PIPE (tiles that leave room for ONE workgroup per CU: N = 1024 / 768 / ... in double): the workgroup is
+    // persistent and loads its NEXT tile into registers while the passes of the current one run out of LDS.
+    // With a single workgroup on the CU nothing else would overlap the three phases — measured at 1024^3
+    // in double, 17 us per tile = 6 us load + 5 us passes + 6 us store, where the memory side alone needs 12.
+    constexpr bool PIPE = ColPipe<T, LOGN, RB>::value;
+    constexpr bool ONE_TILE = !PIPE && N < PMX_COL_STRIDE_FROM;
+    constexpr bool P2 = LOGN < 16;      // power-of-two length: additive addressing (line_offset, lds_at)
+    const int64_t step = ONE_TILE ? ntiles : (int64_t)gridDim.x;
+    // (the launcher keeps the tile count below 2^31: a 32-bit division, a dozen scalar instructions
+    // instead of the ~150 of the 64-bit one)
+    auto place = [&](int64_t tile, int64_t &a, int64_t &b0) __attribute__((always_inline)) {
         const uint32_t ua = (uint32_t)tile / (uint32_t)tilesB;
-        const int64_t a = ua, b0 = (int64_t)((uint32_t)tile - ua * (uint32_t)tilesB) * W;
+        a = ua;
+        b0 = (int64_t)((uint32_t)tile - ua * (uint32_t)tilesB) * W;
+    };
+    // load: RPT rows per thread, all loads issued before the first LDS store
+    auto load_tile = [&](int64_t tile, cpx<T> (&ld)[RPT]) __attribute__((always_inline)) {
+        int tj = tj_, col = col_;
+        if (PIPE) asm volatile("" : "+v"(tj), "+v"(col));       // (no hoisting of the addresses: see the loop below)
+        int64_t a, b0;
+        place(tile, a, b0);
         const bool colok = b0 + col < g.B;
         // plain: one base per tile, lanes add their column; REMAP: a base per lane
         const cpx<T> *ibase = src + a * g.in.sa + (REMAP ? (colok ? col_offset(g.in, b0 + col) : 0) : b0);
+        const int lcol = REMAP ? 0 : col;
+        const cpx<T> *ithread = ibase + (line_offset(g.in, tj) + lcol);
+        int64_t uoff[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            ld[u] = cpx<T>{0, 0};
+            uoff[u] = P2 ? uniform_offset<PIPE>(line_offset(g.in, u * TPC)) : 0;
+        }
+        if (colok) {
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                int n = tj + u * TPC;
+                if (P2) ld[u] = ithread[uoff[u]];
+                else ld[u] = ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + lcol];
+            }
+        }
+    };
+    cpx<T> ld[RPT];
+    auto do_tile = [&](int64_t tile) __attribute__((always_inline)) {
+        // (the lane's position is made opaque per trip: everything derived from it — the LDS addresses of
+        // every pass — would otherwise be hoisted out of the loop and held in registers across it, 70+
+        // VGPRs spilled at N = 1024; recomputing them costs a few dozen instructions per tile)
+        int tj = tj_, col = col_;
+        if (!ONE_TILE) asm volatile("" : "+v"(tj), "+v"(col));
+        const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);
+        int64_t a, b0;
+        place(tile, a, b0);
+        const bool colok = b0 + col < g.B;
         cpx<T> *obase = dst + a * g.out.sa + (REMAP ? (colok ? col_offset(g.out, b0 + col) : 0) : b0);
         const int lcol = REMAP ? 0 : col;
         ColK ck = {0, 0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         __syncthreads();
-        constexpr bool P2 = LOGN < 16;      // power-of-two length: additive addressing (line_offset, lds_at)
-        const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);
-        const cpx<T> *ithread = ibase + (line_offset(g.in, tj) + lcol);
         cpx<T> *othread = obase + (line_offset(g.out, tj) + lcol);
-        // load: RPT rows per thread, all loads issued before the first LDS store
-        cpx<T> ld[RPT];
-#pragma unroll
-        for (int u = 0; u < RPT; u++) ld[u] = cpx<T>{0, 0};
-        if (colok) {
-#pragma unroll
-            for (int u = 0; u < RPT; u++) {
-                int n = tj + u * TPC;
-                if (P2) ld[u] = ithread[line_offset(g.in, u * TPC)];
-                else ld[u] = ibase[(int64_t)(n >> g.in.sh) * g.in.shi + (int64_t)(n & g.in.mask) * g.in.sn + lcol];
-            }
-        }
+        if (!PIPE) load_tile(tile, ld);
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
             int n = tj + u * TPC;
@@ -563,21 +620,52 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
             buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col)] = v;
         }
         __syncthreads();
+        if (PIPE && tile + step < ntiles) load_tile(tile + step, ld);
+#ifndef PMX_EXP_NOPASS
         run_passes<T, LOGN, INV, RB, HT>(buf, tw, col, tj);
+#endif
         // store
         const T sc = (T)g.scale;
-        if (colok) {
+        int64_t uoff[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) uoff[u] = P2 ? uniform_offset<PIPE>(line_offset(g.out, u * TPC)) : 0;
+        auto store_lines = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
                 int n = tj + u * TPC;
                 cpx<T> v = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
-                if (P2) othread[line_offset(g.out, u * TPC)] = v;
+                if (P2) othread[uoff[u]] = v;
                 else obase[(int64_t)(n >> g.out.sh) * g.out.shi + (int64_t)(n & g.out.mask) * g.out.sn + lcol] = v;
             }
+        };
+        if (PIPE) {
+            // whole tiles store without a lane mask, i.e. without a branch the wave could skip: only then does
+            // the compiler know that RPT stores follow the prefetch loads (see the peeled first tile below).  The
+            // ragged last tile of a plane drains its memory operations instead.
+            if (b0 + W <= g.B) {
+                store_lines();
+            } else {
+                if (colok) store_lines();
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            }
+        } else if (colok) {
+            store_lines();
         }
+    };
+    int64_t tile = blockIdx.x;
+    if (PIPE) {
+        // The first tile is peeled off the loop: the loop is then only ever entered with "8 loads, then 8 stores"
+        // in flight, and the wait for the prefetched lines at its top lets the stores behind them drain on their
+        // own (s_waitcnt vmcnt(15..8)).  Entered straight from the prologue's loads, the compiler has to merge the
+        // two states into vmcnt(7..0): every tile would wait for the write acknowledgements of the one before.
+        if (tile >= ntiles) return;
+        load_tile(tile, ld);
+        do_tile(tile);
+        tile += step;
     }
+    for (; tile < ntiles; tile += step) do_tile(tile);
 }
 
 // The last pass of r2c and the first pass of c2r run along the same axis: for a caller that goes r2c -> transfer ->
@@ -592,7 +680,8 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 #define PMX_ROUND_WAVES 4
 #endif
 template <typename T, int LOGN, bool APPLY, int RB>
-__global__ void __launch_bounds__((Len<LOGN>::N / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))), PMX_ROUND_WAVES)
+__global__ void __launch_bounds__((Len<LOGN>::N / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))),
+                                   (RoundPipe<T, LOGN, RB>::value ? 1 : PMX_ROUND_WAVES))
 colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 {
     constexpr int N = Len<LOGN>::N;
@@ -607,50 +696,91 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
     const int tid = threadIdx.x;
     for (int n = tid; n < (HT ? N / 2 : N); n += NT) tw[n] = twiddle[n];
     const int64_t tilesB = (g.B + W - 1) / W;
-    const int col = tid % W, tj = tid / W;
-    const int64_t tile = blockIdx.x;
-    if (tile >= tilesB) return;
-    const int64_t b0 = tile * W;
-    const bool colok = b0 + col < g.B;
-    cpx<T> *base = data + b0;
-    ColK ck = {0, 0, 0};
-    if (APPLY && colok) ck = column_k(g, b0 + col);
-    __syncthreads();
+    const int col_ = tid % W, tj_ = tid / W;
+    // PIPE: as in colfft_kernel (see RoundPipe for why it is off)
+    constexpr bool PIPE = RoundPipe<T, LOGN, RB>::value;
     constexpr bool P2 = LOGN < 16;
-    const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);
-    cpx<T> *ithread = base + ((int64_t)tj * g.in.sn + col);
-    cpx<T> *othread = base + ((int64_t)tj * g.out.sn + col);
+    const int64_t step = PIPE ? (int64_t)gridDim.x : tilesB;
+    auto load_tile = [&](int64_t tile, cpx<T> (&ld)[RPT]) __attribute__((always_inline)) {
+        int tj = tj_, col = col_;
+        if (PIPE) asm volatile("" : "+v"(tj), "+v"(col));
+        const int64_t b0 = tile * W;
+        const bool colok = b0 + col < g.B;
+        const cpx<T> *ithread = data + b0 + ((int64_t)tj * g.in.sn + col);
+        int64_t uoff[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            ld[u] = cpx<T>{0, 0};
+            uoff[u] = uniform_offset<PIPE>((int64_t)(u * TPC) * g.in.sn);
+        }
+        if (colok) {
+#pragma unroll
+            for (int u = 0; u < RPT; u++) ld[u] = ithread[uoff[u]];
+        }
+    };
     cpx<T> ld[RPT];
+    auto do_tile = [&](int64_t tile) __attribute__((always_inline)) {
+        int tj = tj_, col = col_;
+        if (PIPE) asm volatile("" : "+v"(tj), "+v"(col));
+        const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);
+        const int64_t b0 = tile * W;
+        const bool colok = b0 + col < g.B;
+        ColK ck = {0, 0, 0};
+        if (APPLY && colok) ck = column_k(g, b0 + col);
+        cpx<T> *othread = data + b0 + ((int64_t)tj * g.out.sn + col);
+        __syncthreads();
+        if (!PIPE) load_tile(tile, ld);
 #pragma unroll
-    for (int u = 0; u < RPT; u++) ld[u] = cpx<T>{0, 0};
-    if (colok) {
+        for (int u = 0; u < RPT; u++) buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)] = ld[u];
+        __syncthreads();
+        if (PIPE && tile + step < tilesB) load_tile(tile + step, ld);
+        run_passes<T, LOGN, false, RB, HT>(buf, tw, col, tj);
+        // what the forward pass would have stored and the inverse pass loaded: the mode times the forward scale,
+        // then the transfer function
+        const T sc = (T)g.scale;
+        // (PIPE: one line at a time — unrolled, the double-precision transfer arithmetic of all RPT lines is
+        // interleaved and, with the prefetched tile held in registers, spills 90-200 VGPRs)
+#pragma unroll PIPE ? 1 : RPT
+        for (int u = 0; u < RPT; u++) {
+            int n = tj + u * TPC;
+            const int at = P2 ? (PIPE ? lds_at<T, RB, false>(row_base<T, RB, false>(n, col), 0) : lds_at<T, RB, false>(tb, u * TPC))
+                              : lds_index<T, RB>(n, col);
+            cpx<T> v = buf[at];
+            v.x *= sc;
+            v.y *= sc;
+            if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
+            buf[at] = v;
+        }
+        __syncthreads();
+        run_passes<T, LOGN, true, RB, HT>(buf, tw, col, tj);
+        int64_t uoff[RPT];
 #pragma unroll
-        for (int u = 0; u < RPT; u++) ld[u] = ithread[(int64_t)(u * TPC) * g.in.sn];
-    }
+        for (int u = 0; u < RPT; u++) uoff[u] = uniform_offset<PIPE>((int64_t)(u * TPC) * g.out.sn);
+        auto store_lines = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < RPT; u++) buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)] = ld[u];
+            for (int u = 0; u < RPT; u++)
+                othread[uoff[u]] = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)];
+        };
+        if (PIPE) {
+            if (b0 + W <= g.B) {
+                store_lines();
+            } else {
+                if (colok) store_lines();
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see colfft_kernel
+            }
+        } else if (colok) {
+            store_lines();
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile >= tilesB) return;
     __syncthreads();
-    run_passes<T, LOGN, false, RB, HT>(buf, tw, col, tj);
-    // what the forward pass would have stored and the inverse pass loaded: the mode times the forward scale,
-    // then the transfer function
-    const T sc = (T)g.scale;
-#pragma unroll
-    for (int u = 0; u < RPT; u++) {
-        int n = tj + u * TPC;
-        const int at = P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col);
-        cpx<T> v = buf[at];
-        v.x *= sc;
-        v.y *= sc;
-        if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
-        buf[at] = v;
+    if (PIPE) {
+        load_tile(tile, ld);
+        do_tile(tile);
+        tile += step;
     }
-    __syncthreads();
-    run_passes<T, LOGN, true, RB, HT>(buf, tw, col, tj);
-    if (colok) {
-#pragma unroll
-        for (int u = 0; u < RPT; u++)
-            othread[(int64_t)(u * TPC) * g.out.sn] = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)];
-    }
+    for (; tile < tilesB; tile += step) do_tile(tile);
 }
 
 // ---- unit-stride real <-> half-complex row transform (the contiguous axis) ----------
@@ -922,6 +1052,18 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
     }
 }
 
+static int compute_units()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 // twiddle tables exp(-2 pi i m / N), one per (N, precision, device), created on first use
 struct TwKey { int n, es, dev; bool operator<(const TwKey &o) const { return n != o.n ? n < o.n : (es != o.es ? es < o.es : dev < o.dev); } };
 static std::map<TwKey, void *> g_tw;
@@ -963,6 +1105,11 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
     unsigned grid = (unsigned)((N < PMX_COL_STRIDE_FROM) ? tiles : (tiles < 256 * 16 ? tiles : 256 * 16));
+    if (ColPipe<T, LOGN, RB>::value) {
+        // persistent workgroups, one per CU (the tile leaves no room for a second)
+        const int64_t cus = compute_units();
+        grid = (unsigned)(tiles < cus ? tiles : cus);
+    }
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
         auto k = colfft_kernel<T, LOGN, INV, AP, RB, RM>;                                                      \
@@ -1194,11 +1341,16 @@ static int launch_round(const ColGeom &g, void *data, const void *tw, bool apply
     size_t lds = (size_t)(N * W + (HalfTw<T, LOGN, RB>::value ? N / 2 : N)) * sizeof(cpx<T>);
     int64_t tiles = (g.B + W - 1) / W;
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
+    unsigned grid = (unsigned)tiles;
+    if (RoundPipe<T, LOGN, RB>::value) {
+        const int64_t cus = compute_units();
+        grid = (unsigned)(tiles < cus ? tiles : cus);
+    }
 #define LAUNCH(AP)                                                                                             \
     do {                                                                                                       \
         auto k = colfft_round_kernel<T, LOGN, AP, RB>;                                                         \
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k<<<(unsigned)tiles, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                              \
+        k<<<grid, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                                       \
     } while (0)
     if (apply) LAUNCH(true); else LAUNCH(false);
 #undef LAUNCH
