@@ -335,7 +335,7 @@ __device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, 
                 const int m = r * k * (N / (NS * R));
                 cpx<T> w;
                 if (HALFTW) {
-                    w = tw[m & (N / 2 - 1)];
+                    w = tw[(m & (N / 2 - 1)) * TWS];
                     if (m & (N / 2)) { w.x = -w.x; w.y = -w.y; }
                 } else {
                     w = tw[m * TWS];
@@ -797,8 +797,20 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 #ifndef PMX_ROW_LPT
 #define PMX_ROW_LPT 8
 #endif
+// Rows whose tile and 2M twiddles fill just over half the LDS (M = 512 in double: 82 KB) keep only the first M
+// twiddles — all the X <-> Z step needs; the passes take w[m + M] = -w[m] — and hold their registers to 128, so
+// that two workgroups share a CU: the row passes of 1024^3 in double 3.9 -> ... ms.
+#ifndef PMX_ROW_HALFTW
+#define PMX_ROW_HALFTW 1
+#endif
+template <typename T, int LOGM, int RB> struct RowHalfTw {
+    static constexpr int M = Len<LOGM>::N, W = RB / (int)sizeof(cpx<T>);
+    static constexpr size_t full = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>), half = (size_t)(M * W + M + W) * sizeof(cpx<T>);
+    static constexpr bool value = PMX_ROW_HALFTW && LOGM < 16 && full > 80 * 1024 && half <= 80 * 1024;
+};
+
 template <typename T, int LOGM, bool INV, int RB>
-__global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)))
+__global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)), (RowHalfTw<T, LOGM, RB>::value ? 4 : 1))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
               int64_t rpp, int64_t plane_extra)
 {
@@ -809,11 +821,11 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
     constexpr int NT = TPC * W;
     extern __shared__ __align__(16) unsigned char smem[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
-    cpx<T> *tw = buf + M * W;          // 2M entries: exp(-2 pi i m / 2M)
-    cpx<T> *xm = tw + 2 * M;           // W entries: the Nyquist mode X[M] of every row
-    const int tid = threadIdx.x;
-    for (int n = tid; n < 2 * M; n += NT) tw[n] = twiddle[n];
-    const int col = tid % W, tj = tid / W;
+    constexpr bool HT = RowHalfTw<T, LOGM, RB>::value;
+    cpx<T> *tw = buf + M * W;          // 2M entries: exp(-2 pi i m / 2M) (HT: the first M)
+    cpx<T> *xm = tw + (HT ? M : 2 * M);           // W entries: the Nyquist mode X[M] of every row
+    const int tid0 = threadIdx.x;
+    for (int n = tid0; n < (HT ? M : 2 * M); n += NT) tw[n] = twiddle[n];
     const T sc = (T)scale;
     const int64_t ntiles = (nrows + W - 1) / W;
     using Rd = Radices<LOGM>;
@@ -823,6 +835,11 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
     // 2M twiddles per tile costs more than the registers bring: 1024^3 3.5 % slower — so only below)
     constexpr bool ONE_TILE = PMX_ROW_ONE_TILE && M < 512;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += (ONE_TILE ? ntiles : (int64_t)gridDim.x)) {
+        // (the lane's position is opaque per trip, as in the column kernel: what derives from it is recomputed
+        // per tile instead of being carried in registers across the loop)
+        int tidl = tid0;
+        if (!ONE_TILE) asm volatile("" : "+v"(tidl));
+        const int tid = tidl, col = tid % W, tj = tid / W;
         const int64_t r0 = tile * W;
         // rows are grouped in planes of rpp rows (a multiple of W: a tile never straddles two
         // planes) whose stride exceeds rpp*pitch by plane_extra elements
@@ -896,7 +913,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             }
             {
                 const RowBase<T, RB> tb = row_base<T, RB>(tj, col);
-                run_passes_p2<T, LOGM, INV, RB, false, TPC, 2, true, 0, 1>(buf, tw, tb, col, tj);
+                run_passes_p2<T, LOGM, INV, RB, HT, TPC, 2, true, 0, 1>(buf, tw, tb, col, tj);
             }
             if (!INV) {
                 // Z -> X for k = 0..M-1 (k = n: fixed per thread), then the Nyquist mode and the rest of its line
@@ -984,7 +1001,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
         int Ns = 1;
         if constexpr (LOGM < 16) {
             const RowBase<T, RB> tb = row_base<T, RB>(tj, col);
-            run_passes_p2<T, LOGM, INV, RB, false, TPC, 2, true, 0, 1>(buf, tw, tb, col, tj);
+            run_passes_p2<T, LOGM, INV, RB, HT, TPC, 2, true, 0, 1>(buf, tw, tb, col, tj);
         } else {
         if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB>(buf, tw, M, Ns, TPC, col, tj, 2);
         Ns *= Rd::r[0];
@@ -1178,7 +1195,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = M / PMX_ROW_LPT * W;
     static_assert(NT <= 1024 && NT % 64 == 0, "row kernel: workgroup size");
-    size_t lds = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>);
+    size_t lds = (size_t)(M * W + (RowHalfTw<T, LOGM, RB>::value ? M : 2 * M) + W) * sizeof(cpx<T>);
     int64_t tiles = (nrows + W - 1) / W;
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 row tiles in one pass");
     unsigned grid = (unsigned)((PMX_ROW_ONE_TILE && M < 512) ? tiles : (tiles < 256 * 64 ? tiles : 256 * 64));
@@ -1332,12 +1349,25 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     return dispatch_logn<float>(g, data, data, tw, inverse != 0, apply, st);
 }
 
+// Tile width of the round-trip kernel: where the 128-byte tile leaves room for one workgroup per CU only, 64-byte
+// rows (two or three workgroups).  Unlike the plain passes — which are at the rate of their bare loads and stores
+// either way — this kernel computes for a third of its time (two transforms and the transfer function), and a
+// second workgroup on the CU is what overlaps that with memory: 1024^3 in double 6.8 -> 5.35 ms per launch,
+// c2r of 1024^3 in float 8.4 -> 7.7 ms, of 768^3 in double 6.8 -> 6.7 ms.  (N = 640 in double measured the other way,
+// 3.9 -> 4.2 ms, and keeps its 128-byte rows.)
+#ifndef PMX_ROUND_NARROW
+#define PMX_ROUND_NARROW 1
+#endif
+template <typename T, int LOGN, int RB0> struct RoundRB {
+    static constexpr int value = (PMX_ROUND_NARROW && RB0 > 64 && LOGN != 39 && ColPipe<T, LOGN, RB0>::bytes > 80 * 1024) ? 64 : RB0;
+};
 template <typename T, int LOGN, int RB>
 static int launch_round(const ColGeom &g, void *data, const void *tw, bool apply, hipStream_t st)
 {
     constexpr int N = Len<LOGN>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = N / Rpt<T, LOGN>::value * W;
+    static_assert(NT <= 1024 && NT % 64 == 0, "round-trip kernel: workgroup size");
     size_t lds = (size_t)(N * W + (HalfTw<T, LOGN, RB>::value ? N / 2 : N)) * sizeof(cpx<T>);
     int64_t tiles = (g.B + W - 1) / W;
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
@@ -1362,17 +1392,19 @@ template <typename T>
 static int dispatch_round(const ColGeom &g, void *data, const void *tw, bool apply, hipStream_t st)
 {
     switch (g.logN) {
-    case 6: return launch_round<T, 6, 128>(g, data, tw, apply, st);
-    case 7: return launch_round<T, 7, 128>(g, data, tw, apply, st);
-    case 8: return launch_round<T, 8, 128>(g, data, tw, apply, st);
-    case 9: return launch_round<T, 9, 128>(g, data, tw, apply, st);
-    case 10: return launch_round<T, 10, (sizeof(T) == 8 ? PMX_RB_D1024 : 128)>(g, data, tw, apply, st);
-    case 11: return launch_round<T, 11, 64>(g, data, tw, apply, st);
-    case 22: return launch_round<T, 22, 128>(g, data, tw, apply, st);
-    case 23: return launch_round<T, 23, 128>(g, data, tw, apply, st);
-    case 24: return launch_round<T, 24, PMX_RB768>(g, data, tw, apply, st);
-    case 38: return launch_round<T, 38, 128>(g, data, tw, apply, st);
-    case 39: return launch_round<T, 39, (sizeof(T) == 4 ? 64 : 128)>(g, data, tw, apply, st);
+#define ROUND(LC, RB0) return launch_round<T, LC, RoundRB<T, LC, (RB0)>::value>(g, data, tw, apply, st)
+    case 6: ROUND(6, 128);
+    case 7: ROUND(7, 128);
+    case 8: ROUND(8, 128);
+    case 9: ROUND(9, 128);
+    case 10: ROUND(10, 128);
+    case 11: ROUND(11, 64);
+    case 22: ROUND(22, 128);
+    case 23: ROUND(23, 128);
+    case 24: ROUND(24, PMX_RB768);
+    case 38: ROUND(38, 128);
+    case 39: ROUND(39, (sizeof(T) == 4 ? 64 : 128));
+#undef ROUND
     }
     set_error("pmx_colfft_roundtrip: length code %d is not built", g.logN);
     return PMX_EUNSUPPORTED;
