@@ -467,7 +467,8 @@ template <typename T, int LOGN, int RB> struct HalfTw {
 template <typename T, int LOGN, int RB> struct ColPipe {
     static constexpr size_t bytes = (size_t)(Len<LOGN>::N * (RB / (int)sizeof(cpx<T>))
                                              + (HalfTw<T, LOGN, RB>::value ? Len<LOGN>::N / 2 : Len<LOGN>::N)) * sizeof(cpx<T>);
-    static constexpr bool value = PMX_COL_PIPE && bytes > 80 * 1024;
+    // (N = 2048 in float, 16 lines per thread, spills under the prefetch: left as it was)
+    static constexpr bool value = PMX_COL_PIPE && bytes > 80 * 1024 && !(sizeof(T) == 4 && LOGN == 11);
 };
 
 // The round-trip kernel (colfft_round_kernel) has the same persistent form behind PMX_ROUND_PIPE, off by default: its
@@ -557,7 +558,9 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
     // persistent and loads its NEXT tile into registers while the passes of the current one run out of LDS.
     // With a single workgroup on the CU nothing else would overlap the three phases — measured at 1024^3
     // in double, 17 us per tile = 6 us load + 5 us passes + 6 us store, where the memory side alone needs 12.
-    constexpr bool PIPE = ColPipe<T, LOGN, RB>::value;
+    // (not the float kernels with the fused transfer: its double-precision arithmetic beside the prefetched tile
+    // spills a few registers at N = 1024 / 2048)
+    constexpr bool PIPE = ColPipe<T, LOGN, RB>::value && !(APPLY && sizeof(T) == 4);
     constexpr bool ONE_TILE = !PIPE && N < PMX_COL_STRIDE_FROM;
     constexpr bool P2 = LOGN < 16;      // power-of-two length: additive addressing (line_offset, lds_at)
     const int64_t step = ONE_TILE ? ntiles : (int64_t)gridDim.x;
@@ -1122,7 +1125,7 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
     unsigned grid = (unsigned)((N < PMX_COL_STRIDE_FROM) ? tiles : (tiles < 256 * 16 ? tiles : 256 * 16));
-    if (ColPipe<T, LOGN, RB>::value) {
+    if (ColPipe<T, LOGN, RB>::value && !(apply && sizeof(T) == 4)) {
         // persistent workgroups, one per CU (the tile leaves no room for a second)
         const int64_t cus = compute_units();
         grid = (unsigned)(tiles < cus ? tiles : cus);
