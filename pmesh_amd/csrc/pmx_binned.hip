@@ -614,7 +614,16 @@ __device__ __forceinline__ void region_tables(const pmx_painter &p, const BinGeo
 }
 
 // per-particle setup shared by paint and readout: weights and local base of the stencil
-template <int KIND>
+// all three axes are the whole periodic mesh (the one-rank case): see particle_setup
+__device__ __forceinline__ bool whole_mesh(const pmx_painter &p, const BinGeom &g)
+{
+    bool w = true;
+#pragma unroll
+    for (int d = 0; d < 3; d++) w = w && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];
+    return w;
+}
+
+template <int KIND, bool WHOLE = false>
 __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGeom &g, const int *t,
                                                const double *x, double (*V)[Tuned<KIND>::S], int *lb)
 {
@@ -625,7 +634,9 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
         int I[S];
         Tuned<KIND>::axis(X, p.order[d], p.scale[d], I, V[d]);
         const int per = (int)p.period[d], siz = (int)p.size[d];      // (32-bit compares: see local_base32)
-        if (g.o[d] == 0 && per == siz) {
+        // WHOLE: the caller has checked the condition for all three axes (whole_mesh()): no branch, and the
+        // general path is not even in the instruction stream of the loop
+        if (WHOLE || (g.o[d] == 0 && per == siz)) {
             // the axis is the whole periodic mesh, a multiple of the (power of two) tile extent
             // (pmx_binplan_supported): the base cell relative to the particle's tile is I0 mod T, whatever
             // period the coordinate is in — two instructions instead of the wrap, the shift into the block
@@ -692,7 +703,7 @@ __device__ __forceinline__ int fixed_exponent(const pmx_painter &p, double mb, i
 __device__ __forceinline__ double pow2(int f) { return __longlong_as_double((long long)(1023 + f) << 52); }
 
 // The particles [start, start + count) of a tile's list are deposited into its LDS region.
-template <int KIND, int TTHREADS, bool SORTED, bool FIXED = false>
+template <int KIND, int TTHREADS, bool SORTED, bool FIXED = false, int PE = 0, bool WHOLE = false>
 __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                              const DVec &mass, double mass_scalar, const uint32_t *list,
                                              int64_t start, int count, double *lds, double scale = 1.0)
@@ -717,7 +728,7 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             if (idx[u] >= 0) {
-                x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
+                x[u][0] = pos_get<PE>(pos, idx[u], 0); x[u][1] = pos_get<PE>(pos, idx[u], 1); x[u][2] = pos_get<PE>(pos, idx[u], 2);
                 // (sorted: idx is the list slot; a per-particle mass lives at the row the list names)
                 m[u] = mass.data ? mass.get(sorted ? (int64_t)list[idx[u]] : idx[u], 0) : mass_scalar;
             }
@@ -741,7 +752,7 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
             if (idx[u] < 0) continue;
             int lb[3];
             double V[3][S];
-            particle_setup<KIND>(p, g, t, x[u], V, lb);
+            particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
             // a plan that no longer matches the positions (rewritten behind the cache's back)
             // must not index outside the LDS region
             if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
@@ -782,8 +793,23 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     if (PMX_EXP_NOATOM && sink == 12345.678) lds[0] = sink;
 }
 
+// (the form of the loop chosen once per launch: see tile_gather_any)
+template <int KIND, int TTHREADS, bool SORTED, bool FIXED>
+__device__ __forceinline__ void tile_deposit_any(bool whole, const pmx_painter &p, const BinGeom &g, const int *t,
+                                                 const DVec &pos, const DVec &mass, double mass_scalar,
+                                                 const uint32_t *list, int64_t start, int count, double *lds, double scale)
+{
+    if (whole) {
+        if (pos.elsize == 8) tile_deposit<KIND, TTHREADS, SORTED, FIXED, 8, true>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        else tile_deposit<KIND, TTHREADS, SORTED, FIXED, 4, true>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+    } else {
+        if (pos.elsize == 8) tile_deposit<KIND, TTHREADS, SORTED, FIXED, 8, false>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        else tile_deposit<KIND, TTHREADS, SORTED, FIXED, 4, false>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+    }
+}
+
 // The particles [start, start + count) of a tile's list read their values from its LDS region.
-template <int KIND, typename T, int TTHREADS, bool SORTED>
+template <int KIND, typename T, int TTHREADS, bool SORTED, int PE = 0, bool WHOLE = false>
 __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                             const DVec &out, const uint32_t *list, int64_t start, int count,
                                             const T *lds)
@@ -803,7 +829,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             if (idx[u] >= 0) {
-                x[u][0] = pos.get(idx[u], 0); x[u][1] = pos.get(idx[u], 1); x[u][2] = pos.get(idx[u], 2);
+                x[u][0] = pos_get<PE>(pos, idx[u], 0); x[u][1] = pos_get<PE>(pos, idx[u], 1); x[u][2] = pos_get<PE>(pos, idx[u], 2);
             }
         }
 #pragma unroll
@@ -811,7 +837,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
             if (idx[u] < 0) continue;
             int lb[3];
             double V[3][S];
-            particle_setup<KIND>(p, g, t, x[u], V, lb);
+            particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
             if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
             double value = 0;
 #pragma unroll
@@ -825,6 +851,24 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
                 }
             out.set(idx[u], 0, value);
         }
+    }
+}
+
+// One choice per launch instead of one per position component and axis: the element size of the positions and
+// "every axis is the whole periodic mesh" (`whole`, whole_mesh()) select a form of the loop in which the other
+// cases do not appear at all.  Left in the loop they were 30 wave-uniform branches per trip of two particles:
+// config 3 (fp32 positions) readout 1.54 -> 1.25 ms, paint 1.81 -> 1.68; fp64 positions 2-4 %.
+template <int KIND, typename T, int TTHREADS, bool SORTED>
+__device__ __forceinline__ void tile_gather_any(bool whole, const pmx_painter &p, const BinGeom &g, const int *t,
+                                                const DVec &pos, const DVec &out, const uint32_t *list, int64_t start,
+                                                int count, const T *lds)
+{
+    if (whole) {
+        if (pos.elsize == 8) tile_gather<KIND, T, TTHREADS, SORTED, 8, true>(p, g, t, pos, out, list, start, count, lds);
+        else tile_gather<KIND, T, TTHREADS, SORTED, 4, true>(p, g, t, pos, out, list, start, count, lds);
+    } else {
+        if (pos.elsize == 8) tile_gather<KIND, T, TTHREADS, SORTED, 8, false>(p, g, t, pos, out, list, start, count, lds);
+        else tile_gather<KIND, T, TTHREADS, SORTED, 4, false>(p, g, t, pos, out, list, start, count, lds);
     }
 }
 
@@ -917,6 +961,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
     const int nt2 = g.nt[2];
     const int nseg = (nt2 + ZSEG - 1) / ZSEG;
     const int64_t nwork = (g.ntiles / nt2) * nseg;
+    const bool whole = whole_mesh(pwr, g);
     for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
       const int64_t column = w / nseg;
       const int seg = (int)(w - column * nseg);
@@ -968,7 +1013,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             }
             __syncthreads();
         }
-        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        tile_deposit_any<KIND, TTHREADS, SORTED, FIXED>(whole, pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -1070,6 +1115,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
     __shared__ T lds[Rg::template glds<T>()];
     __shared__ int64_t tab[Rg::R0 + Rg::R1 + Rg::R2];
+    const bool whole = whole_mesh(p, g);
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t start = offsets[tile];
         // (what a crowded tile holds beyond g.chunk entries is read out by readout_heavy_kernel)
@@ -1087,7 +1133,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
             lds[r * Rg::template gpitch<T>() + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;   // outside the block reads as 0
         }
         __syncthreads();
-        tile_gather<KIND, T, TTHREADS, SORTED>(p, g, t, pos, out, list, start, count, lds);
+        tile_gather_any<KIND, T, TTHREADS, SORTED>(whole, p, g, t, pos, out, list, start, count, lds);
         __syncthreads();
     }
 }
@@ -1142,7 +1188,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
             scale = pow2(f);
             inv = pow2(-f);
         }
-        tile_deposit<KIND, TTHREADS, SORTED, FIXED>(pwr, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
+        tile_deposit_any<KIND, TTHREADS, SORTED, FIXED>(whole_mesh(pwr, g), pwr, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             const int c = q % R2, r = q / R2;
@@ -1186,7 +1232,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, 
             lds[r * Rg::template gpitch<T>() + c] = in ? *(const T *)(canvas + goff) : (T)0;
         }
         __syncthreads();
-        tile_gather<KIND, T, TTHREADS, SORTED>(p, g, t, pos, out, list, offsets[tile] + first, count, lds);
+        tile_gather_any<KIND, T, TTHREADS, SORTED>(whole_mesh(p, g), p, g, t, pos, out, list, offsets[tile] + first, count, lds);
         __syncthreads();
     }
 }

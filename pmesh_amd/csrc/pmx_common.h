@@ -47,6 +47,15 @@ struct DVec {
     }
 };
 
+// position loads with the element size known at compile time (PE = 4 / 8) or read from the vector (PE = 0):
+// the tile kernels choose once per launch (see tile_gather) instead of once per component
+template <int PE> __device__ __forceinline__ double pos_get(const DVec &pos, int64_t i, int c)
+{
+    if (PE == 0) return pos.get(i, c);
+    const char *q = pos.data + i * pos.stride0 + c * pos.stride1;
+    return PE == 8 ? *(const double *)q : (double)*(const float *)q;
+}
+
 inline DVec dvec(const pmx_vec *v)
 {
     DVec d;
