@@ -1357,12 +1357,16 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
 // either way — this kernel computes for a third of its time (two transforms and the transfer function), and a
 // second workgroup on the CU is what overlaps that with memory: 1024^3 in double 6.8 -> 5.35 ms per launch,
 // c2r of 1024^3 in float 8.4 -> 7.7 ms, of 768^3 in double 6.8 -> 6.7 ms.  (N = 640 in double measured the other way,
-// 3.9 -> 4.2 ms, and keeps its 128-byte rows.)
+// 3.9 -> 4.2 ms, and keeps its 128-byte rows; at N = 512, where two workgroups of the 128-byte tile share a CU already,
+// 64-byte rows cost fp64 2 % and gave fp32 2 %: PMX_ROUND_NARROW_FROM stays at the one-workgroup limit.)
 #ifndef PMX_ROUND_NARROW
 #define PMX_ROUND_NARROW 1
 #endif
+#ifndef PMX_ROUND_NARROW_FROM
+#define PMX_ROUND_NARROW_FROM (80 * 1024)
+#endif
 template <typename T, int LOGN, int RB0> struct RoundRB {
-    static constexpr int value = (PMX_ROUND_NARROW && RB0 > 64 && LOGN != 39 && ColPipe<T, LOGN, RB0>::bytes > 80 * 1024) ? 64 : RB0;
+    static constexpr int value = (PMX_ROUND_NARROW && RB0 > 64 && (LOGN < 16 || LOGN == 24) && ColPipe<T, LOGN, RB0>::bytes > PMX_ROUND_NARROW_FROM) ? 64 : RB0;
 };
 template <typename T, int LOGN, int RB>
 static int launch_round(const ColGeom &g, void *data, const void *tw, bool apply, hipStream_t st)
