@@ -1099,13 +1099,22 @@ static int get_twiddles(int N, int es, void **out, hipStream_t st)
     if (it != g_tw.end()) { *out = it->second; return PMX_OK; }
     void *d = nullptr;
     PMX_HIP_CHECK(hipMalloc(&d, (size_t)N * 2 * es));
+    // The second half of the table is the negated first half BY CONSTRUCTION (w[m + N/2] = -w[m]; libm's values of
+    // the two differ in the last bit here and there): the kernels that keep only half the table in LDS (HalfTw,
+    // RowHalfTw) then compute exactly what the others do — the round-trip kernel of N = 1024 in double, on its
+    // narrow tiles, stays bit-identical to the two full-table passes it replaces.  (All lengths are even.)
+    std::vector<double> w(2 * N);
+    for (int m = 0; m < N; m++) {
+        const int q = m < N / 2 ? m : m - N / 2;
+        const double sg = m < N / 2 ? 1.0 : -1.0;
+        w[2 * m] = sg * cos(-2.0 * M_PI * q / N);
+        w[2 * m + 1] = sg * sin(-2.0 * M_PI * q / N);
+    }
     if (es == 8) {
-        std::vector<double> h(2 * N);
-        for (int m = 0; m < N; m++) { h[2 * m] = cos(-2.0 * M_PI * m / N); h[2 * m + 1] = sin(-2.0 * M_PI * m / N); }
-        PMX_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        PMX_HIP_CHECK(hipMemcpy(d, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
     } else {
         std::vector<float> h(2 * N);
-        for (int m = 0; m < N; m++) { h[2 * m] = (float)cos(-2.0 * M_PI * m / N); h[2 * m + 1] = (float)sin(-2.0 * M_PI * m / N); }
+        for (int m = 0; m < 2 * N; m++) h[m] = (float)w[m];
         PMX_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     g_tw[key] = d;

@@ -32,6 +32,42 @@ def test_colfft_lengths(be, elsize, tol, N):
             assert rel(got, want) < tol * numpy.log2(N), (N, A, B, inverse)
 
 
+@pytest.mark.parametrize('elsize,N', [(8, 1024), (4, 1024), (8, 768), (8, 640), (8, 512)])
+def test_colfft_more_tiles_than_compute_units(be, oracle, elsize, N):
+    """Batches of several hundred tiles per plane with a ragged last one: where a tile fills a CU the column kernel is
+    a persistent workgroup that prefetches its next tile (first tile peeled, whole and ragged tiles stored by different
+    paths) — the small batches of test_colfft_lengths give every workgroup one tile.  Then the round-trip kernel on the
+    same batch (its own tile width at these lengths) against the two passes it replaces, bit for bit."""
+    if not be.colfft_supported(N, elsize):
+        pytest.skip('length not built for this precision')
+    cdt = 'c16' if elsize == 8 else 'c8'
+    tol = 2e-15 if elsize == 8 else 1e-6
+    W = 128 // (2 * elsize)
+    A, B = 2, W * 300 + 3
+    rs = numpy.random.RandomState(N + elsize)
+    x = (rs.normal(size=(A, N, B)) + 1j * rs.normal(size=(A, N, B))).astype(cdt)
+    for inverse in (False, True):
+        t = torch.view_as_real(torch.from_numpy(x.copy())).reshape(-1).to(be.device)
+        be.colfft(elsize, inverse, t, A, N, B, scale=0.5)
+        got = t.cpu().numpy().view(cdt).reshape(A, N, B)
+        want = (numpy.fft.ifft(x.astype('c16'), axis=1) * N if inverse else numpy.fft.fft(x.astype('c16'), axis=1)) * 0.5
+        assert rel(got, want) < tol * numpy.log2(N), (N, inverse)
+        for a in range(A):      # the last column of a plane (the ragged tile) and the first of the next
+            assert rel(got[a, :, -3:], want[a, :, -3:]) < tol * numpy.log2(N) * 4
+    if not be.colfft_roundtrip_supported(N, elsize):
+        return
+    n1, n2 = 3, B // 3
+    assert n1 * n2 == B
+    nmesh, box, start = (N, 6, 2 * n2), (100.0, 50.0, 70.0), (0, 3, 0)
+    tr = oracle.make_transfer(laplace_pow=-1, grad_dir=0)
+    one = torch.view_as_real(torch.from_numpy(x[0].copy())).reshape(-1).to(be.device)
+    two = one.clone()
+    be.colfft_roundtrip(elsize, one, N, B, scale=1.0 / N, transfer=tr, n1=n1, n2=n2, start=start, nmesh=nmesh, boxsize=box)
+    be.colfft(elsize, False, two, 1, N, B, scale=1.0 / N)
+    be.colfft(elsize, True, two, 1, N, B, transfer=tr, n1=n1, n2=n2, start=start, nmesh=nmesh, boxsize=box)
+    assert torch.equal(one, two)
+
+
 @pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
 @pytest.mark.parametrize('n', [128, 256, 512, 1024, 2048, 384, 768, 1536, 640, 1280])
 def test_rowfft_lengths(be, elsize, tol, n):
