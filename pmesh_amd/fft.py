@@ -566,21 +566,12 @@ class Plan(object):
                 be.slab_pack(Y, W1, n0l, N1, m2, e1o, elb)                  # split axis 1 by P0
             out = bufout.storage
             colc.alltoall(W1[:sum(s2)], out[:sum(r2)], s2, r2)              # row ranges of (N0, m1, m2)
-            self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
-        else:
-            S = bufin.storage
-            if not same:
-                ncplx = 2 * N0 * m1 * m2
-                W0[:ncplx].copy_(bufin.storage[:ncplx])
-                S = W0
-            if transfer is not None and m1 * m2:
-                # the local block is (N0, m1, m2) at the global start the caller passes
-                # (0, o_start[1], o_start[2]): the transfer rides on the axis-0 pass as on slabs
-                t, start, nmesh, boxsize = transfer
-                be.colfft(self.elsize, True, S, 1, N0, m1 * m2, transfer=t, n1=m1, n2=m2,
-                          start=start, nmesh=nmesh, boxsize=boxsize)
+            if c2c:
+                self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
             else:
-                self._col(be, S, 1, N0, m1 * m2, True)
+                self._last_pencil_pass(be, out, N0, m1, m2, norm)
+        else:
+            S = self._first_pencil_pass(be, bufin, same, transfer, W0, N0, m1, m2)
             colc.alltoall(S[:sum(r2)], W1[:sum(s2)], r2, s2)
             if fuse1:
                 if n0l and m2:
@@ -653,8 +644,10 @@ class Plan(object):
             u_to_t(bufin.storage, bufout.storage)
         elif self.forward:
             t.execute(bufin, tb)
+            settle(TB)                     # (the transposed plan may have left its last pass as a note)
             t_to_u(TB, bufout.storage)
         else:
+            forget(TB)
             u_to_t(bufin.storage, TB)
             t.execute(tb, bufout)
 
@@ -728,19 +721,9 @@ class Plan(object):
                 w2.append(colc.alltoall_views(send, recv, async_op=True))
             for w in w2:
                 w.wait()
-            self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
+            self._last_pencil_pass(be, out, N0, m1, m2, norm)
         else:
-            S = bufin.storage
-            if not same:
-                ncplx = 2 * N0 * m1 * m2
-                W0[:ncplx].copy_(bufin.storage[:ncplx])
-                S = W0
-            if transfer is not None and m1 * m2:
-                t, start, nmesh, boxsize = transfer
-                be.colfft(es, True, S, 1, N0, m1 * m2, transfer=t, n1=m1, n2=m2, start=start, nmesh=nmesh,
-                          boxsize=boxsize)
-            else:
-                self._col(be, S, 1, N0, m1 * m2, True)
+            S = self._first_pencil_pass(be, bufin, same, transfer, W0, N0, m1, m2)
             w2 = []
             for (a, n), q2 in zip(planes, o2):
                 blk = 2 * n * m1 * m2
@@ -937,6 +920,59 @@ class Plan(object):
             else:
                 be.colfft_roundtrip(es, out, N0, nb)
         out._pmx_pending = _Pending(self.partition, run, fused, 'slab')
+
+    def _last_pencil_pass(self, be, out, N0, m1, m2, norm):
+        """the axis-0 pass on the (N0, m1, m2) block the second transpose of a pencil transform delivered (it carries
+        the 1 / prod(Nmesh)) — now, or deferred like the slab one"""
+        es = self.elsize
+        if m1 * m2 == 0:
+            return
+
+        def run():
+            self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
+        if not (DEFER_LAST_PASS and COLFFT != 'never' and hasattr(be, 'colfft_roundtrip') and
+                be.colfft_roundtrip_supported(N0, es) and be.colfft_supported(N0, es)):
+            return run()
+
+        def fused(transfer):
+            if transfer is not None:
+                t, start, nmesh, boxsize = transfer
+                be.colfft_roundtrip(es, out, N0, m1 * m2, scale=norm, transfer=t, n1=m1, n2=m2, start=start,
+                                    nmesh=nmesh, boxsize=boxsize)
+            else:
+                be.colfft_roundtrip(es, out, N0, m1 * m2, scale=norm)
+        out._pmx_pending = _Pending(self.partition, run, fused, 'slab')
+
+    def _first_pencil_pass(self, be, bufin, same, transfer, W0, N0, m1, m2):
+        """first stage of c2r on pencils: the inverse axis-0 pass on the local (N0, m1, m2) block, with the transfer
+        function riding on it — or, when the forward transform left its last pass for us, both passes and the
+        transfer as one kernel.  Returns the storage the spectrum of the next stage lives in."""
+        es = self.elsize
+        S = bufin.storage
+        pend = getattr(S, '_pmx_pending', None)
+        taken = False
+        if pend is not None:
+            S._pmx_pending = None
+            if pend.kind == 'slab' and same and pend.partition is self.partition:
+                pend.fused(transfer)
+                taken = True
+            else:
+                pend.run()
+        if not same:
+            ncplx = 2 * N0 * m1 * m2
+            W0[:ncplx].copy_(bufin.storage[:ncplx])
+            S = W0
+        if taken:
+            pass
+        elif transfer is not None and m1 * m2:
+            # the local block is (N0, m1, m2) at the global start the caller passes
+            # (0, o_start[1], o_start[2]): the transfer rides on the axis-0 pass as on slabs
+            t, start, nmesh, boxsize = transfer
+            be.colfft(es, True, S, 1, N0, m1 * m2, transfer=t, n1=m1, n2=m2,
+                      start=start, nmesh=nmesh, boxsize=boxsize)
+        else:
+            self._col(be, S, 1, N0, m1 * m2, True)
+        return S
 
     def _take_over_forward_pass(self, be, st, transfer, N0, N1, N2c, sn):
         """first stage of c2r on one rank: if the forward transform left its last pass for us, both axis-0 passes

@@ -591,6 +591,55 @@ def case_deferred_last_pass_on_slabs(be, comm):
         F.DEFER_LAST_PASS, F.OVERLAP_CHUNKS = saved
 
 
+def case_deferred_last_pass_on_pencils(be, comm):
+    """fft.DEFER_LAST_PASS on a 2-d process mesh: r2c leaves the axis-0 pass on the block the second transpose
+    delivered (single or pipelined exchanges alike); an in-place c2r of the same partition runs both axis-0 passes
+    and the transfer as one kernel; whatever else looks at the spectrum settles it.  Same bits as the eager transforms."""
+    from pmesh_amd import fft as F
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    shapes = {4: [2, 2], 6: [2, 3], 8: [2, 4]}
+    if comm.size not in shapes:
+        return
+    np_ = shapes[comm.size]
+    saved = F.DEFER_LAST_PASS, F.OVERLAP_CHUNKS
+    T = Transfer.dx1(2)
+    try:
+        for Nmesh in ([64, 64, 128], [128, 64, 64], [64, 72, 128]):
+            data = numpy.random.RandomState(5).normal(size=Nmesh)
+            for chunks in (1, 2):
+                F.OVERLAP_CHUNKS = chunks
+                res = {}
+                for defer in (False, True):
+                    F.DEFER_LAST_PASS = defer
+                    pm = ParticleMesh(BoxSize=[3.0, 2.0, 5.0], Nmesh=Nmesh, comm=comm, dtype='f8', np=np_)
+
+                    def fresh():
+                        return pm.create('real', value=data[pm.create('real').slices])
+                    a = numpy.asarray(fresh().r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=T))      # fused
+                    b = numpy.asarray(fresh().r2c(out=Ellipsis).c2r(out=Ellipsis))                  # no transfer
+                    ck = fresh().r2c(out=Ellipsis)
+                    spec = numpy.asarray(ck).copy()                                                 # looked at: settles
+                    c = numpy.asarray(ck.c2r(out=Ellipsis, transfer=T))
+                    ck = fresh().r2c()                                                              # out of place
+                    d = numpy.asarray(ck.c2r(transfer=T))
+                    ck = fresh().r2c(out=Ellipsis)                                                  # abandoned, then reused
+                    note = getattr(ck._base.storage, '_pmx_pending', None)
+                    if defer and ck.size:
+                        assert note is not None and note.kind == 'slab', (chunks, note)
+                    else:
+                        assert note is None
+                    e = numpy.asarray(fresh().r2c(out=Ellipsis).c2r(out=Ellipsis))
+                    cu = fresh().r2c(out=Ellipsis).cast(type='untransposedcomplex')                 # cast settles
+                    f = numpy.asarray(cu).copy()
+                    res[defer] = [a, b, spec, c, d, e, f]
+                for x, y in zip(res[False], res[True]):
+                    assert_array_equal(x, y)
+                assert_allclose(res[True][1], data[pm.create('real').slices], rtol=0, atol=1e-12)
+    finally:
+        F.DEFER_LAST_PASS, F.OVERLAP_CHUNKS = saved
+
+
 def case_pencil_untransposed_and_c2c(be, comm):
     """every plan of the reference on a 2-d process mesh (pm.py:1332-1349 builds all eight): the untransposed
     complex layout — distributed like the real field, (N0 / P0, N1 / P1, N2c) — r2c / c2r through it and casts both
@@ -749,7 +798,7 @@ def case_comm_trace(be, comm):
 
 
 CASES = [case_comm_trace, case_async_ghost_exchange, case_length_check_is_collective, case_promote_and_pack, case_pencil,
-         case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+         case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 
