@@ -956,23 +956,31 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
     // a segment stages its z-face: those cells are single 8-byte atomics in separate sectors for
     // halo_merge, 13 % of the halo cells but half of its time (404 -> 248 us at 512^3 with 3 of 4
     // z-faces gone).
-    constexpr int NCARRY = Rg::R0 * R1 * (S - 1);
+    // [r3] WALK_X (PCS, see walk_x()): the segments run along x instead and carry the x-face — the planes a >= T0,
+    // (S - 1) R1 R2 cells, 62 % of the halo of a PCS tile where the z-face is 12 %.  The carry is a block of whole
+    // region rows moved to the front of the region.
+    constexpr bool WALK_X = walk_x(S);
+    constexpr int NCARRY = WALK_X ? (S - 1) * R1 * Rg::R2 : Rg::R0 * R1 * (S - 1);
     constexpr int CPT = (NCARRY + TTHREADS - 1) / TTHREADS > 0 ? (NCARRY + TTHREADS - 1) / TTHREADS : 1;
-    const int nt2 = g.nt[2];
-    const int nseg = (nt2 + ZSEG - 1) / ZSEG;
-    const int64_t nwork = (g.ntiles / nt2) * nseg;
+    const int ntw = WALK_X ? g.nt[0] : g.nt[2];                   // tiles along the walk axis
+    const int64_t tstride = WALK_X ? (int64_t)g.nt[1] * g.nt[2] : 1;      // tile index step along it
+    const int nseg = (ntw + ZSEG - 1) / ZSEG;
+    const int64_t ncolumn = g.ntiles / ntw;
+    const int64_t nwork = ncolumn * nseg;
     const bool whole = whole_mesh(pwr, g);
     for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
       const int64_t column = w / nseg;
       const int seg = (int)(w - column * nseg);
-      const int t2a = seg * ZSEG, t2b = (t2a + ZSEG < nt2) ? t2a + ZSEG : nt2;
-      bool live = false;                        // the region holds the z-halo of the previous tile
+      const int t2a = seg * ZSEG, t2b = (t2a + ZSEG < ntw) ? t2a + ZSEG : ntw;
+      // first tile of the column: (0, t1, t2) = `column` itself under WALK_X, (t0, t1, 0) else
+      const int64_t tile0 = WALK_X ? column : column * ntw;
+      bool live = false;                        // the region holds the carried face of the previous tile
       double scale = 1.0, inv = 1.0;
       if (FIXED) {
-          // one scale for the segment: the z-halo carried from tile to tile keeps its meaning
+          // one scale for the segment: the face carried from tile to tile keeps its meaning
           int64_t nseg_part = 0;
           for (int t2 = t2a; t2 < t2b; t2++) {
-              const uint32_t c = counts[column * nt2 + t2];
+              const uint32_t c = counts[tile0 + t2 * tstride];
               nseg_part += c < (uint32_t)g.chunk ? c : (uint32_t)g.chunk;
           }
           const int f = MODE == 2 ? *dexp : fixed_exponent(pwr, mstats ? mstats[0] : fabs(mass_scalar), nseg_part);
@@ -980,7 +988,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
           inv = pow2(-f);
       }
       for (int t2 = t2a; t2 < t2b; t2++) {
-        const int64_t tile = column * nt2 + t2;
+        const int64_t tile = tile0 + t2 * tstride;
         const bool last = (t2 == t2b - 1);
         int t[3];
         tile_coords(g, tile, t);
@@ -994,8 +1002,13 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             for (int u = 0; u < CPT; u++) {
                 int q = threadIdx.x + u * TTHREADS;
                 if (q < NCARRY) {
-                    int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
-                    carry[u] = lds[Rg::dat(r, T2 + c)];
+                    if (WALK_X) {
+                        const int c = q % Rg::R2, r = q / Rg::R2;             // r = a R1 + b of the destination, a < S - 1
+                        carry[u] = lds[Rg::dat(T0 * R1 + r, c)];
+                    } else {
+                        int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
+                        carry[u] = lds[Rg::dat(r, T2 + c)];
+                    }
                 }
             }
             __syncthreads();
@@ -1007,8 +1020,13 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             for (int u = 0; u < CPT; u++) {
                 int q = threadIdx.x + u * TTHREADS;
                 if (q < NCARRY) {
-                    int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
-                    lds[Rg::dat(r, c)] = carry[u];
+                    if (WALK_X) {
+                        const int c = q % Rg::R2, r = q / Rg::R2;
+                        lds[Rg::dat(r, c)] = carry[u];
+                    } else {
+                        int c = q % (S - 1 > 0 ? S - 1 : 1), r = q / (S - 1 > 0 ? S - 1 : 1);
+                        lds[Rg::dat(r, c)] = carry[u];
+                    }
                 }
             }
             __syncthreads();
@@ -1041,7 +1059,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             for (int h = threadIdx.x; h < Rg::HALO; h += TTHREADS) {
                 int a, b, c;
                 Rg::halo_decode(h, &a, &b, &c);
-                if (!last && c >= T2) continue;           // carried to the next tile instead
+                if (!last && (WALK_X ? a >= T0 : c >= T2)) continue;           // carried to the next tile instead
                 hbase[h] = (T)cell_value<MODE>(lds[Rg::dat(a * R1 + b, c)], inv);
             }
         }
@@ -1064,21 +1082,24 @@ __global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGe
 {
     if (!batch_is_mine(mstats, want_odd)) return;      // (only the deterministic path has two staging buffers)
     using Rg = Region<S>;
+    constexpr bool WALK_X = walk_x(S);
     for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         int t[3];
         tile_coords(g, tile, t);
         // paint_tile_kernel staged this tile iff it has particles, or an earlier tile of its z
         // segment has (the z-halo carried through it), or every tile was written (overwrite)
-        const int t2a = (t[2] / ZSEG) * ZSEG;
+        const int tw = WALK_X ? t[0] : t[2];
+        const int64_t tstride = WALK_X ? (int64_t)g.nt[1] * g.nt[2] : 1;
+        const int t2a = (tw / ZSEG) * ZSEG;
         bool staged = overwrite != 0;
-        for (int k = t2a; k <= t[2] && !staged; k++) staged = counts[tile - (t[2] - k)] != 0;
+        for (int k = t2a; k <= tw && !staged; k++) staged = counts[tile - (tw - k) * tstride] != 0;
         if (!staged) continue;
-        const bool last = (t[2] == g.nt[2] - 1) || (t[2] % ZSEG == ZSEG - 1);
+        const bool last = (tw == (WALK_X ? g.nt[0] : g.nt[2]) - 1) || (tw % ZSEG == ZSEG - 1);
         const T *hbase = halo + tile * (int64_t)Rg::HALO;
         for (int h = threadIdx.x; h < Rg::HALO; h += TBLOCK) {
             int a, b, c;
             Rg::halo_decode(h, &a, &b, &c);
-            if (!last && c >= T2) continue;     // not staged: carried to the next tile in LDS
+            if (!last && (WALK_X ? a >= T0 : c >= T2)) continue;     // not staged: carried to the next tile in LDS
             T v = hbase[h];
             int64_t goff;
             if (INTEGER) {
@@ -1711,7 +1732,8 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     int rc = plan_ensure(&pl->halo, &pl->cap_halo, need > 0 ? need : 16);
     if (rc) return rc;
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-    const int64_t nwork = (g.ntiles / g.nt[2]) * ((g.nt[2] + ZSEG - 1) / ZSEG);   // z segments of tiles
+    const int ntw = walk_x(g.S) ? g.nt[0] : g.nt[2];
+    const int64_t nwork = (g.ntiles / ntw) * ((ntw + ZSEG - 1) / ZSEG);   // segments of tiles along the walk axis
     unsigned pgrid = (unsigned)(nwork < 65535 * 8 ? nwork : 65535 * 8);
     T *halo = (T *)pl->halo;
     const int sorted = pl->sorted ? 1 : 0;

@@ -24,7 +24,16 @@ constexpr int TBLOCK = 256;
 #ifndef PMX_ZSEG
 #define PMX_ZSEG 4
 #endif
-constexpr int ZSEG = PMX_ZSEG;        // tiles per z segment of paint_tile_kernel
+constexpr int ZSEG = PMX_ZSEG;        // tiles per segment of paint_tile_kernel
+// The axis along which paint_tile_kernel walks its segments and carries the halo face in LDS: z (the face of T0 x T1
+// rows of S - 1 cells: few cells, but every row a piece of its own for halo_merge's atomics) or x (the face of
+// (S - 1) R1 rows of R2 cells: most of the halo's cells, in long rows).  What halo_merge pays for is pieces, not cells:
+// measured at 512^3 in double, z-walk against x-walk, CIC 247 / 317 us, PCS 634 / 517 us (paint_tile_kernel itself
+// the same either way), TSC within 1-2 % both ways.  So: x for PCS, z below.  PMX_WALK_AXIS = 0 / 2 forces one.
+#ifndef PMX_WALK_AXIS
+#define PMX_WALK_AXIS -1
+#endif
+constexpr bool walk_x(int S) { return PMX_WALK_AXIS == 0 || (PMX_WALK_AXIS < 0 && S >= 4); }
 #ifndef PMX_TILE_THREADS
 #define PMX_TILE_THREADS 512
 #endif
