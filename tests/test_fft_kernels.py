@@ -38,6 +38,8 @@ def test_colfft_more_tiles_than_compute_units(be, oracle, elsize, N):
     a persistent workgroup that prefetches its next tile (first tile peeled, whole and ragged tiles stored by different
     paths) — the small batches of test_colfft_lengths give every workgroup one tile.  Then the round-trip kernel on the
     same batch (its own tile width at these lengths) against the two passes it replaces, bit for bit."""
+    if be.name != 'hip':
+        pytest.skip('the persistent forms exist in the HIP kernels only')
     if not be.colfft_supported(N, elsize):
         pytest.skip('length not built for this precision')
     cdt = 'c16' if elsize == 8 else 'c8'
