@@ -15,7 +15,24 @@ CSRC = os.path.join(ROOT, 'pmesh_amd', 'csrc')
 HIPCC = '/opt/rocm/bin/hipcc'
 
 
+_TABLES = {}
+
+
 def resources(source):
+    """resource table of one source file; the first call compiles BOTH files of this module side by side
+    (a minute each: the suite's longest test otherwise)"""
+    if not _TABLES:
+        from concurrent.futures import ThreadPoolExecutor
+        names = ['pmx_colfft.hip', 'pmx_binned.hip']
+        with ThreadPoolExecutor(len(names)) as pool:
+            for name, table in zip(names, pool.map(_compile_resources, names)):
+                _TABLES[name] = table
+    if source not in _TABLES:
+        _TABLES[source] = _compile_resources(source)
+    return _TABLES[source]
+
+
+def _compile_resources(source):
     cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math',
            '-I' + os.path.join(ROOT, 'include'), '-c', os.path.join(CSRC, source), '-o', os.devnull,
            '-Rpass-analysis=kernel-resource-usage']
