@@ -278,6 +278,15 @@ int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64_t B, doubl
                          const pmx_transfer *transfer, int64_t n1, int64_t n2, const int64_t *start,
                          const int64_t *nmesh, const double *boxsize, int64_t n_stride, void *stream);
 
+/* Scheduling of the column passes whose tile fills a compute unit (N = 1024 in both precisions, 768 / 640 in double).
+ * persistent = 1 (default): one workgroup per CU walks a fixed share of the tiles and prefetches its next one —
+ * the faster form when the GPU is the kernel's alone.  persistent = 0: one workgroup per tile, placed by the hardware
+ * as CUs become free — what a process should choose whose transforms overlap with collectives (RCCL's kernels hold
+ * CUs for the length of a transfer; a persistent workgroup that cannot be placed beside them starts when another has
+ * finished its whole share).  Process-wide; the host side selects 0 for plans on more than one rank.  No PFFT
+ * counterpart (pfft.Plan has no such knob). */
+int pmx_colfft_configure(int32_t persistent);
+
 /* The axis-1 pass of a pencil transform (PFFT's 2-d process mesh, pm.py:1417-1434) between its two
  * global transposes: src is the (A, N, B) array cut into ranges of nsplit_in lines (the receive
  * buffer of one all-to-all), dst the same array cut into ranges of nsplit_out lines (the send

@@ -105,6 +105,7 @@ DEVICE_ONLY = {
     'colfft': (C.c_int, [_i32, _i32, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
                          _P(_i64), _P(_f64), _i64, _i64, _vp]),
     'colfft_roundtrip_supported': (C.c_int, [_i64, _i32]),
+    'colfft_configure': (C.c_int, [_i32]),
     'colfft_roundtrip': (C.c_int, [_i32, _vp, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64), _P(_i64), _P(_f64),
                                    _i64, _vp]),
     'colfft_split': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _i64, _vp]),

@@ -102,6 +102,11 @@ class HipBackend(object):
                   _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3),
                   int(a_stride), int(n_stride), self.stream())
 
+    def colfft_configure(self, persistent):
+        """process-wide: persistent (prefetching) column passes where a tile fills a CU, or one workgroup per tile
+        (for transforms that overlap with collectives) — pmx_colfft_configure"""
+        self.call('colfft_configure', int(bool(persistent)))
+
     def colfft_roundtrip_supported(self, n, elsize):
         return self.lib.pmx_colfft_roundtrip_supported(int(n), int(elsize)) == 0
 

@@ -22,6 +22,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -1072,6 +1073,9 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
     }
 }
 
+// pmx_colfft_configure: persistent (prefetching) column passes, or one workgroup per tile
+static std::atomic<int> g_persistent{1};
+
 static int compute_units()
 {
     static int n = 0;
@@ -1134,10 +1138,13 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     int64_t tiles = g.A * ((g.B + W - 1) / W);
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
     unsigned grid = (unsigned)((N < PMX_COL_STRIDE_FROM) ? tiles : (tiles < 256 * 16 ? tiles : 256 * 16));
-    if (ColPipe<T, LOGN, RB>::value && !(apply && sizeof(T) == 4)) {
-        // persistent workgroups, one per CU (the tile leaves no room for a second)
+    if (ColPipe<T, LOGN, RB>::value && !(apply && sizeof(T) == 4) && g_persistent.load(std::memory_order_relaxed)) {
+        // persistent workgroups, one per CU (the tile leaves no room for a second); with grid = tiles the same
+        // kernel runs one tile per workgroup (its loop makes one trip, nothing is prefetched)
         const int64_t cus = compute_units();
         grid = (unsigned)(tiles < cus ? tiles : cus);
+    } else if (ColPipe<T, LOGN, RB>::value && !(apply && sizeof(T) == 4)) {
+        grid = (unsigned)tiles;
     }
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
@@ -1424,6 +1431,12 @@ static int dispatch_round(const ColGeom &g, void *data, const void *tw, bool app
     }
     set_error("pmx_colfft_roundtrip: length code %d is not built", g.logN);
     return PMX_EUNSUPPORTED;
+}
+
+extern "C" int pmx_colfft_configure(int32_t persistent)
+{
+    g_persistent.store(persistent ? 1 : 0, std::memory_order_relaxed);
+    return PMX_OK;
 }
 
 extern "C" int pmx_colfft_roundtrip_supported(int64_t n, int32_t elsize)

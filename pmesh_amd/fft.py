@@ -403,11 +403,21 @@ class _Storage(object):
 class Plan(object):
     """pfft.Plan(...).execute(bufin, bufout) for one direction."""
 
+    _shared_gpu_told = False
+
     def __init__(self, partition, forward, dtype, inplace):
         self.partition = partition
         self.forward = forward
         self.inplace = inplace
         self.elsize = numpy.dtype(dtype).itemsize
+        if partition.nproc > 1 and not Plan._shared_gpu_told:
+            # transforms on several ranks overlap with RCCL's kernels, which hold compute units for the length of a
+            # transfer: the column passes then run one workgroup per tile instead of a persistent one per CU, whose
+            # fixed share of the tiles would wait for a free CU as a whole (pmx_colfft_configure)
+            Plan._shared_gpu_told = True
+            be = backend.get()
+            if hasattr(be, 'colfft_configure'):
+                be.colfft_configure(0)
         self._plans = {}
         self._work = None
         self.sibling = None       # untransposed plans: the plan of the transposed partition

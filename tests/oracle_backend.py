@@ -125,6 +125,9 @@ class OracleBackend(object):
         y = numpy.fft.ifft(x, axis=1) * N if inverse else numpy.fft.fft(x, axis=1)
         arr[...] = y * scale
 
+    def colfft_configure(self, persistent):
+        pass
+
     def colfft_roundtrip_supported(self, n, elsize):
         return self.colfft_supported(n, elsize)
 

@@ -40,6 +40,7 @@ def test_colfft_more_tiles_than_compute_units(be, oracle, elsize, N):
     same batch (its own tile width at these lengths) against the two passes it replaces, bit for bit."""
     if be.name != 'hip':
         pytest.skip('the persistent forms exist in the HIP kernels only')
+    be.colfft_configure(1)      # (a multi-rank test earlier in this process may have switched them off)
     if not be.colfft_supported(N, elsize):
         pytest.skip('length not built for this precision')
     cdt = 'c16' if elsize == 8 else 'c8'
@@ -56,6 +57,12 @@ def test_colfft_more_tiles_than_compute_units(be, oracle, elsize, N):
         assert rel(got, want) < tol * numpy.log2(N), (N, inverse)
         for a in range(A):      # the last column of a plane (the ragged tile) and the first of the next
             assert rel(got[a, :, -3:], want[a, :, -3:]) < tol * numpy.log2(N) * 4
+        # the same kernels with one workgroup per tile (what plans on several ranks select): same bits
+        be.colfft_configure(0)
+        t2 = torch.view_as_real(torch.from_numpy(x.copy())).reshape(-1).to(be.device)
+        be.colfft(elsize, inverse, t2, A, N, B, scale=0.5)
+        be.colfft_configure(1)
+        assert torch.equal(t, t2)
     if not be.colfft_roundtrip_supported(N, elsize):
         return
     n1, n2 = 3, B // 3
