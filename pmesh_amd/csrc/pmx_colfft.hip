@@ -386,8 +386,25 @@ __device__ __forceinline__ ColK column_k(const ColGeom &g, int64_t b)
     return c;
 }
 
-template <typename T> __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, const ColK &c, cpx<T> v)
+// FORM 1: the transfer is i k_d / k^2 times an amplitude (laplace_pow == -1, grad_dir >= 0: every force component of
+// a PM step) — the same operations as the general form below in the same order, without its questions: per element
+// the general form asks three wave-uniform ones, which the compiler turns into branches (and register moves at
+// their joins) in every one of the RPT unrolled copies.  The kernels ask once, around the loop.
+template <typename T, int FORM = 0>
+__device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, const ColK &c, cpx<T> v)
 {
+    if (FORM == 1) {
+        const double k0 = kcoord(g, 0, i0);
+        const double k2 = k0 * k0 + c.k12sq;
+        const double qq = (k2 == 0) ? 1.0 : k2;
+        double re = g.t.amplitude;
+        re *= 1.0 / qq;
+        const double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.k1 : c.k2);     // (selects, no branch)
+        const double im = re * D;
+        re = 0;
+        const double ar = v.x, ai = v.y;
+        return {(T)(re * ar - im * ai), (T)(re * ai + im * ar)};
+    }
     const double k0 = kcoord(g, 0, i0);
     const double k2 = k0 * k0 + c.k12sq;
     double re = g.t.amplitude, im = 0;
@@ -744,16 +761,32 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         const T sc = (T)g.scale;
         // (PIPE: one line at a time — unrolled, the double-precision transfer arithmetic of all RPT lines is
         // interleaved and, with the prefetched tile held in registers, spills 90-200 VGPRs)
+        // (not N = 2048 in float: the second copy of the loop costs that kernel 18 spilled registers)
+        const bool force_form = APPLY && !(sizeof(T) == 4 && LOGN == 11) && g.t.laplace_pow == -1 && g.t.grad_dir >= 0;      // apply_simple<T, 1>
+        if (force_form) {
 #pragma unroll PIPE ? 1 : RPT
-        for (int u = 0; u < RPT; u++) {
-            int n = tj + u * TPC;
-            const int at = P2 ? (PIPE ? lds_at<T, RB, false>(row_base<T, RB, false>(n, col), 0) : lds_at<T, RB, false>(tb, u * TPC))
-                              : lds_index<T, RB>(n, col);
-            cpx<T> v = buf[at];
-            v.x *= sc;
-            v.y *= sc;
-            if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
-            buf[at] = v;
+            for (int u = 0; u < RPT; u++) {
+                int n = tj + u * TPC;
+                const int at = P2 ? (PIPE ? lds_at<T, RB, false>(row_base<T, RB, false>(n, col), 0) : lds_at<T, RB, false>(tb, u * TPC))
+                                  : lds_index<T, RB>(n, col);
+                cpx<T> v = buf[at];
+                v.x *= sc;
+                v.y *= sc;
+                if (colok) v = apply_simple<T, 1>(g, n, ck, v);
+                buf[at] = v;
+            }
+        } else {
+#pragma unroll PIPE ? 1 : RPT
+            for (int u = 0; u < RPT; u++) {
+                int n = tj + u * TPC;
+                const int at = P2 ? (PIPE ? lds_at<T, RB, false>(row_base<T, RB, false>(n, col), 0) : lds_at<T, RB, false>(tb, u * TPC))
+                                  : lds_index<T, RB>(n, col);
+                cpx<T> v = buf[at];
+                v.x *= sc;
+                v.y *= sc;
+                if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
+                buf[at] = v;
+            }
         }
         __syncthreads();
         run_passes<T, LOGN, true, RB, HT>(buf, tw, col, tj);
