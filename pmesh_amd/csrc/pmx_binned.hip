@@ -36,6 +36,19 @@
 
 #include "pmx_binplan.h"
 
+// This file compiles as one unit (PMX_BINNED_PART undefined or 0: scripts/build_variant.sh, the resource test) or as
+// four — the plan and its bin kernels (1), paint on double / float canvases (2 / 4: pmx_binned_paint.hip,
+// pmx_binned_paint_f4.hip), readout (3: pmx_binned_readout.hip) —
+// which the Makefile builds side by side: the tile kernels come in a dozen template forms each and took 100 s of the
+// 105 s a clean build needs.  The parts differ only in which host launchers (and with them which kernel
+// instantiations) they contain; kernels that are not templates are `static`, every part that launches one has its own.
+#ifndef PMX_BINNED_PART
+#define PMX_BINNED_PART 0
+#endif
+#define PMX_PART_PLAN (PMX_BINNED_PART == 0 || PMX_BINNED_PART == 1)
+#define PMX_PART_PAINT (PMX_BINNED_PART == 0 || PMX_BINNED_PART == 2 || PMX_BINNED_PART == 4)    // 4: the float canvases
+#define PMX_PART_READOUT (PMX_BINNED_PART == 0 || PMX_BINNED_PART == 3)
+
 namespace pmx {
 
 // DENSE: positions are a contiguous (n, 3) array.  A lane-per-particle load of 3 elements
@@ -428,7 +441,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
 }
 
 // exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup
-__global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
+static __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
                                                         unsigned long long *cursor, const uint32_t *gate)
 {
     __shared__ int64_t sh[1024];
@@ -459,7 +472,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, 
     if (threadIdx.x == 0) offsets[ntiles] = carry;
 }
 
-__global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
+static __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
                                                              uint32_t *list, const uint32_t *gate, uint32_t *inv)
 {
     constexpr int U = 4;
@@ -540,7 +553,7 @@ __global__ void __launch_bounds__(TBLOCK) sort_copy_kernel(const uint32_t *list,
 }
 
 // out[i] = sorted[inv[i]]: the results of a readout in list order back into row order
-__global__ void __launch_bounds__(TBLOCK) unsort_kernel(const double *sorted, const uint32_t *inv, int64_t n, DVec out)
+static __global__ void __launch_bounds__(TBLOCK) unsort_kernel(const double *sorted, const uint32_t *inv, int64_t n, DVec out)
 {
     const int64_t stride = (int64_t)gridDim.x * TBLOCK;
     for (int64_t i0 = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i0 < n; i0 += 4 * stride) {
@@ -556,7 +569,7 @@ __global__ void __launch_bounds__(TBLOCK) unsort_kernel(const double *sorted, co
     }
 }
 
-__global__ void __launch_bounds__(TBLOCK) bin_zero_kernel(uint32_t *counts, int64_t nbuckets, const uint32_t *gate)
+static __global__ void __launch_bounds__(TBLOCK) bin_zero_kernel(uint32_t *counts, int64_t nbuckets, const uint32_t *gate)
 {
     if (*gate == 0) return;
     for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < nbuckets; i += (int64_t)gridDim.x * TBLOCK)
@@ -1118,7 +1131,7 @@ __global__ void __launch_bounds__(TBLOCK) halo_merge_kernel(pmx_painter p, BinGe
 }
 
 // entries of `out` for particles that are in no tile (they touch no local cell) read 0
-__global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint32_t *list, const int64_t *offsets,
+static __global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint32_t *list, const int64_t *offsets,
                                                               const uint32_t *counts, int64_t ntiles, DVec out, int sorted)
 {
     const int64_t n = counts[ntiles];   // the common case: nothing was dropped
@@ -1164,7 +1177,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
 
 // ---- crowded tiles ------------------------------------------------------------------------
 // work items (tile, piece >= 1) for what the tiles hold beyond `chunk` list entries
-__global__ void __launch_bounds__(TBLOCK) heavy_items_kernel(const uint32_t *counts, int64_t ntiles, int chunk,
+static __global__ void __launch_bounds__(TBLOCK) heavy_items_kernel(const uint32_t *counts, int64_t ntiles, int chunk,
                                                              uint64_t *items, uint32_t *nitems, uint32_t cap)
 {
     for (int64_t tile = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * TBLOCK) {
@@ -1263,7 +1276,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, 
 
 // stats[0] = max |m| over the finite masses (as the bit pattern of a non-negative double, which orders like an
 // integer), stats[1] = how many are not finite
-__global__ void __launch_bounds__(TBLOCK) mass_stats_kernel(DVec mass, int64_t n, unsigned long long *stats)
+static __global__ void __launch_bounds__(TBLOCK) mass_stats_kernel(DVec mass, int64_t n, unsigned long long *stats)
 {
     double mx = 0;
     unsigned long long odd = 0;
@@ -1284,14 +1297,14 @@ __global__ void __launch_bounds__(TBLOCK) mass_stats_kernel(DVec mass, int64_t n
     }
 }
 // stats[1] (double) = stats[2] (integer count)
-__global__ void mass_stats_finish_kernel(unsigned long long *stats)
+static __global__ void mass_stats_finish_kernel(unsigned long long *stats)
 {
     ((double *)stats)[1] = (double)stats[2];
 }
 
 // deterministic paint: the one scale of the batch.  A cell can receive from the particles of the (at most) 8 tiles
 // whose regions contain it: n = 8 max(counts).
-__global__ void __launch_bounds__(1024) det_scale_kernel(pmx_painter p, const uint32_t *counts, int64_t ntiles,
+static __global__ void __launch_bounds__(1024) det_scale_kernel(pmx_painter p, const uint32_t *counts, int64_t ntiles,
                                                          const double *mstats, double mass_scalar, int32_t *dexp)
 {
     __shared__ uint32_t mx[1024];
@@ -1323,6 +1336,7 @@ __global__ void __launch_bounds__(TBLOCK) det_finish_kernel(pmx_painter p, char 
     }
 }
 
+#if PMX_PART_PLAN
 int plan_ensure(void **ptr, size_t *cap, size_t need)
 {
     if (need <= *cap) return PMX_OK;
@@ -1333,6 +1347,7 @@ int plan_ensure(void **ptr, size_t *cap, size_t need)
     *cap = need;
     return PMX_OK;
 }
+#endif
 
 static bool same_geometry(const pmx_painter &a, const pmx_painter &b)
 {
@@ -1354,6 +1369,7 @@ static int halo_cells(int S)
 
 using namespace pmx;
 
+#if PMX_PART_PLAN
 extern "C" int pmx_binplan_create(pmx_binplan **plan)
 {
     PMX_REQUIRE(plan != nullptr, PMX_EINVAL, "plan pointer is NULL");
@@ -1726,9 +1742,15 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     return PMX_OK;
 }
 
+#endif   // PMX_PART_PLAN
+
+#if PMX_PART_PAINT
 template <typename T>
-static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
-                          int overwrite, hipStream_t st)
+#if PMX_BINNED_PART == 0
+static
+#endif
+int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
+                   int overwrite, hipStream_t st)
 {
     const BinGeom &g = pl->g;
     size_t need = (size_t)g.ntiles * (size_t)halo_cells(g.S) * sizeof(T);
@@ -1831,6 +1853,12 @@ static int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, D
     return PMX_OK;
 }
 
+#if PMX_BINNED_PART == 4
+template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, DVec, DVec, double, int, hipStream_t);
+#else
+#if PMX_BINNED_PART == 2
+extern template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, DVec, DVec, double, int, hipStream_t);
+#endif
 extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *canvas, const pmx_vec *pos,
                                 const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream)
 {
@@ -1853,7 +1881,11 @@ extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *ca
     if (p.canvas_elsize == 8) return paint_binned_t<double>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
     return paint_binned_t<float>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
 }
+#endif   // PMX_BINNED_PART != 4
 
+#endif   // PMX_PART_PAINT
+
+#if PMX_PART_READOUT
 extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const void *canvas, const pmx_vec *pos,
                                   const pmx_vec *out, void *stream)
 {
@@ -1935,3 +1967,4 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }
+#endif   // PMX_PART_READOUT

@@ -29,6 +29,18 @@
 
 #include "pmx_common.h"
 
+// This file compiles as one unit (PMX_COLFFT_PART undefined or 0: scripts/build_variant.sh, the resource test) or as two,
+// built side by side by the Makefile: the C ABI with the double-precision kernels (1) and the float kernels
+// (2: pmx_colfft_f4.hip) — 80 s of compilation otherwise, the longest step of a clean build.
+#ifndef PMX_COLFFT_PART
+#define PMX_COLFFT_PART 0
+#endif
+#if PMX_COLFFT_PART == 0
+#define PMX_DISPATCH static
+#else
+#define PMX_DISPATCH
+#endif
+
 namespace pmx {
 
 template <typename T> struct cpx { T x, y; };
@@ -1107,7 +1119,13 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
 }
 
 // pmx_colfft_configure: persistent (prefetching) column passes, or one workgroup per tile
+#if PMX_COLFFT_PART == 2
+extern std::atomic<int> g_persistent;
+#elif PMX_COLFFT_PART == 1
+std::atomic<int> g_persistent{1};
+#else
 static std::atomic<int> g_persistent{1};
+#endif
 
 static int compute_units()
 {
@@ -1210,7 +1228,7 @@ static int launch_colfft(const ColGeom &g, const void *src, void *dst, const voi
 #define PMX_RB768 (sizeof(T) == 4 ? 64 : 128)
 #endif
 template <typename T>
-static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
+PMX_DISPATCH int dispatch_logn(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
                          hipStream_t st)
 {
     switch (g.logN) {
@@ -1238,6 +1256,11 @@ static int dispatch_logn(const ColGeom &g, const void *src, void *dst, const voi
     set_error("pmx_colfft: length code %d is not built", g.logN);
     return PMX_EUNSUPPORTED;
 }
+#if PMX_COLFFT_PART == 1
+extern template int dispatch_logn<float>(const ColGeom &, const void *, void *, const void *, bool, bool, hipStream_t);
+#elif PMX_COLFFT_PART == 2
+template int dispatch_logn<float>(const ColGeom &, const void *, void *, const void *, bool, bool, hipStream_t);
+#endif
 
 template <typename T, int LOGM, int RB = 128>
 static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
@@ -1265,7 +1288,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
 }
 
 template <typename T>
-static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, double scale, const void *tw,
+PMX_DISPATCH int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, double scale, const void *tw,
                          bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st)
 {
     switch (logm) {
@@ -1286,12 +1309,18 @@ static int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, dou
     set_error("pmx_rowfft: length code %d is not built", logm);
     return PMX_EUNSUPPORTED;
 }
+#if PMX_COLFFT_PART == 1
+extern template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t);
+#elif PMX_COLFFT_PART == 2
+template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t);
+#endif
 
 }  // namespace pmx
 
 using namespace pmx;
 
 // PMX_OK if the real row transform of length n (n reals <-> n/2+1 modes) is built
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
@@ -1301,10 +1330,12 @@ extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
     if (lc < 32) return (n >= 384 && n <= 1536) ? PMX_OK : PMX_EUNSUPPORTED;      // 3 * 2^k: 384, 768, 1536
     return (n == 640 || n == 1280) ? PMX_OK : PMX_EUNSUPPORTED;                   // 5 * 2^k
 }
+#endif
 
 // In-place real <-> half-complex transform of `nrows` rows of n reals (inverse = 0: r2c,
 // n reals -> n/2+1 modes; 1: c2r), row pitch `pitch` COMPLEX elements (>= n/2+1), result
 // multiplied by `scale`; unnormalised in both directions.
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
                           double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream)
 {
@@ -1329,6 +1360,7 @@ extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t n
         return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
     return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
 }
+#endif
 
 static ColAddr plain_addr(int64_t N, int64_t B)
 {
@@ -1338,6 +1370,7 @@ static ColAddr plain_addr(int64_t N, int64_t B)
 }
 
 // PMX_OK if a column FFT of length n (element size elsize = 4|8 per component) is built
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 {
     if (elsize != 4 && elsize != 8) return PMX_EINVAL;
@@ -1351,12 +1384,14 @@ extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
     if (n < 320 || n > 1280) return PMX_EUNSUPPORTED;                    // 5 * 2^k: 320, 640, 1280
     return (n == 1280 && elsize == 4) ? PMX_EUNSUPPORTED : PMX_OK;
 }
+#endif
 
 // In-place FFT along the middle axis of the (A, N, B) complex array `data`.
 // inverse: 0 forward (exp(-i..)), 1 backward; result multiplied by `scale`.
 // t == NULL: plain transform.  t != NULL (SIMPLE transfers only: no gauss/deconv, spectral
 // gradient, laplace_pow in -1..1): A must be 1 and B = n1*n2; element (i0, i1, i2) is
 // multiplied by T(k) before the transform, with the index bookkeeping of pmx_apply_transfer.
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
                           double scale, const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
                           const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride,
@@ -1400,6 +1435,7 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     // float: 16 columns x 8 B = 128-byte rows, 16 lines per thread: 1024 threads at N = 1024
     return dispatch_logn<float>(g, data, data, tw, inverse != 0, apply, st);
 }
+#endif
 
 // Tile width of the round-trip kernel: where the 128-byte tile leaves room for one workgroup per CU only, 64-byte
 // rows (two or three workgroups).  Unlike the plain passes — which are at the rate of their bare loads and stores
@@ -1445,7 +1481,7 @@ static int launch_round(const ColGeom &g, void *data, const void *tw, bool apply
 }
 
 template <typename T>
-static int dispatch_round(const ColGeom &g, void *data, const void *tw, bool apply, hipStream_t st)
+PMX_DISPATCH int dispatch_round(const ColGeom &g, void *data, const void *tw, bool apply, hipStream_t st)
 {
     switch (g.logN) {
 #define ROUND(LC, RB0) return launch_round<T, LC, RoundRB<T, LC, (RB0)>::value>(g, data, tw, apply, st)
@@ -1465,13 +1501,21 @@ static int dispatch_round(const ColGeom &g, void *data, const void *tw, bool app
     set_error("pmx_colfft_roundtrip: length code %d is not built", g.logN);
     return PMX_EUNSUPPORTED;
 }
+#if PMX_COLFFT_PART == 1
+extern template int dispatch_round<float>(const ColGeom &, void *, const void *, bool, hipStream_t);
+#elif PMX_COLFFT_PART == 2
+template int dispatch_round<float>(const ColGeom &, void *, const void *, bool, hipStream_t);
+#endif
 
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft_configure(int32_t persistent)
 {
     g_persistent.store(persistent ? 1 : 0, std::memory_order_relaxed);
     return PMX_OK;
 }
+#endif
 
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft_roundtrip_supported(int64_t n, int32_t elsize)
 {
     int rc = pmx_colfft_supported(n, elsize);
@@ -1479,7 +1523,9 @@ extern "C" int pmx_colfft_roundtrip_supported(int64_t n, int32_t elsize)
     const int code = length_code(n);
     return (code == 25 || code == 40) ? PMX_EUNSUPPORTED : PMX_OK;      // 1536 / 1280: one-precision kernels, not built here
 }
+#endif
 
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64_t B, double scale,
                                     const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
                                     const int64_t *nmesh, const double *boxsize, int64_t n_stride, void *stream)
@@ -1516,6 +1562,7 @@ extern "C" int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64
     if (elsize == 8) return dispatch_round<double>(g, data, tw, apply, st);
     return dispatch_round<float>(g, data, tw, apply, st);
 }
+#endif
 
 // The axis-1 pass of a slab-decomposed transform fused with the pack / unpack around the
 // global transpose (the work of pmx_slab_pack for equal, power-of-two ranges of nsplit lines):
@@ -1524,6 +1571,7 @@ extern "C" int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64
 //                array — the send buffer of the all-to-all;
 //   inverse = 1: src is that split layout (the receive buffer), dst the plain (A, N, B) array.
 // src and dst must not overlap.
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A,
                                 int64_t N, int64_t B, int64_t nsplit, double scale, int64_t plain_pitch,
                                 void *stream)
@@ -1559,12 +1607,14 @@ extern "C" int pmx_colfft_split(int32_t elsize, int32_t inverse, const void *src
     if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, false, st);
     return dispatch_logn<float>(g, src, dst, tw, inverse != 0, false, st);
 }
+#endif
 
 // The axis-1 pass of a PENCIL transform, between its two global transposes: both sides are split
 // layouts of the same (A, N, B) array — src cut into ranges of nsplit_in lines (what the
 // all-to-all of one process-mesh direction delivered), dst into ranges of nsplit_out lines (what
 // the all-to-all of the other direction sends); 0 = plain dense.  The unpack before and the pack
 // after the pass (two pmx_slab_pack sweeps over the block) ride on its load and store.
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft_resplit(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A,
                                   int64_t N, int64_t B, int64_t nsplit_in, int64_t nsplit_out, double scale,
                                   void *stream)
@@ -1599,6 +1649,7 @@ extern "C" int pmx_colfft_resplit(int32_t elsize, int32_t inverse, const void *s
     if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, false, st);
     return dispatch_logn<float>(g, src, dst, tw, inverse != 0, false, st);
 }
+#endif
 
 // The axis-0 pass of a slab transform on ONE chunk of the last axis (pipelined transposes: the
 // all-to-all of chunk c overlaps the passes of chunks c-1 and c+1).  `full` is the standard
@@ -1609,6 +1660,7 @@ extern "C" int pmx_colfft_resplit(int32_t elsize, int32_t inverse, const void *s
 //   to_full = 0: FFT along N of the chunk's columns gathered from `full`, result dense in
 //                `chunk` (c2r, first stage; t != NULL multiplies by the transfer function first,
 //                see pmx_colfft; start[] is the global start of the full block).
+#if PMX_COLFFT_PART != 2
 extern "C" int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, void *full, int64_t N,
                                 int64_t n1, int64_t cw, int64_t pitch, int64_t coff, int32_t to_full,
                                 double scale, const pmx_transfer *t, const int64_t *start,
@@ -1655,3 +1707,4 @@ extern "C" int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, vo
     if (elsize == 8) return dispatch_logn<double>(g, src, dst, tw, inverse != 0, apply, st);
     return dispatch_logn<float>(g, src, dst, tw, inverse != 0, apply, st);
 }
+#endif

@@ -1,6 +1,7 @@
 #!/bin/bash
 # scripts/build_variant.sh <name> "<EXTRA flags>" [file.hip ...]: builds pmesh_amd/libpmesh_amd_<name>.so with the
 # given files recompiled under EXTRA (default: pmx_binned.hip), the other objects of the product build as they are.
+# (pmx_binned.hip and pmx_colfft.hip are built in parts by the Makefile; a variant compiles the whole file as one unit.)
 name=$1; flags=$2; shift 2
 files=${@:-pmx_binned.hip}
 cd pmesh_amd/csrc
@@ -9,6 +10,10 @@ for f in pmx_core pmx_window pmx_binned pmx_domain pmx_transfer pmx_synth pmx_ff
   if echo " $files " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -I../../include $flags -c $f.hip -o /tmp/${f}_$name.o || exit 1
     objs="$objs /tmp/${f}_$name.o"
-  else objs="$objs $f.o"; fi
+  else
+    objs="$objs $f.o"
+    [ $f = pmx_binned ] && objs="$objs pmx_binned_paint.o pmx_binned_paint_f4.o pmx_binned_readout.o"
+    [ $f = pmx_colfft ] && objs="$objs pmx_colfft_f4.o"
+  fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpmesh_amd_$name.so $objs -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
