@@ -217,18 +217,22 @@ struct ColGeom {
 // row number, so that the row sets a wave touches in every Stockham pass (consecutive rows
 // when reading, rows 8 or 64 apart when writing) always split evenly over the two halves:
 // all passes are bank-conflict free without padding.
-template <typename T, int RB = 128> __device__ __forceinline__ int lds_index(int row, int col)
+template <typename T, int RB = 128, bool ROT = true> __device__ __forceinline__ int lds_index(int row, int col)
 {
     constexpr int W = RB / (int)sizeof(cpx<T>);
+    // ROT = false: the column kernels' tiles, without the rotation of the column slot (see RowBase below)
+    const int slot = ROT ? (col + row) & (W - 1) : col;
     if (RB == 256) {
         // a tile row is a whole bank row: any set of rows is conflict free; the column slot is
         // still rotated by the row number for the transposing accesses
-        return row * W + ((col + row) & (W - 1));
+        return row * W + slot;
     }
-    int half = (row ^ (row >> 3) ^ (row >> 6) ^ (row >> 9)) & 1;
+    // parity of bits 0, 3, 6, 9 in two folds
+    int x = row ^ (row >> 3);
+    x ^= x >> 6;
     // the column slot is rotated by the row number: a wave that walks along a column
     // (the transposing load/store of the row kernel) then also spreads over all banks
-    return ((row >> 1) * 2 + half) * W + ((col + row) & (W - 1));
+    return ((row & ~1) | (x & 1)) * W + slot;
 }
 
 // The same index in two steps, for rows of the form `row + c` with c a compile-time constant whose set
@@ -277,7 +281,7 @@ template <typename T, int RB, bool ROT = true> __device__ __forceinline__ int ld
 // butterflies of all W columns at once.
 // HALFTW: `tw` holds only the first N/2 entries of the table (w[m + N/2] = -w[m]); used where the
 // full table would not fit beside the tile (N = 2048 in double).
-template <typename T, bool INV, int R, int RB = 128, bool HALFTW = false>
+template <typename T, bool INV, int R, int RB = 128, bool HALFTW = false, bool ROT = true>
 __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int N, int Ns, int tpc /*threads per column*/,
                                               int col, int tj, int twstride = 1)
 {
@@ -293,7 +297,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
         int k = j % Ns;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            cpx<T> x = buf[lds_index<T, RB>(j + r * nb, col)];
+            cpx<T> x = buf[lds_index<T, RB, ROT>(j + r * nb, col)];
             if (r > 0 && Ns > 1) {
                 // twiddle exp(-+ 2 pi i r k / (Ns R)) from the length-N table
                 int m = r * k * (N / (Ns * R));
@@ -320,7 +324,7 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
         int k = j % Ns;
         int base = (j - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; r++) buf[lds_index<T, RB>(base + r * Ns, col)] = v[q][r];
+        for (int r = 0; r < R; r++) buf[lds_index<T, RB, ROT>(base + r * Ns, col)] = v[q][r];
     }
     __syncthreads();
 }
@@ -533,27 +537,27 @@ __device__ __forceinline__ void run_passes(cpx<T> *buf, const cpx<T> *tw, int co
     }
     int Ns = 1;
     using Rd = Radices<LOGN>;
-    if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+    if (Rd::r[0] == 8) stockham_pass<T, INV, 8, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
     Ns *= Rd::r[0];
     if (Rd::n > 1) {
-        if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[1] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        if (Rd::r[1] == 8) stockham_pass<T, INV, 8, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[1] == 4) stockham_pass<T, INV, 4, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[1] == 3) stockham_pass<T, INV, 3, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[1] == 5) stockham_pass<T, INV, 5, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
         Ns *= Rd::r[1];
     }
     if (Rd::n > 2) {
-        if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[2] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        if (Rd::r[2] == 8) stockham_pass<T, INV, 8, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[2] == 4) stockham_pass<T, INV, 4, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[2] == 3) stockham_pass<T, INV, 3, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[2] == 5) stockham_pass<T, INV, 5, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
         Ns *= Rd::r[2];
     }
     if (Rd::n > 3) {
-        if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
-        else if (Rd::r[3] == 5) stockham_pass<T, INV, 5, RB, HT>(buf, tw, N, Ns, TPC, col, tj);
+        if (Rd::r[3] == 8) stockham_pass<T, INV, 8, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[3] == 4) stockham_pass<T, INV, 4, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[3] == 3) stockham_pass<T, INV, 3, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
+        else if (Rd::r[3] == 5) stockham_pass<T, INV, 5, RB, HT, false>(buf, tw, N, Ns, TPC, col, tj);
         Ns *= Rd::r[3];
     }
 }
@@ -650,7 +654,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
             int n = tj + u * TPC;
             cpx<T> v = ld[u];
             if (APPLY && colok) v = apply_simple<T>(g, n, ck, v);
-            buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col)] = v;
+            buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB, false>(n, col)] = v;
         }
         __syncthreads();
         if (PIPE && tile + step < ntiles) load_tile(tile + step, ld);
@@ -666,7 +670,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
                 int n = tj + u * TPC;
-                cpx<T> v = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(n, col)];
+                cpx<T> v = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB, false>(n, col)];
                 v.x *= sc;
                 v.y *= sc;
                 if (P2) othread[uoff[u]] = v;
@@ -764,7 +768,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         __syncthreads();
         if (!PIPE) load_tile(tile, ld);
 #pragma unroll
-        for (int u = 0; u < RPT; u++) buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)] = ld[u];
+        for (int u = 0; u < RPT; u++) buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB, false>(tj + u * TPC, col)] = ld[u];
         __syncthreads();
         if (PIPE && tile + step < tilesB) load_tile(tile + step, ld);
         run_passes<T, LOGN, false, RB, HT>(buf, tw, col, tj);
@@ -780,7 +784,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
             for (int u = 0; u < RPT; u++) {
                 int n = tj + u * TPC;
                 const int at = P2 ? (PIPE ? lds_at<T, RB, false>(row_base<T, RB, false>(n, col), 0) : lds_at<T, RB, false>(tb, u * TPC))
-                                  : lds_index<T, RB>(n, col);
+                                  : lds_index<T, RB, false>(n, col);
                 cpx<T> v = buf[at];
                 v.x *= sc;
                 v.y *= sc;
@@ -792,7 +796,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
             for (int u = 0; u < RPT; u++) {
                 int n = tj + u * TPC;
                 const int at = P2 ? (PIPE ? lds_at<T, RB, false>(row_base<T, RB, false>(n, col), 0) : lds_at<T, RB, false>(tb, u * TPC))
-                                  : lds_index<T, RB>(n, col);
+                                  : lds_index<T, RB, false>(n, col);
                 cpx<T> v = buf[at];
                 v.x *= sc;
                 v.y *= sc;
@@ -808,7 +812,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         auto store_lines = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < RPT; u++)
-                othread[uoff[u]] = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB>(tj + u * TPC, col)];
+                othread[uoff[u]] = buf[P2 ? lds_at<T, RB, false>(tb, u * TPC) : lds_index<T, RB, false>(tj + u * TPC, col)];
         };
         if (PIPE) {
             if (b0 + W <= g.B) {
