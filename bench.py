@@ -282,6 +282,14 @@ def main():
     from pmesh_amd.transfer import Transfer
 
     be = backend.get()                     # raises if the HIP library / GPU is missing
+    # what the library was built with: a build that contains wrong-result timing experiments (-DPMX_EXPERIMENT,
+    # PMX_EXP_*) is never reported as a number
+    build_flags = be.lib.pmx_build_flags().decode()
+    nocheck = os.environ.get('PMESH_AMD_BENCH_NOCHECK') == '1'
+    if ('PMX_EXP' in build_flags) and not nocheck:
+        raise SystemExit('bench.py: %s was built with experiment switches (%s): its results are wrong by design; '
+                         'no bench line.  (PMESH_AMD_BENCH_NOCHECK=1 runs it for kernel traces, without a line.)'
+                         % (backend.library_path(), build_flags))
     comm = default_comm()
     N = args.mesh
     Np_side = args.particles or N
@@ -359,6 +367,10 @@ def main():
         set_b = pos.numel() * pos.element_size()
         work_b = 14 * nloc + 6 * e * N ** 3 // world          # bin lists + mesh, work buffers, halo staging
         nextra = 2 if free_b > 3 * set_b + work_b else 1      # (+1: the temporary of the random step)
+        if world > 1:
+            # every rank must build the same number of sets: each costs one collective decompose below, and the
+            # local figures (free memory, nloc after --migrate on a clustered set) differ from rank to rank
+            nextra = int(comm.allreduce(nextra, op='min'))
         for k in range(nextra):
             step = torch.randn(pos.shape, dtype=tdt, device=be.device, generator=gen) * (args.drift * L / N)
             psets.append(psets[-1] + step)
@@ -480,7 +492,7 @@ def main():
     # sanity: mass conservation and a finite result (size-independent properties)
     check = pm.paint(pos, mass=mass, layout=layout)
     msum = check.csum()
-    if os.environ.get('PMESH_AMD_BENCH_NOCHECK') == '1':      # timing experiments with wrong results
+    if nocheck:      # timing experiments with wrong results (-DPMX_EXPERIMENT builds): kernel traces only, no bench line
         msum = mtot
     assert abs(msum - mtot) <= 1e-9 * mtot if args.dtype == 'f8' else abs(msum - mtot) <= 1e-3 * mtot, (msum, mtot)
     assert bool(numpy.isfinite(f).all()) if args.host_arrays else bool(torch.isfinite(f).all())
@@ -572,13 +584,18 @@ def main():
                          'algorithmic_bytes_per_particle': algorithmic_bytes(dom, e, pe, nu, me),
                          'particles_per_launch': units, 'ms_per_launch': single[dom]},
         }
+        line['build_flags'] = build_flags
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args)
             except Exception as ex:          # the baseline never takes the benchmark down
                 line['cpu_baseline'] = {'value': None, 'unit': 'particles/s', 'cores': 1,
                                         'kind': 'port', 'sample': 'failed: %r' % (ex,)}
-        print(json.dumps(line), flush=True)
+        if nocheck:
+            print('PMESH_AMD_BENCH_NOCHECK=1: the result was not checked, no bench line is printed '
+                  '(%.3f ms per cycle, for kernel traces only)' % ms_per_step, file=sys.stderr, flush=True)
+        else:
+            print(json.dumps(line), flush=True)
     if world > 1 or launched:
         import torch.distributed as dist
         dist.barrier()

@@ -91,6 +91,9 @@ typedef struct pmx_vec {
 
 const char *pmx_last_error(void);
 int pmx_version(void);
+/* the compiler line libpmesh_amd.so was built with (csrc/Makefile); a build that contains wrong-result timing
+ * experiments carries -DPMX_EXPERIMENT there and bench.py refuses to report numbers for it */
+const char *pmx_build_flags(void);
 /* number of visible HIP devices (0 if none); never throws */
 int pmx_device_count(void);
 
@@ -134,14 +137,12 @@ int pmx_readout(const pmx_painter *p, const void *canvas, const pmx_vec *pos, co
 typedef struct pmx_binplan pmx_binplan;
 int pmx_binplan_create(pmx_binplan **plan);
 int pmx_binplan_destroy(pmx_binplan *plan);
-/* Which kernels the next builds of this plan serve: 0 = tile form (one workgroup accumulates a
- * tile of 8 x 16 x 32 cells in LDS), -1 (default) = the library's choice (the tiles), 2 = tiles
- * with the chunk form of the single-pass rebuild (what plans with a tile-ordered copy use; a test
- * hook), 1 = walk form (a workgroup walks a patch of 16 x 32 columns plane by plane with the
- * stencil of every cell in registers: csrc/pmx_walk.hip, TSC and PCS) — a measured alternative that
- * is no faster on MI355X and only part of a `make WALK=1` build: PMX_EUNSUPPORTED
- * otherwise.  Same results in every form (readout bit-identical, paint up to the order of the
- * additions into a cell). */
+/* Which kernels the next builds of this plan serve: 0 / -1 (default) = tile form (one workgroup
+ * accumulates a tile of 8 x 16 x 32 cells in LDS), 2 = tiles with the chunk form of the single-pass
+ * rebuild (what plans with a tile-ordered copy use; a test hook).  1 was the walk form of rounds
+ * 2-3 (a measured alternative that was no faster on MI355X; removed): PMX_EUNSUPPORTED.
+ * Same results in every form (readout bit-identical, paint up to the order of the additions into
+ * a cell). */
 int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
 /* Deterministic paint (the reference's scatter is a serial loop, pmesh/_window.pyx:157-165: the same call gives
  * the same bits).  on = 1: pmx_paint_binned accumulates every cell as a 64-bit integer in units of 2^-f — the
@@ -152,11 +153,16 @@ int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
  * contribution of the reference's sum.  Default 0: S >= 3 windows still accumulate their LDS regions in fixed
  * point (it is the faster form), the halos are merged with floating-point atomics. */
 int pmx_binplan_deterministic(pmx_binplan *plan, int32_t on);
-/* The fixed-point regions of pmx_paint_binned need the largest |mass| of a per-particle mass array and must know
- * that every mass is finite; by default a reduction kernel in front of every paint finds out (one read of the
- * masses).  A caller that knows (masses that do not change between time steps) says so once per paint: bound >= 0
- * and finite = all masses are finite and |mass| <= bound; anything else (negative, NaN, Inf) = unknown. */
-int pmx_binplan_mass_bound(pmx_binplan *plan, double bound);
+/* The fixed-point regions of pmx_paint_binned (S >= 3 windows, deterministic paint) take one scale 2^-f per
+ * z segment from the largest |mass| of a per-particle mass array, and must know that every mass is finite and
+ * that the masses do not span more than 2^20 (a batch that does — or that holds a NaN / Inf — is painted by the
+ * floating-point form of the same kernels, exactly as in round 2; see INTEGRATION.md section 1 for the error
+ * model).  By default a reduction kernel in front of every paint finds out (one read of the masses).
+ * pmx_mass_stats runs that reduction on its own: stats = 4 doubles of device memory (contents opaque);
+ * pmx_binplan_mass_stats hands them to the NEXT pmx_paint_binned of the plan, which then skips its own pass
+ * (a time-stepping caller computes them once per mass array).  stats = NULL: back to the default. */
+int pmx_mass_stats(const pmx_vec *mass, int64_t n, double *stats, void *stream);
+int pmx_binplan_mass_stats(pmx_binplan *plan, const double *stats);
 /* Rows without spatial coherence (catalogues in file order, shuffled sets) make every access
  * through the index list a sector of its own.  A plan can instead carry a copy of the positions
  * in tile order (one gather per build): paint and readout stream it, readout writes its results

@@ -84,13 +84,15 @@ PROTOTYPES = {
 DEVICE_ONLY = {
     'last_error': (C.c_char_p, []),
     'version': (C.c_int, []),
+    'build_flags': (C.c_char_p, []),
     'device_count': (C.c_int, []),
     'window_set_table': (C.c_int, [_i32, _P(_f64), _i32, _f64]),
     'binplan_create': (C.c_int, [_P(_vp)]),
     'binplan_destroy': (C.c_int, [_vp]),
     'binplan_configure': (C.c_int, [_vp, _i32]),
     'binplan_deterministic': (C.c_int, [_vp, _i32]),
-    'binplan_mass_bound': (C.c_int, [_vp, _f64]),
+    'mass_stats': (C.c_int, [_P(Vec), _i64, _vp, _vp]),
+    'binplan_mass_stats': (C.c_int, [_vp, _vp]),
     'binplan_overflows': (C.c_int, [_vp, _P(C.c_uint32)]),
     'binplan_sorted': (C.c_int, [_vp, _i32, _P(_i32)]),
     'binplan_supported': (C.c_int, [_P(Painter), _i64]),

@@ -115,29 +115,6 @@ class Staged(object):
         return self.host.ndim
 
 
-# device copies of READ-ONLY host arrays (flags.writeable == False: the caller cannot have changed them
-# between two calls) found again by their buffer: [key, array (kept alive: the address stays taken), tensor]
-_READONLY_SLOTS = 4
-_readonly = []
-
-
-def _readonly_copy(a, device):
-    key = (a.__array_interface__['data'][0], a.shape, a.strides, a.dtype.str, str(device))
-    for e in _readonly:
-        if e[0] == key:
-            _readonly.remove(e)
-            _readonly.append(e)
-            return e[2]
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')          # torch warns that the array is not writable; it is only read
-        src = a if all(s >= 0 for s in a.strides) else numpy.ascontiguousarray(a)
-        t = upload(torch.from_numpy(src), device)
-    _readonly.append([key, a, t])
-    del _readonly[:-_READONLY_SLOTS]
-    return t
-
-
 def to_device(x, device, what='array', allow_int=False):
     """-> (tensor on `device`, came_from_host).  Lists become float64."""
     if isinstance(x, Staged):
@@ -152,10 +129,9 @@ def to_device(x, device, what='array', allow_int=False):
         a = numpy.asarray(x)
         if a.dtype == object:
             raise TypeError('%s: unsupported dtype object' % what)
-        if (not a.flags.writeable and a.ndim and a.nbytes >= (1 << 20) and a.dtype.byteorder in ('=', '|', '<')
-                and device.type == 'cuda' and (allow_int or a.dtype.str[1:] in ('f4', 'f8'))):
-            # a large read-only array: its device copy is remembered (same buffer -> same contents)
-            return _readonly_copy(a, device), True
+        # (No implicit memo of device copies: `flags.writeable == False` does not mean the contents cannot change — a
+        # read-only view of a writable base, setflags, mode='r' memory maps.  A caller who passes the same array to
+        # many calls registers it once with ParticleMesh.stage, which is explicit about who refreshes it.)
         if not a.flags.writeable:
             a = a.copy()
         if a.dtype.byteorder not in ('=', '|', '<'):

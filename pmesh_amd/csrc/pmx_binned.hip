@@ -59,9 +59,8 @@ namespace pmx {
 // next build of slowly moving particles can reuse the ranges (single pass, see bin_onepass)
 __host__ __device__ __forceinline__ int64_t slot_capacity(int64_t c) { return c + (c >> 2) + 64; }
 
-// bucket of a particle at x: its tile (tile form: tiles in C order; walk form: the planes of a patch
-// column follow each other, a workgroup walks along axis 0), or g.ntiles if it touches no local cell
-template <int KIND, bool WALK>
+// bucket of a particle at x: its tile (tiles in C order), or g.ntiles if it touches no local cell
+template <int KIND>
 __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const BinGeom &g, const double *x)
 {
     constexpr int S = Tuned<KIND>::S;
@@ -76,11 +75,10 @@ __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const B
         Tuned<KIND>::axis(ok ? X : 0.0, 0, 1.0, I, V);
         int i0w = 0;
         ok = ok && local_base<KIND>(p, d, I[0], &i0w);
-        tt[d] = (int)((unsigned)(i0w + g.o[d]) / (unsigned)bucket_ext<WALK>(d));      // (never negative for a particle that counts)
+        tt[d] = (int)((unsigned)(i0w + g.o[d]) / (unsigned)tile_ext(d));      // (never negative for a particle that counts)
     }
     // (32-bit: pmx_binplan_build refuses more than 2^31 buckets; the 64-bit multiplies cost four issue slots each)
-    const int tb = WALK ? (tt[1] * g.nt[2] + tt[2]) * g.nt[0] + tt[0]
-                        : (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+    const int tb = (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
     return ok ? (int64_t)tb : g.ntiles;
 }
 
@@ -91,7 +89,7 @@ __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const B
 // Particles that touch no local cell go to bucket `ntiles`.  gate != NULL: do nothing unless
 // *gate != 0 (the fallback launches after a single-pass build are always enqueued and only
 // run if it overflowed — no host synchronisation).
-template <int KIND, bool DENSE, int MODE, bool WALK, bool SORTP>
+template <int KIND, bool DENSE, int MODE, bool SORTP>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
                                                            int32_t *tid, uint32_t *counts, uint32_t *flags,
                                                            const int64_t *offsets, uint32_t *list,
@@ -161,7 +159,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
         for (int u = 0; u < U; u++) {
             int64_t i = base + u * TBLOCK + threadIdx.x;
             t[u] = -1;
-            if (i < n) t[u] = (int)particle_bucket<KIND, WALK>(p, g, xin[u]);
+            if (i < n) t[u] = (int)particle_bucket<KIND>(p, g, xin[u]);
             // wave-aggregated counting: find the lanes that share my tile (ballots only)
             same[u] = 0;
             if (noagg) {
@@ -258,8 +256,9 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
 constexpr int BLOCK_ITERS = PMX_BLOCK_ITERS;                     // trips of TBLOCK * PMX_ONEPASS_U rows
 constexpr int BLOCK_ROWS = TBLOCK * PMX_ONEPASS_U * BLOCK_ITERS;
 constexpr int BLOCK_HT = 128;                       // entries of the LDS table (a power of two)
-#ifndef PMX_EXP_BINFLOOR
-#define PMX_EXP_BINFLOOR 0                          // timing experiment, see bin_block_kernel
+#if !defined(PMX_EXPERIMENT) || !defined(PMX_EXP_BINFLOOR)
+#undef PMX_EXP_BINFLOOR
+#define PMX_EXP_BINFLOOR 0                          // timing experiment (-DPMX_EXPERIMENT builds only), see bin_block_kernel
 #endif
 // 16-byte pieces of the TBLOCK * U dense rows from `base` on, one per thread and q: -> bytes requested
 template <int NPRE, int U>
@@ -354,7 +353,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int64_t i = base + u * TBLOCK + threadIdx.x;
-                const int t = i < n ? (int)particle_bucket<KIND, false>(p, g, xin[u]) : -1;
+                const int t = i < n ? (int)particle_bucket<KIND>(p, g, xin[u]) : -1;
                 // the lanes that share my tile (ballots only)
                 unsigned long long same = 0, active = __ballot(t >= 0);
                 while (active) {
@@ -665,7 +664,7 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
     }
 }
 
-// timing experiments (wrong results; bench with PMESH_AMD_BENCH_NOCHECK=1): where does the deposit spend its time?
+// timing experiments (wrong results; -DPMX_EXPERIMENT builds only, profiled with PMESH_AMD_BENCH_NOCHECK=1, which prints no bench line): where does the deposit spend its time?
 //   PMX_EXP_NOATOM: the weights are computed and folded into one register, nothing goes to LDS
 //   PMX_EXP_NOWEIGHT: the LDS atomics with a constant instead of the weight products
 #ifndef PMX_FIXED_POINT
@@ -674,11 +673,12 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
 #ifndef PMX_FIXED_MIN_S
 #define PMX_FIXED_MIN_S 3
 #endif
-#ifndef PMX_EXP_NOATOM
+#if !defined(PMX_EXPERIMENT) || !defined(PMX_EXP_NOATOM)
+#undef PMX_EXP_NOATOM
 #define PMX_EXP_NOATOM 0
 #endif
-
-#ifndef PMX_EXP_NOWEIGHT
+#if !defined(PMX_EXPERIMENT) || !defined(PMX_EXP_NOWEIGHT)
+#undef PMX_EXP_NOWEIGHT
 #define PMX_EXP_NOWEIGHT 0
 #endif
 
@@ -1274,32 +1274,50 @@ __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, 
     }
 }
 
-// stats[0] = max |m| over the finite masses (as the bit pattern of a non-negative double, which orders like an
-// integer), stats[1] = how many are not finite
+// The masses of a batch as the fixed-point kernels need to know them (stats: 4 x 8 bytes, zeroed first):
+//   [0] max |m| over the finite masses (the bit pattern of a non-negative double orders like an integer),
+//   [2] how many are not finite, [3] the complement of the bits of the smallest non-zero |m| (0: none seen; the
+//   complement so that a zeroed word and atomicMax do).
+// mass_stats_finish_kernel then sets [1] (double): 0 = the fixed-point kernels serve the batch, != 0 = its
+// floating-point twin does: a NaN / Inf mass, or masses spread over more than FIXED_MASS_RANGE_LOG2 binary
+// orders of magnitude.  The one scale of a segment comes from the LARGEST |mass|; a contribution of a mass 2^-R
+// of that is rounded to 2^-50 + R of itself, where the reference's floating adds keep 2^-53 of the cell's sum:
+// beyond R = 20 (two species at 1 : 1e-6) the light species would lose more than the 1e-9 relative that
+// INTEGRATION.md section 1 promises for cells that only light particles reach.
+constexpr int FIXED_MASS_RANGE_LOG2 = 20;
 static __global__ void __launch_bounds__(TBLOCK) mass_stats_kernel(DVec mass, int64_t n, unsigned long long *stats)
 {
-    double mx = 0;
+    double mx = 0, mn = 1.7976931348623157e308;
     unsigned long long odd = 0;
     for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * TBLOCK) {
         const double m = fabs(mass.get(i, 0));
-        if (m <= 1.7e308) mx = m > mx ? m : mx;
-        else odd++;
+        if (m <= 1.7e308) {
+            mx = m > mx ? m : mx;
+            mn = (m > 0 && m < mn) ? m : mn;
+        } else odd++;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_down(mx, off);
+        const double o = __shfl_down(mx, off), q = __shfl_down(mn, off);
         mx = o > mx ? o : mx;
+        mn = q < mn ? q : mn;
         odd += __shfl_down(odd, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&stats[0], (unsigned long long)__double_as_longlong(mx));
+        if (mn < 1.7976931348623157e308) atomicMax(&stats[3], ~(unsigned long long)__double_as_longlong(mn));
         if (odd) atomicAdd(&stats[2], odd);
     }
 }
-// stats[1] (double) = stats[2] (integer count)
 static __global__ void mass_stats_finish_kernel(unsigned long long *stats)
 {
-    ((double *)stats)[1] = (double)stats[2];
+    const double mx = __longlong_as_double((long long)stats[0]);
+    bool floating = stats[2] != 0;
+    if (stats[3] != 0) {
+        const double mn = __longlong_as_double((long long)~stats[3]);
+        if (ilogb(mx) - ilogb(mn) > FIXED_MASS_RANGE_LOG2) floating = true;
+    }
+    ((double *)stats)[1] = floating ? 1.0 : 0.0;
 }
 
 // deterministic paint: the one scale of the batch.  A cell can receive from the particles of the (at most) 8 tiles
@@ -1380,10 +1398,8 @@ extern "C" int pmx_binplan_create(pmx_binplan **plan)
 extern "C" int pmx_binplan_configure(pmx_binplan *pl, int32_t form)
 {
     PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
-    PMX_REQUIRE(form >= -1 && form <= 2, PMX_EINVAL, "form must be -1 (auto), 0 (tiles), 1 (walk) or 2 (tiles, chunk rebuild)");
-#ifndef PMX_WITH_WALK
-    PMX_REQUIRE(form != 1, PMX_EUNSUPPORTED, "the walk kernels are not part of this build (make WALK=1)");
-#endif
+    PMX_REQUIRE(form >= -1 && form <= 2, PMX_EINVAL, "form must be -1 (auto), 0 (tiles) or 2 (tiles, chunk rebuild)");
+    PMX_REQUIRE(form != 1, PMX_EUNSUPPORTED, "form 1 (the walk kernels of rounds 2-3) is no longer part of the library");
     if (pl->form != form) pl->have_history = false;
     pl->form = form;
     return PMX_OK;
@@ -1396,10 +1412,10 @@ extern "C" int pmx_binplan_deterministic(pmx_binplan *pl, int32_t on)
     return PMX_OK;
 }
 
-extern "C" int pmx_binplan_mass_bound(pmx_binplan *pl, double bound)
+extern "C" int pmx_binplan_mass_stats(pmx_binplan *pl, const double *stats)
 {
     PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
-    pl->mass_bound = bound;          // < 0, NaN or Inf: unknown, found on the device by every paint
+    pl->mass_stats_ext = stats;      // NULL: found by the next paint itself
     return PMX_OK;
 }
 
@@ -1433,7 +1449,6 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->flags) (void)hipFree(pl->flags);
     if (pl->host_flag) (void)hipHostFree(pl->host_flag);
     if (pl->halo) (void)hipFree(pl->halo);
-    if (pl->unit_flags) (void)hipFree(pl->unit_flags);
     if (pl->pos_copy) (void)hipFree(pl->pos_copy);
     if (pl->inv) (void)hipFree(pl->inv);
     if (pl->out_sorted) (void)hipFree(pl->out_sorted);
@@ -1489,17 +1504,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     BinGeom g;
     g.kind = p.kind;
     g.S = native_support(p.kind);
-    // Which form: the tile kernels.  (The walk kernels of pmx_walk.hip — S^2 instead of S^3 LDS
-    // operations per particle for TSC / PCS — measured no faster on MI355X, DESIGN.md "walk form":
-    // they are only part of a `make WALK=1` build and only chosen by form 1.)
-#ifdef PMX_WITH_WALK
-    bool walk = pl->form == 1;
-    if (g.S < 3 || !walk_layout_ok(pos)) walk = false;      // built for TSC / PCS; rows gathered by LDS-DMA
-#else
-    constexpr bool walk = false;
-#endif
-    g.walk = walk ? 1 : 0;
-    const int T[3] = {walk ? 1 : T0, walk ? P1 : T1, walk ? P2 : T2};
+    const int T[3] = {T0, T1, T2};
     g.ntiles = 1;
     for (int d = 0; d < 3; d++) {
         bool full = p.period[d] > 0 && p.size[d] == p.period[d];
@@ -1507,20 +1512,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         g.nt[d] = (int32_t)((p.size[d] + g.o[d] + T[d] - 1) / T[d]);
         g.ntiles *= g.nt[d];
     }
-    g.lseg = g.nseg = 0;
     g.chunk = 1 << 30;
-    g.nunits = 0;
-    if (walk) {
-        // segments of the walk along axis 0: long (the S-1 trailing planes of a segment are staged
-        // like halo cells) but enough units to fill 256 CUs a few times over
-        const int64_t patches = (int64_t)g.nt[1] * g.nt[2];
-        int lseg = 64;
-        while (lseg > 16 && patches * ((g.nt[0] + lseg - 1) / lseg) < 2048) lseg /= 2;
-        g.lseg = lseg;
-        g.nseg = (g.nt[0] + lseg - 1) / lseg;
-        g.nunits = patches * g.nseg;
-    }
-    if (!walk) {
+    {
         // list entries of a tile that its own workgroup takes: four times the mean population, at
         // least 16384; what a crowded tile holds beyond that is cut into pieces of the same size
         int64_t mean = g.ntiles > 0 ? npart / g.ntiles : 0;
@@ -1532,7 +1525,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     // and particle count (a time-stepping caller: particles move a fraction of a tile per
     // step) and reuse has not just failed (back-off after an overflow).
     bool reuse = pl->built && pl->have_history && pl->npart == npart && npart > 0 &&
-                 same_geometry(p, pl->painter) && pl->g.ntiles == g.ntiles && pl->g.walk == g.walk &&
+                 same_geometry(p, pl->painter) && pl->g.ntiles == g.ntiles &&
                  (!pl->sorted || pl->cap_copy >= pl->cap_list * 3 * (size_t)pos->elsize);
     if (pl->host_flag) {
         uint32_t seen = *(volatile uint32_t *)pl->host_flag;   // stale at worst: a hint only
@@ -1603,30 +1596,25 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         // contiguous (n, 3) rows on a 16-byte boundary take the dense staging path
         const bool dense = pos->stride1 == pos->elsize && pos->stride0 == 3 * (int64_t)pos->elsize &&
                            (((uintptr_t)pos->data) & 15) == 0;
-#define BC2(K, MODE, GRID, GATE, W, SP)                                                                           \
+#define BC2(K, MODE, GRID, GATE, SP)                                                                              \
     do {                                                                                                        \
-        if (dense) bin_count_kernel<K, true, MODE, W, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
+        if (dense) bin_count_kernel<K, true, MODE, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
                 pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp);                             \
-        else bin_count_kernel<K, false, MODE, W, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
+        else bin_count_kernel<K, false, MODE, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
                 pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp);                             \
     } while (0)
-#define BC(K, MODE, GRID, GATE, W)                                                                              \
+#define BC(K, MODE, GRID, GATE)                                                                                 \
     do {                                                                                                        \
-        if (inv != nullptr && !W) BC2(K, MODE, GRID, GATE, false, true);                                        \
-        else BC2(K, MODE, GRID, GATE, W, false);                                                                \
+        if (inv != nullptr) BC2(K, MODE, GRID, GATE, true);                                                     \
+        else BC2(K, MODE, GRID, GATE, false);                                                                   \
     } while (0)
-#ifdef PMX_WITH_WALK
-#define BCW(K, MODE, GRID, GATE) BC(K, MODE, GRID, GATE, true)
-#else
-#define BCW(K, MODE, GRID, GATE) do { } while (0)
-#endif
 #define BCK(MODE, GRID, GATE)                                                                                   \
     do {                                                                                                        \
         switch (p.kind) {                                                                                       \
-        case PMX_TUNED_NNB: BC(PMX_TUNED_NNB, MODE, GRID, GATE, false); break;                                  \
-        case PMX_TUNED_CIC: BC(PMX_TUNED_CIC, MODE, GRID, GATE, false); break;                                  \
-        case PMX_TUNED_TSC: if (walk) BCW(PMX_TUNED_TSC, MODE, GRID, GATE); else BC(PMX_TUNED_TSC, MODE, GRID, GATE, false); break; \
-        default: if (walk) BCW(PMX_TUNED_PCS, MODE, GRID, GATE); else BC(PMX_TUNED_PCS, MODE, GRID, GATE, false); break; \
+        case PMX_TUNED_NNB: BC(PMX_TUNED_NNB, MODE, GRID, GATE); break;                                         \
+        case PMX_TUNED_CIC: BC(PMX_TUNED_CIC, MODE, GRID, GATE); break;                                         \
+        case PMX_TUNED_TSC: BC(PMX_TUNED_TSC, MODE, GRID, GATE); break;                                         \
+        default: BC(PMX_TUNED_PCS, MODE, GRID, GATE); break;                                                    \
         }                                                                                                       \
     } while (0)
         const uint32_t *nogate = nullptr;
@@ -1642,7 +1630,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         // breaks of the tile sequence per 64 consecutive rows above which the row order counts as
         // incoherent (lattice order: a handful; random order: 63)
         auto incoherent = [&](double breaks, double rows) { return breaks * 64.0 > 24.0 * rows; };
-        if (reuse && pl->sort_pref < 0 && !walk && pl->host_groups[2] == (uint32_t)npart && pl->host_groups[1] > 4096 &&
+        if (reuse && pl->sort_pref < 0 && pl->host_groups[2] == (uint32_t)npart && pl->host_groups[1] > 4096 &&
             incoherent(pl->host_groups[0], (double)pl->host_groups[1]) != pl->sorted)
             reuse = false;       // the order of the rows changed its character since the plan was built: start over
         if (!reuse) pl->sorted = false;
@@ -1657,7 +1645,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             copy_gate = pl->sorted ? pl->flags : nullptr;
             // (measured, block against chunk form of the single pass, same box: 512^3 f8 1.01 vs 1.17 ms, 768^3 3.22 vs
             // 3.76, clustered 0.96 vs 1.27, 12-byte rows 0.90 vs 0.96, config 3 0.86 vs 1.08, 256^3 0.17 vs 0.20)
-            if (!walk && inv == nullptr && pl->form != 2) {
+            if (inv == nullptr && pl->form != 2) {
                 // rows in a coherent order, no tile-ordered copy: one request per tile and block of rows
                 const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
                 const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);
@@ -1688,7 +1676,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             // decides from it without waiting.  Only a plan object that has never measured rows like these
             // synchronises: once in its life for a time-stepping caller.
             bool want = pl->sort_pref == 1;
-            if (pl->sort_pref < 0 && !walk && npart >= (1 << 16)) {
+            if (pl->sort_pref < 0 && npart >= (1 << 16)) {
                 const double was = (double)pl->host_groups[2];
                 const bool known = pl->have_measure && pl->host_groups[1] > 4096 &&
                                    fabs((double)npart - was) * 8.0 <= (double)npart;
@@ -1700,7 +1688,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                 }
                 want = pl->host_groups[1] > 0 && incoherent(pl->host_groups[0], (double)pl->host_groups[1]);
             }
-            if (want && !walk) {
+            if (want) {
                 const size_t es = (size_t)pos->elsize;
                 rc = plan_ensure(&pl->pos_copy, &pl->cap_copy, pl->cap_list * 3 * es); if (rc) return rc;
                 size_t ci = pl->cap_inv * 4;
@@ -1714,10 +1702,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate, inv);
         }
 #undef BCK
-#undef BCW
 #undef BC
 #undef BC2
-        if (pl->sort_pref < 0 && !walk && npart >= (1 << 16)) {
+        if (pl->sort_pref < 0 && npart >= (1 << 16)) {
             // what this build saw of the row order, read by the NEXT build (stale at worst: a hint)
             PMX_HIP_CHECK(hipMemcpyAsync(pl->host_groups, pl->flags + 1, 8, hipMemcpyDeviceToHost, st));
             pl->host_groups[2] = (uint32_t)npart;
@@ -1733,7 +1720,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     } else {
         bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nullptr);
     }
-    if (npart > 0 && !walk)
+    if (npart > 0)
         heavy_items_kernel<<<grid_for(g.ntiles, TBLOCK, 1024), TBLOCK, 0, st>>>(pl->counts, g.ntiles, g.chunk, pl->heavy_items,
                                                                                pl->nheavy, (uint32_t)pl->cap_heavy);
     PMX_HIP_CHECK(hipGetLastError());
@@ -1780,10 +1767,12 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
     const double *mstats = nullptr;
     bool run_fixed = fixed_kind, run_float = !fixed_kind;
     if (fixed_kind) {
-        if (mass.data && pl->mass_bound >= 0 && pl->mass_bound <= 1.7e308) {
-            // the caller knows the largest |mass| (pmx_binplan_mass_bound) and that all masses are finite: no pass over
-            // them; the kernels read the bound where a scalar mass would stand (unused with a mass array)
-            ms = pl->mass_bound;
+        if (mass.data && pl->mass_stats_ext) {
+            // the caller has run pmx_mass_stats on these very masses (once per mass array and version: a
+            // time-stepping caller's masses do not change): no pass over them in front of this paint
+            mstats = pl->mass_stats_ext;
+            pl->mass_stats_ext = nullptr;
+            run_float = true;
         } else if (mass.data) {
             if (!pl->mstats) PMX_HIP_CHECK(hipMalloc((void **)&pl->mstats, 32));
             PMX_HIP_CHECK(hipMemsetAsync(pl->mstats, 0, 32, st));
@@ -1859,6 +1848,18 @@ template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, D
 #if PMX_BINNED_PART == 2
 extern template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, DVec, DVec, double, int, hipStream_t);
 #endif
+extern "C" int pmx_mass_stats(const pmx_vec *mass, int64_t n, double *stats, void *stream)
+{
+    PMX_REQUIRE(stats != nullptr, PMX_EINVAL, "stats is NULL");
+    PMX_REQUIRE(n == 0 || vec_ok(mass), PMX_EINVAL, "mass must be (n,) f4/f8");
+    hipStream_t st = (hipStream_t)stream;
+    PMX_HIP_CHECK(hipMemsetAsync(stats, 0, 32, st));
+    if (n > 0) mass_stats_kernel<<<grid_for(n, TBLOCK, 2048), TBLOCK, 0, st>>>(dvec(mass), n, (unsigned long long *)stats);
+    mass_stats_finish_kernel<<<1, 1, 0, st>>>((unsigned long long *)stats);
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
 extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *canvas, const pmx_vec *pos,
                                 const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream)
 {
@@ -1869,15 +1870,6 @@ extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *ca
     PMX_REQUIRE(pl->npart == 0 || vec_ok(pos), PMX_EINVAL, "pos");
     pmx_painter p = *p_;
     hipStream_t st = (hipStream_t)stream;
-#ifdef PMX_WITH_WALK
-    if (pl->g.walk) {
-        PMX_REQUIRE(walk_layout_ok(pos), PMX_EINVAL, "positions are not laid out as at pmx_binplan_build");
-        PMX_REQUIRE(!(mass && mass->data) || (mass->stride0 % 4 == 0 && ((uintptr_t)mass->data) % 4 == 0 &&
-                                              (mass->elsize == 4 || mass->elsize == 8)),
-                    PMX_EINVAL, "mass must be float / double on 4-byte boundaries");
-        return paint_walk(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
-    }
-#endif
     if (p.canvas_elsize == 8) return paint_binned_t<double>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
     return paint_binned_t<float>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
 }
@@ -1916,12 +1908,6 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         dout.stride0 = 8; dout.stride1 = 0; dout.elsize = 8;
     }
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
-#ifdef PMX_WITH_WALK
-    if (g.walk) {
-        PMX_REQUIRE(walk_layout_ok(pos), PMX_EINVAL, "positions are not laid out as at pmx_binplan_build");
-        return readout_walk(pl, p, canvas, dpos, dout, st);
-    }
-#endif
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
 #define RT(K, T) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
                       else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)

@@ -1,5 +1,4 @@
-// pmx_binplan.h — the bin plan (particles ordered by mesh tile / plane bucket) shared by the
-// tile kernels (pmx_binned.hip) and the walk kernels (pmx_walk.hip).
+// pmx_binplan.h — the bin plan (particles ordered by mesh tile) of the tile kernels (pmx_binned.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -48,24 +47,12 @@ constexpr int UNROLL = PMX_UNROLL;    // particles in flight per lane in the til
 #define PMX_ONEPASS_U 2
 #endif
 
-// Walk form (pmx_walk.hip): buckets are single mesh planes of a patch of P1 x P2 columns; a
-// workgroup walks a segment of `lseg` planes of one patch along axis 0.
-#ifndef PMX_WALK_P1
-#define PMX_WALK_P1 16
-#endif
-constexpr int P1 = PMX_WALK_P1, P2 = 32;
-constexpr int WTHREADS = P1 * P2;     // one thread per column of the patch
-
 struct BinGeom {
     int32_t kind, S;
-    int32_t nt[3];        // tiles per axis (walk form: nt[0] = planes of a patch column)
+    int32_t nt[3];        // tiles per axis
     int32_t o[3];         // tile-space offset per axis (S-1 unless the axis is the full period)
-    int64_t ntiles;       // buckets: tiles, or planes x patches in the walk form
-    int32_t walk;         // 0: tiles of T0 x T1 x T2 cells; 1: plane buckets of 1 x P1 x P2 cells
-    int32_t lseg;         // walk form: planes per segment
-    int32_t nseg;         // walk form: segments per patch column
-    int32_t chunk;        // tile form: list entries of a tile that the tile kernels take themselves
-    int64_t nunits;       // walk form: patches x segments (one workgroup each)
+    int64_t ntiles;       // tiles of T0 x T1 x T2 cells
+    int32_t chunk;        // list entries of a tile that the tile kernels take themselves
 };
 
 template <int S> struct Region {
@@ -151,9 +138,7 @@ struct pmx_binplan {
     uint32_t *host_flag = nullptr;          // pinned, device-visible: overflows seen so far
     void *halo = nullptr;       // staging of the halo cells: ntiles * Region<S>::HALO elements
     size_t cap_halo = 0;
-    uint32_t *unit_flags = nullptr;   // walk form: unit was painted (its staging is valid)
-    size_t cap_units = 0;
-    int form = -1;              // -1: chosen per build; 0: tile kernels; 1: walk kernels
+    int form = -1;              // -1 / 0: tile kernels; 2: tile kernels with the chunk form of the single-pass rebuild
     // Rows whose order has no spatial coherence (catalogues in file order, shuffled sets): the
     // index list then sends every position gather, and every result store of readout, to a
     // sector of its own.  The plan keeps a copy of the positions in TILE ORDER instead (one
@@ -176,8 +161,8 @@ struct pmx_binplan {
     uint64_t *heavy_items = nullptr;   // (tile << 20) | piece, piece >= 1
     size_t cap_heavy = 0;
     uint32_t *nheavy = nullptr;        // device: number of items of this build
-    double *mstats = nullptr;          // device: [0] max |m| of the finite per-particle masses, [1] non-finite ones
-    double mass_bound = -1.0;          // largest |mass| of the per-particle masses of the next paint, if the caller knows it
+    double *mstats = nullptr;          // device: [0] max |m| of the finite per-particle masses, [1] != 0: the floating-point kernels serve the batch
+    const double *mass_stats_ext = nullptr;   // the same four words computed by the caller (pmx_mass_stats) for the masses of the next paint
     int deterministic = 0;             // paint through a dense int64 copy of the block: bit-reproducible
     void *dscratch = nullptr;          // that copy (+ the batch's exponent behind it)
     size_t cap_dscratch = 0;
@@ -195,10 +180,6 @@ struct pmx_binplan {
 namespace pmx {
 
 __device__ __forceinline__ int tile_ext(int d) { return d == 0 ? T0 : (d == 1 ? T1 : T2); }
-template <bool WALK> __device__ __forceinline__ int bucket_ext(int d)
-{
-    return WALK ? (d == 0 ? 1 : (d == 1 ? P1 : P2)) : tile_ext(d);
-}
 
 // true modulo with a fast path for indices within one period of the box
 __device__ __forceinline__ int wrap_fast(int i, int n)
@@ -251,11 +232,6 @@ __device__ __forceinline__ bool local_base(const pmx_painter &p, int d, int I0, 
     return local_base32<KIND>((int)p.period[d], (int)p.size[d], I0, i0w);
 }
 
-// launchers of pmx_walk.hip
-int paint_walk(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
-               int overwrite, hipStream_t st);
-int readout_walk(pmx_binplan *pl, const pmx_painter &p, const void *canvas, DVec pos, DVec out, hipStream_t st);
 int plan_ensure(void **ptr, size_t *cap, size_t need);
-bool walk_layout_ok(const pmx_vec *pos);
 
 }  // namespace pmx

@@ -658,7 +658,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         }
         __syncthreads();
         if (PIPE && tile + step < ntiles) load_tile(tile + step, ld);
-#ifndef PMX_EXP_NOPASS      // timing experiment (wrong numbers): the kernel's loads and stores without its transform
+#if !(defined(PMX_EXPERIMENT) && defined(PMX_EXP_NOPASS))      // (timing experiment, wrong numbers: the kernel's loads and stores without its transform)
         run_passes<T, LOGN, INV, RB, HT>(buf, tw, col, tj);
 #endif
         // store

@@ -7,6 +7,16 @@
 
 #include "../../include/pmesh_amd.h"
 
+// Timing experiments that compute WRONG results (atomics or weights compiled out, transforms skipped) exist
+// only in a build made with -DPMX_EXPERIMENT (scripts/build_variant.sh); a default build cannot contain them:
+// naming one of their switches without it is a compile error, and pmx_build_flags() lets a caller see what a
+// library was built with (bench.py refuses to print a line for an experiment build).
+#ifndef PMX_EXPERIMENT
+#if defined(PMX_EXP_NOATOM) || defined(PMX_EXP_NOWEIGHT) || defined(PMX_EXP_NOPASS) || defined(PMX_EXP_BINFLOOR)
+#error "PMX_EXP_* switches produce wrong results: they need -DPMX_EXPERIMENT as well"
+#endif
+#endif
+
 namespace pmx {
 
 void set_error(const char *fmt, ...);

@@ -17,7 +17,6 @@ Counts and indices are int32 as in the reference while they fit, int64 beyond
 2^31 particles per rank (the reference asserts there, domain.py:590).
 """
 import ctypes as C
-import heapq
 
 import numpy
 import torch
@@ -573,22 +572,24 @@ class GridND(object):
         self.size = int(numpy.prod(self.shape))
 
         if DomainAssign is None:
+            # domain k of a grid with more domains than ranks goes to the rank r with r * size // P <= k < (r + 1) *
+            # size // P (contiguous, near-equal runs; domain.py:381-388); with ranks to spare, domain k to rank k
+            k = numpy.arange(self.size, dtype='i8')
             if comm.size >= self.size:
-                DomainAssign = numpy.array(range(self.size), dtype='int32')
+                DomainAssign = k
             else:
-                DomainAssign = numpy.empty(self.size, dtype='int32')
-                for i in range(comm.size):
-                    start = i * self.size // comm.size
-                    end = (i + 1) * self.size // comm.size
-                    DomainAssign[start:end] = i
+                bounds = numpy.arange(1, comm.size + 1, dtype='i8') * self.size // comm.size
+                DomainAssign = numpy.searchsorted(bounds, k, side='right')
         self.DomainAssign = numpy.asarray(DomainAssign, dtype='int32')
 
-        dd = numpy.zeros(self.shape, dtype='int16')
-        for i, edge in enumerate(self.edges):
-            dd1 = edge[1:] == edge[:-1]
-            dd1 = dd1.reshape([-1 if ii == i else 1 for ii in range(self.ndim)])
-            dd[...] |= dd1
-        self.DomainDegenerate = dd.ravel()
+        # a domain is degenerate when it has zero width along some axis (domain.py:392-400)
+        flat_axes = [numpy.diff(e) == 0 for e in self.edges]
+        degenerate = numpy.zeros(tuple(self.shape), dtype=bool)
+        for axis, flat in enumerate(flat_axes):
+            sel = [None] * self.ndim
+            sel[axis] = slice(None)
+            degenerate |= flat[tuple(sel)]
+        self.DomainDegenerate = degenerate.ravel().astype('int16')
         self._dev = None
         self._update_primary_regions()
 
@@ -651,32 +652,31 @@ class GridND(object):
             recorded in self.DomainAssign (domain.py:469-501). """
         if self.size <= self.comm.size:
             return
-        domains = sorted([(domainload[i], i) for i in range(self.size)], reverse=True)
-        processes = [(0, i) for i in range(self.comm.size)]
-        heapq.heapify(processes)
+        # longest-processing-time greedy (domain.py:485-498): domains in order of decreasing (load, index), each to
+        # the rank that carries the least so far, the lowest such rank on a tie
+        load = numpy.asarray(domainload, dtype='f8')
+        order = numpy.lexsort((numpy.arange(self.size), load))[::-1]
+        carried = numpy.zeros(self.comm.size, dtype='f8')
         assign = self.DomainAssign.copy()
-        for dload, dindex in domains:
-            pload, rank = heapq.heappop(processes)
-            pload += dload
-            assign[dindex] = rank
-            heapq.heappush(processes, (pload, rank))
+        for k in order:
+            r = int(numpy.argmin(carried))
+            carried[r] += load[k]
+            assign[k] = r
         self.DomainAssign = assign
         self._update_primary_regions()
 
     def _update_primary_regions(self):
-        my_domains = numpy.where(self.DomainAssign == self.comm.rank)[0]
-        N = len(my_domains)
-        if N == 0:
-            primary_region = None
-        else:
-            primary_region = {}
-            primary_region['start'] = numpy.empty((N, self.ndim))
-            primary_region['end'] = numpy.empty((N, self.ndim))
-            for i in range(N):
-                domain_index = numpy.unravel_index(my_domains[i], self.shape, order='C')
-                primary_region['start'][i] = numpy.array([g[r] for g, r in zip(self.edges, domain_index)])
-                primary_region['end'][i] = numpy.array([g[r + 1] for g, r in zip(self.edges, domain_index)])
-        self.primary_region = primary_region
+        """primary_region: the lower and upper corners of the domains of this rank, (N, ndim) each, or None if it
+        has none (domain.py:503-517)"""
+        mine = numpy.flatnonzero(self.DomainAssign == self.comm.rank)
+        if len(mine) == 0:
+            self.primary_region = None
+            return
+        cells = numpy.unravel_index(mine, tuple(self.shape))
+        self.primary_region = {
+            'start': numpy.stack([e[c] for e, c in zip(self.edges, cells)], axis=1).astype('f8'),
+            'end': numpy.stack([e[c + 1] for e, c in zip(self.edges, cells)], axis=1).astype('f8'),
+        }
 
     def isprimary(self, pos, transform=None):
         """ True where the position falls into the primary region of this rank

@@ -19,6 +19,7 @@ Partitions are block distributions with block = ceil(N / P) (FFTW-MPI / PFFT
 default): rank r owns [r*block, min((r+1)*block, N)).
 """
 import os
+import weakref
 import warnings
 
 import numpy
@@ -899,37 +900,55 @@ class Plan(object):
         transform that may follow at once (DEFER_LAST_PASS)"""
         es = self.elsize
 
-        def run():
-            be.colfft(es, False, st, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
         if not (DEFER_LAST_PASS and hasattr(be, 'colfft_roundtrip') and be.colfft_roundtrip_supported(N0, es)):
-            return run()
+            return be.colfft(es, False, st, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
+        # (the note hangs on the storage: its closures hold the storage weakly, or a field dropped before its c2r
+        # would only be freed by the cyclic collector)
+        ref = weakref.ref(st)
+        del st
+
+        def run():
+            st = ref()
+            if st is not None:
+                be.colfft(es, False, st, 1, N0, N1 * N2c, scale=norm, n_stride=sn)
 
         def fused(transfer):
+            st = ref()
+            if st is None:
+                return
             if transfer is not None:
                 t, start, nmesh, boxsize = transfer
                 be.colfft_roundtrip(es, st, N0, N1 * N2c, scale=norm, transfer=t, n1=N1, n2=N2c, start=start,
                                     nmesh=nmesh, boxsize=boxsize, n_stride=sn)
             else:
                 be.colfft_roundtrip(es, st, N0, N1 * N2c, scale=norm, n_stride=sn)
-        st._pmx_pending = _Pending(self.partition, run, fused, 'local')
+        ref()._pmx_pending = _Pending(self.partition, run, fused, 'local')
 
     def _last_slab_pass(self, be, out, N0, n1loc, N2c, nb):
         """the axis-0 pass on the block a slab transpose delivered (one exchange) — now, or deferred"""
         es = self.elsize
 
-        def run():
-            be.colfft(es, False, out, 1, N0, nb)
         if not (DEFER_LAST_PASS and hasattr(be, 'colfft_roundtrip') and be.colfft_roundtrip_supported(N0, es)):
-            return run()
+            return be.colfft(es, False, out, 1, N0, nb)
+        ref = weakref.ref(out)
+        del out
+
+        def run():
+            out = ref()
+            if out is not None:
+                be.colfft(es, False, out, 1, N0, nb)
 
         def fused(transfer):
+            out = ref()
+            if out is None:
+                return
             if transfer is not None:
                 t, start, nmesh, boxsize = transfer
                 be.colfft_roundtrip(es, out, N0, nb, transfer=t, n1=n1loc, n2=N2c, start=start, nmesh=nmesh,
                                     boxsize=boxsize)
             else:
                 be.colfft_roundtrip(es, out, N0, nb)
-        out._pmx_pending = _Pending(self.partition, run, fused, 'slab')
+        ref()._pmx_pending = _Pending(self.partition, run, fused, 'slab')
 
     def _last_pencil_pass(self, be, out, N0, m1, m2, norm):
         """the axis-0 pass on the (N0, m1, m2) block the second transpose of a pencil transform delivered (it carries
@@ -938,20 +957,28 @@ class Plan(object):
         if m1 * m2 == 0:
             return
 
-        def run():
-            self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
         if not (DEFER_LAST_PASS and COLFFT != 'never' and hasattr(be, 'colfft_roundtrip') and
                 be.colfft_roundtrip_supported(N0, es) and be.colfft_supported(N0, es)):
-            return run()
+            return self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
+        ref = weakref.ref(out)
+        del out
+
+        def run():
+            out = ref()
+            if out is not None:
+                self._col(be, out, 1, N0, m1 * m2, False, scale=norm)
 
         def fused(transfer):
+            out = ref()
+            if out is None:
+                return
             if transfer is not None:
                 t, start, nmesh, boxsize = transfer
                 be.colfft_roundtrip(es, out, N0, m1 * m2, scale=norm, transfer=t, n1=m1, n2=m2, start=start,
                                     nmesh=nmesh, boxsize=boxsize)
             else:
                 be.colfft_roundtrip(es, out, N0, m1 * m2, scale=norm)
-        out._pmx_pending = _Pending(self.partition, run, fused, 'slab')
+        ref()._pmx_pending = _Pending(self.partition, run, fused, 'slab')
 
     def _first_pencil_pass(self, be, bufin, same, transfer, W0, N0, m1, m2):
         """first stage of c2r on pencils: the inverse axis-0 pass on the local (N0, m1, m2) block, with the transfer
@@ -1284,11 +1311,14 @@ class Plan(object):
                 be.colfft_split(es, False, X[2 * b0:], W1[o:o + n], n0loc, N1, cw, n1loc, scale=norm, plain_pitch=pi)
                 works.append(comm.alltoall(W1[o:o + n], W2[o:o + n], async_op=True))
             out = bufout.storage
+            oref = weakref.ref(out)            # (the note hangs on `out`: no cycle through its closure)
 
             def run():
+                dst = oref()
                 for (b0, cw), o, w in zip(chunks, offs, works):
                     w.wait()
-                    be.colfft_chunk(es, False, W2[o:], out, N0, n1loc, cw, N2c, b0, True)
+                    if dst is not None:
+                        be.colfft_chunk(es, False, W2[o:], dst, N0, n1loc, cw, N2c, b0, True)
             if DEFER_LAST_PASS and hasattr(be, 'colfft_roundtrip') and be.colfft_roundtrip_supported(N0, es):
                 # the chunks stay where the all-to-alls deliver them: an in-place c2r that follows at once runs
                 # both axis-0 passes and the transfer on them as one kernel and sends them straight back

@@ -619,6 +619,9 @@ class RealField(Field):
     def r2c(self, out=None):
         """ Perform real to complex transformation (pm.py:655-694); normalised by
             1/prod(Nmesh) on the forward transform (pm.py:692). """
+        # a field object of the caller's: views of its value taken BEFORE this call must hold the finished spectrum
+        # afterwards (in the reference `value` is a plain array, pm.py:234-242), so nothing is left deferred on it
+        callers = out is not None and not is_inplace(out) and out is not self
         if out is None:
             out = TransposedComplexField(self.pm)
         if is_inplace(out):
@@ -630,6 +633,8 @@ class RealField(Field):
         T = 'U' if isinstance(out, UntransposedComplexField) else 'T'
         plan = self.pm.plans[('ipforward' if inplace else 'forward') + T]
         plan.execute(self._base, out._base)
+        if callers:
+            _fft.settle(out._base.storage)
         return out
 
     def ctranspose(self, axes):

@@ -14,6 +14,7 @@ import os
 import sys
 
 import threading
+import weakref
 
 import numpy
 import torch
@@ -74,10 +75,9 @@ BINNED_MIN_PARTICLES = 1 << 17
 # point).  Measured break-even on a 64 x 512 x 512 block (scripts/thresh_probe.py):
 # CIC 2^20 particles, PCS 2^17; thin ghost bands at a slab face sit well below both.
 BINNED_MIN_DENSITY = {1: 0.06, 2: 0.06, 3: 0.02, 4: 0.008}
-# Which binned kernels: 'auto' / 'never': the tile kernels (csrc/pmx_binned.hip); 'always': the walk
-# form of csrc/pmx_walk.hip for TSC / PCS — a measured alternative that is no faster on MI355X and only
-# exists in a `make WALK=1` build of the library (PmxError otherwise); 'chunks': the tile kernels with
-# the chunk form of the single-pass rebuild (a test hook: what plans with a tile-ordered copy use).
+# Which form of the binned kernels: 'auto' / 'never': the tile kernels (csrc/pmx_binned.hip); 'chunks': the
+# tile kernels with the chunk form of the single-pass rebuild (a test hook: what plans with a tile-ordered
+# copy use).  ('always' used to select the walk kernels of rounds 2-3, removed: PmxError.)
 WALK = os.environ.get('PMESH_AMD_WALK', 'auto')
 _FORMS = {'auto': -1, 'never': 0, 'always': 1, 'chunks': 2}
 _SORTS = {'auto': -1, 'never': 0, 'always': 1}
@@ -210,18 +210,27 @@ def clear_bin_cache():
     bin_cache().clear()
 
 
-_mass_bounds = []          # [(data_ptr, version, shape, dtype), tensor (kept alive), bound]
+_mass_stats_memo = []      # [key, weak reference to the mass tensor, its statistics (4 doubles on the device)]
 
 
-def _mass_bound(m):
+def _mass_stats(be, m, mv):
+    """What the fixed-point paint needs to know about a per-particle mass array (largest and smallest |mass|,
+    all finite: include/pmesh_amd.h, pmx_mass_stats), computed ON THE DEVICE once per tensor and version — a
+    time-stepping caller's masses do not change — with no temporary and no host synchronisation.  The memo
+    holds the tensor by weak reference: nothing keeps a caller's masses alive, and an address that has been
+    reused by another tensor is never mistaken for the old one."""
     key = (m.data_ptr(), version_of(m), tuple(m.shape), m.stride(), m.dtype)
-    for e in _mass_bounds:
-        if e[0] == key:
+    for e in _mass_stats_memo:
+        if e[0] == key and e[1]() is m:
             return e[2]
-    b = float(m.abs().max()) if m.numel() else 0.0          # NaN if any mass is NaN: "unknown" to the library
-    _mass_bounds.append((key, m, b))
-    del _mass_bounds[:-4]
-    return b
+    stats = torch.empty(4, dtype=torch.float64, device=m.device)
+    be.call('mass_stats', C.byref(mv), m.shape[0], stats.data_ptr(), be.stream())
+    try:
+        ref = weakref.ref(m)
+    except TypeError:
+        return stats
+    _mass_stats_memo[:] = [e for e in _mass_stats_memo if e[1]() is not None][-3:] + [[key, ref, stats]]
+    return stats
 
 
 def _binned_ok(be, painter, pos, n, hs):
@@ -434,9 +443,11 @@ class ResampleWindow(object):
         hv = vec(hs) if hs is not None else None
         if n and _binned_ok(be, p, pos, n, hs):
             plan = bin_cache().lookup(be, pos, p, pv, n)
-            # the largest |mass| of a mass array, found once per tensor and version (a time-stepping caller's
-            # masses do not change): the kernels then need no pass over the masses in front of every paint
-            be.call('binplan_mass_bound', plan, _mass_bound(m) if mv is not None else -1.0)
+            # a caller's mass TENSOR: its statistics are found once per tensor and version, so the kernels need
+            # no pass over the masses in front of every paint (numpy masses make a new device copy per call: the
+            # paint looks at those itself)
+            stats = _mass_stats(be, m, mv) if (mv is not None and is_tensor(mass)) else None
+            be.call('binplan_mass_stats', plan, stats.data_ptr() if stats is not None else None)
             be.call('paint_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv),
                     mass_scalar, int(bool(_overwrite)), be.stream())
         else:

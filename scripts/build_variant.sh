@@ -7,7 +7,11 @@ files=${@:-pmx_binned.hip}
 cd pmesh_amd/csrc
 objs=""
 for f in pmx_core pmx_window pmx_binned pmx_domain pmx_transfer pmx_synth pmx_fft pmx_colfft pmx_whitenoise; do
-  if echo " $files " | grep -q " $f.hip "; then
+  if [ $f = pmx_core ]; then
+    # the variant says what it is: pmx_build_flags() = the product's compiler line + the files and flags of the variant
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -I../../include "-DPMX_VARIANT_FLAGS=\" | variant $name: $files: $flags\"" -c $f.hip -o /tmp/${f}_$name.o || exit 1
+    objs="$objs /tmp/${f}_$name.o"
+  elif echo " $files " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -I../../include $flags -c $f.hip -o /tmp/${f}_$name.o || exit 1
     objs="$objs /tmp/${f}_$name.o"
   else

@@ -37,23 +37,13 @@ def hip():
     backend.reset()
 
 
-@pytest.fixture(params=['tiles', 'walk', 'sorted', 'chunks'])
+@pytest.fixture(params=['tiles', 'sorted', 'chunks'])
 def form(request, hip):
     """the forms of the binned kernels: the tile kernels through the index list
-    (csrc/pmx_binned.hip), the walk kernels (csrc/pmx_walk.hip; TSC and PCS, the others stay on
-    the tiles), the tile kernels on the plan's tile-ordered copy of the positions, and the tile
-    kernels with the chunk form of the single-pass rebuild (bin_count_kernel<MODE 1> instead of
+    (csrc/pmx_binned.hip), the tile kernels on the plan's tile-ordered copy of the positions, and the
+    tile kernels with the chunk form of the single-pass rebuild (bin_count_kernel<MODE 1> instead of
     bin_block_kernel, which 'tiles' takes)"""
-    import ctypes as C
-    if request.param == 'walk':
-        # the walk form is only part of a `make WALK=1` build of the library
-        plan = C.c_void_p()
-        hip.call('binplan_create', C.byref(plan))
-        rc = hip.lib.pmx_binplan_configure(plan, 1)
-        hip.call('binplan_destroy', plan)
-        if rc != 0:
-            pytest.skip('libpmesh_amd.so was built without the walk kernels (make WALK=1)')
-    window.WALK = {'walk': 'always', 'chunks': 'chunks'}.get(request.param, 'never')
+    window.WALK = {'chunks': 'chunks'}.get(request.param, 'never')
     window.SORTED = 'always' if request.param == 'sorted' else 'never'
     window.clear_bin_cache()
     yield request.param
@@ -362,6 +352,47 @@ def test_fixed_point_regions_over_the_range_of_masses(hip, oracle, name, scale_m
             want = numpy.zeros(shape)
             oracle.Window(W.kind).paint(want, pos_h, mass=mh, diffdir=diffdir, transform=oaff)
             assert_allclose(c.cpu().numpy(), want, rtol=0, atol=1e-12 * abs(want).max())
+
+
+@pytest.mark.parametrize('name', ['tsc', 'pcs'])
+@pytest.mark.parametrize('ratio', [1e-3, 1e-6, 1e-7, 1e-20])
+def test_fixed_point_regions_with_two_species(hip, oracle, name, ratio):
+    """per-particle masses of two species in ONE batch, heavy (1) in one half of the box and light (ratio) in the
+    other, so that there are cells only light particles reach.  The fixed-point regions take their unit from the
+    LARGEST |mass| (2^-50 of it per contribution): up to a spread of 2^20 the batch stays in fixed point and every
+    cell is within 64 adds x 2^-50 x max |m| of the oracle (the bound INTEGRATION.md section 1 states); beyond it
+    the floating-point form of the kernels serves the batch and every cell — also those of the light species alone,
+    20 decades below the heavy one — agrees to 1e-12 of ITS OWN sum, as with the reference's floating adds.  The
+    statistics come from pmx_mass_stats (mass tensors) and from the paint's own pass (numpy masses)."""
+    W = windows[name]
+    N = 64
+    rs = numpy.random.RandomState(29)
+    n = 60000
+    pos_h = rs.uniform(0, N, size=(n, 3))
+    heavy = pos_h[:, 0] < N / 2
+    pos_h[heavy, 0] = rs.uniform(4, N / 2 - 4, size=int(heavy.sum()))           # (a gap of 8 cells between the species)
+    pos_h[~heavy, 0] = rs.uniform(N / 2 + 4, N - 4, size=int((~heavy).sum()))
+    mass_h = numpy.where(heavy, 1.0, ratio)
+    aff = Affine(3, period=N)
+    oaff = oracle.Affine(3, period=N)
+    want = numpy.zeros((N, N, N))
+    oracle.Window(W.kind).paint(want, pos_h, mass=mass_h, transform=oaff)
+    light_cells = numpy.zeros((N, N, N), dtype=bool)
+    light_cells[N // 2 + 2:N - 2] = True
+    assert (want[light_cells] > 0).mean() > 0.5 and want[light_cells].max() < 100 * ratio
+    pos = torch.from_numpy(pos_h).to(hip.device)
+    window.BINNED = 'always'
+    for mass in (torch.from_numpy(mass_h).to(hip.device), mass_h):
+        window.clear_bin_cache()
+        c = torch.zeros((N, N, N), dtype=torch.float64, device=hip.device)
+        W.paint(c, pos, mass=mass, transform=aff)
+        assert_binned_ran()
+        got = c.cpu().numpy()
+        err = abs(got - want)
+        if ratio >= 2.0 ** -20:
+            assert (err <= 64 * 2.0 ** -50 + 1e-13 * want).all(), err.max()
+        else:
+            assert (err <= 1e-12 * want).all(), (err / numpy.maximum(want, 1e-300)).max()
 
 
 def test_two_live_particle_sets_keep_their_plans(hip):

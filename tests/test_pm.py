@@ -721,8 +721,33 @@ def test_deferred_last_pass_is_invisible(be, Nmesh, dtype):
             # the spectrum is never looked at: the buffer is painted over / transformed again
             real2 = pm.create('real', base=ck._base, value=data * 2)
             return numpy.asarray(real2.r2c(out=Ellipsis))
+        if scenario == 'heldview':
+            # a view of the caller's own complex field taken BEFORE r2c(out=field) holds the finished spectrum
+            # afterwards, as a plain array attribute would (pm.py:234-242): nothing stays deferred on such a field
+            target = pm.create('complex')
+            held = target.value
+            real3 = pm.create('real', value=data)
+            real3.r2c(out=target)
+            return held.cpu().numpy().copy(), numpy.asarray(target).copy()
+        if scenario == 'dropped':
+            # a field dropped with its last pass still deferred is freed without the cyclic collector
+            import gc
+            import weakref
+            gc.disable()
+            try:
+                real4 = pm.create('real', value=data)
+                ck4 = real4.r2c(out=Ellipsis)
+                w = weakref.ref(ck4._base.storage)
+                del real4, ck4
+                alive = w() is not None
+            finally:
+                gc.enable()
+            return numpy.array([alive])
     try:
-        for scenario in ('fused', 'plain', 'peek', 'callable', 'outofplace', 'abandon'):
+        held, fresh = run(True, 'heldview')
+        assert_array_equal(held, fresh)
+        assert_array_equal(run(True, 'dropped'), [False])
+        for scenario in ('fused', 'plain', 'peek', 'callable', 'outofplace', 'abandon', 'heldview'):
             a, b = run(False, scenario), run(True, scenario)
             if isinstance(a, tuple):
                 for x, y in zip(a, b):
