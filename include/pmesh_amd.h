@@ -215,6 +215,12 @@ int pmx_decompose_fill(int32_t nranks, const uint64_t *masks, int64_t npart,
 /* Layout.exchange pack (domain.py:188 `data.take(indices)`): dst row j = src row indices[j]. */
 int pmx_take_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const void *indices,
                   int32_t index_elsize, int64_t nrows, void *dst, void *stream);
+/* The same into rows `dst_stride` bytes apart: one column of a row that packs several arrays side by side — what
+ * Layout.exchange(pack=True) ships (domain.py:161-166, pack_arrays 59-80) — written where it travels from, without
+ * gathering the columns one by one and concatenating them.  indices = NULL: dst row j = src row j (a column taken
+ * out of packed rows on the receiving side). */
+int pmx_pack_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const void *indices,
+                  int32_t index_elsize, int64_t nrows, void *dst, int64_t dst_stride, void *stream);
 /* Layout.gather mode='sum' (domain.py:294-295, bincountv 26-48):
  * out[i*ncol + c] = sum over j with indices[j] == i of values[j*ncol + c], for all
  * i < nout (rows that receive nothing become 0, as numpy.bincount does).

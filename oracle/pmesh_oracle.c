@@ -621,6 +621,19 @@ int pmo_take_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const
     return PMX_OK;
 }
 
+/* the same into rows dst_stride bytes apart (a column of packed rows; domain.py:59-80 pack_arrays +
+ * 188 take); indices == NULL: row j of the source */
+int pmo_pack_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const void *indices,
+                  int32_t index_elsize, int64_t nrows, void *dst, int64_t dst_stride, void *stream)
+{
+    (void)stream;
+    for (int64_t j = 0; j < nrows; j++) {
+        int64_t i = !indices ? j : (index_elsize == 8 ? ((const int64_t *)indices)[j] : ((const int32_t *)indices)[j]);
+        memcpy((char *)dst + j * dst_stride, (const char *)src + i * src_stride0, row_bytes);
+    }
+    return PMX_OK;
+}
+
 /* bincountv (domain.py:26-48): numpy.bincount accumulates the weights in
  * double, in ascending j, and the per-bin totals are then cast to the output
  * dtype (out[ind] = bincount(...) overwrites all nout rows). */

@@ -72,6 +72,7 @@ PROTOTYPES = {
     'decompose_count': (C.c_int, [_P(Grid), _P(Vec), _P(_f64), _P(_f64), _i64, _vp, _vp, _vp]),
     'decompose_fill': (C.c_int, [_i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     'take_rows': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i64, _vp, _vp]),
+    'pack_rows': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i64, _vp, _i64, _vp]),
     'scatter_add': (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i64, _vp, _i64, _vp]),
     'apply_transfer': (C.c_int, [_P(Transfer), _i32, _i32, _vp, _P(_i64), _vp, _P(_i64),
                                  _P(_i64), _P(_i64), _P(_i64), _P(_f64), _vp]),

@@ -66,7 +66,8 @@ class _Traced(object):
 
     def wait(self):
         r = self.work.wait()
-        self.rec[4] = _stamp(self.t)
+        if self.rec[4] is None:          # (a handle may be waited for again by whoever reuses its buffers)
+            self.rec[4] = _stamp(self.t)
         return r
 
 
@@ -226,11 +227,13 @@ class _Staged(object):
     def wait(self):
         if self.work is not None:
             self.work.wait()
-        o = 0
-        for v in self.recv_views:
-            n = v.numel()
-            v.copy_(self.staging[o:o + n].view(v.shape))
-            o += n
+        if self.staging is not None:
+            o = 0
+            for v in self.recv_views:
+                n = v.numel()
+                v.copy_(self.staging[o:o + n].view(v.shape))
+                o += n
+            self.staging = None          # (waiting again is a no-op)
         return True
 
 

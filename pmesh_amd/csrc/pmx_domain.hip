@@ -336,6 +336,24 @@ __global__ void __launch_bounds__(256) take_rows_kernel(const char *src, int64_t
     }
 }
 
+// the same with the output rows `dst_stride` bytes apart (one column of a row that packs several arrays side
+// by side: Layout.exchange(pack=True) without the concatenation of separately gathered columns);
+// indices == NULL: row j of the source (the inverse: a column out of packed rows)
+template <typename IDX>
+__global__ void __launch_bounds__(256) pack_rows_kernel(const char *src, int64_t src_stride0, int64_t row_bytes,
+                                                        const IDX *indices, int64_t nrows, char *dst,
+                                                        int64_t dst_stride)
+{
+    int64_t words = row_bytes >> 2;
+    int64_t total = nrows * words;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t j = t / words, w = t - j * words;
+        int64_t i = indices ? (int64_t)indices[j] : j;
+        *(uint32_t *)(dst + j * dst_stride + 4 * w) = *(const uint32_t *)(src + i * src_stride0 + 4 * w);
+    }
+}
+
 template <typename T, typename IDX>
 __global__ void __launch_bounds__(256) scatter_add_kernel(const T *values, int ncol,
                                                           const IDX *indices, int64_t nrows,
@@ -453,6 +471,23 @@ extern "C" int pmx_take_rows(const void *src, int64_t src_stride0, int64_t row_b
         take_rows_kernel<int64_t><<<grid, 256, 0, st>>>((const char *)src, src_stride0, row_bytes, (const int64_t *)indices, nrows, (char *)dst);
     else
         take_rows_kernel<int32_t><<<grid, 256, 0, st>>>((const char *)src, src_stride0, row_bytes, (const int32_t *)indices, nrows, (char *)dst);
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_pack_rows(const void *src, int64_t src_stride0, int64_t row_bytes, const void *indices,
+                             int32_t index_elsize, int64_t nrows, void *dst, int64_t dst_stride, void *stream)
+{
+    PMX_REQUIRE(row_bytes > 0 && (row_bytes & 3) == 0, PMX_EINVAL, "row_bytes must be a multiple of 4");
+    PMX_REQUIRE((dst_stride & 3) == 0 && dst_stride >= row_bytes, PMX_EINVAL, "dst_stride must be a multiple of 4, at least row_bytes");
+    PMX_REQUIRE(indices == nullptr || index_elsize == 4 || index_elsize == 8, PMX_EINVAL, "index_elsize must be 4 or 8");
+    if (nrows == 0) return PMX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned grid = grid_for(nrows * (row_bytes >> 2), 256);
+    if (indices != nullptr && index_elsize == 8)
+        pack_rows_kernel<int64_t><<<grid, 256, 0, st>>>((const char *)src, src_stride0, row_bytes, (const int64_t *)indices, nrows, (char *)dst, dst_stride);
+    else
+        pack_rows_kernel<int32_t><<<grid, 256, 0, st>>>((const char *)src, src_stride0, row_bytes, (const int32_t *)indices, nrows, (char *)dst, dst_stride);
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }

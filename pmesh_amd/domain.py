@@ -17,6 +17,7 @@ Counts and indices are int32 as in the reference while they fit, int64 beyond
 2^31 particles per rank (the reference asserts there, domain.py:590).
 """
 import ctypes as C
+import weakref
 
 import numpy
 import torch
@@ -112,6 +113,61 @@ def pack_arrays(seq):
     return out
 
 
+#: An exchange whose rows add up to this many bytes or more sends its arrays ONE BY ONE, each straight from its
+#: gathered rows into the tensor the caller receives (no packed copy on either side: the packing exists to save
+#: collectives, and a collective of hundreds of megabytes is not latency bound); below it the arrays of
+#: exchange(pack=True) / exchange_remote travel packed side by side in one all-to-all-v.
+PACK_BYTES_MAX = 256 << 20
+
+
+class _Scratch(object):
+    """Send / receive staging of the exchanges of one communicator (held on the communicator object: a rank has
+    one, a thread rank of the tests its own).  The reference keeps one send and one receive buffer per call
+    (domain.py:185-206); a time-stepping caller builds a new Layout every step, so the buffers outlive the
+    layouts: sized from what the previous steps needed plus a quarter, reused, never shrunk.  A buffer that an
+    asynchronous exchange is still reading or writing is waited for before it is handed out again."""
+
+    def __init__(self):
+        self.buffers = {}      # name -> [uint8 tensor, handle of the exchange that uses it or None]
+
+    def get(self, name, nbytes, device):
+        e = self.buffers.get(name)
+        if e is not None and e[1] is not None:
+            e[1].wait()
+            e[1] = None
+        if e is None or e[0].numel() < nbytes or e[0].device != device:
+            if e is not None:
+                e[0] = None                      # (free before the larger one is made)
+            e = self.buffers[name] = [torch.empty(int(nbytes) + int(nbytes) // 4 + 256, dtype=torch.uint8, device=device), None]
+        return e[0][:nbytes]
+
+    def busy(self, name, work):
+        if work is not None and name in self.buffers:
+            self.buffers[name][1] = work
+
+    def nbytes(self):
+        return sum(e[0].numel() for e in self.buffers.values() if e[0] is not None)
+
+
+def _scratch_of(comm):
+    s = getattr(comm, '_pmx_scratch', None)
+    if s is None:
+        s = comm._pmx_scratch = _Scratch()
+    return s
+
+
+def _row_bytes(t):
+    rb = t.element_size()
+    for n in t.shape[1:]:
+        rb *= n
+    return rb
+
+
+def _typed(buf, dtype, shape):
+    """a contiguous byte buffer as a tensor of `dtype` and `shape` (views only)"""
+    return buf.view(dtype).reshape(shape)
+
+
 class Layout(object):
     """
     The communication layout of a domain decomposition (domain.py:82-318).
@@ -198,7 +254,9 @@ class Layout(object):
 
     def _exchange_packed(self, args):
         """exchange(pack=True): the gathered rows of every array side by side in one byte row per
-        item, one all-to-all-v for all of them (domain.py:161-166, pack_arrays)."""
+        item, one all-to-all-v for all of them (domain.py:161-166, pack_arrays).  Every column is gathered
+        straight into its place in the packed rows (pmx_pack_rows) of a reused send buffer; large exchanges go
+        array by array instead (PACK_BYTES_MAX)."""
         be = backend.get()
         cols, hosts = [], []
         message = 'the length of data does not match that used to build the layout'
@@ -210,76 +268,89 @@ class Layout(object):
         if len(set(len(t) for t in cols)) > 1:
             raise ValueError('the shape of the data does not match across different columns.')
         wrong = self._wrong_length(len(cols[0]), self.sendlength, 'exchange', message)
+        if wrong:
+            cols = [torch.zeros((self.sendlength,) + tuple(t.shape[1:]), dtype=t.dtype, device=be.device) for t in cols]
         nsend = int(self.sendcounts.sum())
-        parts, metas = [], []
-        for t in cols:
-            trailing = tuple(t.shape[1:])
+        width = sum(_row_bytes(t) for t in cols)
+        if max(nsend, self.recvlength) * width >= PACK_BYTES_MAX:
+            out = []
+            for t, host in zip(cols, hosts):
+                r = self._exchange_impl(be, t, checked=True)
+                out.append(to_numpy(r) if host else r)
             if wrong:
-                t = torch.zeros((self.sendlength,) + trailing, dtype=t.dtype, device=be.device)
-            rb = t.element_size()
-            for s_ in trailing:
-                rb *= s_
-            if nsend:
-                rows = self._take(be, t, self.indices, nsend)
-                parts.append(rows.reshape(nsend, -1).view(torch.uint8).reshape(nsend, rb))
-            metas.append((t.dtype, trailing, rb))
-        packed = torch.cat(parts, dim=1) if nsend else torch.empty((0, sum(m[2] for m in metas)),
-                                                                   dtype=torch.uint8, device=be.device)
-        recv = torch.empty((self.recvlength, packed.shape[1]), dtype=torch.uint8, device=be.device)
+                raise ValueError(message)
+            return tuple(out)
+        scratch = _scratch_of(self.comm)
+        packed = scratch.get('send', nsend * width, be.device).view(nsend, width)
+        off = 0
+        for t in cols:
+            self._take(be, t, self.indices, nsend, out=packed, out_offset=off)
+            off += _row_bytes(t)
+        recv = scratch.get('recv', self.recvlength * width, be.device).view(self.recvlength, width)
         self.comm.alltoallv(packed, self.sendcounts, recv, self.recvcounts)
         if wrong:
             raise ValueError(message)
         out, off = [], 0
-        for (dt, trailing, rb), host in zip(metas, hosts):
-            r = recv[:, off:off + rb].contiguous().view(dt).reshape((self.recvlength,) + trailing)
+        for t, host in zip(cols, hosts):
+            rb = _row_bytes(t)
+            r = self._column(be, recv, off, rb, t.dtype, tuple(t.shape[1:]))
             off += rb
             out.append(to_numpy(r) if host else r)
         return tuple(out)
 
     @staticmethod
-    def _take(be, data, indices, nrows):
-        """rows `indices` of data, contiguous (data.take(indices, axis=0), domain.py:188)"""
+    def _column(be, packed, offset, row_bytes, dtype, trailing):
+        """the column at byte `offset` of packed rows as a dense tensor of its own"""
+        n = packed.shape[0]
+        r = torch.empty((n,) + trailing, dtype=dtype, device=packed.device)
+        if n:
+            be.call('pack_rows', packed.data_ptr() + offset, packed.shape[1], row_bytes, None, 4, n,
+                    r.data_ptr(), row_bytes, be.stream())
+        return r
+
+    @staticmethod
+    def _take(be, data, indices, nrows, out=None, out_offset=0):
+        """rows `indices` of data, contiguous (data.take(indices, axis=0), domain.py:188) — or, with `out` (packed
+        byte rows, (nrows, width) uint8), written as the column at byte `out_offset` of those rows"""
         trailing = tuple(data.shape[1:])
-        row_bytes = data.element_size()
-        for s in trailing:
-            row_bytes *= s
+        row_bytes = _row_bytes(data)
         if data.dim() > 1 and not data[0:1].is_contiguous() and data.shape[0] > 0:
             data = data.contiguous()
+        if nrows and row_bytes % 4:
+            raise TypeError('rows must be a multiple of 4 bytes')
+        stride0 = data.stride(0) * data.element_size() if data.shape[0] > 1 else row_bytes
+        if out is not None:
+            if nrows:
+                be.call('pack_rows', data.data_ptr(), stride0, row_bytes, indices.data_ptr(), indices.element_size(),
+                        nrows, out.data_ptr() + out_offset, out.shape[1], be.stream())
+            return out
         buffer = torch.empty((nrows,) + trailing, dtype=data.dtype, device=be.device)
         if nrows:
-            if row_bytes % 4:
-                raise TypeError('rows must be a multiple of 4 bytes')
-            stride0 = data.stride(0) * data.element_size() if data.shape[0] > 1 else row_bytes
             be.call('take_rows', data.data_ptr(), stride0, row_bytes, indices.data_ptr(),
                     indices.element_size(), nrows, buffer.data_ptr(), be.stream())
         return buffer
 
-    def _exchange_impl(self, be, data):
-        data = promote(data, self.comm)
-        data, host = to_device(data, be.device, 'data', allow_int=True)
+    def _exchange_impl(self, be, data, checked=False):
         message = 'the length of data does not match that used to build the layout'
-        wrong = self._wrong_length(len(data), self.sendlength, 'exchange', message)
-        if wrong:
-            data = torch.zeros((self.sendlength,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
+        wrong = False
+        host = False
+        if not checked:
+            data = promote(data, self.comm)
+            data, host = to_device(data, be.device, 'data', allow_int=True)
+            wrong = self._wrong_length(len(data), self.sendlength, 'exchange', message)
+            if wrong:
+                data = torch.zeros((self.sendlength,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         trailing = tuple(data.shape[1:])
-        row_bytes = data.element_size()
-        for s in trailing:
-            row_bytes *= s
-        if data.dim() > 1 and not data[0:1].is_contiguous() and data.shape[0] > 0:
-            data = data.contiguous()
         nsend = int(self.sendcounts.sum())
-        buffer = torch.empty((nsend,) + trailing, dtype=data.dtype, device=be.device)
-        if nsend:
-            if row_bytes % 4:
-                raise TypeError('rows must be a multiple of 4 bytes')
-            stride0 = data.stride(0) * data.element_size() if data.shape[0] > 1 else row_bytes
-            be.call('take_rows', data.data_ptr(), stride0, row_bytes, self.indices.data_ptr(),
-                    self.indices.element_size(), nsend, buffer.data_ptr(), be.stream())
         if self.comm.size == 1:
-            recvbuffer = buffer
+            recvbuffer = self._take(be, data, self.indices, nsend)
         else:
+            # the gathered rows live in the communicator's send buffer (reused from call to call, domain.py:185-190)
+            rb = _row_bytes(data)
+            send = _scratch_of(self.comm).get('send', nsend * rb, be.device).view(nsend, rb)
+            self._take(be, data, self.indices, nsend, out=send)
             recvbuffer = torch.empty((self.recvlength,) + trailing, dtype=data.dtype, device=be.device)
-            self.comm.alltoallv(buffer, self.sendcounts, recvbuffer, self.recvcounts)
+            self.comm.alltoallv(_typed(send, data.dtype, (nsend,) + trailing), self.sendcounts, recvbuffer, self.recvcounts)
         if wrong:
             raise ValueError(message)
         return to_numpy(recvbuffer) if host else recvbuffer
@@ -328,61 +399,94 @@ class Layout(object):
         memo = getattr(self, '_memo_remote', None)
         if not isinstance(memo, dict):
             memo = self._memo_remote = {}
-        missing = [i for i, k in enumerate(keys) if k not in memo]
-        st = dict(arrays=arrays, keys=keys, memo=memo, missing=missing, many=len(arrays_in) > 1, work=None, wrong=False)
+        missing = [i for i, k in enumerate(keys) if k not in memo or memo[k][0]() is not arrays[i]]
+        st = dict(arrays=arrays, keys=keys, memo=memo, missing=missing, many=len(arrays_in) > 1, works=[], wrong=False)
         if not missing:
             return st
         message = 'the length of data does not match that used to build the layout'
         wrong = False
         for i in missing:
             wrong = self._wrong_length(len(arrays[i]), self.sendlength, 'exchange', message) or wrong
-        parts, metas = [], []
+        src = []
         for i in missing:
             a = arrays[i]
-            trailing = tuple(a.shape[1:])
             if wrong:
-                a = torch.zeros((self.sendlength,) + trailing, dtype=a.dtype, device=be.device)
-            rb = a.element_size()
-            for s_ in trailing:
-                rb *= s_
-            metas.append((a.dtype, trailing, rb))
-            if nsend:
-                parts.append(self._take(be, a, idx, nsend))
-        if len(missing) == 1:
-            dt, trailing, rb = metas[0]
-            recv = torch.empty((nrecv,) + trailing, dtype=dt, device=be.device)
-            send = parts[0] if nsend else torch.empty((0,) + trailing, dtype=dt, device=be.device)
+                a = torch.zeros((self.sendlength,) + tuple(a.shape[1:]), dtype=a.dtype, device=be.device)
+            src.append(a)
+        width = sum(_row_bytes(a) for a in src)
+        scratch = _scratch_of(self.comm)
+        got = []
+        if len(src) == 1 or max(nsend, nrecv) * width >= PACK_BYTES_MAX:
+            # array by array, each from the communicator's send buffer straight into the tensor the kernels will
+            # read (the received rows are kept — the readouts after a paint find them — so that tensor has to exist
+            # anyway; nothing else is allocated)
+            for k, a in enumerate(src):
+                rb = _row_bytes(a)
+                name = 'send%d' % k
+                send = scratch.get(name, nsend * rb, be.device).view(nsend, rb)
+                self._take(be, a, idx, nsend, out=send)
+                recv = torch.empty((nrecv,) + tuple(a.shape[1:]), dtype=a.dtype, device=be.device)
+                if self.comm.size > 1:
+                    w = self.comm.alltoallv(_typed(send, a.dtype, (nsend,) + tuple(a.shape[1:])), sc, recv, rc, async_op=async_op)
+                    st['works'].append(w)
+                    scratch.busy(name, w)
+                got.append(recv)
+            st.update(packed=None)
         else:
-            width = sum(m[2] for m in metas)
-            send = (torch.cat([q.reshape(nsend, -1).view(torch.uint8).reshape(nsend, m[2]) for q, m in zip(parts, metas)],
-                              dim=1) if nsend else torch.empty((0, width), dtype=torch.uint8, device=be.device))
-            recv = torch.empty((nrecv, width), dtype=torch.uint8, device=be.device)
-        if self.comm.size > 1:
-            st['work'] = self.comm.alltoallv(send, sc, recv, rc, async_op=async_op)
-        st.update(wrong=wrong, message=message, metas=metas, recv=recv, send=send, nrecv=nrecv)
+            send = scratch.get('send0', nsend * width, be.device).view(nsend, width)
+            off = 0
+            for a in src:
+                self._take(be, a, idx, nsend, out=send, out_offset=off)
+                off += _row_bytes(a)
+            recv = scratch.get('recv', nrecv * width, be.device).view(nrecv, width)
+            if self.comm.size > 1:
+                w = self.comm.alltoallv(send, sc, recv, rc, async_op=async_op)
+                st['works'].append(w)
+                scratch.busy('send0', w)
+            st.update(packed=recv)
+        st.update(wrong=wrong, message=message, src=src, got=got, nrecv=nrecv)
         return st
 
     def _exchange_remote_end(self, st):
         memo, keys = st['memo'], st['keys']
         if st['missing']:
-            if st['work'] is not None:
-                st['work'].wait()
+            be = backend.get()
+            for w in st['works']:
+                if w is not None:
+                    w.wait()
             if st['wrong']:
                 raise ValueError(st['message'])
-            recv, metas, nrecv = st['recv'], st['metas'], st['nrecv']
-            if len(st['missing']) == 1:
-                got = [recv]
-            else:
-                got, off = [], 0
-                for dt, trailing, rb in metas:
-                    got.append(recv[:, off:off + rb].contiguous().view(dt).reshape((nrecv,) + trailing))
+            got = st['got']
+            if st['packed'] is not None:
+                off = 0
+                for a in st['src']:
+                    rb = _row_bytes(a)
+                    got.append(self._column(be, st['packed'], off, rb, a.dtype, tuple(a.shape[1:])))
                     off += rb
             for i, r in zip(st['missing'], got):
-                memo[keys[i]] = (st['arrays'][i], r)      # (the source tensor is kept alive: its address stays taken)
-            while len(memo) > 4:
-                memo.pop(next(iter(memo)))
+                # (a weak reference to the source tensor: the memo must not keep a caller's array alive, and an
+                # address reused by another tensor must not pass for the old one)
+                try:
+                    ref = weakref.ref(st['arrays'][i])
+                except TypeError:
+                    ref = (lambda t: (lambda: t))(st['arrays'][i])
+                memo[keys[i]] = (ref, r)
+            # ONE received set per source tensor, and no more than the arrays of this call plus what is small:
+            # received rows of earlier position sets are dropped first (they are the caller's old time steps)
+            current = set(keys)
+            budget = max(PACK_BYTES_MAX, sum(memo[k][1].numel() * memo[k][1].element_size() for k in current if k in memo))
+            def held():
+                return sum(v[1].numel() * v[1].element_size() for v in memo.values())
+            for k in list(memo):
+                if k in current:
+                    continue
+                if memo[k][0]() is None or len(memo) > 4 or held() > budget:
+                    memo.pop(k)
             st['missing'] = []
-        res = [memo[k][1] for k in keys]
+        res = []
+        for i, k in enumerate(keys):
+            ref, r = memo[k]
+            res.append(r)
         return tuple(res) if st['many'] else res[0]
 
     def gather_remote_add(self, data, out, async_op=False):
@@ -398,8 +502,10 @@ class Layout(object):
         if wrong:
             data = torch.zeros((nrecv,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         data = data.contiguous()
-        back = torch.empty((nsend,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
+        scratch = _scratch_of(self.comm)
+        back = _typed(scratch.get('back', nsend * _row_bytes(data), be.device), data.dtype, (nsend,) + tuple(data.shape[1:]))
         work = self.comm.alltoallv(data, rc, back, sc, async_op=async_op)
+        scratch.busy('back', work)
 
         def finish(target):
             if work is not None:

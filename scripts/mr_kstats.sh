@@ -4,7 +4,16 @@ tag=$1; shift
 repo=$PWD; out=$PWD/gpurun_out/$tag; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python3 $repo/scripts/mr_probe.py "$@" > $out/log 2>&1
+rc=$?
 cd $repo
+# a run that did not finish (out of memory, a failed check) leaves NO kernel table: a table divided by the cycles it
+# was asked for would pass for a measurement (round 3's "367 ms" came from a run that died in its third cycle)
+if [ $rc -ne 0 ] || ! grep -q "ms wall per cycle" $out/log; then
+  echo "mr_kstats.sh: the probed program FAILED (exit $rc): no kernel table written" >&2
+  tail -5 $out/log >&2
+  rm -rf $out/stats gpurun_out/${tag}_kernel_stats.csv
+  exit 1
+fi
 f=$(find $out/stats -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/${tag}_kernel_stats.csv
 tail -2 $out/log

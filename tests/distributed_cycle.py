@@ -104,7 +104,7 @@ def run(args):
     if not args.ghosts_only:
         PM.GHOSTS_ONLY = 'never'
     np_ = [int(x) for x in args.np.split('x')] if args.np else [P]
-    results, parts, kept, block0 = {}, {}, {}, {}
+    results, parts, kept, block0, staging = {}, {}, {}, {}, {}
 
     def rank_main(comm):
         r = comm.rank
@@ -140,13 +140,38 @@ def run(args):
         sync()
         comm.Barrier()
         results[r] = (time.perf_counter() - t0, float(f.sum()), int(layout.remote_recvlength))
+        from pmesh_amd.domain import _scratch_of
+        staging[r] = _scratch_of(comm).nbytes()
         if args.check or args.oracle_planes:
             parts[r] = f
             kept[r] = (pos, mass)
         _window.bin_cache().destroy(be)           # the rank's plans die with its thread
 
+    # the device's own account of its memory (torch's allocator AND the hipMalloc'd bin plans / FFT work buffers of
+    # libpmesh_amd.so), sampled while the ranks run: the peak is what a box must have free for this case
+    low = {'free': None, 'stop': False}
+
+    def sampler():
+        while not low['stop']:
+            f_b, _ = torch.cuda.mem_get_info()
+            low['free'] = f_b if low['free'] is None else min(low['free'], f_b)
+            time.sleep(0.02)
+    watch = None
+    if be.device.type == 'cuda':
+        import threading
+        watch = threading.Thread(target=sampler, daemon=True)
+        watch.start()
     run_ranks(P, rank_main)
     t = max(v[0] for v in results.values()) / max(1, args.steps)
+    if be.device.type == 'cuda':
+        # what the decomposed cycle needed at its peak, all ranks together on the one device (torch's allocator;
+        # the bin plans and FFT work buffers of libpmesh_amd.so come on top: hipMalloc, see mem_get_info below)
+        free_b, total_b = torch.cuda.mem_get_info()
+        print('peak device memory of the %d ranks: %.1f GB in use on the device at the worst sample (%.1f GB allocated by '
+              'torch at its peak, %.1f GB reserved; exchange staging %.1f GB of it)'
+              % (P, (total_b - (low['free'] if low['free'] is not None else free_b)) / 1e9,
+                 torch.cuda.max_memory_allocated() / 1e9, torch.cuda.max_memory_reserved() / 1e9,
+                 sum(staging.values()) / 1e9), flush=True)
     print('ranks %d (np %s) mesh %d %s %s%s: %.3f ms wall per cycle (all ranks on one GPU), ghosts received per rank %s, '
           'checksum %.6e' % (P, np_, N, args.window, args.data, ' x2' if args.double else '', 1e3 * t,
                              [v[2] for v in results.values()][:4], sum(v[1] for v in results.values())), flush=True)
@@ -187,12 +212,22 @@ def run(args):
     if args.check:
         # the same cycle on one rank (the single-GPU path, itself pinned to the oracle at full size)
         _window.clear_bin_cache()
-        pos = torch.cat([kept[r][0] for r in range(P)])
-        mass = torch.cat([kept[r][1] for r in range(P)]) if args.mass == 'array' else 1.0
+        # the ranks' particles in one array each, moved rank by rank (never two copies of the whole set)
         sizes = [len(kept[r][0]) for r in range(P)]
-        kept.clear()
-        if be.device.type == 'cuda':
-            torch.cuda.empty_cache()
+        first = kept[0]
+        pos = torch.empty((sum(sizes),) + tuple(first[0].shape[1:]), dtype=first[0].dtype, device=be.device)
+        mass = torch.empty(sum(sizes), dtype=first[1].dtype, device=be.device) if args.mass == 'array' else 1.0
+        del first
+        off = 0
+        for r in range(P):
+            p_r, m_r = kept.pop(r)
+            pos[off:off + sizes[r]] = p_r
+            if args.mass == 'array':
+                mass[off:off + sizes[r]] = m_r
+            off += sizes[r]
+            del p_r, m_r
+            if be.device.type == 'cuda':
+                torch.cuda.empty_cache()
         pm1 = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype='f8', resampler=args.window)
         one = pm1.paint(pos, mass=mass).r2c(out=Ellipsis).c2r(out=Ellipsis, transfer=Transfer.dx1(0)).readout(pos)
         scale = float(one.abs().max())
@@ -203,6 +238,12 @@ def run(args):
         print('distributed (%d ranks) vs one rank: max |diff| = %.3e (result scale %.3e) -> %.2e relative'
               % (P, worst, scale, worst / scale), flush=True)
         assert worst <= 1e-11 * scale
+    if watch is not None:
+        low['stop'] = True
+        watch.join()
+        _, total_b = torch.cuda.mem_get_info()
+        print('peak device memory of the whole run (with the one-rank check): %.1f GB of %.1f'
+              % ((total_b - low['free']) / 1e9, total_b / 1e9), flush=True)
     return t
 
 

@@ -88,10 +88,15 @@ def test_multi_gpu_configs_decomposed_on_thread_ranks(config):
     import os
     import subprocess
     import sys
+    # the child process needs the memory this (pytest) process still holds in its allocator cache and plans
+    from pmesh_amd import backend, window
+    window.bin_cache().destroy(backend.get()) if torch.cuda.is_available() else None
+    backend.reset()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    need = 110e9 if config == 'C4' else 200e9
+    need = 80e9 if config == 'C4' else 190e9       # measured peaks: see the "peak device memory" line the child prints
     if free < need:
-        pytest.skip('needs %.0f GB of free HBM' % (need / 1e9))
+        pytest.skip('needs %.0f GB of free HBM, %.0f are free' % (need / 1e9, free / 1e9))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, 'tests', 'distributed_cycle.py'), '--ranks', '8', '--mesh', '1024',
            '--steps', '1', '--warmup', '1', '--check', '1', '--oracle-planes', '2']
@@ -103,7 +108,7 @@ def test_multi_gpu_configs_decomposed_on_thread_ranks(config):
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500)
     print(out.stdout[-2000:])
     assert out.returncode == 0, out.stdout[-2000:] + '\n' + out.stderr[-4000:]
-    assert 'vs one rank' in out.stdout and 'vs oracle' in out.stdout
+    assert 'vs one rank' in out.stdout and 'vs oracle' in out.stdout and 'peak device memory' in out.stdout
 
 
 def _slab_subset(pos, N, L, k0, nplanes, margin):
