@@ -144,6 +144,14 @@ int pmx_binplan_destroy(pmx_binplan *plan);
  * Same results in every form (readout bit-identical, paint up to the order of the additions into
  * a cell). */
 int pmx_binplan_configure(pmx_binplan *plan, int32_t form);
+/* Arithmetic of pmx_readout_binned.  The cell indices of a particle are always the reference's bit for bit
+ * (floor(pos * scale + translate) in double precision without FMA, _window_tuned_*.h).  on = 1: the weights and
+ * the sum are also formed operation by operation as the reference does (_window_generics.h:213-242): results
+ * bit-identical to pmx_readout and to the CPU reference.  on = 0 (default): the weights are the same polynomials
+ * evaluated in one offset with fused multiply-adds, and the S^3 products are summed as nested FMAs in the type of
+ * the canvas — a third of the instructions; results within 1e-14 (double canvas) / 1e-6 (float canvas) of the
+ * exact form relative to the sum of |weight x cell|, inside the tolerance the parity tests allow for values. */
+int pmx_binplan_exact(pmx_binplan *plan, int32_t on);
 /* Deterministic paint (the reference's scatter is a serial loop, pmesh/_window.pyx:157-165: the same call gives
  * the same bits).  on = 1: pmx_paint_binned accumulates every cell as a 64-bit integer in units of 2^-f — the
  * LDS regions, the halos between tiles (integer atomics on a dense int64 copy of the block) and the pieces of

@@ -91,6 +91,7 @@ DEVICE_ONLY = {
     'binplan_create': (C.c_int, [_P(_vp)]),
     'binplan_destroy': (C.c_int, [_vp]),
     'binplan_configure': (C.c_int, [_vp, _i32]),
+    'binplan_exact': (C.c_int, [_vp, _i32]),
     'binplan_deterministic': (C.c_int, [_vp, _i32]),
     'mass_stats': (C.c_int, [_P(Vec), _i64, _vp, _vp]),
     'binplan_mass_stats': (C.c_int, [_vp, _vp]),

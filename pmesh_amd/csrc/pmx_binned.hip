@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "pmx_binplan.h"
 
@@ -664,6 +665,31 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
     }
 }
 
+// The same with the weights of the RELAXED forms (pmx_window_dev.h, Fast<KIND, F>): the first cell is the
+// reference's bit for bit (Tuned<KIND>::first, double precision, no FMA); the weights are polynomials in the one
+// offset d = X - I_ref, formed in double, evaluated in F.
+template <int KIND, bool WHOLE, typename F>
+__device__ __forceinline__ void particle_setup_fast(const pmx_painter &p, const BinGeom &g, const int *t,
+                                                    const double *x, F (*V)[Tuned<KIND>::S], int *lb)
+{
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double X = x[d] * p.scale[d] + p.translate[d];
+        const int I0 = Tuned<KIND>::first(X);
+        const F off = (F)(X - (double)(I0 + Fast<KIND, F>::REF));
+        Fast<KIND, F>::axis(off, p.order[d], (F)p.scale[d], V[d]);
+        const int per = (int)p.period[d], siz = (int)p.size[d];
+        if (WHOLE || (g.o[d] == 0 && per == siz)) {
+            lb[d] = I0 & (tile_ext(d) - 1);
+            continue;
+        }
+        int w = wrap_fast(I0, per);
+        int i0w = w;
+        if (per > 0 && w >= siz) i0w = w - per;
+        lb[d] = i0w + g.o[d] - t[d] * tile_ext(d);
+    }
+}
+
 // timing experiments (wrong results; -DPMX_EXPERIMENT builds only, profiled with PMESH_AMD_BENCH_NOCHECK=1, which prints no bench line): where does the deposit spend its time?
 //   PMX_EXP_NOATOM: the weights are computed and folded into one register, nothing goes to LDS
 //   PMX_EXP_NOWEIGHT: the LDS atomics with a constant instead of the weight products
@@ -716,7 +742,11 @@ __device__ __forceinline__ int fixed_exponent(const pmx_painter &p, double mb, i
 __device__ __forceinline__ double pow2(int f) { return __longlong_as_double((long long)(1023 + f) << 52); }
 
 // The particles [start, start + count) of a tile's list are deposited into its LDS region.
-template <int KIND, int TTHREADS, bool SORTED, bool FIXED = false, int PE = 0, bool WHOLE = false>
+// WF: double / float = the weights of the RELAXED form in that precision (fixed-point regions of the S >= 3 windows:
+// the sum is rounded to 2^-f anyway, and to the canvas type once more for float canvases); void = the reference's
+// arithmetic, operation by operation (NNB / CIC, whose sums are doubles and reproduce the reference bit for bit on
+// exactly summable inputs, the floating-point twin and the deterministic mode)
+template <int KIND, int TTHREADS, bool SORTED, bool FIXED = false, int PE = 0, bool WHOLE = false, typename WF = void>
 __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                              const DVec &mass, double mass_scalar, const uint32_t *list,
                                              int64_t start, int count, double *lds, double scale = 1.0)
@@ -765,7 +795,16 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
             if (idx[u] < 0) continue;
             int lb[3];
             double V[3][S];
-            particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
+            constexpr bool FAST = !std::is_same<WF, void>::value;
+            if constexpr (FAST) {
+                using WT = typename std::conditional<FAST, WF, double>::type;
+                WT W[3][S];
+                particle_setup_fast<KIND, WHOLE, WT>(p, g, t, x[u], W, lb);
+#pragma unroll
+                for (int d = 0; d < 3; d++)
+#pragma unroll
+                    for (int a = 0; a < S; a++) V[d][a] = (double)W[d][a];
+            } else particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
             // a plan that no longer matches the positions (rewritten behind the cache's back)
             // must not index outside the LDS region
             if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
@@ -807,22 +846,26 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
 }
 
 // (the form of the loop chosen once per launch: see tile_gather_any)
-template <int KIND, int TTHREADS, bool SORTED, bool FIXED>
+template <int KIND, int TTHREADS, bool SORTED, bool FIXED, typename WF = void>
 __device__ __forceinline__ void tile_deposit_any(bool whole, const pmx_painter &p, const BinGeom &g, const int *t,
                                                  const DVec &pos, const DVec &mass, double mass_scalar,
                                                  const uint32_t *list, int64_t start, int count, double *lds, double scale)
 {
     if (whole) {
-        if (pos.elsize == 8) tile_deposit<KIND, TTHREADS, SORTED, FIXED, 8, true>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
-        else tile_deposit<KIND, TTHREADS, SORTED, FIXED, 4, true>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        if (pos.elsize == 8) tile_deposit<KIND, TTHREADS, SORTED, FIXED, 8, true, WF>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        else tile_deposit<KIND, TTHREADS, SORTED, FIXED, 4, true, WF>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
     } else {
-        if (pos.elsize == 8) tile_deposit<KIND, TTHREADS, SORTED, FIXED, 8, false>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
-        else tile_deposit<KIND, TTHREADS, SORTED, FIXED, 4, false>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        if (pos.elsize == 8) tile_deposit<KIND, TTHREADS, SORTED, FIXED, 8, false, WF>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        else tile_deposit<KIND, TTHREADS, SORTED, FIXED, 4, false, WF>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
     }
 }
 
 // The particles [start, start + count) of a tile's list read their values from its LDS region.
-template <int KIND, typename T, int TTHREADS, bool SORTED, int PE = 0, bool WHOLE = false>
+// RELAX: the weights of pmx_window_dev.h's Fast<KIND, F> and the sum as nested fused multiply-adds — sum_a Wx[a]
+// (sum_b Wy[b] (sum_c Wz[c] cell)) — in F = the canvas type: S^3 + S^2 + S FMAs instead of the 3 S^3 + S^2
+// products and adds of the reference's order (which the other form keeps bit for bit: window.EXACT).  Within
+// 1e-14 (double) / 1e-6 (float) of the exact form relative to sum |w cell|.
+template <int KIND, typename T, int TTHREADS, bool SORTED, int PE = 0, bool WHOLE = false, bool RELAX = false>
 __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                             const DVec &out, const uint32_t *list, int64_t start, int count,
                                             const T *lds)
@@ -849,6 +892,27 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
         for (int u = 0; u < UNROLL; u++) {
             if (idx[u] < 0) continue;
             int lb[3];
+            if constexpr (RELAX) {
+                T W[3][S];
+                particle_setup_fast<KIND, WHOLE, T>(p, g, t, x[u], W, lb);
+                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+                T acc = 0;
+#pragma unroll
+                for (int a = 0; a < S; a++) {
+                    T plane = 0;
+#pragma unroll
+                    for (int b = 0; b < S; b++) {
+                        const int rowoff = ((lb[0] + a) * R1 + (lb[1] + b)) * Rg::template gpitch<T>() + lb[2];
+                        T row = 0;
+#pragma unroll
+                        for (int c = 0; c < S; c++) row = fma_(lds[rowoff + c], W[2][c], row);
+                        plane = fma_(W[1][b], row, plane);
+                    }
+                    acc = fma_(W[0][a], plane, acc);
+                }
+                out.set(idx[u], 0, (double)acc);
+                continue;
+            }
             double V[3][S];
             particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
             if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
@@ -871,17 +935,17 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
 // "every axis is the whole periodic mesh" (`whole`, whole_mesh()) select a form of the loop in which the other
 // cases do not appear at all.  Left in the loop they were 30 wave-uniform branches per trip of two particles:
 // config 3 (fp32 positions) readout 1.54 -> 1.25 ms, paint 1.81 -> 1.68; fp64 positions 2-4 %.
-template <int KIND, typename T, int TTHREADS, bool SORTED>
+template <int KIND, typename T, int TTHREADS, bool SORTED, bool RELAX = false>
 __device__ __forceinline__ void tile_gather_any(bool whole, const pmx_painter &p, const BinGeom &g, const int *t,
                                                 const DVec &pos, const DVec &out, const uint32_t *list, int64_t start,
                                                 int count, const T *lds)
 {
     if (whole) {
-        if (pos.elsize == 8) tile_gather<KIND, T, TTHREADS, SORTED, 8, true>(p, g, t, pos, out, list, start, count, lds);
-        else tile_gather<KIND, T, TTHREADS, SORTED, 4, true>(p, g, t, pos, out, list, start, count, lds);
+        if (pos.elsize == 8) tile_gather<KIND, T, TTHREADS, SORTED, 8, true, RELAX>(p, g, t, pos, out, list, start, count, lds);
+        else tile_gather<KIND, T, TTHREADS, SORTED, 4, true, RELAX>(p, g, t, pos, out, list, start, count, lds);
     } else {
-        if (pos.elsize == 8) tile_gather<KIND, T, TTHREADS, SORTED, 8, false>(p, g, t, pos, out, list, start, count, lds);
-        else tile_gather<KIND, T, TTHREADS, SORTED, 4, false>(p, g, t, pos, out, list, start, count, lds);
+        if (pos.elsize == 8) tile_gather<KIND, T, TTHREADS, SORTED, 8, false, RELAX>(p, g, t, pos, out, list, start, count, lds);
+        else tile_gather<KIND, T, TTHREADS, SORTED, 4, false, RELAX>(p, g, t, pos, out, list, start, count, lds);
     }
 }
 
@@ -923,6 +987,15 @@ __device__ __forceinline__ bool batch_is_mine(const double *mstats, int want_odd
     const bool odd = mstats != nullptr && mstats[1] != 0.0;
     return odd == (want_odd != 0);
 }
+
+// which weights the deposit of a paint kernel forms: the RELAXED ones in the canvas' precision for the fixed-point
+// regions of the S >= 3 windows (MODE 1), the reference's for everything else (see tile_deposit)
+#ifndef PMX_FAST_DEPOSIT
+#define PMX_FAST_DEPOSIT 1
+#endif
+template <int KIND, typename T, int MODE> struct DepositWeights {
+    using type = typename std::conditional<(PMX_FAST_DEPOSIT && MODE == 1 && Tuned<KIND>::S >= 3), T, void>::type;
+};
 
 // waves per SIMD the compiler must leave room for (the register budget): the regions allow 4 / 3 / 2 workgroups of
 // 512 threads per CU for CIC / TSC / PCS, i.e. 8 / 6 / 4 waves per SIMD; the fixed-point TSC kernel came out at 84-90
@@ -1044,7 +1117,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             }
             __syncthreads();
         }
-        tile_deposit_any<KIND, TTHREADS, SORTED, FIXED>(whole, pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        tile_deposit_any<KIND, TTHREADS, SORTED, FIXED, typename DepositWeights<KIND, T, MODE>::type>(whole, pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -1140,7 +1213,7 @@ static __global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint3
         out.set(sorted ? start + j : (int64_t)list[start + j], 0, 0.0);
 }
 
-template <int KIND, typename T, int TTHREADS, bool SORTED>
+template <int KIND, typename T, int TTHREADS, bool SORTED, bool RELAX>
 __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                               DVec pos, DVec out, const uint32_t *list,
                                                               const int64_t *offsets, const uint32_t *counts)
@@ -1170,7 +1243,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
             lds[r * Rg::template gpitch<T>() + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;   // outside the block reads as 0
         }
         __syncthreads();
-        tile_gather_any<KIND, T, TTHREADS, SORTED>(whole, p, g, t, pos, out, list, start, count, lds);
+        tile_gather_any<KIND, T, TTHREADS, SORTED, RELAX>(whole, p, g, t, pos, out, list, start, count, lds);
         __syncthreads();
     }
 }
@@ -1225,7 +1298,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
             scale = pow2(f);
             inv = pow2(-f);
         }
-        tile_deposit_any<KIND, TTHREADS, SORTED, FIXED>(whole_mesh(pwr, g), pwr, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
+        tile_deposit_any<KIND, TTHREADS, SORTED, FIXED, typename DepositWeights<KIND, T, MODE>::type>(whole_mesh(pwr, g), pwr, g, t, pos, mass, mass_scalar, list, offsets[tile] + first, count, lds, scale);
         __syncthreads();
         for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
             const int c = q % R2, r = q / R2;
@@ -1243,7 +1316,7 @@ __global__ void __launch_bounds__(TTHREADS) paint_heavy_kernel(pmx_painter p, Bi
     }
 }
 
-template <int KIND, typename T, int TTHREADS, bool SORTED>
+template <int KIND, typename T, int TTHREADS, bool SORTED, bool RELAX>
 __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, BinGeom g, const char *canvas, DVec pos,
                                                                DVec out, const uint32_t *list, const int64_t *offsets,
                                                                const uint32_t *counts, const uint64_t *items,
@@ -1269,7 +1342,7 @@ __global__ void __launch_bounds__(TTHREADS) readout_heavy_kernel(pmx_painter p, 
             lds[r * Rg::template gpitch<T>() + c] = in ? *(const T *)(canvas + goff) : (T)0;
         }
         __syncthreads();
-        tile_gather_any<KIND, T, TTHREADS, SORTED>(whole_mesh(p, g), p, g, t, pos, out, list, offsets[tile] + first, count, lds);
+        tile_gather_any<KIND, T, TTHREADS, SORTED, RELAX>(whole_mesh(p, g), p, g, t, pos, out, list, offsets[tile] + first, count, lds);
         __syncthreads();
     }
 }
@@ -1402,6 +1475,13 @@ extern "C" int pmx_binplan_configure(pmx_binplan *pl, int32_t form)
     PMX_REQUIRE(form != 1, PMX_EUNSUPPORTED, "form 1 (the walk kernels of rounds 2-3) is no longer part of the library");
     if (pl->form != form) pl->have_history = false;
     pl->form = form;
+    return PMX_OK;
+}
+
+extern "C" int pmx_binplan_exact(pmx_binplan *pl, int32_t on)
+{
+    PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
+    pl->exact = on ? 1 : 0;
     return PMX_OK;
 }
 
@@ -1909,8 +1989,11 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     }
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
-#define RT(K, T) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
-                      else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)
+    const bool relax = pl->exact == 0;
+    // (NNB has nothing to relax: one cell, weight 1)
+#define RT2(K, T, RX) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
+                      else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)
+#define RT(K, T) do { if (relax && K != PMX_TUNED_NNB) RT2(K, T, (K != PMX_TUNED_NNB)); else RT2(K, T, false); } while (0)
     if (p.canvas_elsize == 8) {
         switch (p.kind) {
         case PMX_TUNED_NNB: RT(PMX_TUNED_NNB, double); break;
@@ -1927,10 +2010,12 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         }
     }
 #undef RT
+#undef RT2
     {
         const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
-#define RH(K, T) do { if (sorted) readout_heavy_kernel<K, T, TileThreads<K, T>::readout, true><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); \
-                      else readout_heavy_kernel<K, T, TileThreads<K, T>::readout, false><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); } while (0)
+#define RH2(K, T, RX) do { if (sorted) readout_heavy_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); \
+                      else readout_heavy_kernel<K, T, TileThreads<K, T>::readout, false, RX><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); } while (0)
+#define RH(K, T) do { if (relax && K != PMX_TUNED_NNB) RH2(K, T, (K != PMX_TUNED_NNB)); else RH2(K, T, false); } while (0)
         if (p.canvas_elsize == 8) {
             switch (p.kind) {
             case PMX_TUNED_NNB: RH(PMX_TUNED_NNB, double); break;
@@ -1947,6 +2032,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
             }
         }
 #undef RH
+#undef RH2
     }
     if (sorted)
         unsort_kernel<<<grid_for(pl->npart, TBLOCK), TBLOCK, 0, st>>>(pl->out_sorted, pl->inv, pl->npart, caller_out);

@@ -163,6 +163,7 @@ struct pmx_binplan {
     uint32_t *nheavy = nullptr;        // device: number of items of this build
     double *mstats = nullptr;          // device: [0] max |m| of the finite per-particle masses, [1] != 0: the floating-point kernels serve the batch
     const double *mass_stats_ext = nullptr;   // the same four words computed by the caller (pmx_mass_stats) for the masses of the next paint
+    int exact = 0;                     // readout in the reference's arithmetic, operation by operation (bit-identical to pmx_readout)
     int deterministic = 0;             // paint through a dense int64 copy of the block: bit-reproducible
     void *dscratch = nullptr;          // that copy (+ the batch's exponent behind it)
     size_t cap_dscratch = 0;

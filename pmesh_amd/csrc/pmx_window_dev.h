@@ -136,4 +136,68 @@ template <> struct Tuned<PMX_TUNED_PCS> {
     }
 };
 
+// ---- the same weights from fewer instructions (the RELAXED forms of the tile kernels) ----------------------
+// The cell index of a particle is floor(pos * scale + translate [+ 0.5]) in double precision without FMA,
+// bit for bit the reference's (Tuned<KIND>::first); everything AFTER the index may differ from the reference's
+// arithmetic within the tolerance SURVEY.md 8(d) / BASELINE.json's north_star state for field values.  Here the
+// weights are polynomials in ONE offset d = X - I_ref (CIC: the first cell, d in [0, 1); TSC: the centre cell,
+// d in [-1/2, 1/2); PCS: the second cell, d in [0, 1)) evaluated with fused multiply-adds in the precision F
+// of the canvas (float canvases: d is formed in double, converted once, and the weights cost packed-rate fp32
+// instructions instead of half-rate fp64 ones).  Same polynomials as _window_tuned_cic/tsc/pcs.h, expanded:
+//   TSC  W(0) = 3/4 - d^2,  W(-1) = (1/2 - d)^2 / 2,  W(+1) = (1/2 + d)^2 / 2
+//   PCS  W(0) = 2/3 - d^2 + d^3/2,  W(1) = 2/3 - e^2 - e^3/2 (e = d - 1),  W(-1) = -e^3/6,  W(2) = d^3/6
+// Errors: <= 3 ulp of F per weight (relative 3e-16 / 2e-7), against 1-2 ulp of double for the reference's form.
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <int KIND, typename F> struct Fast;
+
+template <typename F> struct Fast<PMX_TUNED_NNB, F> {
+    static constexpr int REF = 0;      // d = X - (I[0] + REF)
+    __device__ static __forceinline__ void axis(F d, int order, F scale, F *V) { V[0] = order == 0 ? (F)1 : (F)0; }
+};
+template <typename F> struct Fast<PMX_TUNED_CIC, F> {
+    static constexpr int REF = 0;
+    __device__ static __forceinline__ void axis(F d, int order, F scale, F *V)
+    {
+        if (order == 0) { V[1] = d; V[0] = (F)1 - d; }
+        else { V[1] = scale; V[0] = -scale; }
+    }
+};
+template <typename F> struct Fast<PMX_TUNED_TSC, F> {
+    static constexpr int REF = 1;
+    __device__ static __forceinline__ void axis(F d, int order, F scale, F *V)
+    {
+        const F lo = (F)0.5 - d, hi = (F)0.5 + d;
+        if (order == 0) {
+            V[1] = fma_(-d, d, (F)0.75);
+            V[0] = ((F)0.5 * lo) * lo;
+            V[2] = ((F)0.5 * hi) * hi;
+        } else {
+            V[1] = ((F)-2 * d) * scale;
+            V[0] = -lo * scale;
+            V[2] = hi * scale;
+        }
+    }
+};
+template <typename F> struct Fast<PMX_TUNED_PCS, F> {
+    static constexpr int REF = 1;
+    __device__ static __forceinline__ void axis(F d, int order, F scale, F *V)
+    {
+        const F e = d - (F)1, d2 = d * d, e2 = e * e;
+        if (order == 0) {
+            V[1] = fma_(d2, fma_((F)0.5, d, (F)-1), (F)(2.0 / 3.0));
+            V[2] = fma_(e2, fma_((F)-0.5, e, (F)-1), (F)(2.0 / 3.0));
+            V[0] = e2 * (e * (F)(-1.0 / 6.0));
+            V[3] = d2 * (d * (F)(1.0 / 6.0));
+        } else {
+            // quirk Q1: no scale factor in the tuned PCS derivative
+            V[1] = d * fma_((F)1.5, d, (F)-2);
+            V[2] = e * fma_((F)-1.5, e, (F)-2);
+            V[0] = (F)-0.5 * e2;
+            V[3] = (F)0.5 * d2;
+        }
+    }
+};
+
 }  // namespace pmx

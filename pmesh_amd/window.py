@@ -91,6 +91,12 @@ SORTED = os.environ.get('PMESH_AMD_SORTED', 'auto')
 # Costs one more sweep over the block (measured at 512^3: bench.py --deterministic 1).  Batches the tile kernels cannot
 # take (2-d meshes, hsml, tables) still use floating-point atomics.
 DETERMINISTIC = os.environ.get('PMESH_AMD_DETERMINISTIC', '0') not in ('0', '', 'false', 'False')
+# Arithmetic of the tile-binned READOUT (include/pmesh_amd.h: pmx_binplan_exact).  The cell indices are the reference's
+# bit for bit either way.  False (default): weights and sums from fused multiply-adds in the canvas' precision — a third
+# of the instructions, results within 1e-14 (f8) / 1e-6 (f4) of the reference's relative to sum |weight x cell|.  True:
+# every product and sum formed as the reference forms it (_window_generics.h:213-242): bit-identical to the CPU
+# reference and to the direct kernels (what rounds 1-3 always did).
+EXACT = os.environ.get('PMESH_AMD_EXACT', '0') not in ('0', '', 'false', 'False')
 
 
 class _BinCache(object):
@@ -116,6 +122,7 @@ class _BinCache(object):
             if e[0] == key and e[3]:
                 e[4] = self._tick()
                 be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
+                be.call('binplan_exact', e[1], int(bool(EXACT)))
                 return e[1]
         # a plan that last served the same geometry and particle count rebuilds in a single
         # pass over the positions (csrc/pmx_binned.hip: slot ranges of the previous build)
@@ -147,6 +154,7 @@ class _BinCache(object):
             e = min(free or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape
         be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
+        be.call('binplan_exact', e[1], int(bool(EXACT)))
         be.call('binplan_configure', e[1], _FORMS[WALK])
         be.call('binplan_sorted', e[1], _SORTS[SORTED], None)
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())

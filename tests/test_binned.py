@@ -30,9 +30,9 @@ def hip():
     from pmesh_amd import backend
     backend.reset()
     b = backend.get()
-    old, oldw, olds = window.BINNED, window.WALK, window.SORTED
+    old, oldw, olds, olde = window.BINNED, window.WALK, window.SORTED, window.EXACT
     yield b
-    window.BINNED, window.WALK, window.SORTED = old, oldw, olds
+    window.BINNED, window.WALK, window.SORTED, window.EXACT = old, oldw, olds, olde
     window.clear_bin_cache()
     backend.reset()
 
@@ -76,6 +76,7 @@ def assert_binned_ran():
 @pytest.mark.parametrize('name', TUNED)
 @pytest.mark.parametrize('case', range(len(CASES)))
 def test_binned_equals_direct(hip, form, oracle, name, case):
+    window.EXACT = True            # the bit-identical form of the binned readout (pmx_binplan_exact)
     shape, period, scale, translate = CASES[case]
     W = windows[name]
     rs = numpy.random.RandomState(100 + case)
@@ -119,6 +120,46 @@ def test_binned_equals_direct(hip, form, oracle, name, case):
     c3 = torch.full(shape, 7.0, dtype=torch.float64, device=hip.device)
     W.paint(c3, pos, transform=aff)
     assert_allclose(c3.cpu().numpy(), c2.cpu().numpy() + 7.0, rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs'])
+@pytest.mark.parametrize('case', range(len(CASES)))
+def test_default_readout_within_tolerance_of_the_exact_form(hip, form, oracle, name, case):
+    """The DEFAULT binned readout (window.EXACT = False): the cell indices are the reference's bit for bit, the
+    weights come from FMA polynomials in the canvas' precision and the S^3 products are summed as nested FMAs.
+    Against the oracle (= the exact form) on every geometry of CASES, f8 / f4 canvases, f8 / f4 positions, plain and
+    gradient weights: within 1e-13 (f8 canvas) / 2e-6 (f4 canvas) of the largest |cell| x the bound of the
+    weights' absolute sum — and WHICH particles read zero (dropped outside the block) is the same exactly."""
+    shape, period, scale, translate = CASES[case]
+    W = windows[name]
+    rs = numpy.random.RandomState(300 + case)
+    n = 20000
+    pos_h = rs.uniform(-40, 110, size=(n, 3))
+    aff = Affine(3, scale=scale, translate=translate, period=period)
+    oaff = oracle.Affine(3, scale=scale, translate=translate, period=period)
+    window.BINNED = 'always'
+    for dt, tdt, tol in (('f8', torch.float64, 1e-13), ('f4', torch.float32, 2e-6)):
+        field_h = rs.normal(size=shape).astype(dt)
+        field = torch.from_numpy(field_h).to(hip.device)
+        for ptype in ('f8', 'f4'):
+            ph = pos_h.astype(ptype)
+            pos = torch.from_numpy(ph).to(hip.device)
+            for diffdir in (None, 1):
+                want = oracle.Window(W.kind).readout(field_h, ph, diffdir=diffdir, transform=oaff)
+                window.EXACT = False
+                window.clear_bin_cache()
+                got = W.readout(field, pos, diffdir=diffdir, transform=aff).cpu().numpy()
+                assert_binned_ran()
+                window.EXACT = True
+                window.clear_bin_cache()
+                exact = W.readout(field, pos, diffdir=diffdir, transform=aff).cpu().numpy()
+                assert_array_equal(exact, want)
+                sc = numpy.atleast_1d(numpy.asarray(scale, dtype='f8'))
+                wb = 1.0 if diffdir is None else 2.0 * abs(sc[min(diffdir, len(sc) - 1)]) + 2.0
+                assert_allclose(got, want, rtol=0, atol=tol * wb * abs(field_h).max())
+                assert_array_equal(got == 0, want == 0)
+                if dt == 'f8':
+                    assert abs(got - want).max() > 0 or name == 'cic'        # (it IS another arithmetic)
 
 
 @pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs'])
@@ -166,6 +207,7 @@ def test_crowded_tile_is_split(hip, oracle, name):
     entries): 70000 particles inside one tile and across its faces, 2000 elsewhere; dyadic positions
     and masses, so CIC / TSC paint must equal the oracle bit for bit, accumulate and overwrite;
     readout bit-identical."""
+    window.EXACT = True            # the bit-identical form of the binned readout (pmx_binplan_exact)
     W = windows[name]
     N = 64
     rs = numpy.random.RandomState(12)
@@ -439,6 +481,7 @@ def test_rebuild_from_history_and_overflow(hip, form, oracle, name):
     not depend on that: (1) slightly moved particles (ranges hold), (2) a completely different
     distribution of the same size (ranges overflow -> exact two-pass build on the device),
     (3) the builds after the overflow (back-off), all against the oracle; readout bit-exact."""
+    window.EXACT = True            # the bit-identical form of the binned readout (pmx_binplan_exact)
     W = windows[name]
     N, n = 64, 60000
     window.BINNED = 'always'
@@ -474,6 +517,7 @@ def test_block_rebuild_with_more_tiles_than_table_entries(hip, oracle, name, str
     """the block form of the single-pass rebuild counts a block of 4096 rows per tile in an LDS table
     of 128 entries; rows in random order over a 128^3 mesh (512 tiles) overflow it, and the groups
     that find no entry go to the global counters themselves"""
+    window.EXACT = True            # the bit-identical form of the binned readout (pmx_binplan_exact)
     W = windows[name]
     N = 128
     window.BINNED, window.WALK, window.SORTED = 'always', 'never', 'never'
@@ -508,6 +552,7 @@ def test_random_geometries_over_moving_particles(hip, seed):
     particles partly outside — over three steps of moving particles (first build, then single-pass
     rebuilds): binned paint equals direct paint within the fp64 tolerance, binned readout equals direct
     readout bit for bit."""
+    window.EXACT = True            # the bit-identical form of the binned readout (pmx_binplan_exact)
     rs = numpy.random.RandomState(1000 + seed)
     name = TUNED[seed % 4]
     W = windows[name]
@@ -555,6 +600,7 @@ def test_random_geometries_over_moving_particles(hip, seed):
 def test_rebuild_drops_and_nonperiodic(hip, form, oracle):
     """history rebuilds with particles that touch no local cell (their own bucket) on a
     non-periodic sub-block: dropped particles read 0 and paint nothing"""
+    window.EXACT = True            # the bit-identical form of the binned readout (pmx_binplan_exact)
     W = windows['tsc']
     window.BINNED = 'always'
     window.clear_bin_cache()

@@ -162,9 +162,10 @@ def test_multi_gpu_configs_per_gpu_load_on_one_gpu(config):
         mass = 0.5 + (torch.arange(copies * nlat, device=be.device, dtype=torch.int64) % 1024).to(torch.float64) / 1024.0
         mtot = float(mass.sum())
     pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], dtype='f8', resampler=name)
-    saved = window.BINNED
+    saved, saved_exact = window.BINNED, window.EXACT
     try:
         window.BINNED = 'auto'
+        window.EXACT = True            # (the readout below is compared with the oracle's bit for bit)
         rho = pm.paint(pos, mass=mass)
         assert any(e[3] for e in window.bin_cache().entries), 'the tile-binned path was not taken'
         assert abs(rho.csum() / mtot - 1) < 1e-10                      # mass conservation
@@ -213,6 +214,6 @@ def test_multi_gpu_configs_per_gpu_load_on_one_gpu(config):
         assert numpy.array_equal(got, want), abs(got - want).max()
         print('%s readout of %d particles bit-identical to the oracle' % (config, len(ph)))
     finally:
-        window.BINNED = saved
+        window.BINNED, window.EXACT = saved, saved_exact
         window.clear_bin_cache()
         backend.reset()
