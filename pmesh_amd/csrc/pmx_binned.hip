@@ -759,6 +759,12 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     // the first use, so several dependent gathers are in flight per lane
     // SWAP (TSC, PCS): odd lanes deposit their second particle first, see below
     constexpr bool SWAP = S >= 3 && UNROLL == 2;
+    // ([r4] measured and dropped: dealing the 64 list entries of a wave to its lanes so that neighbouring entries — the
+    // ones a jittered lattice puts on one cell — sit in different 16-lane groups of the LDS.  scripts/ldsatomic_groups.hip:
+    // a 64-bit LDS atomic is served in groups of 16 consecutive lanes, two lanes of a group on one address cost 12.3
+    // instead of 6.5 clocks per instruction, on one bank 8.3, lanes of different groups meet for free; the deal took the
+    // benchmark's pattern from 12.1 to 8.4 clocks there — and changed nothing in this kernel: TSC f4 paint 1.65 / 1.65 ms,
+    // PCS 2.77 / 2.90, with the odd-lane swap on top 1.78 / 3.22.  The kernel is not waiting for those conflicts.)
     double sink = 0;
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];

@@ -850,6 +850,14 @@ class GridND(object):
         Npoint = len(pos)
         P = self.comm.size
         counts_dtype = 'int32' if index_dtype == torch.int32 else 'int64'
+        if (P == 1 and self.periodic and self.size == 1 and int(self.DomainAssign[0]) == 0
+                and not int(self.DomainDegenerate[0])):
+            # ONE periodic domain on one rank: every position — finite or not, whatever the smoothing — resolves to
+            # it exactly once (the wrapped patch of gridnd_fill, _domain.pyx:62-118, names domain 0 however often
+            # and the targets are unique): sendcounts = [N], indices = 0 .. N - 1, nothing to classify
+            return Layout(comm=self.comm, sendlength=Npoint, sendcounts=numpy.array([Npoint], dtype=counts_dtype),
+                          indices=torch.arange(Npoint, dtype=index_dtype, device=be.device),
+                          recvcounts=numpy.array([Npoint], dtype=counts_dtype))
         if Npoint != 0:
             masks = torch.empty(Npoint, dtype=torch.int64, device=be.device)
             counts = torch.zeros(P, dtype=torch.int64, device=be.device)
