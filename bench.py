@@ -462,6 +462,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         f = cycle(ev[k])
+    t_issue = time.perf_counter() - t0           # the host has enqueued every cycle (it may have waited inside collectives)
     torch.cuda.synchronize()
     comm.Barrier()
     elapsed = time.perf_counter() - t0
@@ -585,6 +586,11 @@ def main():
                          'particles_per_launch': units, 'ms_per_launch': single[dom]},
         }
         line['build_flags'] = build_flags
+        # to take a multi-GPU line apart: what the kernels of this rank took stage by stage (stages_ms: events on the
+        # stream, so a stage that waits for a collective contains the wait), what the collectives took (comm) and how
+        # long the host needed to enqueue a cycle — the cycle is bound by the host when this approaches ms_per_step
+        line['host_issue_ms_per_step'] = 1e3 * t_issue / args.steps
+        line['stages_sum_ms'] = sum(stage_ms.values())
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args)

@@ -1678,7 +1678,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     DVec dpos = dvec(pos);
     if (npart > 0) {
         const unsigned full_grid = grid_for((npart + 3) / 4, TBLOCK);
-        const unsigned small_grid = full_grid < 512 ? full_grid : 512;     // gated launches: cheap to skip (25 us with 2048 workgroups, per rank and cycle)
+        const unsigned small_grid = full_grid < 128 ? full_grid : 128;     // gated launches: cheap to skip (a launch of 512 workgroups that return at once still took 22-25 us per rank and cycle, profiles/r03_h_multirank8_*; the repair they stand for is rare and may be slow)
         // contiguous (n, 3) rows on a 16-byte boundary take the dense staging path
         const bool dense = pos->stride1 == pos->elsize && pos->stride0 == 3 * (int64_t)pos->elsize &&
                            (((uintptr_t)pos->data) & 15) == 0;

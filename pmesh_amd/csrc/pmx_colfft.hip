@@ -333,8 +333,16 @@ __device__ __forceinline__ void stockham_pass(cpx<T> *buf, const cpx<T> *tw, int
 // tb = row_base(tj, col) of the calling kernel: the legs of butterfly j = tj + q * TPC are the rows
 // tj + (q * TPC + r * N/R) (tj < TPC <= N/R: disjoint bits).  The arithmetic is that of stockham_pass,
 // operation for operation: the results are bit-identical.
-template <typename T, bool INV, int R, int RB, bool HALFTW, int N, int NS, int TPC, int TWS, bool ROT>
-__device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj)
+// LOP: an operation on every element as it is loaded, given its row n (the round-trip kernel's scale and transfer
+// function ride on the loads of the first inverse pass: the rows a thread loads there are the rows it would have
+// rewritten in a sweep of its own, with a barrier and an LDS round trip in between)
+struct NoLoadOp {
+    static constexpr bool active = false;
+    template <typename V> __device__ __forceinline__ V operator()(int, V x) const { return x; }
+};
+template <typename T, bool INV, int R, int RB, bool HALFTW, int N, int NS, int TPC, int TWS, bool ROT, typename LOP = NoLoadOp>
+__device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj,
+                                                 const LOP &lop = LOP())
 {
     constexpr int nb = N / R;
     constexpr int per = nb / TPC;
@@ -348,6 +356,7 @@ __device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, 
 #pragma unroll
         for (int r = 0; r < R; r++) {
             cpx<T> x = buf[lds_at<T, RB, ROT>(tb, q * TPC + r * nb)];
+            if (LOP::active) x = lop(tj + q * TPC + r * nb, x);
             if (r > 0 && NS > 1) {
                 const int m = r * k * (N / (NS * R));
                 cpx<T> w;
@@ -512,15 +521,29 @@ template <typename T, int LOGN, int RB> struct ColPipe {
 #ifndef PMX_ROUND_PIPE
 #define PMX_ROUND_PIPE 0
 #endif
-template <typename T, int LOGN, int RB> struct RoundPipe { static constexpr bool value = PMX_ROUND_PIPE && ColPipe<T, LOGN, RB>::value; };
+// [r4] PMX_ROUND_PIPE2: the same persistent, prefetching form for the tiles of which TWO fit a CU (N = 512 in double:
+// 74 KB, 90 VGPRs — the 32 registers of the prefetched tile stay inside the 128 that four waves per SIMD leave): two
+// workgroups per CU, each loading its next tile while the two transforms of the current one run.
+#ifndef PMX_ROUND_PIPE2
+#define PMX_ROUND_PIPE2 0
+#endif
+template <typename T, int LOGN, int RB> struct RoundPipe2 {
+    static constexpr bool value = PMX_ROUND_PIPE2 && LOGN < 16 && !ColPipe<T, LOGN, RB>::value && ColPipe<T, LOGN, RB>::bytes > 53 * 1024;
+};
+template <typename T, int LOGN, int RB> struct RoundPipe {
+    static constexpr bool value = (PMX_ROUND_PIPE && ColPipe<T, LOGN, RB>::value) || RoundPipe2<T, LOGN, RB>::value;
+};
 
 // the Stockham passes of an N-point transform over the LDS-resident tile (compile-time radices)
-template <typename T, int LOGN, bool INV, int RB, bool HT, int TPC, int TWS, bool ROT, int I, int NS>
-__device__ __forceinline__ void run_passes_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj)
+template <typename T, int LOGN, bool INV, int RB, bool HT, int TPC, int TWS, bool ROT, int I, int NS, typename LOP = NoLoadOp>
+__device__ __forceinline__ void run_passes_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj,
+                                              const LOP &lop = LOP())
 {
     using Rd = Radices<LOGN>;
     if constexpr (I < Rd::n) {
-        stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT>(buf, tw, tb, col, tj);
+        // (the load operation belongs to the first pass only)
+        if constexpr (I == 0) stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT, LOP>(buf, tw, tb, col, tj, lop);
+        else stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT>(buf, tw, tb, col, tj);
         run_passes_p2<T, LOGN, INV, RB, HT, TPC, TWS, ROT, I + 1, NS * Rd::r[I]>(buf, tw, tb, col, tj);
     }
 }
@@ -716,9 +739,29 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
 #ifndef PMX_ROUND_WAVES
 #define PMX_ROUND_WAVES 4
 #endif
+#ifndef PMX_ROUND_FUSE_OP
+#define PMX_ROUND_FUSE_OP 0       // (measured: 512^3 f8 c2r 1.240 -> 1.230 ms, f4 0.760 -> 0.902, 1024^3 f8 11.97 -> 12.80: the transfer arithmetic in the butterfly registers costs the other lengths their occupancy)
+#endif
+// what the round-trip kernel does to a mode between its two transforms: times the forward scale, then the transfer
+// function (FORM as in apply_simple; APPLY false or a column beyond the block: the scale alone)
+template <typename T, bool APPLY, int FORM> struct RoundOp {
+    static constexpr bool active = true;
+    const ColGeom &g;
+    const ColK &ck;
+    T sc;
+    bool colok;
+    __device__ __forceinline__ cpx<T> operator()(int n, cpx<T> v) const
+    {
+        v.x *= sc;
+        v.y *= sc;
+        if (APPLY && colok) v = apply_simple<T, FORM>(g, n, ck, v);
+        return v;
+    }
+};
+
 template <typename T, int LOGN, bool APPLY, int RB>
 __global__ void __launch_bounds__((Len<LOGN>::N / Rpt<T, LOGN>::value * (RB / (int)sizeof(cpx<T>))),
-                                   (RoundPipe<T, LOGN, RB>::value ? 1 : PMX_ROUND_WAVES))
+                                   ((RoundPipe<T, LOGN, RB>::value && !RoundPipe2<T, LOGN, RB>::value) ? 1 : PMX_ROUND_WAVES))
 colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 {
     constexpr int N = Len<LOGN>::N;
@@ -779,6 +822,21 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         // interleaved and, with the prefetched tile held in registers, spills 90-200 VGPRs)
         // (not N = 2048 in float: the second copy of the loop costs that kernel 18 spilled registers)
         const bool force_form = APPLY && !(sizeof(T) == 4 && LOGN == 11) && g.t.laplace_pow == -1 && g.t.grad_dir >= 0;      // apply_simple<T, 1>
+        // [r4] power-of-two lengths: scale and transfer on the loads of the first inverse pass — the rows tj + u TPC this
+        // thread would rewrite below are exactly the legs of its first inverse butterflies (N / R = TPC for radix 8, a
+        // multiple of it for radix 4), so the values are the same bit for bit, and one LDS round trip with its barrier
+        // (of seven per tile) is gone
+        constexpr bool FUSE_OP = PMX_ROUND_FUSE_OP && P2 && !PIPE;
+        if constexpr (FUSE_OP) {
+            constexpr int TPCc = N / RPT;
+            if (force_form) {
+                const RoundOp<T, APPLY, 1> op{g, ck, sc, colok};
+                run_passes_p2<T, LOGN, true, RB, HT, TPCc, 1, false, 0, 1, RoundOp<T, APPLY, 1>>(buf, tw, tb, col, tj, op);
+            } else {
+                const RoundOp<T, APPLY, 0> op{g, ck, sc, colok};
+                run_passes_p2<T, LOGN, true, RB, HT, TPCc, 1, false, 0, 1, RoundOp<T, APPLY, 0>>(buf, tw, tb, col, tj, op);
+            }
+        } else {
         if (force_form) {
 #pragma unroll PIPE ? 1 : RPT
             for (int u = 0; u < RPT; u++) {
@@ -806,6 +864,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         }
         __syncthreads();
         run_passes<T, LOGN, true, RB, HT>(buf, tw, col, tj);
+        }
         int64_t uoff[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; u++) uoff[u] = uniform_offset<PIPE>((int64_t)(u * TPC) * g.out.sn);
@@ -1468,8 +1527,9 @@ static int launch_round(const ColGeom &g, void *data, const void *tw, bool apply
     int64_t tiles = (g.B + W - 1) / W;
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 tiles in one column pass");
     unsigned grid = (unsigned)tiles;
-    if (RoundPipe<T, LOGN, RB>::value) {
-        const int64_t cus = compute_units();
+    if (RoundPipe<T, LOGN, RB>::value && (!RoundPipe2<T, LOGN, RB>::value || g_persistent.load(std::memory_order_relaxed))) {
+        // (the two-per-CU form follows pmx_colfft_configure like the column passes: one tile per workgroup on several ranks)
+        const int64_t cus = compute_units() * (RoundPipe2<T, LOGN, RB>::value ? 2 : 1);
         grid = (unsigned)(tiles < cus ? tiles : cus);
     }
 #define LAUNCH(AP)                                                                                             \

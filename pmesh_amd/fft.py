@@ -213,6 +213,20 @@ class Partition(object):
 #: number of chunks of the last axis the slab transposes are pipelined over (the all-to-all of
 #: a chunk runs under the column passes of its neighbours); 1: one exchange per transform
 OVERLAP_CHUNKS = int(os.environ.get('PMESH_AMD_OVERLAP_CHUNKS', '2'))
+#: ... but never chunks of fewer bytes than this per rank (of the local complex block): what a chunk buys is its share of
+#: the wire time hidden under its neighbours' kernels, what it costs is a set of launches that fill the device badly —
+#: at 512^3 on 8 ranks a chunk of 67 MB runs its column passes in 36-55 us per launch (profiles/r03_h_multirank8_*:
+#: 8 % more kernel time than one launch for the whole block) against ~100 us of wire per chunk; a quarter of that is
+#: where the launches cost what they hide.  (The rate of a link is not measured here: one GPU.  PMESH_AMD_OVERLAP_MIN_MB.)
+OVERLAP_MIN_CHUNK_BYTES = int(float(os.environ.get('PMESH_AMD_OVERLAP_MIN_MB', '16')) * (1 << 20))
+
+
+def _overlap_chunks(local_bytes):
+    """how many chunks a transpose of `local_bytes` per rank is pipelined over"""
+    C = int(OVERLAP_CHUNKS)
+    if OVERLAP_MIN_CHUNK_BYTES > 0:
+        C = min(C, int(local_bytes // OVERLAP_MIN_CHUNK_BYTES))
+    return C
 
 
 def _async_exchange_works(comm):
@@ -666,7 +680,7 @@ class Plan(object):
         """[(first plane, planes)] of the local axis-0 range if both transposes of the pencil transform
         can be pipelined over chunks of planes: the fused axis-1 pass, equal plane ranges on all ranks
         (the chunk boundaries must agree) and asynchronous exchanges on both sub-communicators"""
-        C = int(OVERLAP_CHUNKS)
+        C = _overlap_chunks(2 * self.elsize * int(numpy.prod(p.local_o_shape, dtype='i8')))
         if C < 2 or not fuse1 or n0l * P0 != N0 or n0l < 2 * C:
             return None
         if not (hasattr(rowc, 'alltoall_views') and hasattr(colc, 'alltoall_views')):
@@ -1268,7 +1282,7 @@ class Plan(object):
         """[(first column, width)] of the last axis if the transposes can be pipelined: equal
         power-of-two blocks on both sides and enough columns; widths are multiples of 8 columns
         (128-byte lines of complex128) except for the last chunk"""
-        C = int(OVERLAP_CHUNKS)
+        C = _overlap_chunks(2 * self.elsize * N0 * n1loc * N2c)
         if C < 2 or not hasattr(be, 'colfft_chunk') or N2c < 64:
             return None
         if not _async_exchange_works(p.procmesh.comm):

@@ -18,6 +18,17 @@ import torch.distributed as dist
 from numpy.testing import assert_array_equal, assert_allclose, assert_almost_equal
 
 
+
+def _pipeline_everything():
+    """the cases below are about the CORRECTNESS of the pipelined transposes on meshes of a few dozen cells: no
+    minimum chunk size (fft.OVERLAP_MIN_CHUNK_BYTES keeps production transforms from cutting chunks that cost
+    more in launches than they hide of the wire)"""
+    from pmesh_amd import fft as _F
+    _F.OVERLAP_MIN_CHUNK_BYTES = 0
+
+
+_pipeline_everything()
+
 def setup():
     use_hip = os.environ.get('PMESH_MP_BACKEND', 'double') == 'hip'
     if use_hip:
