@@ -104,7 +104,9 @@ class Partition(object):
         if nd == 1 and P > 1:
             raise ValueError("Running 1d transforms on multiple ranks is not supported")
         self.nproc = P
-        self.pencil = len(np_) == 2 and P > 1 and min(np_) > 1
+        # (a 2-d process mesh [P, 1] IS the slab: axis 0 of the real field distributed, axis 1 of the transposed spectrum;
+        # [1, P] distributes axes 1 and 2, as PFFT lays it out: the pencil schedule with a first group of one)
+        self.pencil = len(np_) == 2 and P > 1 and np_[1] > 1
         if self.pencil:
             if nd != 3:
                 raise ValueError('a 2-d process mesh needs a 3-d mesh')

@@ -1113,15 +1113,12 @@ class ParticleMesh(object):
             # most square factorisation of the communicator; a slab for 2-d meshes
             if len(Nmesh) >= 3:
                 np = list(_fft.split_size_2d(self.comm.size))
-                if min(np) == 1:
-                    # a degenerate process mesh is a slab.  [P, 1] distributes axis 0: exactly the
-                    # slab [P] built here.  [1, P] (P = 3, 5, 7, ...) distributes axis 1 under PFFT;
-                    # it is built as the slab [P] too (axis 0 distributed) — said aloud.
-                    if np[0] == 1 and np[1] > 1:
-                        warnings.warn('ParticleMesh(np=None) on %d ranks: the reference uses the process mesh %s '
-                                      '(axis 1 distributed); pmesh_amd uses the slab [%d] (axis 0 distributed)'
-                                      % (self.comm.size, np, self.comm.size), stacklevel=2)
+                if np[1] == 1:
+                    # [P, 1] distributes axis 0 alone: exactly the slab [P], one transpose per transform
                     np = [self.comm.size]
+                # ([1, P] — what split_size_2d gives for P = 3, 5, 7, ... — distributes axis 1 of the real field, as
+                # PFFT lays it out; callers that read pm.partition see the reference's edges.  Rounds 1-3 built the
+                # slab [P] here instead.  `np=[P]` asks for the slab explicitly.)
             elif len(Nmesh) == 2:
                 np = [self.comm.size]
             else:

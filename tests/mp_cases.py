@@ -435,8 +435,15 @@ def case_cycle(be, comm):
     share = numpy.array_split(numpy.arange(len(allpos)), comm.size)[comm.rank]
     pos = allpos[share]
     pm = ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler='cic')
+    # np=None: the reference's process mesh (pm.py:1317-1325, pfft.split_size_2d) — on 3 ranks [1, 3], which
+    # distributes axis 1 of the real field and leaves axis 0 whole, as PFFT lays it out
+    from pmesh_amd.fft import split_size_2d
+    want_np = list(split_size_2d(comm.size))
+    assert pm.np == (want_np if want_np[1] > 1 else [comm.size]), (pm.np, want_np)
     layout = pm.decompose(pos)
     rho = pm.paint(pos, layout=layout)
+    if len(pm.np) == 2 and pm.np[0] == 1:
+        assert rho.shape[0] == N and rho.shape[1] < N and rho.shape[2] == N, rho.shape
     Ntot = comm.allreduce(len(pos))
     assert Ntot == N ** 3
     rho[...] *= 1.0 * pm.Nmesh.prod() / Ntot                  # nbody.py:205-207
