@@ -966,9 +966,15 @@ __device__ __forceinline__ void tile_gather_any(bool whole, const pmx_painter &p
 #ifndef PMX_TILE_THREADS_PCS
 #define PMX_TILE_THREADS_PCS 512
 #endif
+// [r4] the PCS readout of a double canvas: its 81 KB region lets two workgroups share a CU, its 75-81 VGPRs six waves a
+// SIMD — 768 threads fill what 512 leave empty (24 instead of 16 waves per CU): 2.03 -> 1.77 ms at 512^3, clustered
+// 2.61 -> 2.48, config 5's per-GPU load 35.3 -> 34.3 (1024 threads: 2.38 / 3.20 / 44.8, one workgroup per CU)
+#ifndef PMX_TILE_THREADS_PCS_READOUT
+#define PMX_TILE_THREADS_PCS_READOUT 768
+#endif
 template <int KIND, typename T> struct TileThreads {
     static constexpr int paint = KIND == PMX_TUNED_PCS ? PMX_TILE_THREADS_PCS : PMX_TILE_THREADS;
-    static constexpr int readout = KIND == PMX_TUNED_PCS ? PMX_TILE_THREADS_PCS : PMX_TILE_THREADS;
+    static constexpr int readout = KIND == PMX_TUNED_PCS ? PMX_TILE_THREADS_PCS_READOUT : PMX_TILE_THREADS;
 };
 template <int KIND> struct TileThreads<KIND, float> {
     static constexpr int paint = KIND == PMX_TUNED_PCS ? PMX_TILE_THREADS_PCS : PMX_TILE_THREADS;

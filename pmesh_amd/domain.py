@@ -138,7 +138,10 @@ class _Scratch(object):
         if e is None or e[0].numel() < nbytes or e[0].device != device:
             if e is not None:
                 e[0] = None                      # (free before the larger one is made)
-            e = self.buffers[name] = [torch.empty(int(nbytes) + int(nbytes) // 4 + 256, dtype=torch.uint8, device=device), None]
+            # a quarter of slack for what the next steps may need, at most 64 MB of it (ghost counts of a time-stepping
+            # caller wander by per cents; a buffer of gigabytes must not cost another quarter of itself)
+            slack = min(int(nbytes) // 4, 64 << 20) + 256
+            e = self.buffers[name] = [torch.empty(int(nbytes) + slack, dtype=torch.uint8, device=device), None]
         return e[0][:nbytes]
 
     def busy(self, name, work):
@@ -483,6 +486,8 @@ class Layout(object):
                 if memo[k][0]() is None or len(memo) > 4 or held() > budget:
                     memo.pop(k)
             st['missing'] = []
+        for k in [k for k, v in memo.items() if v[0]() is None]:
+            memo.pop(k)                            # (rows received for a tensor that no longer exists)
         res = []
         for i, k in enumerate(keys):
             ref, r = memo[k]
@@ -503,9 +508,11 @@ class Layout(object):
             data = torch.zeros((nrecv,) + tuple(data.shape[1:]), dtype=data.dtype, device=be.device)
         data = data.contiguous()
         scratch = _scratch_of(self.comm)
-        back = _typed(scratch.get('back', nsend * _row_bytes(data), be.device), data.dtype, (nsend,) + tuple(data.shape[1:]))
+        # (the buffer the rows were sent FROM takes what comes back for them: the outward exchange is long over —
+        # get() waits for it if not — and the results are never wider than the positions)
+        back = _typed(scratch.get('send0', nsend * _row_bytes(data), be.device), data.dtype, (nsend,) + tuple(data.shape[1:]))
         work = self.comm.alltoallv(data, rc, back, sc, async_op=async_op)
-        scratch.busy('back', work)
+        scratch.busy('send0', work)
 
         def finish(target):
             if work is not None:

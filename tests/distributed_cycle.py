@@ -51,6 +51,10 @@ def parse(argv=None):
                     help='1: compare the result of every rank with the one-rank cycle on the same particles')
     ap.add_argument('--backend', default='hip', choices=['hip', 'double'],
                     help="double: the oracle double of tests/oracle_backend.py (a CPU rehearsal of this script's flow)")
+    ap.add_argument('--migrate', type=int, default=0,
+                    help='1: every particle moves to the rank that owns its cell first, once (bench.py --gpus N does: what a '
+                         'time-stepping code does after its first decompose); 0: the ranks keep their slabs of lattice ids and '
+                         'on a pencil mesh three quarters of the rows travel as "ghosts" in every cycle')
     ap.add_argument('--oracle-planes', type=int, default=0,
                     help='K > 0: the first K planes of rank 0 painted block against the CPU oracle')
     return ap.parse_args(argv)
@@ -110,9 +114,17 @@ def run(args):
         r = comm.rank
         pos, mass = _generate(be, args, torch, r, P, modes)
         pm = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler=args.window, np=np_)
+        if args.migrate and P > 1:
+            home = pm.domain.decompose(pos, smoothing=0, _scale=pm.affine.scale)
+            if args.mass == 'array':
+                pos, mass = home.exchange(pos, mass)
+            else:
+                pos = home.exchange(pos)
+            del home
         T = Transfer.dx1(0)
         rho = pm.create('real')
         layout = pm.decompose(pos)
+        result = torch.empty(len(pos), dtype=torch.float64, device=be.device)      # lives across cycles, as a caller keeps it
 
         def cycle(keep_block=False):
             _window.clear_bin_cache()
@@ -127,7 +139,7 @@ def run(args):
                 back = ck.c2r(out=Ellipsis, transfer=T)
             else:
                 back = ck.apply(T, out=Ellipsis).c2r(out=Ellipsis)
-            return back.readout(pos, layout=layout)
+            return back.readout(pos, layout=layout, out=result)
         for k in range(args.warmup):
             cycle(keep_block=(k == 0))
         if args.warmup == 0 and args.oracle_planes:

@@ -765,6 +765,28 @@ def case_promote_and_pack(be, comm):
     unpacked = layout.exchange(pos, mass, ident, pack=False)
     for x, y in zip(one, unpacked):
         assert_array_equal(x, y)
+    # large exchanges travel array by array (domain.PACK_BYTES_MAX: no packed copy on either side): forced here
+    saved = domain.PACK_BYTES_MAX
+    try:
+        domain.PACK_BYTES_MAX = 0
+        rec = C.trace(True) if hasattr(comm, '_dist') else None
+        big = layout.exchange(pos, mass, ident)
+        if rec is not None:
+            C.trace(False)
+            assert len(rec) == 3, rec
+        for x, y in zip(one, big):
+            assert x.dtype == y.dtype and x.shape == y.shape
+            assert_array_equal(x, y)
+    finally:
+        domain.PACK_BYTES_MAX = saved
+    # the staging of the exchanges lives on the communicator and is reused by the layouts that follow
+    staging = domain._scratch_of(comm)
+    held = staging.nbytes()
+    layout2 = dcop.decompose(pos[:, :1], smoothing=0.05)
+    again = layout2.exchange(pos, mass, ident)
+    assert staging.nbytes() == held                 # nothing new was allocated for the same exchange
+    for x, y in zip(one, again):
+        assert_array_equal(x, y)
 
 
 def case_async_ghost_exchange(be, comm):
@@ -789,6 +811,24 @@ def case_async_ghost_exchange(be, comm):
     a.gather_remote_add(vals, out1)
     b.gather_remote_add(vals.clone(), None, async_op=True).wait(out2)
     assert torch.allclose(out1, out2, rtol=0, atol=1e-15)
+    # array by array (what exchanges of hundreds of MB do, domain.PACK_BYTES_MAX) == packed; the received rows are
+    # remembered per source tensor — weakly: a tensor that is gone, or another one at its address, never hits
+    saved = domain.PACK_BYTES_MAX
+    try:
+        domain.PACK_BYTES_MAX = 0
+        c = dcop.decompose(pos[:, :1], smoothing=0.08)
+        h = c.exchange_remote(pos, mass, async_op=True)
+        rp3, rm3 = h.wait()
+        assert torch.equal(rp, rp3) and torch.equal(rm, rm3)
+    finally:
+        domain.PACK_BYTES_MAX = saved
+    assert len(c._memo_remote) == 2
+    pos2 = pos.clone()
+    rq = c.exchange_remote(pos2)
+    assert torch.equal(rq, rp) and rq is not rp3
+    del pos2, rq
+    c.exchange_remote(mass)                                                    # (an exchange sweeps the memo)
+    assert all(v[0]() is not None for v in c._memo_remote.values())
 
 
 def case_comm_trace(be, comm):

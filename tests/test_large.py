@@ -103,8 +103,10 @@ def test_multi_gpu_configs_decomposed_on_thread_ranks(config):
     if config == 'C4':
         cmd += ['--window', 'cic']
     else:
+        # (--migrate 1, as bench.py --gpus N: without it three quarters of the rows of every rank travel as "ghosts" on the
+        # pencil mesh — that case runs at 512^3 in test_multirank.py — and this one needs 300 of the device's 309 GB)
         cmd += ['--np', '2x4', '--window', 'pcs', '--data', 'clustered', '--double', '1', '--mass', 'array',
-                '--pos-dtype', 'f4']
+                '--pos-dtype', 'f4', '--migrate', '1']
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500)
     print(out.stdout[-2000:])
     assert out.returncode == 0, out.stdout[-2000:] + '\n' + out.stderr[-4000:]
