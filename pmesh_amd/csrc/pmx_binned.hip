@@ -955,6 +955,29 @@ __device__ __forceinline__ void tile_gather_any(bool whole, const pmx_painter &p
     }
 }
 
+// [r4] The tile kernels are bound by a chain of dependent loads per trip — list entry -> position row — at the
+// bytes a CU keeps in flight (scripts/kernel_split.sh: with its atomics compiled out TSC f4 paint still takes 0.96 of its
+// 1.36 ms, PCS f8 1.56 of 2.35, at ~4 TB/s of real traffic).  The tile's slice of the index list is contiguous and
+// known when the workgroup arrives: one lane per 128-byte line asks for it BEFORE the region is zeroed / staged, so
+// that the list loads of every trip find their line in the L2 instead of in HBM.  The value itself is not used; the
+// caller keeps it alive until behind its next barrier (list_touch_done), where the compiler waits for it for free.
+// Measured (same box, off / on): PCS paint 2.76 -> 2.60 ms, clustered 3.55 -> 3.38; TSC paint 1.62 -> 1.65, CIC the
+// same; the readouts LOSE (one more live register: PCS on 768 threads 1.68 -> 2.46 ms, TSC f4 1.08 -> 1.16): on for
+// PCS paint only.
+#ifndef PMX_LIST_PREFETCH
+#define PMX_LIST_PREFETCH 1
+#endif
+__device__ __forceinline__ uint32_t list_touch(const uint32_t *list, int64_t start, int count)
+{
+    uint32_t v = 0;
+    if (PMX_LIST_PREFETCH && (int)threadIdx.x * 32 < count) v = list[start + (int)threadIdx.x * 32];
+    return v;
+}
+__device__ __forceinline__ void list_touch_done(uint32_t v)
+{
+    if (PMX_LIST_PREFETCH) asm volatile("" ::"v"(v));
+}
+
 // Threads of a tile workgroup.  The LDS region fixes the workgroups per CU (4 / 3 / 2 for CIC /
 // TSC / PCS in double); with 256 threads that left 16 / 12 / 8 waves per CU on kernels that spend
 // 60 % of their cycles parked on memory.  512 threads double the waves at the same LDS and still
@@ -1094,6 +1117,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
         // (what a crowded tile holds beyond g.chunk entries is painted by paint_heavy_kernel)
         const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
         if (count == 0 && !overwrite && !live) continue;   // nothing to add; uniform per workgroup
+        const uint32_t touched = (SORTED || S < 4) ? 0u : list_touch(list, start, count);
         double carry[CPT];
         if (S > 1 && live) {
 #pragma unroll
@@ -1129,6 +1153,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             }
             __syncthreads();
         }
+        list_touch_done(touched);
         tile_deposit_any<KIND, TTHREADS, SORTED, FIXED, typename DepositWeights<KIND, T, MODE>::type>(whole, pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
