@@ -1117,7 +1117,9 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
         // (what a crowded tile holds beyond g.chunk entries is painted by paint_heavy_kernel)
         const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
         if (count == 0 && !overwrite && !live) continue;   // nothing to add; uniform per workgroup
-        const uint32_t touched = (SORTED || S < 4) ? 0u : list_touch(list, start, count);
+        constexpr bool TOUCH = !SORTED && S >= 4;
+        uint32_t touched = 0;
+        if constexpr (TOUCH) touched = list_touch(list, start, count);
         double carry[CPT];
         if (S > 1 && live) {
 #pragma unroll
@@ -1153,7 +1155,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
             }
             __syncthreads();
         }
-        list_touch_done(touched);
+        if constexpr (TOUCH) list_touch_done(touched);
         tile_deposit_any<KIND, TTHREADS, SORTED, FIXED, typename DepositWeights<KIND, T, MODE>::type>(whole, pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells

@@ -16,4 +16,6 @@ cat gpurun_out/${tag}_inst_counts.txt | cut -c1-220
 scripts/sweep.sh ${tag}_sweep
 scripts/mr_kstats.sh ${tag}_mr8_512 --ranks 8 --mesh 512 --steps 5 | tail -3
 scripts/mr_kstats.sh ${tag}_mr8_1024_c4 --ranks 8 --mesh 1024 --steps 2 --warmup 1 | tail -3
-scripts/mr_kstats.sh ${tag}_mr8_1024_c5 --ranks 8 --np 2x4 --mesh 1024 --window pcs --data clustered --double 1 --mass array --pos-dtype f4 --steps 2 --warmup 1 | tail -3
+scripts/mr_kstats.sh ${tag}_mr8_1024_c5 --ranks 8 --np 2x4 --mesh 1024 --window pcs --data clustered --double 1 --mass array --pos-dtype f4 --steps 2 --warmup 1 --migrate 1 | tail -3
+scripts/mr_kstats.sh ${tag}_mr8_1024_c5_nomigrate --ranks 8 --np 2x4 --mesh 1024 --window pcs --data clustered --double 1 --mass array --pos-dtype f4 --steps 2 --warmup 1 | tail -3
+grep -h "peak device\|wall per cycle" gpurun_out/${tag}_mr8_*/log
