@@ -346,6 +346,8 @@ def main():
             pos = home.exchange(pos)
         nloc = int(pos.shape[0])
         del home
+        from pmesh_amd.domain import release_staging
+        release_staging(comm)              # (the staging of this one-off exchange is the size of the particle set)
     transfer = Transfer.dx1(0)             # T(k) = i k_x / k^2
     rho = pm.create('real')
     t_order = 0.0

@@ -232,9 +232,16 @@ __global__ void __launch_bounds__(DBLOCK) classify_kernel(GridD g, DVec pos, F3 
                 m = particle_targets(g, sil, sir);
                 masks[i] = m;
             }
-            for (int r = 0; r < g.nranks; r++) {
-                unsigned long long b = __ballot((m >> r) & 1);
-                if ((threadIdx.x & 63) == 0 && b) atomicAdd(&lcount[r], (unsigned)__popcll(b));
+            // (rows in a coherent order: the 64 particles of a wave are bound for ONE rank and nothing else — one
+            // comparison and one add instead of a ballot and an add per rank)
+            const uint64_t m0 = __shfl(m, 0);
+            if (__ballot(m != m0) == 0 && (m0 & (m0 - 1)) == 0) {
+                if ((threadIdx.x & 63) == 0 && m0) atomicAdd(&lcount[__ffsll((long long)m0) - 1], 64u);
+            } else {
+                for (int r = 0; r < g.nranks; r++) {
+                    unsigned long long b = __ballot((m >> r) & 1);
+                    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&lcount[r], (unsigned)__popcll(b));
+                }
             }
         }
         __syncthreads();

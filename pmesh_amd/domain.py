@@ -151,6 +151,21 @@ class _Scratch(object):
     def nbytes(self):
         return sum(e[0].numel() for e in self.buffers.values() if e[0] is not None)
 
+    def clear(self):
+        """give the staging back (after a one-off exchange much larger than what the steps that follow need: the
+        migration of every particle to its owner)"""
+        for e in self.buffers.values():
+            if e[1] is not None:
+                e[1].wait()
+        self.buffers = {}
+
+
+def release_staging(comm):
+    """free the exchange staging of `comm` (it is rebuilt at the size the next exchanges need)"""
+    s = getattr(comm, '_pmx_scratch', None)
+    if s is not None:
+        s.clear()
+
 
 def _scratch_of(comm):
     s = getattr(comm, '_pmx_scratch', None)

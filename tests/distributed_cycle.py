@@ -121,6 +121,8 @@ def run(args):
             else:
                 pos = home.exchange(pos)
             del home
+            from pmesh_amd.domain import release_staging
+            release_staging(comm)
         T = Transfer.dx1(0)
         rho = pm.create('real')
         layout = pm.decompose(pos)

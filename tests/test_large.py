@@ -92,9 +92,11 @@ def test_multi_gpu_configs_decomposed_on_thread_ranks(config):
     from pmesh_amd import backend, window
     window.bin_cache().destroy(backend.get()) if torch.cuda.is_available() else None
     backend.reset()
+    import gc
+    gc.collect()                                   # (fields and meshes of earlier tests that wait in reference cycles)
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    need = 80e9 if config == 'C4' else 190e9       # measured peaks: see the "peak device memory" line the child prints
+    need = 130e9 if config == 'C4' else 240e9      # measured peaks 114 / 225 GB (the "peak device memory" line the child prints; profiles/r04_b_multirank8_*.log)
     if free < need:
         pytest.skip('needs %.0f GB of free HBM, %.0f are free' % (need / 1e9, free / 1e9))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
