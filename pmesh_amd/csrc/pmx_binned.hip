@@ -1042,9 +1042,13 @@ template <int KIND, typename T, int MODE> struct DepositWeights {
 #define PMX_PAINT_WAVES_CIC 1
 #endif
 // (the variants on the tile-ordered copy would spill a few bytes under that budget: they keep the default)
+#ifndef PMX_PAINT_WAVES_PCS
+#define PMX_PAINT_WAVES_PCS 1
+#endif
 template <int KIND, bool SORTED> constexpr int paint_min_waves()
 {
-    return (KIND == PMX_TUNED_TSC && !SORTED) ? PMX_PAINT_WAVES_TSC : (KIND == PMX_TUNED_CIC ? PMX_PAINT_WAVES_CIC : 1);
+    return (KIND == PMX_TUNED_TSC && !SORTED) ? PMX_PAINT_WAVES_TSC
+         : (KIND == PMX_TUNED_CIC ? PMX_PAINT_WAVES_CIC : ((KIND == PMX_TUNED_PCS && !SORTED) ? PMX_PAINT_WAVES_PCS : 1));
 }
 
 template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE>

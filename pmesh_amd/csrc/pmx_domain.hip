@@ -219,6 +219,9 @@ __global__ void __launch_bounds__(DBLOCK) classify_kernel(GridD g, DVec pos, F3 
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (threadIdx.x < PMX_MAXRANKS) lcount[threadIdx.x] = 0;
         __syncthreads();
+        // ([r4] measured: all DSUB x 3 loads of a chunk requested before the first row is classified — 48 more live
+        // registers — took the kernel from 2.39 to 2.93 ms per 1.3e8 rows: it is bound by its instructions, not by
+        // the latency of its loads)
         for (int k = 0; k < DSUB; k++) {
             int64_t i = chunk * DCHUNK + k * DBLOCK + threadIdx.x;
             uint64_t m = 0;

@@ -218,7 +218,9 @@ def clear_bin_cache():
     bin_cache().clear()
 
 
-_mass_stats_memo = []      # [key, weak reference to the mass tensor, its statistics (4 doubles on the device)]
+# [key, weak reference to the mass tensor, its statistics (4 doubles on the device)]: per host thread, like the plan
+# cache (ranks that run as threads of one process would evict each other's entries: every paint recomputed its statistics)
+_mass_stats_tls = threading.local()
 
 
 def _mass_stats(be, m, mv):
@@ -228,6 +230,9 @@ def _mass_stats(be, m, mv):
     holds the tensor by weak reference: nothing keeps a caller's masses alive, and an address that has been
     reused by another tensor is never mistaken for the old one."""
     key = (m.data_ptr(), version_of(m), tuple(m.shape), m.stride(), m.dtype)
+    _mass_stats_memo = getattr(_mass_stats_tls, 'memo', None)
+    if _mass_stats_memo is None:
+        _mass_stats_memo = _mass_stats_tls.memo = []
     for e in _mass_stats_memo:
         if e[0] == key and e[1]() is m:
             return e[2]
