@@ -416,9 +416,11 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
           for _ in range(args.steps)]
 
-    result = torch.empty(nloc, dtype=torch.float64, device=be.device)
+    # the caller's result buffer, in the precision the run is in (the reference's `out` takes any float type,
+    # window.py:165-221; algorithmic_bytes charges the result at the mesh element size): an fp32 run keeps fp32 results
+    result = torch.empty(nloc, dtype=torch.float64 if e == 8 else torch.float32, device=be.device)
     if args.host_arrays:
-        result = numpy.empty(nloc, dtype='f8')
+        result = numpy.empty(nloc, dtype='f8' if e == 8 else 'f4')
 
     ncycle = [0]
 
@@ -457,6 +459,14 @@ def main():
 
     for _ in range(args.warmup):
         cycle()
+    # The interpreter's cyclic collector walks every object alive — millions after `import torch` — when its oldest
+    # generation comes due, which on a fresh box happened in the third cycle of the process: ~40 ms of host time with
+    # the GPU idle, inside the c2r stage of the first timed step whenever --warmup < 3 (found with
+    # PMESH_AMD_BENCH_STEPS=1; the kernels have nothing to do with it).  What exists now is collected once and set
+    # aside (a time-stepping code does the same after its set-up); the collector stays on for what the cycles allocate.
+    import gc
+    gc.collect()
+    gc.freeze()
     from pmesh_amd import comm as _comm
     records = _comm.trace(True) if world > 1 else None
     comm.Barrier()
@@ -491,6 +501,10 @@ def main():
     stage_ms = {}
     for i, s in enumerate(stages):
         stage_ms[s] = sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
+    if os.environ.get('PMESH_AMD_BENCH_STEPS') == '1':          # per-step stage times (a hiccup inside the timed region shows here)
+        for k in range(args.steps):
+            print('step %d: %s' % (k, ' '.join('%s %.3f' % (s, ev[k][i].elapsed_time(ev[k][i + 1])) for i, s in enumerate(stages))),
+                  file=sys.stderr, flush=True)
 
     # sanity: mass conservation and a finite result (size-independent properties)
     check = pm.paint(pos, mass=mass, layout=layout)

@@ -682,7 +682,7 @@ class RealField(Field):
             be = backend.get()
             dpos, host = to_device(pos, be.device, 'pos')
             # a caller's device buffer takes the result directly (no fresh tensor per call)
-            direct = (is_tensor(out) and out.device == be.device and out.dtype == torch.float64 and
+            direct = (is_tensor(out) and out.device == be.device and out.dtype in (torch.float64, torch.float32) and
                       out.dim() == 1 and out.shape[0] == dpos.shape[0] and out.is_contiguous())
             pending = None
             if layout.comm.size > 1:
