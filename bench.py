@@ -60,8 +60,8 @@ def algorithmic_bytes(stage, e, pe, nu=1.0, me=0):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--mesh', type=int, default=512)
     ap.add_argument('--particles', type=int, default=None, help='lattice size per side (default: mesh)')
     ap.add_argument('--window', default='cic', choices=['nnb', 'cic', 'tsc', 'pcs'])
