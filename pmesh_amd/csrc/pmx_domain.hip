@@ -334,12 +334,24 @@ __global__ void __launch_bounds__(DBLOCK) fill_kernel(const uint64_t *masks, int
             uint64_t m = i < n ? masks[i] : 0;
             // (a wave whose particles all stay on one rank — the rule in lattice order — asks one ballot that matters)
             const unsigned long long any = __ballot(m != 0);
-            for (int r = 0; r < nranks; r++) {
-                unsigned long long b = any ? __ballot((m >> r) & 1) : 0ull;
-                if (lane == 0) wcount[wave][r] = (unsigned)__popcll(b);
+            // (the 64 particles of the wave bound for ONE rank and nothing else — the rule in a coherent order: no ballots)
+            const uint64_t m0 = __shfl(m, 0);
+            const bool uni = any && __ballot(m != m0) == 0 && (m0 & (m0 - 1)) == 0;
+            const int r0 = uni ? __ffsll((long long)m0) - 1 : 0;
+            if (uni) {
+                if (lane < nranks) wcount[wave][lane] = lane == r0 ? 64u : 0u;
+            } else {
+                for (int r = 0; r < nranks; r++) {
+                    unsigned long long b = any ? __ballot((m >> r) & 1) : 0ull;
+                    if (lane == 0) wcount[wave][r] = (unsigned)__popcll(b);
+                }
             }
             __syncthreads();
-            if (any) {
+            if (uni) {
+                unsigned before = (unsigned)lane;
+                for (int w = 0; w < wave; w++) before += wcount[w][r0];
+                indices[rbase[r0] + before] = (IDX)i;
+            } else if (any) {
                 for (int r = 0; r < nranks; r++) {
                     const bool hit = (m >> r) & 1;
                     unsigned long long b = __ballot(hit);
