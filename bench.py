@@ -97,6 +97,11 @@ def parse():
                          'fastpm caller passes them: every paint / readout stages them over PCIe (diagnostic: '
                          'the reported rate then is PCIe inclusive and is NOT the headline metric); 2: the same with '
                          'the position arrays registered once (ParticleMesh.stage) and refreshed once per cycle')
+    ap.add_argument('--out-field', type=int, default=0,
+                    help='0: pm.paint(pos) returns a new field every cycle, as the callers of the reference write it '
+                         '(fastpm: pm.paint(x, layout=layout)) — on one rank the halo merge of the tile kernels then rides '
+                         'on the row pass of r2c (pm.HALO_DEFER); 1: the cycle paints into one field object of the '
+                         "caller's (out=rho), whose value must be complete when paint returns: merge kernel inside paint")
     ap.add_argument('--fuse-apply', type=int, default=1,
                     help='1: the transfer multiplication rides on the first pass of c2r (c2r(transfer=))')
     ap.add_argument('--deterministic', type=int, default=0,
@@ -423,6 +428,7 @@ def main():
         result = numpy.empty(nloc, dtype='f8' if e == 8 else 'f4')
 
     ncycle = [0]
+    halo_deferred = [False]       # the last paint left its halo merge to the row pass of r2c (pm.HALO_DEFER)
 
     def cycle(marks=None):
         def mark(i):
@@ -442,9 +448,11 @@ def main():
         if (layout is None or args.ghosts_only) and args.host_arrays != 1:
             pm.resampler.prebin(rho.value, getattr(pos, 'tensor', pos), pm.affine)      # tile binning, shared by paint+readout
         mark(1)
-        pm.paint(pos, mass=mass, hold=False, layout=layout, out=rho)   # includes the zero fill
+        # (includes the zero fill)
+        painted = pm.paint(pos, mass=mass, hold=False, layout=layout, out=rho if args.out_field else None)
+        halo_deferred[0] = getattr(painted._base.storage, '_pmx_halo', None) is not None
         mark(2)
-        rhok = rho.r2c(out=Ellipsis)
+        rhok = painted.r2c(out=Ellipsis)
         mark(3)
         if not args.fuse_apply:
             rhok.apply(transfer, out=Ellipsis)
@@ -528,8 +536,8 @@ def main():
         ach = algorithmic_bytes(dom, e, pe, nu, me) * units / (single[dom] * 1e-3) / 1e9
         binned = any(e[3] for e in _window.bin_cache().entries)
         if binned:
-            kname = {'paint': 'paint_tile_kernel+halo_merge_kernel', 'readout': 'readout_tile_kernel',
-                     'apply': 'transfer_kernel'}[dom]
+            kname = {'paint': 'paint_tile_kernel' if halo_deferred[0] else 'paint_tile_kernel+halo_merge_kernel',
+                     'readout': 'readout_tile_kernel', 'apply': 'transfer_kernel'}[dom]
         else:
             kname = {'paint': 'paint_tuned_kernel', 'readout': 'readout_tuned_kernel',
                      'apply': 'transfer_kernel'}[dom]
@@ -564,6 +572,9 @@ def main():
                                          % ('slab' if len(np_) == 1 else 'pencil', np_,
                                             'ghosts only' if args.ghosts_only else 'all particles')),
                        'particles': ntot, 'apply': 'fused into c2r' if args.fuse_apply else 'separate kernel',
+                       'halo_merge': ('gathered by the row pass of r2c from the staging buffer of the tile kernels '
+                                      '(no kernel of its own; its time shows under r2c)' if halo_deferred[0]
+                                      else 'halo_merge_kernel inside paint'),
                        'fft': ('LDS row + column FFT kernels' + (
                            ', the last pass of r2c deferred into the first of c2r (one kernel for both and the transfer; '
                            'its time shows under c2r)' if world == 1 and _fft.DEFER_LAST_PASS and args.fuse_apply else ''))

@@ -195,6 +195,30 @@ int pmx_paint_binned(pmx_binplan *plan, const pmx_painter *p, void *canvas, cons
                      const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream);
 int pmx_readout_binned(pmx_binplan *plan, const pmx_painter *p, const void *canvas,
                        const pmx_vec *pos, const pmx_vec *out, void *stream);
+/* [r4] The halo merge of a paint left to its consumer.  pmx_paint_binned ends with a pass that adds the staged
+ * halos of all tiles (the cells of a tile's region beyond its own box) to their owners with atomics: a
+ * read-modify-write of a quarter (CIC) to two thirds (PCS) of the mesh on top of the paint itself.  In the PM cycle
+ * the next reader of the mesh is the forward row pass of r2c (pm.py:1795-1869 -> pm.py:655-694), which can add the
+ * staged values while it loads the rows: no pass of their own, no atomics.
+ * pmx_paint_binned_defer : as pmx_paint_binned; *deferred = 1 if the merge was left out (one rank's whole periodic
+ *                          mesh, overwrite != 0, not deterministic, a row length pmx_rowfft_halo gathers for), else 0
+ *                          and the call is pmx_paint_binned.  While a plan holds staged halos it refuses to build or
+ *                          paint (PMX_EINVAL): one of the next two calls comes first.
+ * pmx_halo_merge         : the merge pmx_paint_binned would have run (no-op if nothing is staged).
+ * pmx_rowfft_halo        : pmx_rowfft (forward) on rows [x0 * rows_per_plane, ...) of the painted canvas, the staged
+ *                          halos added to every row as it is loaded; last != 0 releases the plan (the caller has
+ *                          transformed every plane).  Values equal pmx_halo_merge + pmx_rowfft up to the order of
+ *                          the additions into a cell. */
+int pmx_paint_binned_defer(pmx_binplan *plan, const pmx_painter *p, void *canvas, const pmx_vec *pos,
+                           const pmx_vec *mass, double mass_scalar, int32_t overwrite, int32_t *deferred,
+                           void *stream);
+int pmx_halo_merge(pmx_binplan *plan, const pmx_painter *p, void *canvas, void *stream);
+int pmx_binplan_halo_source(pmx_binplan *plan, const void *canvas, int32_t elsize, const void **halo,
+                            int32_t *S, int32_t *nt, int32_t consume);
+int pmx_rowfft_halo_supported(int64_t n, int32_t elsize);
+int pmx_rowfft_halo(int32_t elsize, void *data, int64_t nrows, int64_t n, int64_t pitch, double scale,
+                    int64_t rows_per_plane, int64_t plane_pitch, pmx_binplan *plan, const void *canvas,
+                    int64_t x0, int32_t last, void *stream);
 
 /* ---- domain decomposition (pmesh/domain.py:561-652 + _domain.pyx:9-122) -- */
 typedef struct pmx_grid {

@@ -101,6 +101,11 @@ DEVICE_ONLY = {
     'binplan_build': (C.c_int, [_vp, _P(Painter), _P(Vec), _i64, _vp]),
     'paint_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _f64, _i32, _vp]),
     'readout_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _vp]),
+    'paint_binned_defer': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _f64, _i32, _P(_i32), _vp]),
+    'halo_merge': (C.c_int, [_vp, _P(Painter), _vp, _vp]),
+    'binplan_halo_source': (C.c_int, [_vp, _vp, _i32, _P(_vp), _P(_i32), _P(_i32), _i32]),
+    'rowfft_halo_supported': (C.c_int, [_i64, _i32]),
+    'rowfft_halo': (C.c_int, [_i32, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp, _vp, _i64, _i32, _vp]),
     'fft_create': (C.c_int, [_P(_vp), _i32, _i32, _i32, _P(_i64), _P(_i64), _i64, _P(_i64), _i64,
                              _i64, _f64, _i32]),
     'fft_execute': (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -155,6 +155,14 @@ class HipBackend(object):
         self.call('rowfft', elsize, int(bool(inverse)), data.data_ptr(), nrows, n, pitch, float(scale),
                   int(rows_per_plane), int(plane_pitch), self.stream())
 
+    def rowfft_halo(self, elsize, data, nrows, n, pitch, rows_per_plane, plane_pitch, plan, canvas_ptr, x0, last,
+                    scale=1.0):
+        """the forward rowfft on planes x0 ... of a canvas whose paint left its halo merge to this pass
+        (pmx_paint_binned_defer): the staged halos are added to the rows as they are loaded; last: the plan is
+        released"""
+        self.call('rowfft_halo', elsize, data.data_ptr(), nrows, n, pitch, float(scale), int(rows_per_plane),
+                  int(plane_pitch), plan, C.c_void_p(canvas_ptr), int(x0), int(bool(last)), self.stream())
+
     # -- slab transposes --------------------------------------------------
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
         """(n0, n1, n2) -> blocks by n1 range (inverse: blocks -> (n0, n1, n2))"""

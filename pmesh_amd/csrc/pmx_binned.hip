@@ -1619,6 +1619,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                                  void *stream)
 {
     PMX_REQUIRE(pl != nullptr, PMX_EINVAL, "plan is NULL");
+    PMX_REQUIRE(!pl->halo_pending, PMX_EINVAL,
+                "the halos of the last paint of this plan are still staged (pmx_halo_merge / pmx_rowfft_halo first)");
     int rc = pmx_binplan_supported(p_, npart);
     if (rc) return rc;
     PMX_REQUIRE(npart == 0 || (vec_ok(pos) && pos->ncol >= 3), PMX_EINVAL, "pos must be (n, >=3) f4/f8");
@@ -1860,9 +1862,11 @@ template <typename T>
 static
 #endif
 int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos, DVec mass, double ms,
-                   int overwrite, hipStream_t st)
+                   int overwrite, int defer, hipStream_t st)
 {
     const BinGeom &g = pl->g;
+    PMX_REQUIRE(!pl->halo_pending, PMX_EINVAL,
+                "the halos of the previous paint of this plan are still staged (pmx_halo_merge / pmx_rowfft_halo first)");
     size_t need = (size_t)g.ntiles * (size_t)halo_cells(g.S) * sizeof(T);
     int rc = plan_ensure(&pl->halo, &pl->cap_halo, need > 0 ? need : 16);
     if (rc) return rc;
@@ -1930,7 +1934,7 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
                    if (run_float) PT3(K, T, 0, (run_fixed ? 1 : 0), p, canvas, halo, overwrite); } while (0)
     // (a batch is served either by the fixed-point or by the floating-point kernels: the merge of the other
     // finds only zeros in its staging buffer... the deterministic one has a staging buffer of its own)
-#define HM(S_) do { if (run_fixed && det) { halo_merge_kernel<S_, double, true><<<grid, TBLOCK, 0, st>>>(pd, g, (char *)pl->dscratch, dhalo, pl->counts, 1, mstats, 0); \
+#define HM(S_) do { if (defer) break; if (run_fixed && det) { halo_merge_kernel<S_, double, true><<<grid, TBLOCK, 0, st>>>(pd, g, (char *)pl->dscratch, dhalo, pl->counts, 1, mstats, 0); \
                                             if (run_float) halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite, mstats, 1); } \
                     else halo_merge_kernel<S_, T><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, halo, pl->counts, overwrite); } while (0)
     switch (p.kind) {
@@ -1962,14 +1966,19 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
         det_finish_kernel<T><<<grid_for(cells, TBLOCK, 8192), TBLOCK, 0, st>>>(p, (char *)canvas, (const long long *)pl->dscratch, dexp, overwrite, mstats);
     }
     PMX_HIP_CHECK(hipGetLastError());
+    if (defer) {
+        pl->halo_pending = 1;
+        pl->halo_elsize = (int)sizeof(T);
+        pl->halo_canvas = canvas;
+    }
     return PMX_OK;
 }
 
 #if PMX_BINNED_PART == 4
-template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, DVec, DVec, double, int, hipStream_t);
+template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, DVec, DVec, double, int, int, hipStream_t);
 #else
 #if PMX_BINNED_PART == 2
-extern template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, DVec, DVec, double, int, hipStream_t);
+extern template int paint_binned_t<float>(pmx_binplan *, const pmx_painter &, void *, DVec, DVec, double, int, int, hipStream_t);
 #endif
 extern "C" int pmx_mass_stats(const pmx_vec *mass, int64_t n, double *stats, void *stream)
 {
@@ -1983,8 +1992,22 @@ extern "C" int pmx_mass_stats(const pmx_vec *mass, int64_t n, double *stats, voi
     return PMX_OK;
 }
 
-extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *canvas, const pmx_vec *pos,
-                                const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream)
+// can the halo merge of a paint be left to the forward row pass of r2c (pmx_rowfft_halo)?  One rank's whole periodic
+// mesh (every tile a full one, halos wrap onto tiles), every cell written by the paint (overwrite), dense rows of a
+// power-of-two length the row kernel gathers for, floating-point staging.
+static bool halo_deferrable(const pmx_binplan *pl, const pmx_painter &p, int overwrite)
+{
+    const BinGeom &g = pl->g;
+    if (!overwrite || pl->deterministic || g.S < 2) return false;
+    for (int d = 0; d < 3; d++)
+        if (g.o[d] != 0 || p.period[d] != p.size[d]) return false;
+    if (p.strides[2] != p.canvas_elsize) return false;
+    return pmx_rowfft_halo_supported(p.size[2], p.canvas_elsize) == PMX_OK;
+}
+
+static int paint_binned_any(pmx_binplan *pl, const pmx_painter *p_, void *canvas, const pmx_vec *pos,
+                            const pmx_vec *mass, double mass_scalar, int32_t overwrite, int32_t defer, int32_t *deferred,
+                            void *stream)
 {
     PMX_REQUIRE(pl && pl->built, PMX_EINVAL, "bin plan is not built");
     PMX_REQUIRE(p_ && same_geometry(*p_, pl->painter), PMX_EINVAL, "painter differs from the one the plan was built for");
@@ -1993,8 +2016,64 @@ extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *ca
     PMX_REQUIRE(pl->npart == 0 || vec_ok(pos), PMX_EINVAL, "pos");
     pmx_painter p = *p_;
     hipStream_t st = (hipStream_t)stream;
-    if (p.canvas_elsize == 8) return paint_binned_t<double>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
-    return paint_binned_t<float>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, st);
+    const int df = (defer && halo_deferrable(pl, p, overwrite)) ? 1 : 0;
+    if (deferred) *deferred = df;
+    if (p.canvas_elsize == 8) return paint_binned_t<double>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, df, st);
+    return paint_binned_t<float>(pl, p, canvas, dvec(pos), dvec(mass), mass_scalar, overwrite, df, st);
+}
+
+extern "C" int pmx_paint_binned(pmx_binplan *pl, const pmx_painter *p_, void *canvas, const pmx_vec *pos,
+                                const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream)
+{
+    return paint_binned_any(pl, p_, canvas, pos, mass, mass_scalar, overwrite, 0, nullptr, stream);
+}
+
+extern "C" int pmx_paint_binned_defer(pmx_binplan *pl, const pmx_painter *p_, void *canvas, const pmx_vec *pos,
+                                      const pmx_vec *mass, double mass_scalar, int32_t overwrite, int32_t *deferred,
+                                      void *stream)
+{
+    PMX_REQUIRE(deferred != nullptr, PMX_EINVAL, "deferred is NULL");
+    return paint_binned_any(pl, p_, canvas, pos, mass, mass_scalar, overwrite, 1, deferred, stream);
+}
+
+extern "C" int pmx_halo_merge(pmx_binplan *pl, const pmx_painter *p_, void *canvas, void *stream)
+{
+    PMX_REQUIRE(pl && pl->built, PMX_EINVAL, "bin plan is not built");
+    if (!pl->halo_pending) return PMX_OK;
+    PMX_REQUIRE(p_ && same_geometry(*p_, pl->painter), PMX_EINVAL, "painter differs from the one the plan was built for");
+    PMX_REQUIRE(canvas == pl->halo_canvas, PMX_EINVAL, "the staged halos belong to another canvas");
+    PMX_REQUIRE(p_->canvas_elsize == pl->halo_elsize, PMX_EINVAL, "canvas element size differs from the staged halos'");
+    const pmx_painter p = *p_;
+    const BinGeom &g = pl->g;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
+#define HMD(S_) do { if (p.canvas_elsize == 8) halo_merge_kernel<S_, double><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, (const double *)pl->halo, pl->counts, 1); \
+                     else halo_merge_kernel<S_, float><<<grid, TBLOCK, 0, st>>>(p, g, (char *)canvas, (const float *)pl->halo, pl->counts, 1); } while (0)
+    switch (g.S) {
+    case 2: HMD(2); break;
+    case 3: HMD(3); break;
+    case 4: HMD(4); break;
+    default: break;
+    }
+#undef HMD
+    pl->halo_pending = 0;
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+// (for pmx_rowfft_halo, csrc/pmx_colfft.hip) the staged halos of the last paint and what the gather has to know
+extern "C" int pmx_binplan_halo_source(pmx_binplan *pl, const void *canvas, int32_t elsize, const void **halo,
+                                       int32_t *S, int32_t *nt, int32_t consume)
+{
+    PMX_REQUIRE(pl && pl->built, PMX_EINVAL, "bin plan is not built");
+    PMX_REQUIRE(pl->halo_pending, PMX_EINVAL, "no staged halos on this plan");
+    PMX_REQUIRE(canvas == pl->halo_canvas, PMX_EINVAL, "the staged halos belong to another canvas");
+    PMX_REQUIRE(elsize == pl->halo_elsize, PMX_EINVAL, "element size differs from the staged halos'");
+    *halo = pl->halo;
+    *S = pl->g.S;
+    for (int d = 0; d < 3; d++) nt[d] = pl->g.nt[d];
+    if (consume) pl->halo_pending = 0;
+    return PMX_OK;
 }
 #endif   // PMX_BINNED_PART != 4
 

@@ -165,6 +165,12 @@ struct pmx_binplan {
     const double *mass_stats_ext = nullptr;   // the same four words computed by the caller (pmx_mass_stats) for the masses of the next paint
     int exact = 0;                     // readout in the reference's arithmetic, operation by operation (bit-identical to pmx_readout)
     int deterministic = 0;             // paint through a dense int64 copy of the block: bit-reproducible
+    // [r4] The halo merge of the last paint left to its consumer: the staged halos of every tile are still in `halo`
+    // and belong to the canvas at `halo_canvas`; pmx_halo_merge adds them with atomics (what the paint itself does
+    // otherwise), pmx_rowfft_halo adds them while the forward row pass of r2c loads the canvas (no sweep of their own).
+    int halo_pending = 0;
+    int halo_elsize = 0;               // element size of the staged values (that of the canvas)
+    const void *halo_canvas = nullptr;
     void *dscratch = nullptr;          // that copy (+ the batch's exponent behind it)
     size_t cap_dscratch = 0;
     void *dhalo = nullptr;             // its halo staging (8 bytes per cell whatever the canvas type)

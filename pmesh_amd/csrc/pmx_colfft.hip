@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "pmx_common.h"
+#include "pmx_binplan.h"     // tile geometry of the paint whose halos the forward row pass can gather
 
 // This file compiles as one unit (PMX_COLFFT_PART undefined or 0: scripts/build_variant.sh, the resource test) or as two,
 // built side by side by the Makefile: the C ABI with the double-precision kernels (1) and the float kernels
@@ -915,17 +916,118 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 #ifndef PMX_ROW_HALFTW
 #define PMX_ROW_HALFTW 1
 #endif
+// [r4] The halo merge of the paint inside the forward row pass (pmx_rowfft_halo).  pmx_paint_binned_defer has left
+// the halo cells of every tile — the part of a tile's region beyond its own T0 x T1 x T2 box — in the plan's staging
+// buffer (compact numbering, Region<S>::halo_index) instead of adding them to their owners with atomics.  A canvas
+// cell (x, y, z) owes up to seven of them: with a = x mod T0, b = y mod T1, c = z mod T2, every (dx, dy, dz) != 0 with
+// dx = 1 only if a < S - 1 (likewise dy, dz) names the tile (tx - dx, ty - dy, tz - dz) (periodic: the one rank's whole
+// mesh) and its region cell (a + dx T0, b + dy T1, c + dz T2) — unless the paint kernel carried that cell to the next
+// tile of its segment in LDS instead of staging it (the walk axis: z for CIC / TSC, x for PCS; every tile but the last
+// of a segment), in which case it arrived in the owner's own flush.  The row pass reads whole rows of the canvas, z
+// contiguous: lane n holds cells 2n, 2n + 1 of its rows and adds what they are owed as it loads them.
+struct HaloSrc {
+    const void *halo;      // staging buffer of the plan (elements of the canvas type)
+    int S, nt0, nt1, nt2;  // window support, tiles per axis
+    int x0;                // plane of row 0 of this launch
+};
+
+// One thread's LPT elements: column n (cells 2n, 2n + 1) of the rows yb, yb + RSTEP, ... of plane x, all inside one tile
+// row (a workgroup's rows start at a multiple of their count, which divides T1); `acc` holds the row's own elements,
+// still on their way: they are only touched when a batch of staged values has arrived.  Two batches — the staged cells of this lane's own
+// z tile, then (the few lanes that hold the first cells of a z tile) those of the z-faces of the tile before — and in
+// each batch every load is issued into a register of its own before anything is added: a gather written per element
+// (load, add, next) makes the compiler wait for memory once per row and source (0.37 -> 0.55 ms at 512^3).  The
+// branch on x is uniform over the workgroup; the rows that are owed y-faces are the first S - 1 of a tile row, i.e.
+// only the thread's first UY elements can be, whatever the window.
+// UB: elements per batch (LPT: all at once; less where the registers of a whole batch would spill).
+template <typename T, int LPT, int RSTEP, int UB>
+__device__ __forceinline__ void halo_gather(const HaloSrc &h, int x, int yb, int n, cpx<T> (&acc)[LPT])
+{
+    constexpr int UY = (3 + RSTEP - 1) / RSTEP < LPT ? (3 + RSTEP - 1) / RSTEP : LPT;     // by0 + u RSTEP < S - 1 <= 3 needs u < UY
+    static_assert(LPT % UB == 0, "halo_gather: batches");
+    const int S1 = h.S - 1;
+    const int R1 = T1 + S1, R2 = T2 + S1;
+    const int NA = S1 * R1 * R2, NB = T0 * S1 * R2, HALO = NA + NB + T0 * T1 * S1;
+    const bool wx = h.S >= 4 ? walk_x(4) : walk_x(2);       // (walk_x is the same for S = 2 and 3)
+    const int tx = x / T0, ax = x % T0, ty = yb / T1, by0 = yb % T1;
+    const int z = 2 * n, tz = z / T2, cz = z % T2;
+    const int txm = tx == 0 ? h.nt0 - 1 : tx - 1, tym = ty == 0 ? h.nt1 - 1 : ty - 1, tzm = tz == 0 ? h.nt2 - 1 : tz - 1;
+    // the tile `tw` of `ntw` along the walk axis stages (does not carry) its face
+    auto last = [&](int tw, int ntw) __attribute__((always_inline)) { return tw == ntw - 1 || (tw % ZSEG) == ZSEG - 1; };
+    const bool xst = ax < S1 && (!wx || last(txm, h.nt0));      // the x-face rows of this plane are staged (uniform)
+    const bool fzs = cz < S1 && (wx || last(tzm, h.nt2));       // this lane's cells are owed staged z-faces
+    const bool two = cz + 1 < S1;
+    const T *base = (const T *)h.halo;
+    const T *t10 = base + ((int64_t)txm * h.nt1 + ty) * h.nt2 * HALO, *t11 = base + ((int64_t)txm * h.nt1 + tym) * h.nt2 * HALO;
+    const T *t01 = base + ((int64_t)tx * h.nt1 + tym) * h.nt2 * HALO, *t00 = base + ((int64_t)tx * h.nt1 + ty) * h.nt2 * HALO;
+    // region rows (T0 + ax, by), (T0 + ax, T1 + by) of the tiles before along x (and y), (ax, T1 + by) of the tile before along y
+    auto rowx = [&](int by) __attribute__((always_inline)) { return (ax * R1 + by) * R2; };
+    auto rowc = [&](int by) __attribute__((always_inline)) { return (ax * R1 + by + T1) * R2; };
+    auto rowy = [&](int by) __attribute__((always_inline)) { return NA + (ax * S1 + by) * R2; };
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: cells (cz, cz + 1) of the rows in this lane's own z tile; pass 1: (T2 + cz, T2 + cz + 1) in the z tile before
+        if (pass == 1 && !fzs) break;
+        const int off = pass == 0 ? tz * HALO + cz : tzm * HALO + T2 + cz;
+        const bool second = pass == 0 || two;
+#pragma unroll
+        for (int ub = 0; ub < LPT; ub += UB) {
+            if (pass == 0 && !xst && ub >= UY) break;           // (uniform) nothing but y-faces in this pass, and those are done
+            T x0[UB], x1[UB], c0[UB], c1[UB], y0[UB], y1[UB], z0[UB], z1[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) x0[k] = x1[k] = z0[k] = z1[k] = c0[k] = c1[k] = y0[k] = y1[k] = (T)0;
+            if (xst) {
+#pragma unroll
+                for (int k = 0; k < UB; k++) {
+                    const T *p = t10 + off + rowx(by0 + (ub + k) * RSTEP);
+                    x0[k] = p[0];
+                    if (second) x1[k] = p[1];
+                }
+#pragma unroll
+                for (int k = 0; k < UB; k++)
+                    if (ub + k < UY && by0 + (ub + k) * RSTEP < S1) {
+                        const T *p = t11 + off + rowc(by0 + (ub + k) * RSTEP);
+                        c0[k] = p[0];
+                        if (second) c1[k] = p[1];
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++)
+                if (ub + k < UY && by0 + (ub + k) * RSTEP < S1) {
+                    const T *p = t01 + off + rowy(by0 + (ub + k) * RSTEP);
+                    y0[k] = p[0];
+                    if (second) y1[k] = p[1];
+                }
+            if (pass == 1) {
+                // (ax, by, T2 + cz) of the tile's own column: the compact z-face
+#pragma unroll
+                for (int k = 0; k < UB; k++) {
+                    const T *p = t00 + tzm * HALO + NA + NB + (ax * T1 + by0 + (ub + k) * RSTEP) * S1 + cz;
+                    z0[k] = p[0];
+                    if (two) z1[k] = p[1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                T a0 = x0[k] + z0[k], a1 = x1[k] + z1[k];
+                if (ub + k < UY) { a0 += c0[k] + y0[k]; a1 += c1[k] + y1[k]; }
+                acc[ub + k].x += a0; acc[ub + k].y += a1;
+            }
+        }
+    }
+}
+
 template <typename T, int LOGM, int RB> struct RowHalfTw {
     static constexpr int M = Len<LOGM>::N, W = RB / (int)sizeof(cpx<T>);
     static constexpr size_t full = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>), half = (size_t)(M * W + M + W) * sizeof(cpx<T>);
     static constexpr bool value = PMX_ROW_HALFTW && LOGM < 16 && full > 80 * 1024 && half <= 80 * 1024;
 };
 
-template <typename T, int LOGM, bool INV, int RB>
+template <typename T, int LOGM, bool INV, int RB, bool HALO = false>
 __global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)), (RowHalfTw<T, LOGM, RB>::value ? 4 : 1))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
-              int64_t rpp, int64_t plane_extra)
+              int64_t rpp, int64_t plane_extra, HaloSrc hs)
 {
+    static_assert(!HALO || (!INV && LOGM < 16), "the halo gather rides on the forward pass of power-of-two rows");
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);   // rows per tile
     constexpr int LPT = PMX_ROW_LPT;   // row elements per thread
@@ -983,6 +1085,12 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                     if (r0 + rt + u * RSTEP < nrows) ld[u] = gthread[(int64_t)(u * RSTEP) * pitch];
             }
             if (INV && tid < W) xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
+            if constexpr (HALO) {
+                // rows r0 .. r0 + W - 1 lie in one plane and one tile row (rpp is a multiple of W, W divides T1; whole
+                // planes: every tile is full): x is the workgroup's, y the row's
+                static_assert(T1 % W == 0, "row kernel: a tile of rows inside one tile row of the mesh");
+                halo_gather<T, LPT, RSTEP, LPT>(hs, hs.x0 + (int)(r0 / rpp), (int)(r0 % rpp) + rt, n, ld);
+            }
 #pragma unroll
             for (int u = 0; u < LPT; u++) buf[at(nb_, rt + u * RSTEP)] = ld[u];
             __syncthreads();
@@ -1327,7 +1435,7 @@ template int dispatch_logn<float>(const ColGeom &, const void *, void *, const v
 
 template <typename T, int LOGM, int RB = 128>
 static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
-                         int64_t rpp, int64_t plane_extra, hipStream_t st)
+                         int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo = nullptr)
 {
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
@@ -1337,14 +1445,25 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     int64_t tiles = (nrows + W - 1) / W;
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 row tiles in one pass");
     unsigned grid = (unsigned)((PMX_ROW_ONE_TILE && M < 512) ? tiles : (tiles < 256 * 64 ? tiles : 256 * 64));
-    if (inverse) {
+    const HaloSrc none = {nullptr, 0, 0, 0, 0, 0};
+    if (halo) {
+        if constexpr (LOGM < 16 && NT % M == 0 && !RowHalfTw<T, LOGM, RB>::value) {
+            PMX_REQUIRE(!inverse && rpp > 0, PMX_EINVAL, "the halo gather rides on the forward pass over whole planes");
+            auto k = rowfft_kernel<T, LOGM, false, RB, true>;
+            PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, *halo);
+        } else {
+            set_error("pmx_rowfft_halo: row length not built");
+            return PMX_EUNSUPPORTED;
+        }
+    } else if (inverse) {
         auto k = rowfft_kernel<T, LOGM, true, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none);
     } else {
         auto k = rowfft_kernel<T, LOGM, false, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none);
     }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -1352,15 +1471,15 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
 
 template <typename T>
 PMX_DISPATCH int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, double scale, const void *tw,
-                         bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st)
+                         bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo)
 {
     switch (logm) {
-    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
-    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
-    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
-    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
+    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
+    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
+    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
     // 2048 reals: 64-byte tile rows (8 float / 4 double rows per workgroup) keep 1024 / 512 threads
-    case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
     // n = 384, 768, 1536 reals: M = 192, 384, 768
     case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
@@ -1373,9 +1492,9 @@ PMX_DISPATCH int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitc
     return PMX_EUNSUPPORTED;
 }
 #if PMX_COLFFT_PART == 1
-extern template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t);
+extern template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *);
 #elif PMX_COLFFT_PART == 2
-template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t);
+template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *);
 #endif
 
 }  // namespace pmx
@@ -1420,8 +1539,54 @@ extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t n
     if (rc) return rc;
     int logm = length_code(n / 2);
     if (elsize == 8)
-        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
-    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st);
+        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr);
+}
+
+// PMX_OK if the forward row pass of n reals can gather the staged halos of a paint (pmx_rowfft_halo): the
+// power-of-two rows whose threads keep one position along the row (all but 2048 reals in double)
+extern "C" int pmx_rowfft_halo_supported(int64_t n, int32_t elsize)
+{
+    int rc = pmx_rowfft_supported(n, elsize);
+    if (rc) return rc;
+    int lc = length_code(n);
+    if (lc >= 16) return PMX_EUNSUPPORTED;
+    // (2048 reals in double: threads that walk along the row; 1024 reals in double and 2048 in float: the kernels
+    // that run two workgroups per CU inside 128 registers, RowHalfTw — the gather's batch of loads spills there)
+    if (n == 2048 || (n == 1024 && elsize == 8)) return PMX_EUNSUPPORTED;
+    return PMX_OK;
+}
+
+extern "C" int pmx_rowfft_halo(int32_t elsize, void *data, int64_t nrows, int64_t n, int64_t pitch, double scale,
+                               int64_t rows_per_plane, int64_t plane_pitch, pmx_binplan *plan, const void *canvas,
+                               int64_t x0, int32_t last, void *stream)
+{
+    int rc = pmx_rowfft_halo_supported(n, elsize);
+    if (rc) { set_error("pmx_rowfft_halo: unsupported length %lld", (long long)n); return rc; }
+    PMX_REQUIRE(data != nullptr && nrows >= 0 && pitch >= n / 2 + 1, PMX_EINVAL, "bad arguments");
+    PMX_REQUIRE(rows_per_plane > 0 && plane_pitch >= rows_per_plane * pitch, PMX_EINVAL, "planes of rows_per_plane rows");
+    PMX_REQUIRE(rows_per_plane % (128 / (2 * elsize)) == 0, PMX_EUNSUPPORTED,
+                "rows_per_plane must be a multiple of the rows of a tile");
+    HaloSrc hs;
+    int32_t nt[3];
+    rc = pmx_binplan_halo_source(plan, canvas, elsize, &hs.halo, &hs.S, nt, last);
+    if (rc) return rc;
+    hs.nt0 = nt[0]; hs.nt1 = nt[1]; hs.nt2 = nt[2];
+    hs.x0 = (int)x0;
+    PMX_REQUIRE(nrows % rows_per_plane == 0, PMX_EINVAL, "whole planes only");
+    PMX_REQUIRE(rows_per_plane == (int64_t)nt[1] * T1 && n == (int64_t)nt[2] * T2 && x0 >= 0 &&
+                x0 * rows_per_plane + nrows <= (int64_t)nt[0] * T0 * rows_per_plane, PMX_EINVAL,
+                "rows do not match the mesh the plan's tiles cover");
+    const int64_t plane_extra = plane_pitch - rows_per_plane * pitch;
+    if (nrows == 0) return PMX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)n, elsize, &tw, st);
+    if (rc) return rc;
+    int logm = length_code(n / 2);
+    if (elsize == 8)
+        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs);
 }
 #endif
 

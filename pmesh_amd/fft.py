@@ -360,7 +360,12 @@ class _Pending(object):
 
 
 def settle(storage):
-    """run a deferred pass on this storage now (no-op if there is none)"""
+    """run what is deferred on this storage now (no-op if there is nothing): the halo merge a paint left to the
+    forward transform (window._HaloDebt), the last pass of a forward transform"""
+    debt = getattr(storage, '_pmx_halo', None)
+    if debt is not None:
+        storage._pmx_halo = None
+        debt.settle()
     pend = getattr(storage, '_pmx_pending', None)
     if pend is not None:
         storage._pmx_pending = None
@@ -371,6 +376,10 @@ def forget(storage):
     """the storage is about to be overwritten as a whole: a deferred pass on it is moot"""
     if getattr(storage, '_pmx_pending', None) is not None:
         storage._pmx_pending = None
+    debt = getattr(storage, '_pmx_halo', None)
+    if debt is not None:
+        storage._pmx_halo = None
+        debt.drop()
 
 
 class LocalBuffer(object):
@@ -452,6 +461,14 @@ class Plan(object):
         if owed is not None:
             self._deferred_on = None
             settle(owed)
+        debt = getattr(bufin.storage, '_pmx_halo', None)
+        if debt is not None:
+            # the halo merge of the paint that made this field: the forward transform of one rank adds the staged
+            # halos inside its row pass (_execute_local_hybrid); anything else needs the finished mesh first
+            mine = (self.forward and p.nproc == 1 and not getattr(p, 'is_c2c', False) and p.ndim == 3 and
+                    bufin.storage is bufout.storage and not (getattr(p, 'pencil', False) and not p.transposed))
+            if not mine:
+                settle(bufin.storage)
         pend = getattr(bufin.storage, '_pmx_pending', None)
         if pend is not None:
             # a deferred forward pass on the input: an in-place inverse transform of the same partition takes it
@@ -816,6 +833,7 @@ class Plan(object):
         inplace = bufin.storage.data_ptr() == bufout.storage.data_ptr()
         if p.ndim == 3 and self._use_colfft(be, n[:2]):
             return self._execute_local_hybrid(be, bufin, bufout, inplace, transfer)
+        settle(bufin.storage)
         if transfer is not None:
             raise NotImplementedError('fused transfer needs the column-FFT path')
 
@@ -845,6 +863,14 @@ class Plan(object):
             bufin = bufout
             inplace = True
         own_rows = inplace and be.rowfft_supported(N2, self.elsize)
+        # the halo merge of the paint that made this field, left to this transform's row pass (window._HaloDebt)
+        debt = getattr(bufin.storage, '_pmx_halo', None) if self.forward else None
+        if debt is not None and not (own_rows and hasattr(be, 'rowfft_halo') and debt.open and
+                                     debt.canvas_ptr == bufin.storage.data_ptr() and
+                                     be.lib.pmx_rowfft_halo_supported(N2, self.elsize) == 0):
+            settle(bufin.storage)
+            debt = None
+        hrpp, hpp = (N1, plane) if plane else (N1, N1 * N2c)
         # Infinity-Cache blocking: the row pass and the axis-1 pass both work inside single
         # planes, so they can run back to back on a block of planes that fits the 256 MiB
         # last-level cache: the second touch of a block is served on die instead of from HBM
@@ -862,8 +888,14 @@ class Plan(object):
                 for b in range(nblk):
                     i0, i1 = b * per, min(N0, (b + 1) * per)
                     blk = st[i0 * plane * es:]
-                    be.rowfft(self.elsize, False, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
+                    if debt is not None:
+                        be.rowfft_halo(self.elsize, blk, (i1 - i0) * N1, N2, N2c, hrpp, hpp, debt.plan, debt.canvas_ptr,
+                                       i0, b == nblk - 1)
+                    else:
+                        be.rowfft(self.elsize, False, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
                     be.colfft(self.elsize, False, blk, i1 - i0, N1, N2c, a_stride=sa)
+                if debt is not None:
+                    debt.taken()
                 self._last_forward_pass(be, st, N0, N1, N2c, norm, sn)
             else:
                 if self._take_over_forward_pass(be, st, transfer, N0, N1, N2c, sn):
@@ -881,7 +913,10 @@ class Plan(object):
                     be.rowfft(self.elsize, True, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
             return
         if self.forward:
-            if own_rows:
+            if debt is not None:
+                be.rowfft_halo(self.elsize, bufin.storage, rows, N2, N2c, hrpp, hpp, debt.plan, debt.canvas_ptr, 0, True)
+                debt.taken()
+            elif own_rows:
                 be.rowfft(self.elsize, False, bufin.storage, rows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
             else:
                 def make():

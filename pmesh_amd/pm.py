@@ -1078,6 +1078,14 @@ def _init_o_coords(partition, Nmesh, BoxSize, dtype, device):
 _pm_cache = weakref.WeakValueDictionary()
 
 
+#: The halo merge of a tile-binned paint (csrc/pmx_binned.hip: halo_merge_kernel) left to the forward transform:
+#: 'fresh' (default): when ParticleMesh.paint makes the field itself (out=None, hold=False, no layout) — r2c on one rank
+#: then adds the staged halos inside its row pass, any other reader of the field runs the merge first; 'never';
+#: 'always': also on a caller's `out` field (views of out.value taken BEFORE the paint then miss the halos until the
+#: field is read through the field object — for callers that know they hold none, e.g. bench.py --out-field).
+HALO_DEFER = __import__('os').environ.get('PMESH_AMD_HALO_DEFER', 'fresh')
+
+
 class ParticleMesh(object):
     """
     ParticleMesh provides an interface to solver for forces with particle mesh method
@@ -1436,11 +1444,25 @@ class ParticleMesh(object):
         """
         transform = transform or self.affine
         resampler = FindResampler(self.resampler if resampler is None else resampler)
-        out = self.create(type=RealField) if out is None else out
+        fresh = out is None
+        part = self._get_partition(RealField)
+        if fresh and layout is None and not hold and not getattr(part, 'is_c2c', False) and backend.get().name == 'hip':
+            # a field of this call's own making that the paint overwrites cell by cell: no zero fill of the buffer
+            # (complex-to-complex meshes: the paint writes the real parts only, the imaginary ones must read 0)
+            out = RealField(self, base=torch.empty(part.alloc_reals, dtype=torch_dtype(self._rdtype),
+                                                   device=backend.get().device))
+        elif fresh:
+            out = self.create(type=RealField)
         if layout is None:
-            # hold=False: "out.value[...] = 0" (pm.py:1852-1853) is folded into the kernel
+            # hold=False: "out.value[...] = 0" (pm.py:1852-1853) is folded into the kernel.
+            # HALO_DEFER: the tile kernels' halo merge is left to the forward transform that usually follows
+            # (window._HaloDebt) — only on a field nobody else holds a view of yet ('fresh'), as a caller's own
+            # field must be complete when this call returns (in the reference `value` is a plain array).
+            defer = None
+            if not hold and (HALO_DEFER == 'always' or (HALO_DEFER == 'fresh' and fresh)):
+                defer = out._base.storage
             resampler.paint(out.value, pos, hsml=hsml, mass=mass, transform=transform, diffdir=gradient,
-                            _overwrite=not hold)
+                            _overwrite=not hold, _defer_to=defer)
             return out
         if _ghosts_only(layout, resampler, transform, hsml):
             # the caller's own particles are painted where they lie (those whose window misses

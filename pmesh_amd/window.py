@@ -99,6 +99,61 @@ DETERMINISTIC = os.environ.get('PMESH_AMD_DETERMINISTIC', '0') not in ('0', '', 
 EXACT = os.environ.get('PMESH_AMD_EXACT', '0') not in ('0', '', 'false', 'False')
 
 
+# The halo merge of a tile-binned paint left to the forward transform that usually follows at once
+# (include/pmesh_amd.h: pmx_paint_binned_defer).  ParticleMesh.paint asks for it when it paints a field of its own
+# making (pm.py: HALO_DEFER); the merge is then a note (`_HaloDebt`) on the field's storage, and whoever reads the
+# field first pays it: RealField.r2c on one rank adds the staged halos inside its first pass (no sweep, no atomics),
+# everyone else (Field.value, a readout, another paint into the field) runs the merge kernel then.  The staged values
+# live in the bin plan: ONE debt per host thread may be outstanding, and every other use of a plan settles it first.
+_debt_tls = threading.local()
+
+
+class _HaloDebt(object):
+    __slots__ = ('be', 'plan', 'painter', 'canvas_ptr', 'storage', 'open', '__weakref__')
+
+    def __init__(self, be, plan, painter, canvas_ptr, storage):
+        self.be, self.plan, self.painter, self.canvas_ptr = be, plan, painter, canvas_ptr
+        self.storage = weakref.ref(storage)
+        self.open = True
+
+    def _close(self):
+        self.open = False
+        st = self.storage()
+        if st is not None and getattr(st, '_pmx_halo', None) is self:
+            st._pmx_halo = None
+        if getattr(_debt_tls, 'debt', None) is self:
+            _debt_tls.debt = None
+
+    def settle(self):
+        """add the staged halos to the canvas now (the merge the paint left out)"""
+        if not self.open:
+            return
+        if self.storage() is None:
+            return self.drop()
+        self.be.call('halo_merge', self.plan, C.byref(self.painter), C.c_void_p(self.canvas_ptr), self.be.stream())
+        self._close()
+
+    def drop(self):
+        """the canvas is gone or about to be overwritten as a whole: the staged halos are moot"""
+        if not self.open:
+            return
+        halo, S, nt = C.c_void_p(), C.c_int32(), (C.c_int32 * 3)()
+        self.be.call('binplan_halo_source', self.plan, C.c_void_p(self.canvas_ptr), int(self.painter.canvas_elsize),
+                     C.byref(halo), C.byref(S), nt, 1)
+        self._close()
+
+    def taken(self):
+        """a forward row pass has added the halos (pmx_rowfft_halo with last = 1 released the plan)"""
+        self._close()
+
+
+def settle_halo_debt():
+    """pay this thread's outstanding halo debt, if any (before a plan is rebuilt, reused or destroyed)"""
+    debt = getattr(_debt_tls, 'debt', None)
+    if debt is not None:
+        debt.settle()
+
+
 class _BinCache(object):
     """A bin plan (particles ordered by mesh tile) depends only on the positions, the
     window and the affine/block geometry; the PM cycle paints and reads out at the same
@@ -117,6 +172,7 @@ class _BinCache(object):
                 tuple(painter.period), tuple(painter.size))
 
     def lookup(self, be, pos, painter, pv, n):
+        settle_halo_debt()
         key = self._key(pos, painter)
         for e in self.entries:
             if e[0] == key and e[3]:
@@ -192,6 +248,10 @@ class _BinCache(object):
             e[0], e[2], e[3] = None, None, False
 
     def destroy(self, be):
+        try:
+            settle_halo_debt()
+        except Exception:
+            pass
         for e in self.entries:
             try:
                 be.call('binplan_destroy', e[1])
@@ -413,7 +473,7 @@ class ResampleWindow(object):
         bin_cache().lookup(be, pos, p, vec(pos), n)
         return True
 
-    def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None, _overwrite=False):
+    def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None, _overwrite=False, _defer_to=None):
         """
             paint to a field (window.py:106-163).
 
@@ -461,8 +521,19 @@ class ResampleWindow(object):
             # paint looks at those itself)
             stats = _mass_stats(be, m, mv) if (mv is not None and is_tensor(mass)) else None
             be.call('binplan_mass_stats', plan, stats.data_ptr() if stats is not None else None)
-            be.call('paint_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv),
-                    mass_scalar, int(bool(_overwrite)), be.stream())
+            if _defer_to is not None and writeback is None and hasattr(be.lib, 'pmx_paint_binned_defer'):
+                # _defer_to: the storage tensor behind `real` (ParticleMesh.paint, a field of its own making): the
+                # halo merge becomes a note on it where the library can leave it to the forward transform
+                deferred = C.c_int32(0)
+                be.call('paint_binned_defer', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv),
+                        mass_scalar, int(bool(_overwrite)), C.byref(deferred), be.stream())
+                if deferred.value:
+                    debt = _HaloDebt(be, plan, p, canvas.data_ptr(), _defer_to)
+                    _defer_to._pmx_halo = debt
+                    _debt_tls.debt = debt
+            else:
+                be.call('paint_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv),
+                        mass_scalar, int(bool(_overwrite)), be.stream())
         else:
             if _overwrite:
                 canvas.zero_()
