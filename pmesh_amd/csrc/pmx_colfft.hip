@@ -932,16 +932,16 @@ struct HaloSrc {
 };
 
 // One thread's LPT elements: column n (cells 2n, 2n + 1) of the rows yb, yb + RSTEP, ... of plane x, all inside one tile
-// row (a workgroup's rows start at a multiple of their count, which divides T1); `acc` holds the row's own elements,
-// still on their way: they are only touched when a batch of staged values has arrived.  Two batches — the staged cells of this lane's own
+// row (a workgroup's rows start at a multiple of their count, which divides T1); `sink(u, a0, a1)` adds to element u —
+// the row's own elements, still on their way: they are only touched when a batch of staged values has arrived.  Two batches — the staged cells of this lane's own
 // z tile, then (the few lanes that hold the first cells of a z tile) those of the z-faces of the tile before — and in
 // each batch every load is issued into a register of its own before anything is added: a gather written per element
 // (load, add, next) makes the compiler wait for memory once per row and source (0.37 -> 0.55 ms at 512^3).  The
 // branch on x is uniform over the workgroup; the rows that are owed y-faces are the first S - 1 of a tile row, i.e.
 // only the thread's first UY elements can be, whatever the window.
 // UB: elements per batch (LPT: all at once; less where the registers of a whole batch would spill).
-template <typename T, int LPT, int RSTEP, int UB>
-__device__ __forceinline__ void halo_gather(const HaloSrc &h, int x, int yb, int n, cpx<T> (&acc)[LPT])
+template <typename T, int LPT, int RSTEP, int UB, typename SINK>
+__device__ __forceinline__ void halo_gather(const HaloSrc &h, int x, int yb, int n, SINK &&sink)
 {
     constexpr int UY = (3 + RSTEP - 1) / RSTEP < LPT ? (3 + RSTEP - 1) / RSTEP : LPT;     // by0 + u RSTEP < S - 1 <= 3 needs u < UY
     static_assert(LPT % UB == 0, "halo_gather: batches");
@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void halo_gather(const HaloSrc &h, int x, int yb, int
             for (int k = 0; k < UB; k++) {
                 T a0 = x0[k] + z0[k], a1 = x1[k] + z1[k];
                 if (ub + k < UY) { a0 += c0[k] + y0[k]; a1 += c1[k] + y1[k]; }
-                acc[ub + k].x += a0; acc[ub + k].y += a1;
+                sink(ub + k, a0, a1);
             }
         }
     }
@@ -1089,10 +1089,23 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 // rows r0 .. r0 + W - 1 lie in one plane and one tile row (rpp is a multiple of W, W divides T1; whole
                 // planes: every tile is full): x is the workgroup's, y the row's
                 static_assert(T1 % W == 0, "row kernel: a tile of rows inside one tile row of the mesh");
-                halo_gather<T, LPT, RSTEP, LPT>(hs, hs.x0 + (int)(r0 / rpp), (int)(r0 % rpp) + rt, n, ld);
+                if constexpr (!HT)
+                    halo_gather<T, LPT, RSTEP, LPT>(hs, hs.x0 + (int)(r0 / rpp), (int)(r0 % rpp) + rt, n,
+                                                    [&](int u, T a0, T a1) __attribute__((always_inline)) { ld[u].x += a0; ld[u].y += a1; });
             }
 #pragma unroll
             for (int u = 0; u < LPT; u++) buf[at(nb_, rt + u * RSTEP)] = ld[u];
+            if constexpr (HALO && HT) {
+                // the kernels that live inside 128 registers (two 512-thread workgroups per CU): the row's own elements
+                // go to LDS first, the staged values are gathered half a batch at a time and added there — every
+                // thread to the slots it has just written, before the barrier
+                halo_gather<T, LPT, RSTEP, LPT / 2>(hs, hs.x0 + (int)(r0 / rpp), (int)(r0 % rpp) + rt, n,
+                                                    [&](int u, T a0, T a1) __attribute__((always_inline)) {
+                                                        cpx<T> v = buf[at(nb_, rt + u * RSTEP)];
+                                                        v.x += a0; v.y += a1;
+                                                        buf[at(nb_, rt + u * RSTEP)] = v;
+                                                    });
+            }
             __syncthreads();
             if (INV) {
                 // X -> Z, pairs (k, M-k) handled together, in place: k in [1, M/2) by all threads (k fixed per
@@ -1447,7 +1460,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     unsigned grid = (unsigned)((PMX_ROW_ONE_TILE && M < 512) ? tiles : (tiles < 256 * 64 ? tiles : 256 * 64));
     const HaloSrc none = {nullptr, 0, 0, 0, 0, 0};
     if (halo) {
-        if constexpr (LOGM < 16 && NT % M == 0 && !RowHalfTw<T, LOGM, RB>::value) {
+        if constexpr (LOGM < 16 && NT % M == 0) {
             PMX_REQUIRE(!inverse && rpp > 0, PMX_EINVAL, "the halo gather rides on the forward pass over whole planes");
             auto k = rowfft_kernel<T, LOGM, false, RB, true>;
             PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1551,9 +1564,8 @@ extern "C" int pmx_rowfft_halo_supported(int64_t n, int32_t elsize)
     if (rc) return rc;
     int lc = length_code(n);
     if (lc >= 16) return PMX_EUNSUPPORTED;
-    // (2048 reals in double: threads that walk along the row; 1024 reals in double and 2048 in float: the kernels
-    // that run two workgroups per CU inside 128 registers, RowHalfTw — the gather's batch of loads spills there)
-    if (n == 2048 || (n == 1024 && elsize == 8)) return PMX_EUNSUPPORTED;
+    // (2048 reals in double: threads that walk along the row, the other element mapping)
+    if (n == 2048 && elsize == 8) return PMX_EUNSUPPORTED;
     return PMX_OK;
 }
 

@@ -57,7 +57,7 @@ def owes(field):
     return getattr(field._base.storage, '_pmx_halo', None) is not None
 
 
-MESHES = [(128, 128, 128), (64, 192, 256), (128, 64, 512)]
+MESHES = [(128, 128, 128), (64, 192, 256), (128, 64, 512), (64, 64, 1024), (64, 64, 2048)]
 
 
 @pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs'])
@@ -65,6 +65,8 @@ MESHES = [(128, 128, 128), (64, 192, 256), (128, 64, 512)]
 @pytest.mark.parametrize('nmesh', MESHES)
 @pytest.mark.parametrize('blocked', [False, True])
 def test_r2c_of_a_deferred_paint_equals_the_eager_one(hip, name, dtype, nmesh, blocked):
+    if nmesh[2] == 2048 and dtype == 'f8':
+        pytest.skip('rows of 2048 doubles keep the merge kernel (pmx_rowfft_halo_supported)')
     pm = ParticleMesh(Nmesh=nmesh, BoxSize=[100.0, 75.0, 130.0], dtype=dtype, resampler=name)
     n = int(numpy.prod(nmesh)) // 2
     pos, mass = particles(pm, n, 11)
@@ -98,7 +100,7 @@ def _eager_value(pm, pos, mass):
 
 
 @pytest.mark.parametrize('name', ['cic', 'tsc', 'pcs'])
-@pytest.mark.parametrize('nmesh', MESHES)
+@pytest.mark.parametrize('nmesh', MESHES[:4])
 def test_dyadic_inputs_bit_for_bit(hip, name, nmesh):
     """exact partial sums: the spectrum of the deferred field equals the eager one bit for bit only if every staged
     halo cell was added to exactly the mesh cell the merge kernel adds it to (the row pass then sees equal rows)"""
