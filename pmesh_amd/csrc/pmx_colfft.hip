@@ -1027,7 +1027,10 @@ __global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
               int64_t rpp, int64_t plane_extra, HaloSrc hs)
 {
-    static_assert(!HALO || !INV, "the halo gather rides on the forward pass");
+    // (measured and taken out again: the same gather in the 3 * 2^k / 5 * 2^k kernels — parity-green, and slower than the
+    // merge kernel it replaces: 384^3 2.56 -> 2.65 ms per cycle, 768^3 20.5 -> 20.9; their row passes pay more for the
+    // registers and the extra latency than the power-of-two ones)
+    static_assert(!HALO || (!INV && LOGM < 16), "the halo gather rides on the forward pass of power-of-two rows");
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);   // rows per tile
     constexpr int LPT = PMX_ROW_LPT;   // row elements per thread
@@ -1196,13 +1199,6 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             ld[u] = (r0 + r < nrows) ? data[(r0 + r) * pitch + n] : cpx<T>{0, 0};
         }
         if (INV && tid < W) xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
-        if constexpr (HALO) {
-            // (3 * 2^k and 5 * 2^k rows whose workgroup is a whole number of rows wide: element u of a thread is column
-            // tid % M of row tid / M + u NT / M, as in the power-of-two kernels)
-            static_assert(NT % M == 0 && T1 % W == 0, "row kernel: thread -> element mapping of the halo gather");
-            halo_gather<T, LPT, NT / M, LPT>(hs, hs.x0 + (int)(r0 / rpp), (int)(r0 % rpp) + tid / M, tid % M,
-                                             [&](int u, T a0, T a1) __attribute__((always_inline)) { ld[u].x += a0; ld[u].y += a1; });
-        }
 #pragma unroll
         for (int u = 0; u < LPT; u++) {
             int flat = tid + u * NT;
@@ -1467,7 +1463,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     unsigned grid = (unsigned)((PMX_ROW_ONE_TILE && M < 512) ? tiles : (tiles < 256 * 64 ? tiles : 256 * 64));
     const HaloSrc none = {nullptr, 0, 0, 0, 0, 0};
     if (halo) {
-        if constexpr (NT % M == 0) {
+        if constexpr (LOGM < 16 && NT % M == 0) {
             PMX_REQUIRE(!inverse && rpp > 0, PMX_EINVAL, "the halo gather rides on the forward pass over whole planes");
             auto k = rowfft_kernel<T, LOGM, false, RB, true>;
             PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1501,12 +1497,12 @@ PMX_DISPATCH int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitc
     // 2048 reals: 64-byte tile rows (8 float / 4 double rows per workgroup) keep 1024 / 512 threads
     case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
     // n = 384, 768, 1536 reals: M = 192, 384, 768
-    case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
-    case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
-    case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
+    case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     // n = 640, 1280 reals: M = 320, 640
-    case 38: return launch_rowfft<T, 38>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
-    case 39: return launch_rowfft<T, 39, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
+    case 38: return launch_rowfft<T, 38>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 39: return launch_rowfft<T, 39, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
     }
     set_error("pmx_rowfft: length code %d is not built", logm);
     return PMX_EUNSUPPORTED;
@@ -1569,11 +1565,10 @@ extern "C" int pmx_rowfft_halo_supported(int64_t n, int32_t elsize)
 {
     int rc = pmx_rowfft_supported(n, elsize);
     if (rc) return rc;
-    // (rows whose tiles are 64 bytes wide hold 4 rows in double — 2048, 1536, 1280 reals: threads that walk along the
-    // row, the other element mapping)
-    const int logm = length_code(n / 2);
-    const bool rb64 = logm == 10 || logm == 24 || logm == 39;
-    if (rb64 && elsize == 8) return PMX_EUNSUPPORTED;
+    // power-of-two rows (the other lengths: measured, a loss), and not 2048 reals in double, whose 64-byte tiles hold
+    // 4 rows: threads that walk along the row, another element mapping
+    if (length_code(n) >= 16) return PMX_EUNSUPPORTED;
+    if (n == 2048 && elsize == 8) return PMX_EUNSUPPORTED;
     return PMX_OK;
 }
 
