@@ -221,3 +221,37 @@ def test_full_cycle_with_the_deferred_merge(hip):
         back = rk.c2r(out=Ellipsis)
         out.append(back.readout(pos).cpu().numpy())
     assert_allclose(out[1], out[0], rtol=0, atol=1e-11 * numpy.abs(out[0]).max())
+
+
+@pytest.mark.parametrize('name', ['cic', 'pcs'])
+@pytest.mark.parametrize('form', ['crowded', 'shuffled-sorted'])
+def test_crowded_tiles_and_tile_ordered_copies(hip, name, form):
+    """the pieces of crowded tiles are added to the mesh with global atomics by a kernel of their own (paint_heavy_kernel)
+    — they commute with the halos the row pass adds later; a plan that streams its tile-ordered copy of the positions
+    (rows in random order) stages the same halos"""
+    pm = ParticleMesh(Nmesh=[128, 128, 128], BoxSize=128.0, dtype='f8', resampler=name)
+    g = torch.Generator(device='cpu').manual_seed(17)
+    n = 1 << 21
+    pos = torch.rand(n, 3, generator=g, dtype=torch.float64) * 128.0
+    if form == 'crowded':
+        # half of the particles in a blob two cells wide: one tile holds 2^20 of them, 250 x its chunk
+        pos[: n // 2] = 40.3 + 0.7 * torch.randn(n // 2, 3, generator=g, dtype=torch.float64)
+        pos = pos % 128.0
+    old_sorted = window.SORTED
+    try:
+        if form == 'shuffled-sorted':
+            window.SORTED = 'always'
+        pos = pos.cuda()
+        mass = (torch.rand(n, generator=g, dtype=torch.float64) + 0.5).cuda()
+        pmod.HALO_DEFER = 'never'
+        window.clear_bin_cache()
+        ek = pm.paint(pos, mass=mass).r2c(out=Ellipsis).value.clone()
+        pmod.HALO_DEFER = 'fresh'
+        window.clear_bin_cache()
+        lazy = pm.paint(pos, mass=mass)
+        assert owes(lazy)
+        lk = lazy.r2c(out=Ellipsis).value
+        assert float((lk - ek).abs().max()) <= 1e-13 * float(ek.abs().max())
+    finally:
+        window.SORTED = old_sorted
+        window.clear_bin_cache()
