@@ -19,6 +19,7 @@ orchestration only.  Objects of the reference that were PFFT's are in
 import functools
 import numbers
 import operator
+import os
 import warnings
 import weakref
 from collections import OrderedDict
@@ -1083,7 +1084,7 @@ _pm_cache = weakref.WeakValueDictionary()
 #: then adds the staged halos inside its row pass, any other reader of the field runs the merge first; 'never';
 #: 'always': also on a caller's `out` field (views of out.value taken BEFORE the paint then miss the halos until the
 #: field is read through the field object — for callers that know they hold none, e.g. bench.py --out-field).
-HALO_DEFER = __import__('os').environ.get('PMESH_AMD_HALO_DEFER', 'fresh')
+HALO_DEFER = os.environ.get('PMESH_AMD_HALO_DEFER', 'fresh')
 
 
 class ParticleMesh(object):
