@@ -31,6 +31,7 @@ from numpy.lib.mixins import NDArrayOperatorsMixin as NDArrayLike
 from . import backend, domain
 from . import fft as _fft
 from ._arrays import to_device, is_tensor, torch_dtype, numpy_dtype, to_numpy
+from ._devarr import DevArr, unwrap as _dev_unwrap
 from .comm import default_comm
 from .transfer import Transfer
 from .window import FindResampler, Affine
@@ -570,15 +571,30 @@ class Field(NDArrayLike):
             raise ValueError("unknown kind of apply function.")
         coords.BoxSize = self.BoxSize
         coords.Nmesh = self.Nmesh
+        # The callable sees numpy-flavoured handles on the device tensors (_devarr.DevArr): numpy ufuncs and the
+        # functions transfer functions use run as torch operations in HBM, masks and nonzero() follow numpy's
+        # conventions.  Whatever it cannot express (TypeError and friends) sends the callable to the host.
+        v = self.value[...]
+        version = v._version
         try:
-            v = self.value[...]
-            v.x, v.i, v.BoxSize, v.Nmesh = x, i, self.BoxSize, self.Nmesh
-            r = func(coords, v)
+            dcoords = xslab([DevArr(c) for c in coords])
+            dcoords.BoxSize, dcoords.Nmesh = self.BoxSize, self.Nmesh
+            dv = DevArr(v)
+            dv.x, dv.i = xslab([DevArr(c) for c in x]), xslab([DevArr(c) for c in i])
+            dv.BoxSize, dv.Nmesh = self.BoxSize, self.Nmesh
+            r = _dev_unwrap(func(dcoords, dv), v.device)
             if not isinstance(r, torch.Tensor):
-                r = torch.as_tensor(r, device=self.value.device)
+                r = torch.as_tensor(r, device=v.device)
             outv[...] = r
-        except (TypeError, RuntimeError, ValueError, AttributeError):
-            self._apply_host(func, kind, outv)
+            return out
+        except (TypeError, RuntimeError, ValueError, AttributeError, NotImplementedError) as ex:
+            failure = ex
+        if v._version != version:
+            # (the host evaluation would start from values the failed attempt has already changed)
+            raise RuntimeError('Field.apply: the callable modified its input in place and then failed on device arrays '
+                               '(%s: %s); return a new array instead, or use operations numpy and torch share'
+                               % (type(failure).__name__, failure))
+        self._apply_host(func, kind, outv)
         return out
 
     def _apply_host(self, func, kind, outv):
