@@ -964,6 +964,44 @@ __device__ __forceinline__ void halo_gather(const HaloSrc &h, int x, int yb, int
     auto rowx = [&](int by) __attribute__((always_inline)) { return (ax * R1 + by) * R2; };
     auto rowc = [&](int by) __attribute__((always_inline)) { return (ax * R1 + by + T1) * R2; };
     auto rowy = [&](int by) __attribute__((always_inline)) { return NA + (ax * S1 + by) * R2; };
+    if (!xst) {
+        // Most workgroups (7 of 8 planes for CIC, 29 of 32 for PCS): no x-face.  What is left — the y-faces of the first
+        // rows of a tile row, and for the lanes at the start of a z tile the z-faces — is ONE batch of loads, issued right
+        // behind the row's own: the gather then costs its bytes, not a memory latency of its own.
+        T y0[UY], y1[UY], w0[UY], w1[UY], z0[LPT], z1[LPT];
+#pragma unroll
+        for (int u = 0; u < LPT; u++) z0[u] = z1[u] = (T)0;
+#pragma unroll
+        for (int u = 0; u < UY; u++) y0[u] = y1[u] = w0[u] = w1[u] = (T)0;
+#pragma unroll
+        for (int u = 0; u < UY; u++)
+            if (by0 + u * RSTEP < S1) {
+                const T *p = t01 + tz * HALO + cz + rowy(by0 + u * RSTEP);
+                y0[u] = p[0]; y1[u] = p[1];
+            }
+        if (fzs) {
+#pragma unroll
+            for (int u = 0; u < LPT; u++) {
+                const T *p = t00 + tzm * HALO + NA + NB + (ax * T1 + by0 + u * RSTEP) * S1 + cz;
+                z0[u] = p[0];
+                if (two) z1[u] = p[1];
+            }
+#pragma unroll
+            for (int u = 0; u < UY; u++)
+                if (by0 + u * RSTEP < S1) {
+                    const T *p = t01 + tzm * HALO + T2 + cz + rowy(by0 + u * RSTEP);
+                    w0[u] = p[0];
+                    if (two) w1[u] = p[1];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < LPT; u++) {
+            T a0 = z0[u], a1 = z1[u];
+            if (u < UY) { a0 += y0[u] + w0[u]; a1 += y1[u] + w1[u]; }
+            sink(u, a0, a1);
+        }
+        return;
+    }
     for (int pass = 0; pass < 2; pass++) {
         // pass 0: cells (cz, cz + 1) of the rows in this lane's own z tile; pass 1: (T2 + cz, T2 + cz + 1) in the z tile before
         if (pass == 1 && !fzs) break;
