@@ -302,6 +302,13 @@ class DevArr(NDArrayOperatorsMixin):
     def item(self):
         return self.t.item()
 
+    def cpu(self):
+        """the values as a host tensor (what callers of this package do with the tensors it hands out elsewhere)"""
+        return self.t.cpu()
+
+    def tolist(self):
+        return self.t.tolist()
+
     def __abs__(self):
         return DevArr(torch.abs(self.t))
 

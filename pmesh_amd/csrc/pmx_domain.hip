@@ -134,15 +134,21 @@ __device__ inline void classify_axis(const GridD &g, int j, double x, double s, 
 }
 
 // gridnd_fill's patch enumeration (_domain.pyx:62-118) -> unique targets as a mask
+// ND > 0: the number of dimensions at compile time (every loop over the axes unrolled, the per-axis arrays in
+// registers: with a run-time count they are indexed dynamically — scratch or a chain of selects per access)
+template <int ND = 0>
 __device__ inline uint64_t particle_targets(const GridD &g, const int *sil, const int *sir)
 {
-    int nd = g.ndim;
+    const int nd = ND > 0 ? ND : g.ndim;
+    constexpr int NB = ND > 0 ? ND : PMX_MAXDIM;      // loop bounds the compiler can unroll; the axes beyond nd are skipped
     int strides[PMX_MAXDIM];
     strides[nd - 1] = 1;
-    for (int j = nd - 2; j >= 0; j--) strides[j] = strides[j + 1] * g.shape[j + 1];
+#pragma unroll
+    for (int j = NB - 2; j >= 0; j--) if (j <= nd - 2) strides[j] = strides[j + 1] * g.shape[j + 1];
     int64_t patch = 1;
     int p[PMX_MAXDIM];
-    for (int j = 0; j < nd; j++) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) if (j < nd) {
         patch *= sir[j] - sil[j];
         p[j] = sil[j];
     }
@@ -150,7 +156,8 @@ __device__ inline uint64_t particle_targets(const GridD &g, const int *sil, cons
     if (patch == 1) {
         // the common case: the particle and its smoothing region lie in one domain
         int64_t target = 0;
-        for (int j = 0; j < nd; j++) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) if (j < nd) {
             int t = p[j];
             if (g.periodic) t = py_mod(t, g.shape[j]);
             target += (int64_t)t * strides[j];
@@ -160,7 +167,8 @@ __device__ inline uint64_t particle_targets(const GridD &g, const int *sil, cons
     }
     for (int64_t q = 0; q < patch; q++) {
         int64_t target = 0;
-        for (int j = 0; j < nd; j++) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) if (j < nd) {
             int t = p[j];
             if (g.periodic) t = py_mod(t, g.shape[j]);
             target += (int64_t)t * strides[j];
@@ -169,21 +177,26 @@ __device__ inline uint64_t particle_targets(const GridD &g, const int *sil, cons
         // quirk Q3: DomainDegenerate is indexed by the rank after the lookup
         if (!g.degenerate[target]) mask |= (uint64_t)1 << target;
         p[nd - 1]++;
-        for (int jj = nd - 1; jj > 0; jj--) {
-            if (p[jj] == sir[jj]) { p[jj] = sil[jj]; p[jj - 1]++; }
-            else break;
-        }
+        bool carry = true;
+#pragma unroll
+        for (int jj = NB - 1; jj > 0; jj--)
+            if (jj <= nd - 1 && carry) {
+                if (p[jj] == sir[jj]) { p[jj] = sil[jj]; p[jj - 1]++; }
+                else carry = false;
+            }
     }
     return mask;
 }
 
 struct F3 { double v[PMX_MAXDIM]; };
 
+template <int ND>
 __global__ void __launch_bounds__(DBLOCK) classify_kernel(GridD g, DVec pos, F3 scale, F3 smoothing,
                                                           int64_t n, uint64_t *masks,
                                                           unsigned long long *counts, int64_t nchunks,
                                                           int64_t *chunk_counts)
 {
+    const int nd = ND > 0 ? ND : g.ndim;
     // a block walks whole chunks of DCHUNK consecutive particles: the per-chunk, per-rank
     // counts that the fill pass needs fall out of the classification (no second pass over the masks)
     __shared__ unsigned int lcount[PMX_MAXRANKS];      // this chunk
@@ -227,12 +240,13 @@ __global__ void __launch_bounds__(DBLOCK) classify_kernel(GridD g, DVec pos, F3 
             uint64_t m = 0;
             if (i < n) {
                 int sil[PMX_MAXDIM], sir[PMX_MAXDIM];
-                for (int j = 0; j < g.ndim; j++) {
+#pragma unroll
+                for (int j = 0; j < (ND > 0 ? ND : PMX_MAXDIM); j++) if (j < nd) {
                     // transform0 (pm.py:1788-1790): scale * x in double
                     double x = scale.v[j] * pos.get(i, j);
                     classify_axis(g, j, x, smoothing.v[j], &sil[j], &sir[j], invw[j]);
                 }
-                m = particle_targets(g, sil, sir);
+                m = particle_targets<ND>(g, sil, sir);
                 masks[i] = m;
             }
             // (rows in a coherent order: the 64 particles of a wave are bound for ONE rank and nothing else — one
@@ -477,7 +491,8 @@ extern "C" int pmx_decompose_count(const pmx_grid *g, const pmx_vec *pos, const 
     int rc = g_scratch.ensure(sizeof(int64_t) * nchunks * g->nranks);
     if (rc) return rc;
     unsigned grid = (unsigned)(nchunks < 256 * 16 ? nchunks : 256 * 16);
-    classify_kernel<<<grid, DBLOCK, 0, st>>>(gd, dvec(pos), sc, sm, npart, masks, (unsigned long long *)counts,
+    auto classify = gd.ndim == 3 ? classify_kernel<3> : (gd.ndim == 2 ? classify_kernel<2> : classify_kernel<1>);      // (PMX_MAXDIM = 3)
+    classify<<<grid, DBLOCK, 0, st>>>(gd, dvec(pos), sc, sm, npart, masks, (unsigned long long *)counts,
                                              nchunks, (int64_t *)g_scratch.ptr);
     PMX_HIP_CHECK(hipGetLastError());
     g_chunk_tag.masks = masks;
