@@ -220,9 +220,9 @@ int pmx_halo_merge(pmx_binplan *plan, const pmx_painter *p, void *canvas, void *
 int pmx_binplan_halo_source(pmx_binplan *plan, const void *canvas, int32_t elsize, const void **halo,
                             int32_t *S, int32_t *nt, int32_t consume);
 int pmx_rowfft_halo_supported(int64_t n, int32_t elsize);
-int pmx_rowfft_halo(int32_t elsize, void *data, int64_t nrows, int64_t n, int64_t pitch, double scale,
+int pmx_rowfft_halo(int32_t elsize, void *data, void *dst, int64_t nrows, int64_t n, int64_t pitch, double scale,
                     int64_t rows_per_plane, int64_t plane_pitch, pmx_binplan *plan, const void *canvas,
-                    int64_t x0, int32_t last, void *stream);
+                    int64_t x0, int32_t last, void *stream);      /* dst: NULL or data = in place, else as pmx_rowfft_to */
 
 /* ---- domain decomposition (pmesh/domain.py:561-652 + _domain.pyx:9-122) -- */
 typedef struct pmx_grid {
@@ -363,6 +363,16 @@ int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, void *full, i
 int pmx_rowfft_supported(int64_t n, int32_t elsize);
 int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
                double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream);
+/* [r4] The same passes from `src` into `dst` (same layout, distinct buffers): the first pass of a transform whose
+ * caller keeps its input — r2c() / c2r() with out=None, the reference's default (pm.py:655-694, 987-1019: PFFT plans
+ * built out of place) — reads the input and writes the result buffer; the remaining passes run in place there.
+ * Replaces a copy of the whole array in front of an in-place transform (and, for c2r(transfer=...), a separate
+ * transfer kernel: the transfer rides on this pass as in pmx_colfft). */
+int pmx_rowfft_to(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t nrows, int64_t n,
+                  int64_t pitch, double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream);
+int pmx_colfft_to(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N, int64_t B,
+                  double scale, const pmx_transfer *transfer, int64_t n1, int64_t n2, const int64_t *start,
+                  const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride, void *stream);
 
 /* Local transpose next to the all-to-all of a distributed FFT (PFFT's global transpose).
  * pmx_slab_pack  : src (n0, n1, n2) C order -> nparts contiguous blocks, block r = (n0,

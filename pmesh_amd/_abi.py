@@ -105,7 +105,10 @@ DEVICE_ONLY = {
     'halo_merge': (C.c_int, [_vp, _P(Painter), _vp, _vp]),
     'binplan_halo_source': (C.c_int, [_vp, _vp, _i32, _P(_vp), _P(_i32), _P(_i32), _i32]),
     'rowfft_halo_supported': (C.c_int, [_i64, _i32]),
-    'rowfft_halo': (C.c_int, [_i32, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp, _vp, _i64, _i32, _vp]),
+    'rowfft_halo': (C.c_int, [_i32, _vp, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp, _vp, _i64, _i32, _vp]),
+    'rowfft_to': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp]),
+    'colfft_to': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
+                            _P(_i64), _P(_f64), _i64, _i64, _vp]),
     'fft_create': (C.c_int, [_P(_vp), _i32, _i32, _i32, _P(_i64), _P(_i64), _i64, _P(_i64), _i64,
                              _i64, _f64, _i32]),
     'fft_execute': (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -156,12 +156,26 @@ class HipBackend(object):
                   int(rows_per_plane), int(plane_pitch), self.stream())
 
     def rowfft_halo(self, elsize, data, nrows, n, pitch, rows_per_plane, plane_pitch, plan, canvas_ptr, x0, last,
-                    scale=1.0):
+                    scale=1.0, dst=None):
         """the forward rowfft on planes x0 ... of a canvas whose paint left its halo merge to this pass
         (pmx_paint_binned_defer): the staged halos are added to the rows as they are loaded; last: the plan is
-        released"""
-        self.call('rowfft_halo', elsize, data.data_ptr(), nrows, n, pitch, float(scale), int(rows_per_plane),
-                  int(plane_pitch), plan, C.c_void_p(canvas_ptr), int(x0), int(bool(last)), self.stream())
+        released; dst: where the rows are written (None: in place)"""
+        self.call('rowfft_halo', elsize, data.data_ptr(), dst.data_ptr() if dst is not None else None, nrows, n, pitch,
+                  float(scale), int(rows_per_plane), int(plane_pitch), plan, C.c_void_p(canvas_ptr), int(x0),
+                  int(bool(last)), self.stream())
+
+    def rowfft_to(self, elsize, inverse, src, dst, nrows, n, pitch, scale=1.0, rows_per_plane=0, plane_pitch=0):
+        """rowfft from `src` into `dst` (same layout)"""
+        self.call('rowfft_to', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), nrows, n, pitch, float(scale),
+                  int(rows_per_plane), int(plane_pitch), self.stream())
+
+    def colfft_to(self, elsize, inverse, src, dst, A, N, B, scale=1.0, transfer=None, n1=1, n2=1,
+                  start=(0, 0, 0), nmesh=(1, 1, 1), boxsize=(1.0, 1.0, 1.0), a_stride=0, n_stride=0):
+        """colfft from `src` into `dst` (same layout)"""
+        self.call('colfft_to', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), A, N, B, float(scale),
+                  C.byref(transfer) if transfer is not None else None, n1, n2,
+                  _abi.i64arr(start, 3), _abi.i64arr(nmesh, 3), _abi.f64arr(boxsize, 3),
+                  int(a_stride), int(n_stride), self.stream())
 
     # -- slab transposes --------------------------------------------------
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):

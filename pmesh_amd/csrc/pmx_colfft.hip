@@ -1063,8 +1063,9 @@ template <typename T, int LOGM, int RB> struct RowHalfTw {
 template <typename T, int LOGM, bool INV, int RB, bool HALO = false>
 __global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)), (RowHalfTw<T, LOGM, RB>::value ? 4 : 1))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
-              int64_t rpp, int64_t plane_extra, HaloSrc hs)
+              int64_t rpp, int64_t plane_extra, HaloSrc hs, cpx<T> *dst_)
 {
+    // dst_: where the rows are written (the same layout as data_); nullptr: in place
     // (measured and taken out again: the same gather in the 3 * 2^k / 5 * 2^k kernels — parity-green, and slower than the
     // merge kernel it replaces: 384^3 2.56 -> 2.65 ms per cycle, 768^3 20.5 -> 20.9; their row passes pay more for the
     // registers and the extra latency than the power-of-two ones)
@@ -1099,6 +1100,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
         // rows are grouped in planes of rpp rows (a multiple of W: a tile never straddles two
         // planes) whose stride exceeds rpp*pitch by plane_extra elements
         cpx<T> *data = data_ + (rpp > 0 ? (r0 / rpp) * plane_extra : 0);
+        cpx<T> *dout = dst_ ? dst_ + (rpp > 0 ? (r0 / rpp) * plane_extra : 0) : data;
         __syncthreads();
         if constexpr (LOGM < 16 && NT % M == 0) {
             // Power-of-two rows.  NT is a multiple of M (all but 2048 reals in double, whose tile has 4 rows), so a thread keeps ONE position along the row for all
@@ -1110,6 +1112,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             const int n = tid & (M - 1), rt = tid / M;
             const bool full = r0 + W <= nrows;                 // all but (at most) the last tile
             cpx<T> *gthread = data + ((r0 + rt) * pitch + n);
+            cpx<T> *gstore = dout + ((r0 + rt) * pitch + n);
             const RowBase<T, RB> nb_ = row_base<T, RB>(n, 0);
             auto at = [&](const RowBase<T, RB> &b, int r) __attribute__((always_inline)) {
                 return b.e[0] + ((b.cr + r) & (W - 1));
@@ -1205,7 +1208,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 for (int u = 0; u < LPT; u++) {
                     const int r = rt + u * RSTEP;
                     cpx<T> X = mode(buf[at(nb_, r)], buf[at(bq, r)], w);
-                    if (full || r0 + r < nrows) gthread[(int64_t)(u * RSTEP) * pitch] = X;
+                    if (full || r0 + r < nrows) gstore[(int64_t)(u * RSTEP) * pitch] = X;
                 }
                 constexpr int LINE = 128 / (int)sizeof(cpx<T>);
                 const int tail = (pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
@@ -1214,7 +1217,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                     const int r = q / tail, j = q - r * tail;
                     if (r0 + r < nrows) {
                         cpx<T> z0 = buf[at(b0, r)];
-                        data[(r0 + r) * pitch + M + j] = (j == 0) ? mode(z0, z0, cpx<T>{(T)-1, (T)0}) : cpx<T>{(T)0, (T)0};
+                        dout[(r0 + r) * pitch + M + j] = (j == 0) ? mode(z0, z0, cpx<T>{(T)-1, (T)0}) : cpx<T>{(T)0, (T)0};
                     }
                 }
             } else {
@@ -1223,7 +1226,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                     const int r = rt + u * RSTEP;
                     cpx<T> v = buf[at(nb_, r)];
                     v.x *= sc; v.y *= sc;
-                    if (full || r0 + r < nrows) gthread[(int64_t)(u * RSTEP) * pitch] = v;
+                    if (full || r0 + r < nrows) gstore[(int64_t)(u * RSTEP) * pitch] = v;
                 }
             }
             continue;
@@ -1320,13 +1323,13 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             };
             for (int q = tid; q < W * M; q += NT) {
                 const int r = q / M, k = q % M;
-                if (r0 + r < nrows) data[(r0 + r) * pitch + k] = mode(r, k);
+                if (r0 + r < nrows) dout[(r0 + r) * pitch + k] = mode(r, k);
             }
             constexpr int LINE = 128 / (int)sizeof(cpx<T>);
             const int tail = (pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
             for (int q = tid; q < W * tail; q += NT) {
                 const int r = q / tail, j = q - r * tail;
-                if (r0 + r < nrows) data[(r0 + r) * pitch + M + j] = (j == 0) ? mode(r, M) : cpx<T>{(T)0, (T)0};
+                if (r0 + r < nrows) dout[(r0 + r) * pitch + M + j] = (j == 0) ? mode(r, M) : cpx<T>{(T)0, (T)0};
             }
         } else {
 #pragma unroll
@@ -1336,7 +1339,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 if (r0 + r < nrows) {
                     cpx<T> v = buf[lds_index<T, RB>(n, r)];
                     v.x *= sc; v.y *= sc;
-                    data[(r0 + r) * pitch + n] = v;
+                    dout[(r0 + r) * pitch + n] = v;
                 }
             }
         }
@@ -1489,7 +1492,7 @@ template int dispatch_logn<float>(const ColGeom &, const void *, void *, const v
 
 template <typename T, int LOGM, int RB = 128>
 static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
-                         int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo = nullptr)
+                         int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo = nullptr, void *dst = nullptr)
 {
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
@@ -1505,7 +1508,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
             PMX_REQUIRE(!inverse && rpp > 0, PMX_EINVAL, "the halo gather rides on the forward pass over whole planes");
             auto k = rowfft_kernel<T, LOGM, false, RB, true>;
             PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, *halo);
+            k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, *halo, (cpx<T> *)dst);
         } else {
             set_error("pmx_rowfft_halo: row length not built");
             return PMX_EUNSUPPORTED;
@@ -1513,11 +1516,11 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     } else if (inverse) {
         auto k = rowfft_kernel<T, LOGM, true, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst);
     } else {
         auto k = rowfft_kernel<T, LOGM, false, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst);
     }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -1525,30 +1528,30 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
 
 template <typename T>
 PMX_DISPATCH int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, double scale, const void *tw,
-                         bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo)
+                         bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo, void *dst)
 {
     switch (logm) {
-    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
-    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
-    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
-    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
+    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
+    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
+    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
+    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
     // 2048 reals: 64-byte tile rows (8 float / 4 double rows per workgroup) keep 1024 / 512 threads
-    case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo);
+    case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
     // n = 384, 768, 1536 reals: M = 192, 384, 768
-    case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
-    case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
-    case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
+    case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
+    case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
     // n = 640, 1280 reals: M = 320, 640
-    case 38: return launch_rowfft<T, 38>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
-    case 39: return launch_rowfft<T, 39, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st);
+    case 38: return launch_rowfft<T, 38>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
+    case 39: return launch_rowfft<T, 39, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
     }
     set_error("pmx_rowfft: length code %d is not built", logm);
     return PMX_EUNSUPPORTED;
 }
 #if PMX_COLFFT_PART == 1
-extern template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *);
+extern template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *, void *);
 #elif PMX_COLFFT_PART == 2
-template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *);
+template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *, void *);
 #endif
 
 }  // namespace pmx
@@ -1572,8 +1575,8 @@ extern "C" int pmx_rowfft_supported(int64_t n, int32_t elsize)
 // n reals -> n/2+1 modes; 1: c2r), row pitch `pitch` COMPLEX elements (>= n/2+1), result
 // multiplied by `scale`; unnormalised in both directions.
 #if PMX_COLFFT_PART != 2
-extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
-                          double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream)
+static int rowfft_any(int32_t elsize, int32_t inverse, void *data, void *dst, int64_t nrows, int64_t n, int64_t pitch,
+                      double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream)
 {
     int rc = pmx_rowfft_supported(n, elsize);
     if (rc) { set_error("pmx_rowfft: unsupported length %lld", (long long)n); return rc; }
@@ -1592,9 +1595,24 @@ extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t n
     rc = get_twiddles((int)n, elsize, &tw, st);
     if (rc) return rc;
     int logm = length_code(n / 2);
+    if (dst == data) dst = nullptr;
     if (elsize == 8)
-        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr);
-    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr);
+        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr, dst);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr, dst);
+}
+
+extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
+                          double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream)
+{
+    return rowfft_any(elsize, inverse, data, nullptr, nrows, n, pitch, scale, rows_per_plane, plane_pitch, stream);
+}
+
+// the same pass from `src` into `dst` (same layout; see pmx_colfft_to)
+extern "C" int pmx_rowfft_to(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t nrows, int64_t n,
+                             int64_t pitch, double scale, int64_t rows_per_plane, int64_t plane_pitch, void *stream)
+{
+    PMX_REQUIRE(dst != nullptr, PMX_EINVAL, "dst is NULL");
+    return rowfft_any(elsize, inverse, (void *)src, dst, nrows, n, pitch, scale, rows_per_plane, plane_pitch, stream);
 }
 
 // PMX_OK if the forward row pass of n reals can gather the staged halos of a paint (pmx_rowfft_halo): the
@@ -1610,10 +1628,11 @@ extern "C" int pmx_rowfft_halo_supported(int64_t n, int32_t elsize)
     return PMX_OK;
 }
 
-extern "C" int pmx_rowfft_halo(int32_t elsize, void *data, int64_t nrows, int64_t n, int64_t pitch, double scale,
+extern "C" int pmx_rowfft_halo(int32_t elsize, void *data, void *dst, int64_t nrows, int64_t n, int64_t pitch, double scale,
                                int64_t rows_per_plane, int64_t plane_pitch, pmx_binplan *plan, const void *canvas,
                                int64_t x0, int32_t last, void *stream)
 {
+    if (dst == data) dst = nullptr;
     int rc = pmx_rowfft_halo_supported(n, elsize);
     if (rc) { set_error("pmx_rowfft_halo: unsupported length %lld", (long long)n); return rc; }
     PMX_REQUIRE(data != nullptr && nrows >= 0 && pitch >= n / 2 + 1, PMX_EINVAL, "bad arguments");
@@ -1638,8 +1657,8 @@ extern "C" int pmx_rowfft_halo(int32_t elsize, void *data, int64_t nrows, int64_
     if (rc) return rc;
     int logm = length_code(n / 2);
     if (elsize == 8)
-        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs);
-    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs);
+        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs, dst);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs, dst);
 }
 #endif
 
@@ -1673,14 +1692,14 @@ extern "C" int pmx_colfft_supported(int64_t n, int32_t elsize)
 // gradient, laplace_pow in -1..1): A must be 1 and B = n1*n2; element (i0, i1, i2) is
 // multiplied by T(k) before the transform, with the index bookkeeping of pmx_apply_transfer.
 #if PMX_COLFFT_PART != 2
-extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
-                          double scale, const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
-                          const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride,
-                          void *stream)
+static int colfft_any(int32_t elsize, int32_t inverse, const void *src, void *data, int64_t A, int64_t N, int64_t B,
+                      double scale, const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
+                      const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride,
+                      void *stream)
 {
     int rc = pmx_colfft_supported(N, elsize);
     if (rc) { set_error("pmx_colfft: unsupported length %lld", (long long)N); return rc; }
-    PMX_REQUIRE(data != nullptr && A >= 0 && B >= 0, PMX_EINVAL, "bad arguments");
+    PMX_REQUIRE(data != nullptr && src != nullptr && A >= 0 && B >= 0, PMX_EINVAL, "bad arguments");
     if (A == 0 || B == 0) return PMX_OK;
     ColGeom g;
     g.A = A; g.B = B; g.N = (int32_t)N; g.scale = scale;
@@ -1712,9 +1731,28 @@ extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A
     void *tw = nullptr;
     rc = get_twiddles((int)N, elsize, &tw, st);
     if (rc) return rc;
-    if (elsize == 8) return dispatch_logn<double>(g, data, data, tw, inverse != 0, apply, st);
+    if (elsize == 8) return dispatch_logn<double>(g, src, data, tw, inverse != 0, apply, st);
     // float: 16 columns x 8 B = 128-byte rows, 16 lines per thread: 1024 threads at N = 1024
-    return dispatch_logn<float>(g, data, data, tw, inverse != 0, apply, st);
+    return dispatch_logn<float>(g, src, data, tw, inverse != 0, apply, st);
+}
+
+extern "C" int pmx_colfft(int32_t elsize, int32_t inverse, void *data, int64_t A, int64_t N, int64_t B,
+                          double scale, const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
+                          const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride,
+                          void *stream)
+{
+    return colfft_any(elsize, inverse, data, data, A, N, B, scale, t, n1, n2, start, nmesh, boxsize, a_stride, n_stride, stream);
+}
+
+// the same pass from `src` into `dst` (same layout, no overlap unless equal): the first pass of a transform whose
+// caller keeps its input (c2r() / r2c() with out=None, the reference's default: pm.py:655-694, 987-1019) reads the
+// input and writes the work buffer, instead of a copy of the whole array in front of an in-place pass
+extern "C" int pmx_colfft_to(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t A, int64_t N, int64_t B,
+                             double scale, const pmx_transfer *t, int64_t n1, int64_t n2, const int64_t *start,
+                             const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride,
+                             void *stream)
+{
+    return colfft_any(elsize, inverse, src, dst, A, N, B, scale, t, n1, n2, start, nmesh, boxsize, a_stride, n_stride, stream);
 }
 #endif
 

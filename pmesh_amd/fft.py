@@ -466,7 +466,7 @@ class Plan(object):
             # the halo merge of the paint that made this field: the forward transform of one rank adds the staged
             # halos inside its row pass (_execute_local_hybrid); anything else needs the finished mesh first
             mine = (self.forward and p.nproc == 1 and not getattr(p, 'is_c2c', False) and p.ndim == 3 and
-                    bufin.storage is bufout.storage and not (getattr(p, 'pencil', False) and not p.transposed))
+                    not (getattr(p, 'pencil', False) and not p.transposed))
             if not mine:
                 settle(bufin.storage)
         pend = getattr(bufin.storage, '_pmx_pending', None)
@@ -797,6 +797,19 @@ class Plan(object):
                 be.slab_pack(Z[q1:], rows, n * n1l, N2c, 1, e2o, elb, inverse=True)
                 self._row(be, rows, n * n1l, N2, N2c, True)
 
+    def fills_output(self):
+        """True if an out-of-place execute(bufin, bufout) writes every element of `bufout` that any later reader looks
+        at, reading `bufin` only in its first pass (one rank, the LDS row / column kernels with their out-of-place
+        first pass): the caller may then hand in uninitialised memory and need not copy the input first"""
+        p = self.partition
+        if p.nproc != 1 or p.ndim != 3 or getattr(p, 'is_c2c', False) or not p.plane_c:
+            return False
+        if getattr(p, 'pencil', False) and not p.transposed:
+            return False
+        be = backend.get()
+        return (hasattr(be, 'rowfft_to') and self._use_colfft(be, [int(x) for x in p.Nmesh[:2]]) and
+                be.rowfft_supported(int(p.Nmesh[2]), self.elsize))
+
     def can_fuse(self):
         """True if execute(..., transfer=) can fold a transfer function into the transform"""
         p = self.partition
@@ -856,21 +869,53 @@ class Plan(object):
         rows = N0 * N1
         plane = p.plane_c                      # padded plane stride (complex elements) or None
         rpp, ppitch, sa, sn = (N1, plane, plane, plane) if plane else (0, 0, 0, 0)
-        if plane and not inplace:
+        # out of place (the reference's default: r2c() / c2r() return a new field): the FIRST pass reads the input and
+        # writes the output buffer (pmx_rowfft_to / pmx_colfft_to), the others run in place there — no copy of the
+        # array in front of an in-place transform
+        oop = bool(plane) and not inplace and hasattr(be, 'rowfft_to') and be.rowfft_supported(N2, self.elsize)
+        if plane and not inplace and not oop:
             # the padded layout is only walked by the in-place kernels: transform a copy
             n = p.i_alloc if self.forward else 2 * p.o_alloc
             bufout.storage[:n].copy_(bufin.storage[:n])
             bufin = bufout
             inplace = True
-        own_rows = inplace and be.rowfft_supported(N2, self.elsize)
+        src0 = bufin.storage                    # what the first pass reads
+        work = bufout.storage if oop else bufin.storage
+        own_rows = (inplace or oop) and be.rowfft_supported(N2, self.elsize)
         # the halo merge of the paint that made this field, left to this transform's row pass (window._HaloDebt)
-        debt = getattr(bufin.storage, '_pmx_halo', None) if self.forward else None
+        debt = getattr(src0, '_pmx_halo', None) if self.forward else None
         if debt is not None and not (own_rows and hasattr(be, 'rowfft_halo') and debt.open and
-                                     debt.canvas_ptr == bufin.storage.data_ptr() and
+                                     debt.canvas_ptr == src0.data_ptr() and
                                      be.lib.pmx_rowfft_halo_supported(N2, self.elsize) == 0):
-            settle(bufin.storage)
+            settle(src0)
             debt = None
         hrpp, hpp = (N1, plane) if plane else (N1, N1 * N2c)
+        # (out of place the input field keeps its debt: its own values still lack the halos this pass has added to
+        # what it wrote elsewhere; whoever reads that field, or needs the plan, runs the merge kernel then)
+        keeps_debt = debt is not None and oop
+
+        def row_forward(blk_in, blk, nrows, x0, last):
+            if debt is not None:
+                be.rowfft_halo(self.elsize, blk_in, nrows, N2, N2c, hrpp, hpp, debt.plan, debt.canvas_ptr, x0,
+                               last and not keeps_debt, dst=blk if oop else None)
+            elif oop:
+                be.rowfft_to(self.elsize, False, blk_in, blk, nrows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
+            else:
+                be.rowfft(self.elsize, False, blk, nrows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
+
+        def first_inverse(st):
+            """the axis-0 pass that starts c2r (with the transfer function riding on it)"""
+            if not oop and self._take_over_forward_pass(be, st, transfer, N0, N1, N2c, sn):
+                return
+            kw = {}
+            if transfer is not None:
+                t, start, nmesh, boxsize = transfer
+                kw = dict(transfer=t, n1=N1, n2=N2c, start=start, nmesh=nmesh, boxsize=boxsize)
+            if oop:
+                be.colfft_to(self.elsize, True, src0, st, 1, N0, N1 * N2c, n_stride=sn, **kw)
+            else:
+                be.colfft(self.elsize, True, st, 1, N0, N1 * N2c, n_stride=sn, **kw)
+
         # Infinity-Cache blocking: the row pass and the axis-1 pass both work inside single
         # planes, so they can run back to back on a block of planes that fits the 256 MiB
         # last-level cache: the second touch of a block is served on die instead of from HBM
@@ -882,30 +927,19 @@ class Plan(object):
             if per < N0:
                 nblk = (N0 + per - 1) // per
         if nblk > 1:
-            st = bufin.storage
+            st = work
             es = 2                                  # real elements per complex element
             if self.forward:
                 for b in range(nblk):
                     i0, i1 = b * per, min(N0, (b + 1) * per)
                     blk = st[i0 * plane * es:]
-                    if debt is not None:
-                        be.rowfft_halo(self.elsize, blk, (i1 - i0) * N1, N2, N2c, hrpp, hpp, debt.plan, debt.canvas_ptr,
-                                       i0, b == nblk - 1)
-                    else:
-                        be.rowfft(self.elsize, False, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
+                    row_forward(src0[i0 * plane * es:], blk, (i1 - i0) * N1, i0, b == nblk - 1)
                     be.colfft(self.elsize, False, blk, i1 - i0, N1, N2c, a_stride=sa)
-                if debt is not None:
+                if debt is not None and not keeps_debt:
                     debt.taken()
                 self._last_forward_pass(be, st, N0, N1, N2c, norm, sn)
             else:
-                if self._take_over_forward_pass(be, st, transfer, N0, N1, N2c, sn):
-                    pass
-                elif transfer is not None:
-                    t, start, nmesh, boxsize = transfer
-                    be.colfft(self.elsize, True, st, 1, N0, N1 * N2c, transfer=t, n1=N1, n2=N2c,
-                              start=start, nmesh=nmesh, boxsize=boxsize, n_stride=sn)
-                else:
-                    be.colfft(self.elsize, True, st, 1, N0, N1 * N2c, n_stride=sn)
+                first_inverse(st)
                 for b in range(nblk):
                     i0, i1 = b * per, min(N0, (b + 1) * per)
                     blk = st[i0 * plane * es:]
@@ -913,11 +947,10 @@ class Plan(object):
                     be.rowfft(self.elsize, True, blk, (i1 - i0) * N1, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
             return
         if self.forward:
-            if debt is not None:
-                be.rowfft_halo(self.elsize, bufin.storage, rows, N2, N2c, hrpp, hpp, debt.plan, debt.canvas_ptr, 0, True)
-                debt.taken()
-            elif own_rows:
-                be.rowfft(self.elsize, False, bufin.storage, rows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)
+            if own_rows:
+                row_forward(src0, work, rows, 0, True)
+                if debt is not None and not keeps_debt:
+                    debt.taken()
             else:
                 def make():
                     return be.fft_create(_abi.PMX_FFT_R2C, self.elsize, [N2], [1], 2 * N2c, [1], N2c,
@@ -927,16 +960,10 @@ class Plan(object):
             be.colfft(self.elsize, False, out, N0, N1, N2c, a_stride=sa)
             self._last_forward_pass(be, out, N0, N1, N2c, norm, sn)
         else:
-            # in place on the complex data (c2r(out=...) made `bufin` a copy when needed)
-            src = bufin.storage
-            if self._take_over_forward_pass(be, src, transfer, N0, N1, N2c, sn):
-                pass
-            elif transfer is not None:
-                t, start, nmesh, boxsize = transfer
-                be.colfft(self.elsize, True, src, 1, N0, N1 * N2c, transfer=t, n1=N1, n2=N2c,
-                          start=start, nmesh=nmesh, boxsize=boxsize, n_stride=sn)
-            else:
-                be.colfft(self.elsize, True, src, 1, N0, N1 * N2c, n_stride=sn)
+            # in place on the complex data (out of place: the first pass has moved it into the output buffer;
+            # without the out-of-place kernels c2r(out=...) made `bufin` a copy)
+            src = work
+            first_inverse(src)
             be.colfft(self.elsize, True, src, N0, N1, N2c, a_stride=sa)
             if own_rows:
                 be.rowfft(self.elsize, True, src, rows, N2, N2c, rows_per_plane=rpp, plane_pitch=ppitch)

@@ -542,7 +542,8 @@ class Field(NDArrayLike):
         understands numpy it is evaluated on the host, slab by slab as the reference does.
         """
         if out is None:
-            out = self.pm.create(type=_gettype(self))
+            # (every value of the new field is written below; only the GPU backend hands out raw memory)
+            out = _blank(_gettype(self), self.pm) if backend.get().name == 'hip' else self.pm.create(type=_gettype(self))
         if is_inplace(out):
             out = self
         if isinstance(out, Field):
@@ -640,7 +641,9 @@ class RealField(Field):
         # afterwards (in the reference `value` is a plain array, pm.py:234-242), so nothing is left deferred on it
         callers = out is not None and not is_inplace(out) and out is not self
         if out is None:
-            out = TransposedComplexField(self.pm)
+            # (one rank, LDS kernels: the first pass of the out-of-place transform writes the whole result)
+            out = (_blank(TransposedComplexField, self.pm) if self.pm.plans['forwardT'].fills_output()
+                   else TransposedComplexField(self.pm))
         if is_inplace(out):
             out = self
         if out is self:
@@ -700,7 +703,7 @@ class RealField(Field):
             dpos, host = to_device(pos, be.device, 'pos')
             # a caller's device buffer takes the result directly (no fresh tensor per call)
             direct = (is_tensor(out) and out.device == be.device and out.dtype in (torch.float64, torch.float32) and
-                      out.dim() == 1 and out.shape[0] == dpos.shape[0] and out.is_contiguous())
+                      out.dim() == 1 and out.shape[0] == dpos.shape[0])      # (any stride: a column of an (n, 3) force array)
             pending = None
             if layout.comm.size > 1:
                 # the ghosts first: their partial sums travel back to their owners (on RCCL's stream) while the
@@ -842,27 +845,38 @@ class BaseComplexField(Field):
             the first pass of the inverse transform when the column-FFT path is active
             (the complex field is then read once less).  `self` is left untouched unless
             the transform is in place (``out=Ellipsis``). """
+        T = 'U' if isinstance(self, UntransposedComplexField) else 'T'
+        if transfer is not None and not isinstance(transfer, Transfer):
+            raise TypeError('transfer must be a pmesh_amd.transfer.Transfer')
+        oop = self.pm.plans['backward' + T].fills_output()
         if out is None:
-            out = RealField(self.pm)
+            out = _blank(RealField, self.pm) if oop and self.pm.comm.size == 1 else RealField(self.pm)
         if is_inplace(out):
             out = self
         if out is self:
             out = RealField(self.pm, self._base)
         assert isinstance(out, RealField)
         inplace = out._base in self._base and self._base in out._base
-        T = 'U' if isinstance(self, UntransposedComplexField) else 'T'
         src = self
+        fusable = transfer is not None and transfer.fusable()
         if not inplace and self.pm.comm.size == 1:
-            # rocFFT may overwrite the input of an out-of-place real inverse; the reference
-            # plans with PRESERVE_INPUT (pm.py:1335): transform a copy, in place in `out`
-            src = self.pm.create(type=_gettype(self), base=out._base, value=self.value)
-            inplace = True
+            if transfer is not None and not (fusable and self.pm.plans['ipbackward' + T].can_fuse()):
+                # a transfer function that is a kernel of its own moves the spectrum while it multiplies: self ->
+                # the buffer of `out`, transformed in place there
+                src = self.pm.create(type=_gettype(self), base=out._base)
+                self.apply(transfer, out=src)
+                transfer = None
+                inplace = True
+            elif not oop:
+                # rocFFT may overwrite the input of an out-of-place real inverse; the reference
+                # plans with PRESERVE_INPUT (pm.py:1335): transform a copy, in place in `out`
+                src = self.pm.create(type=_gettype(self), base=out._base, value=self.value)
+                inplace = True
+            # else: the first pass of the LDS kernels reads `self` and writes `out` (with the transfer riding on it)
         plan = self.pm.plans[('ipbackward' if inplace else 'backward') + T]
         fused = None
         if transfer is not None:
-            if not isinstance(transfer, Transfer):
-                raise TypeError('transfer must be a pmesh_amd.transfer.Transfer')
-            if transfer.fusable() and plan.can_fuse():
+            if fusable and plan.can_fuse():
                 fused = (transfer._cstruct(), src.start, src.Nmesh, src.BoxSize)
             elif src is self and not inplace:
                 src = self.apply(transfer)            # several ranks: the slab path copies anyway
@@ -912,6 +926,13 @@ class TransposedComplexField(BaseComplexField):
 
 # backward-compatbility, alias TranposedComplexField to ComplexField
 ComplexField = TransposedComplexField
+
+
+def _blank(cls, pm):
+    """a new field on uninitialised memory, for whoever is about to write all of it (the padding between the rows and
+    planes of the one-rank layout is never read as values)"""
+    part = pm._get_partition(cls)
+    return cls(pm, base=torch.empty(part.alloc_reals, dtype=torch_dtype(pm._rdtype), device=backend.get().device))
 
 
 def _zeros_like(a):
@@ -1461,6 +1482,11 @@ class ParticleMesh(object):
         """
         transform = transform or self.affine
         resampler = FindResampler(self.resampler if resampler is None else resampler)
+        if layout is not None and layout.comm.size == 1 and not layout.remote_recvlength and \
+                _ghosts_only(layout, resampler, transform, hsml):
+            # one rank, nothing to receive: `pm.paint(x, layout=pm.decompose(x))` — how callers of the reference write
+            # every paint (examples/nbody.py:203-204) — is the paint of the caller's own array
+            layout = None
         fresh = out is None
         part = self._get_partition(RealField)
         if fresh and layout is None and not hold and not getattr(part, 'is_c2c', False) and backend.get().name == 'hip':

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""A caller's time step as examples/nbody.py writes it (force(): paint -> r2c -> three x (apply -> c2r -> readout),
+nbody.py:199-218), on device-resident particles: per-step time with the caller's own numpy-style transfer functions
+(evaluated on device arrays, pmesh_amd/_devarr.py) and with the fused Transfer objects riding on c2r's first pass.
+    python scripts/nbody_steps.py [Nmesh=512] [steps=5]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy, torch
+from pmesh_amd.pm import ParticleMesh
+from pmesh_amd.transfer import Transfer
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+pm = ParticleMesh(BoxSize=float(N), Nmesh=[N, N, N], dtype='f8', resampler='cic')
+Q = pm.generate_uniform_particle_grid(shift=0.5)
+g = torch.Generator(device=Q.device).manual_seed(3)
+X = (Q + 0.3 * torch.randn(Q.shape, generator=g, dtype=Q.dtype, device=Q.device)) % float(N)
+V = torch.zeros_like(X)
+
+
+def force_transfer(direction):            # examples/nbody.py:162-171
+    def filter(k, v):
+        k2 = sum(ki ** 2 for ki in k)
+        k2[k2 == 0] = 1.0
+        C = (v.BoxSize / v.Nmesh)[direction]
+        w = k[direction] * C
+        kfinite = 1.0 / C * 1 / 6.0 * (8 * numpy.sin(w) - numpy.sin(2 * w))
+        return 1j * kfinite / k2 * v
+    return filter
+
+
+def force(X, fused):
+    layout = pm.decompose(X)
+    rho = pm.paint(X, layout=layout)
+    rhok = rho.r2c(out=Ellipsis)
+    F = torch.empty_like(X)
+    for d in range(3):
+        # (the result goes straight into its column of the force array: readout's `out`, window.py:165-221)
+        if fused:
+            rhok.c2r(transfer=Transfer.force(d)).readout(X, layout=layout, out=F[:, d])
+        else:
+            rhok.apply(force_transfer(d)).c2r(out=Ellipsis).readout(X, layout=layout, out=F[:, d])
+    return F
+
+
+for fused in (False, True):
+    x, v = X.clone(), V.clone()
+    F = force(x, fused)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(steps):                # kick - drift - kick
+        v += 0.5e-3 * F
+        x = (x + v) % float(N)
+        F = force(x, fused)
+        v += 0.5e-3 * F
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / steps * 1e3
+    print('N=%d: %s: %.2f ms per step (one paint, one r2c, three c2r + readout; %d particles), |F| max %.3e'
+          % (N, 'fused Transfer.force on c2r' if fused else "the caller's numpy-style force_transfer on device arrays",
+             ms, len(x), float(F.abs().max())), flush=True)

@@ -270,3 +270,46 @@ def test_crowded_tiles_and_tile_ordered_copies(hip, name, form):
     finally:
         window.SORTED = old_sorted
         window.clear_bin_cache()
+
+
+@pytest.mark.parametrize('dtype', ['f8', 'f4'])
+@pytest.mark.parametrize('blocked', [False, True])
+def test_out_of_place_transforms_read_their_input_once_and_keep_it(hip, dtype, blocked):
+    """r2c() / c2r() with out=None — the reference's default (pm.py:655-694, 987-1019) — on one rank: the first pass
+    reads the input and writes the new field (pmx_rowfft_to / pmx_colfft_to, no copy in front of an in-place transform);
+    same bits as the in-place transform of a copy, the input untouched; with a fused transfer; and on a field whose
+    halo merge is still owed (the gather then writes elsewhere and the field keeps its debt)"""
+    from pmesh_amd.transfer import Transfer
+    nmesh = (128, 64, 256)
+    pm = ParticleMesh(Nmesh=nmesh, BoxSize=[64.0, 32.0, 128.0], dtype=dtype, resampler='tsc')
+    _fft.L3_BLOCK_BYTES = (9 * nmesh[1] * (nmesh[2] + 16) * (8 if dtype == 'f8' else 4)) if blocked else 0
+    assert pm.plans['forwardT'].fills_output() and pm.plans['backwardT'].fills_output()
+    pos, mass = particles(pm, int(numpy.prod(nmesh)) // 2, 23)
+    pmod.HALO_DEFER = 'never'
+    rho = pm.paint(pos, mass=mass)
+    before = rho.value.clone()
+    k_oop = rho.r2c()
+    assert torch.equal(rho.value, before)
+    k_ip = rho.copy().r2c(out=Ellipsis)
+    assert torch.equal(k_oop.value, k_ip.value)
+    kbefore = k_oop.value.clone()
+    r_oop = k_oop.c2r()
+    assert torch.equal(k_oop.value, kbefore)
+    r_ip = k_oop.copy().c2r(out=Ellipsis)
+    assert torch.equal(r_oop.value, r_ip.value)
+    tol = 1e-12 if dtype == 'f8' else 2e-5
+    assert float((r_oop.value - before).abs().max()) <= tol * float(before.abs().max())
+    for T in (Transfer.dx1(0), Transfer.force(1), Transfer.potential()):
+        a = k_oop.c2r(transfer=T)
+        assert torch.equal(k_oop.value, kbefore)
+        b = k_oop.apply(T).c2r(out=Ellipsis)
+        assert float((a.value - b.value).abs().max()) <= tol * float(b.value.abs().max())
+    # a field that still owes its halo merge, transformed out of place
+    pmod.HALO_DEFER = 'fresh'
+    lazy = pm.paint(pos, mass=mass)
+    assert owes(lazy)
+    k_lazy = lazy.r2c()
+    assert owes(lazy), 'the input field lost its debt though its own values were never merged'
+    assert float((k_lazy.value - k_ip.value).abs().max()) <= (1e-13 if dtype == 'f8' else 2e-6) * float(k_ip.value.abs().max())
+    assert float((lazy.value - before).abs().max()) <= (1e-12 if dtype == 'f8' else 2e-6) * float(before.abs().max())
+    assert not owes(lazy)
