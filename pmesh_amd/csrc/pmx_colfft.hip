@@ -211,6 +211,10 @@ struct ColGeom {
     int32_t n1, n2;        // B = n1 * n2 for the axis-0 pass
     int64_t start[3], nmesh[3];
     double dw[3], nl[3];
+    // [r4] grad_kind 1 (force_transfer, nbody.py:162-171): D(k_d) = (8 sin w - sin 2w) / (6 C), w = k_d C, C = L / N — a
+    // function of the global index along ONE axis: a table of nmesh[grad_dir] doubles made on the host, so the sines
+    // cost the fused pass one cached load where the stand-alone kernel evaluates them per element.  nullptr: D = k_d.
+    const double *dtab = nullptr;
 };
 
 // LDS layout: one row of the tile = W columns = 128 bytes = half a bank row.  Rows 2m and
@@ -389,7 +393,7 @@ __device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, 
 
 // Fused transfer (SIMPLE forms).  The wavenumbers along axes 1 and 2 depend only on the
 // column, so they are computed once per tile and thread; per element only axis 0 remains.
-struct ColK { double k1, k2, k12sq; };
+struct ColK { double k1, k2, k12sq; double d1, d2; };      // d1 / d2: D along axis 1 / 2 (k1 / k2, or the table's entry)
 
 __device__ __forceinline__ double kcoord(const ColGeom &g, int d, int64_t i)
 {
@@ -409,6 +413,12 @@ __device__ __forceinline__ ColK column_k(const ColGeom &g, int64_t b)
     c.k1 = kcoord(g, 1, i1);
     c.k2 = kcoord(g, 2, i2);
     c.k12sq = c.k1 * c.k1 + c.k2 * c.k2;
+    c.d1 = c.k1;
+    c.d2 = c.k2;
+    if (g.dtab) {
+        if (g.t.grad_dir == 1) c.d1 = g.dtab[(int32_t)i1 + (int32_t)g.start[1]];
+        else if (g.t.grad_dir == 2) c.d2 = g.dtab[(int32_t)i2 + (int32_t)g.start[2]];
+    }
     return c;
 }
 
@@ -425,7 +435,8 @@ __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, con
         const double qq = (k2 == 0) ? 1.0 : k2;
         double re = g.t.amplitude;
         re *= 1.0 / qq;
-        const double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.k1 : c.k2);     // (selects, no branch)
+        double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.d1 : c.d2);     // (selects, no branch)
+        if (g.dtab && g.t.grad_dir == 0) D = g.dtab[(int32_t)i0 + (int32_t)g.start[0]];      // (uniform over the launch)
         const double im = re * D;
         re = 0;
         const double ar = v.x, ai = v.y;
@@ -440,7 +451,8 @@ __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, con
         else if (g.t.laplace_pow == 1) re *= qq;
     }
     if (g.t.grad_dir >= 0) {
-        double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.k1 : c.k2);
+        double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.d1 : c.d2);
+        if (g.dtab && g.t.grad_dir == 0) D = g.dtab[(int32_t)i0 + (int32_t)g.start[0]];
         im = re * D;
         re = 0;
     }
@@ -1405,6 +1417,42 @@ static int get_twiddles(int N, int es, void **out, hipStream_t st)
     return PMX_OK;
 }
 
+// tables of the finite-difference gradient factor D over the global index of one axis (ColGeom::dtab), one per
+// (mesh side, box side, device), created on first use
+struct DtKey { int64_t n; double box; int dev; bool operator<(const DtKey &o) const { return n != o.n ? n < o.n : (box != o.box ? box < o.box : dev < o.dev); } };
+static std::map<DtKey, double *> g_dtab;
+
+static int gradient_table(ColGeom &g, const pmx_transfer *t, const int64_t *nmesh, const double *boxsize)
+{
+    g.dtab = nullptr;
+    if (!t || t->grad_dir < 0 || t->grad_kind == 0) return PMX_OK;
+    const int d = t->grad_dir;
+    int dev = 0;
+    PMX_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    DtKey key{nmesh[d], boxsize[d], dev};
+    auto it = g_dtab.find(key);
+    if (it != g_dtab.end()) { g.dtab = it->second; return PMX_OK; }
+    const int64_t N = nmesh[d];
+    std::vector<double> h((size_t)N);
+    const double C = boxsize[d] / (double)N;
+    for (int64_t gi = 0; gi < N; gi++) {
+        // the wavenumber exactly as kcoord() forms it, then D as pmx_transfer.hip does (nbody.py:166-169)
+        double wi = (double)gi;
+        if (gi >= N / 2) wi -= (double)N;
+        wi *= 2 * M_PI / (double)N;
+        const double k = wi * ((double)N / boxsize[d]);
+        const double w = k * C;
+        h[(size_t)gi] = (1.0 / C) * (1.0 / 6.0) * (8.0 * sin(w) - sin(2.0 * w));
+    }
+    double *dptr = nullptr;
+    PMX_HIP_CHECK(hipMalloc((void **)&dptr, (size_t)N * sizeof(double)));
+    PMX_HIP_CHECK(hipMemcpy(dptr, h.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    g_dtab[key] = dptr;
+    g.dtab = dptr;
+    return PMX_OK;
+}
+
 template <typename T, int LOGN, int RB, bool RM>
 static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const void *tw, bool inverse, bool apply,
                             hipStream_t st)
@@ -1716,10 +1764,12 @@ static int colfft_any(int32_t elsize, int32_t inverse, const void *src, void *da
     if (apply) {
         PMX_REQUIRE(A == 1 && n1 * n2 == B && B < (1ll << 31), PMX_EINVAL,
                     "fused transfer needs the axis-0 pass of one block");
-        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || t->grad_kind == 1) &&
                     t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
                     PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
         g.t = *t;
+        rc = gradient_table(g, t, nmesh, boxsize);
+        if (rc) return rc;
         g.n1 = (int32_t)n1; g.n2 = (int32_t)n2;
         for (int d = 0; d < 3; d++) {
             g.start[d] = start[d]; g.nmesh[d] = nmesh[d];
@@ -1864,10 +1914,12 @@ extern "C" int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64
     const bool apply = t != nullptr;
     if (apply) {
         PMX_REQUIRE(n1 * n2 == B && B < (1ll << 31), PMX_EINVAL, "fused transfer needs the axis-0 pass of one block");
-        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || t->grad_kind == 1) &&
                     t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
                     PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
         g.t = *t;
+        rc = gradient_table(g, t, nmesh, boxsize);
+        if (rc) return rc;
         g.n1 = (int32_t)n1; g.n2 = (int32_t)n2;
         for (int d = 0; d < 3; d++) {
             g.start[d] = start[d]; g.nmesh[d] = nmesh[d];
@@ -2005,10 +2057,12 @@ extern "C" int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, vo
     bool apply = t != nullptr;
     if (apply) {
         PMX_REQUIRE(!to_full && B < (1ll << 31), PMX_EINVAL, "the fused transfer belongs to the gathering pass");
-        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0) &&
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || t->grad_kind == 1) &&
                     t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
                     PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
         g.t = *t;
+        rc = gradient_table(g, t, nmesh, boxsize);
+        if (rc) return rc;
         g.n1 = (int32_t)n1; g.n2 = (int32_t)cw;        // column b = (i1, i2 - coff)
         for (int d = 0; d < 3; d++) {
             g.start[d] = start[d] + (d == 2 ? coff : 0);

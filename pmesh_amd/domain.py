@@ -209,8 +209,20 @@ class Layout(object):
         self.recvoffsets[1:] = self.recvcounts.cumsum()[:-1]
         self.sendlength = sendlength
         self.recvlength = int(self.recvcounts.sum())
-        self.indices = indices     # device tensor, int32/int64
+        # device tensor, int32/int64 — or a callable that makes it the first time somebody asks (the identity
+        # layout of one periodic domain on one rank: paint and readout never read it)
+        self._indices = indices
         self._agreed = set()       # directions whose length check has been held collectively
+
+    @property
+    def indices(self):
+        if callable(self._indices):
+            self._indices = self._indices()
+        return self._indices
+
+    @indices.setter
+    def indices(self, value):
+        self._indices = value
 
     def _wrong_length(self, n, expected, direction, message):
         """The reference allgathers the verdict of the length check on every call, so that every
@@ -878,7 +890,7 @@ class GridND(object):
             # it exactly once (the wrapped patch of gridnd_fill, _domain.pyx:62-118, names domain 0 however often
             # and the targets are unique): sendcounts = [N], indices = 0 .. N - 1, nothing to classify
             return Layout(comm=self.comm, sendlength=Npoint, sendcounts=numpy.array([Npoint], dtype=counts_dtype),
-                          indices=torch.arange(Npoint, dtype=index_dtype, device=be.device),
+                          indices=lambda: torch.arange(Npoint, dtype=index_dtype, device=be.device),
                           recvcounts=numpy.array([Npoint], dtype=counts_dtype))
         if Npoint != 0:
             masks = torch.empty(Npoint, dtype=torch.int64, device=be.device)

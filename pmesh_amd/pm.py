@@ -1482,8 +1482,7 @@ class ParticleMesh(object):
         """
         transform = transform or self.affine
         resampler = FindResampler(self.resampler if resampler is None else resampler)
-        if layout is not None and layout.comm.size == 1 and not layout.remote_recvlength and \
-                _ghosts_only(layout, resampler, transform, hsml):
+        if layout is not None and layout.comm.size == 1 and _ghosts_only(layout, resampler, transform, hsml):
             # one rank, nothing to receive: `pm.paint(x, layout=pm.decompose(x))` — how callers of the reference write
             # every paint (examples/nbody.py:203-204) — is the paint of the caller's own array
             layout = None

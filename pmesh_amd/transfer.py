@@ -66,9 +66,9 @@ class Transfer(object):
         return cls(deconv_pow=FindResampler(resampler).nativesupport)
 
     def fusable(self):
-        """closed forms without transcendentals can ride on the first pass of c2r"""
-        return (self.gauss_r == 0.0 and self.deconv_pow == 0 and -1 <= self.laplace_pow <= 1 and
-                (self.grad_dir < 0 or self.grad_kind == 'spectral'))
+        """closed forms without per-element transcendentals can ride on the first pass of c2r ([r4] the
+        finite-difference gradient too: its sines depend on the index along one axis and come from a table)"""
+        return self.gauss_r == 0.0 and self.deconv_pow == 0 and -1 <= self.laplace_pow <= 1
 
     def _cstruct(self):
         t = _abi.Transfer()

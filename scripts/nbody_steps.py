@@ -47,14 +47,24 @@ def force(X, fused):
 for fused in (False, True):
     x, v = X.clone(), V.clone()
     F = force(x, fused)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(steps):                # kick - drift - kick
+
+    def step(x, v, F):                    # kick - drift - kick
         v += 0.5e-3 * F
         x = (x + v) % float(N)
         F = force(x, fused)
         v += 0.5e-3 * F
+        return x, v, F
+    x, v, F = step(x, v, F)               # (untimed: the first use of every kernel loads its code object)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    st0 = torch.cuda.memory_stats()
+    for _ in range(steps):
+        x, v, F = step(x, v, F)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t) / steps * 1e3
+    st1 = torch.cuda.memory_stats()
+    print('   allocator in the timed loop: %d device allocations, %d frees, reserved %.1f GB'
+          % (st1['num_device_alloc'] - st0['num_device_alloc'], st1['num_device_free'] - st0['num_device_free'],
+             st1['reserved_bytes.all.current'] / 1e9), flush=True)
     print('N=%d: %s: %.2f ms per step (one paint, one r2c, three c2r + readout; %d particles), |F| max %.3e'
           % (N, 'fused Transfer.force on c2r' if fused else "the caller's numpy-style force_transfer on device arrays",
              ms, len(x), float(F.abs().max())), flush=True)

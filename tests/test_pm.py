@@ -383,7 +383,7 @@ def test_c2r_with_fused_transfer(be, dtype, tol):
     ck = pm.create(type='real', value=rs.normal(size=Nmesh).astype(dtype)).r2c()
     before = numpy.asarray(ck).copy()
     for T in (Transfer.dx1(0), Transfer.dx1(2), Transfer.potential(), Transfer(amplitude=2.5),
-              Transfer.force(1), Transfer.lowpass(4.0)):
+              Transfer.force(0), Transfer.force(1), Transfer.force(2), Transfer.lowpass(4.0)):
         want = numpy.asarray(ck.apply(T).c2r())
         got = numpy.asarray(ck.c2r(transfer=T))
         assert rel_l2(got, want) < 10 * tol
