@@ -212,8 +212,11 @@ struct ColGeom {
     int64_t start[3], nmesh[3];
     double dw[3], nl[3];
     // [r4] grad_kind 1 (force_transfer, nbody.py:162-171): D(k_d) = (8 sin w - sin 2w) / (6 C), w = k_d C, C = L / N — a
-    // function of the global index along ONE axis: a table of nmesh[grad_dir] doubles made on the host, so the sines
-    // cost the fused pass one cached load where the stand-alone kernel evaluates them per element.  nullptr: D = k_d.
+    // function of the global index along ONE axis: a table of nmesh[grad_dir] doubles made on the host.  Along axes 1
+    // and 2 the factor belongs to the COLUMN (column_k: one cached load per tile and thread, nothing per element);
+    // along axis 0 it would be a load per element — in the round-trip kernels, which sit at their register limit, that
+    // spills (measured: 60-116 bytes in every float variant) — so that direction keeps its stand-alone kernel.
+    // nullptr: D = k_d.
     const double *dtab = nullptr;
 };
 
@@ -393,7 +396,9 @@ __device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, 
 
 // Fused transfer (SIMPLE forms).  The wavenumbers along axes 1 and 2 depend only on the
 // column, so they are computed once per tile and thread; per element only axis 0 remains.
-struct ColK { double k1, k2, k12sq; double d1, d2; };      // d1 / d2: D along axis 1 / 2 (k1 / k2, or the table's entry)
+// k12sq = k1^2 + k2^2; dcol: the gradient factor D of a gradient along axis 1 or 2 (k1 / k2, or the table's entry) —
+// all a column contributes to its elements' transfer function
+struct ColK { double k12sq, dcol; };
 
 __device__ __forceinline__ double kcoord(const ColGeom &g, int d, int64_t i)
 {
@@ -410,15 +415,11 @@ __device__ __forceinline__ ColK column_k(const ColGeom &g, int64_t b)
     const uint32_t ub = (uint32_t)b, un2 = (uint32_t)g.n2;
     const uint32_t i1 = ub / un2, i2 = ub - i1 * un2;
     ColK c;
-    c.k1 = kcoord(g, 1, i1);
-    c.k2 = kcoord(g, 2, i2);
-    c.k12sq = c.k1 * c.k1 + c.k2 * c.k2;
-    c.d1 = c.k1;
-    c.d2 = c.k2;
-    if (g.dtab) {
-        if (g.t.grad_dir == 1) c.d1 = g.dtab[(int32_t)i1 + (int32_t)g.start[1]];
-        else if (g.t.grad_dir == 2) c.d2 = g.dtab[(int32_t)i2 + (int32_t)g.start[2]];
-    }
+    const double k1 = kcoord(g, 1, i1), k2 = kcoord(g, 2, i2);
+    c.k12sq = k1 * k1 + k2 * k2;
+    c.dcol = g.t.grad_dir == 1 ? k1 : k2;
+    if (g.dtab && g.t.grad_dir > 0)
+        c.dcol = g.dtab[g.t.grad_dir == 1 ? (int32_t)i1 + (int32_t)g.start[1] : (int32_t)i2 + (int32_t)g.start[2]];
     return c;
 }
 
@@ -435,8 +436,7 @@ __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, con
         const double qq = (k2 == 0) ? 1.0 : k2;
         double re = g.t.amplitude;
         re *= 1.0 / qq;
-        double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.d1 : c.d2);     // (selects, no branch)
-        if (g.dtab && g.t.grad_dir == 0) D = g.dtab[(int32_t)i0 + (int32_t)g.start[0]];      // (uniform over the launch)
+        const double D = g.t.grad_dir == 0 ? k0 : c.dcol;     // (a select, no branch)
         const double im = re * D;
         re = 0;
         const double ar = v.x, ai = v.y;
@@ -451,8 +451,7 @@ __device__ __forceinline__ cpx<T> apply_simple(const ColGeom &g, int64_t i0, con
         else if (g.t.laplace_pow == 1) re *= qq;
     }
     if (g.t.grad_dir >= 0) {
-        double D = g.t.grad_dir == 0 ? k0 : (g.t.grad_dir == 1 ? c.d1 : c.d2);
-        if (g.dtab && g.t.grad_dir == 0) D = g.dtab[(int32_t)i0 + (int32_t)g.start[0]];
+        const double D = g.t.grad_dir == 0 ? k0 : c.dcol;
         im = re * D;
         re = 0;
     }
@@ -680,7 +679,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         const bool colok = b0 + col < g.B;
         cpx<T> *obase = dst + a * g.out.sa + (REMAP ? (colok ? col_offset(g.out, b0 + col) : 0) : b0);
         const int lcol = REMAP ? 0 : col;
-        ColK ck = {0, 0, 0};
+        ColK ck = {0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         __syncthreads();
         cpx<T> *othread = obase + (line_offset(g.out, tj) + lcol);
@@ -818,7 +817,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         const RowBase<T, RB> tb = row_base<T, RB, false>(tj, col);
         const int64_t b0 = tile * W;
         const bool colok = b0 + col < g.B;
-        ColK ck = {0, 0, 0};
+        ColK ck = {0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         cpx<T> *othread = data + b0 + ((int64_t)tj * g.out.sn + col);
         __syncthreads();
@@ -1764,7 +1763,7 @@ static int colfft_any(int32_t elsize, int32_t inverse, const void *src, void *da
     if (apply) {
         PMX_REQUIRE(A == 1 && n1 * n2 == B && B < (1ll << 31), PMX_EINVAL,
                     "fused transfer needs the axis-0 pass of one block");
-        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || t->grad_kind == 1) &&
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || (t->grad_kind == 1 && t->grad_dir > 0)) &&
                     t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
                     PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
         g.t = *t;
@@ -1914,7 +1913,7 @@ extern "C" int pmx_colfft_roundtrip(int32_t elsize, void *data, int64_t N, int64
     const bool apply = t != nullptr;
     if (apply) {
         PMX_REQUIRE(n1 * n2 == B && B < (1ll << 31), PMX_EINVAL, "fused transfer needs the axis-0 pass of one block");
-        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || t->grad_kind == 1) &&
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || (t->grad_kind == 1 && t->grad_dir > 0)) &&
                     t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
                     PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
         g.t = *t;
@@ -2057,7 +2056,7 @@ extern "C" int pmx_colfft_chunk(int32_t elsize, int32_t inverse, void *chunk, vo
     bool apply = t != nullptr;
     if (apply) {
         PMX_REQUIRE(!to_full && B < (1ll << 31), PMX_EINVAL, "the fused transfer belongs to the gathering pass");
-        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || t->grad_kind == 1) &&
+        PMX_REQUIRE(t->gauss_r == 0 && t->deconv_pow == 0 && (t->grad_dir < 0 || t->grad_kind == 0 || (t->grad_kind == 1 && t->grad_dir > 0)) &&
                     t->laplace_pow >= -1 && t->laplace_pow <= 1 && t->grad_dir < 3,
                     PMX_EUNSUPPORTED, "only the closed-form transfers without transcendentals can be fused");
         g.t = *t;

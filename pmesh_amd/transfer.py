@@ -67,8 +67,10 @@ class Transfer(object):
 
     def fusable(self):
         """closed forms without per-element transcendentals can ride on the first pass of c2r ([r4] the
-        finite-difference gradient too: its sines depend on the index along one axis and come from a table)"""
-        return self.gauss_r == 0.0 and self.deconv_pow == 0 and -1 <= self.laplace_pow <= 1
+        finite-difference gradient along axes 1 and 2 too: its factor belongs to the column and comes from a table;
+        along axis 0 it would cost the fused kernels a load per element and stays a kernel of its own)"""
+        return (self.gauss_r == 0.0 and self.deconv_pow == 0 and -1 <= self.laplace_pow <= 1 and
+                (self.grad_dir < 0 or self.grad_kind == 'spectral' or self.grad_dir > 0))
 
     def _cstruct(self):
         t = _abi.Transfer()
