@@ -28,11 +28,16 @@ constexpr int ZSEG = PMX_ZSEG;        // tiles per segment of paint_tile_kernel
 // rows of S - 1 cells: few cells, but every row a piece of its own for halo_merge's atomics) or x (the face of
 // (S - 1) R1 rows of R2 cells: most of the halo's cells, in long rows).  What halo_merge pays for is pieces, not cells:
 // measured at 512^3 in double, z-walk against x-walk, CIC 247 / 317 us, PCS 634 / 517 us (paint_tile_kernel itself
-// the same either way), TSC within 1-2 % both ways.  So: x for PCS, z below.  PMX_WALK_AXIS = 0 / 2 forces one.
+// the same either way), TSC within 1-2 % both ways.  So (round 3): x for PCS, z below.  PMX_WALK_AXIS = 0 / 2 forces one.
 #ifndef PMX_WALK_AXIS
 #define PMX_WALK_AXIS -1
 #endif
-constexpr bool walk_x(int S) { return PMX_WALK_AXIS == 0 || (PMX_WALK_AXIS < 0 && S >= 4); }
+// [r4, second session] With the halo merge gathered by the forward row pass (pmx_rowfft_halo) pieces no longer cost
+// atomics, and what counts is the bytes staged: the x-walk stages 40 % fewer for TSC and CIC too.  Same box, z-walk
+// against x-walk under the deferred merge: r2c of TSC f4 0.530 -> 0.483 ms, TSC f8 0.948 -> 0.890, CIC f8 0.838 -> 0.827
+// (paint_tile_kernel +0.02 ms for TSC, unchanged for CIC).  TSC, whose merge KERNEL never cared, walks along x now; CIC
+// stays on z for the callers that still run the merge kernel (several ranks, a caller's own field: 247 against 317 us).
+constexpr bool walk_x(int S) { return PMX_WALK_AXIS == 0 || (PMX_WALK_AXIS < 0 && S >= 3); }
 #ifndef PMX_TILE_THREADS
 #define PMX_TILE_THREADS 512
 #endif

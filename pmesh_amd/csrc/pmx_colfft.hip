@@ -959,7 +959,7 @@ __device__ __forceinline__ void halo_gather(const HaloSrc &h, int x, int yb, int
     const int S1 = h.S - 1;
     const int R1 = T1 + S1, R2 = T2 + S1;
     const int NA = S1 * R1 * R2, NB = T0 * S1 * R2, HALO = NA + NB + T0 * T1 * S1;
-    const bool wx = h.S >= 4 ? walk_x(4) : walk_x(2);       // (walk_x is the same for S = 2 and 3)
+    const bool wx = h.S >= 4 ? walk_x(4) : (h.S == 3 ? walk_x(3) : walk_x(2));
     const int tx = x / T0, ax = x % T0, ty = yb / T1, by0 = yb % T1;
     const int z = 2 * n, tz = z / T2, cz = z % T2;
     const int txm = tx == 0 ? h.nt0 - 1 : tx - 1, tym = ty == 0 ? h.nt1 - 1 : ty - 1, tzm = tz == 0 ? h.nt2 - 1 : tz - 1;
