@@ -90,10 +90,13 @@ class slabiter(object):
         self.i = xslabiter(self, axis, self.nslabs, self.opti)
 
     def __iter__(self):
+        # (the slabs are numpy-flavoured handles on views of the field, _devarr.DevArr, as the arguments of an apply
+        # callable are: `numpy.abs(slab) ** 2`, `slab[...] *= w` work on the device and write through to the field;
+        # `slab.t` is the tensor)
         for irow in range(self.nslabs):
-            s = self.optimized_view[irow]
-            kk = [x[0] if d != self.axis else x[irow] for d, x in enumerate(self.optx)]
-            ii = [x[0] if d != self.axis else x[irow] for d, x in enumerate(self.opti)]
+            s = DevArr(self.optimized_view[irow])
+            kk = [DevArr(x[0] if d != self.axis else x[irow]) for d, x in enumerate(self.optx)]
+            ii = [DevArr(x[0] if d != self.axis else x[irow]) for d, x in enumerate(self.opti)]
             s.x = kk
             s.i = ii
             s.BoxSize = self.BoxSize
@@ -110,7 +113,7 @@ class xslabiter(slabiter):
 
     def _coords_of(self, irow):
         # every axis but the iterated one keeps its single broadcast entry
-        return [x[irow if d == self.axis else 0] for d, x in enumerate(self.optx)]
+        return [DevArr(x[irow if d == self.axis else 0]) for d, x in enumerate(self.optx)]
 
     def __iter__(self):
         for irow in range(self.nslabs):

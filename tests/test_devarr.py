@@ -171,3 +171,26 @@ def test_a_callable_that_needs_numpy_still_runs_and_never_on_damaged_input(be):
         return numpy.fft.fft(v)
     with pytest.raises(RuntimeError, match='modified its input in place'):
         ck.apply(spoils_then_fails)
+
+
+def test_slab_loops_in_numpy_terms(be):
+    """`for k, slab in zip(field.slabs.x, field.slabs)` (pm.py:87-153; how nbodykit's algorithms walk a field): the
+    slabs are device arrays too — numpy functions apply, an in-place update writes through to the field"""
+    pm = ParticleMesh(BoxSize=[8.0, 6.0, 10.0], Nmesh=[8, 6, 10], dtype='f8')
+    rs = numpy.random.RandomState(11)
+    ck = pm.create(type='real', value=rs.normal(size=(8, 6, 10))).r2c()
+    host = numpy.asarray(ck).copy()
+    k = [numpy.asarray(x.cpu()) for x in ck.x]
+    k2full = sum(ki ** 2 for ki in k)
+    want_total = float(numpy.sum(numpy.abs(host) ** 2 * numpy.exp(-k2full)))
+    total = 0.0
+    nslabs = 0
+    for kk, slab in zip(ck.slabs.x, ck.slabs):
+        k2 = sum(ki ** 2 for ki in kk)
+        total += float(numpy.sum(numpy.abs(slab) ** 2 * numpy.exp(-k2)))
+        slab[...] *= numpy.exp(-0.5 * k2)
+        assert slab.BoxSize is not None and len(slab.x) == 3
+        nslabs += 1
+    assert nslabs == ck.shape[0] or nslabs == max(ck.shape)
+    assert abs(total - want_total) <= 1e-12 * abs(want_total)
+    assert_allclose(numpy.asarray(ck), host * numpy.exp(-0.5 * k2full), rtol=1e-13, atol=1e-15)
