@@ -273,6 +273,8 @@ class Field(NDArrayLike):
     def __setitem__(self, index, y):
         if isinstance(y, Field):
             y = y.value
+        if isinstance(y, DevArr):           # (what a slab loop or an apply callable computed)
+            y = y.t
         if isinstance(y, torch.Tensor):
             if y.data_ptr() == self.value.data_ptr() and tuple(y.shape) == tuple(self.value.shape) \
                     and y.stride() == self.value.stride() and index is Ellipsis:
