@@ -2112,10 +2112,10 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
     const bool relax = pl->exact == 0;
-    // (NNB has nothing to relax: one cell, weight 1)
+    // (NNB: one cell, weight 1 — the same bits either way; the lean per-particle setup of the relaxed form is what it takes)
 #define RT2(K, T, RX) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
                       else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)
-#define RT(K, T) do { if (relax && K != PMX_TUNED_NNB) RT2(K, T, (K != PMX_TUNED_NNB)); else RT2(K, T, false); } while (0)
+#define RT(K, T) do { if (relax) RT2(K, T, true); else RT2(K, T, false); } while (0)
     if (p.canvas_elsize == 8) {
         switch (p.kind) {
         case PMX_TUNED_NNB: RT(PMX_TUNED_NNB, double); break;
@@ -2137,7 +2137,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
 #define RH2(K, T, RX) do { if (sorted) readout_heavy_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); \
                       else readout_heavy_kernel<K, T, TileThreads<K, T>::readout, false, RX><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); } while (0)
-#define RH(K, T) do { if (relax && K != PMX_TUNED_NNB) RH2(K, T, (K != PMX_TUNED_NNB)); else RH2(K, T, false); } while (0)
+#define RH(K, T) do { if (relax) RH2(K, T, true); else RH2(K, T, false); } while (0)
         if (p.canvas_elsize == 8) {
             switch (p.kind) {
             case PMX_TUNED_NNB: RH(PMX_TUNED_NNB, double); break;
