@@ -668,7 +668,7 @@ __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGe
 // The same with the weights of the RELAXED forms (pmx_window_dev.h, Fast<KIND, F>): the first cell is the
 // reference's bit for bit (Tuned<KIND>::first, double precision, no FMA); the weights are polynomials in the one
 // offset d = X - I_ref, formed in double, evaluated in F.
-template <int KIND, bool WHOLE, typename F>
+template <int KIND, bool WHOLE, typename F, bool ORDER0 = false>
 __device__ __forceinline__ void particle_setup_fast(const pmx_painter &p, const BinGeom &g, const int *t,
                                                     const double *x, F (*V)[Tuned<KIND>::S], int *lb)
 {
@@ -677,7 +677,7 @@ __device__ __forceinline__ void particle_setup_fast(const pmx_painter &p, const 
         const double X = x[d] * p.scale[d] + p.translate[d];
         const int I0 = Tuned<KIND>::first(X);
         const F off = (F)(X - (double)(I0 + Fast<KIND, F>::REF));
-        Fast<KIND, F>::axis(off, p.order[d], (F)p.scale[d], V[d]);
+        Fast<KIND, F>::axis(off, ORDER0 ? 0 : p.order[d], (F)p.scale[d], V[d]);      // (ORDER0: the caller knows that no axis is differentiated)
         const int per = (int)p.period[d], siz = (int)p.size[d];
         if (WHOLE || (g.o[d] == 0 && per == siz)) {
             lb[d] = I0 & (tile_ext(d) - 1);
@@ -1045,14 +1045,16 @@ template <int KIND, typename T, int MODE> struct DepositWeights {
 #ifndef PMX_PAINT_WAVES_PCS
 #define PMX_PAINT_WAVES_PCS 1
 #endif
-template <int KIND, bool SORTED> constexpr int paint_min_waves()
+// (MODE 2, the deterministic paint: an opt-in path with a second painter live and the larger carry of the x-walk; it
+// spilled 12 bytes per lane under the TSC budget and keeps the compiler's default instead)
+template <int KIND, bool SORTED, int MODE = 0> constexpr int paint_min_waves()
 {
-    return (KIND == PMX_TUNED_TSC && !SORTED) ? PMX_PAINT_WAVES_TSC
+    return MODE == 2 ? 1 : (KIND == PMX_TUNED_TSC && !SORTED) ? PMX_PAINT_WAVES_TSC
          : (KIND == PMX_TUNED_CIC ? PMX_PAINT_WAVES_CIC : ((KIND == PMX_TUNED_PCS && !SORTED) ? PMX_PAINT_WAVES_PCS : 1));
 }
 
 template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE>
-__global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
+__global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>())) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
                                                             const uint32_t *counts, T *halo, int overwrite,
@@ -1191,6 +1193,297 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED>())) p
                 if (!last && (WALK_X ? a >= T0 : c >= T2)) continue;           // carried to the next tile instead
                 hbase[h] = (T)cell_value<MODE>(lds[Rg::dat(a * R1 + b, c)], inv);
             }
+        }
+        live = !last;
+        __syncthreads();
+      }
+    }
+}
+
+// ---- [r5] 32-bit fixed-point regions for FLOAT canvases (S >= 3) ------------------------------------------------
+// A float canvas keeps 24 bits of a cell; the 64-bit fixed-point region above spends an 8-byte LDS atomic, a bias
+// subtraction and a per-row address selection (split layout) on every stencil point for it.  Here the region holds
+// 32-bit integers in units of 2^-f: half the LDS, `ds_add_rtn_u32` instead of `ds_add_u64` (scripts/deposit32_model.hip:
+// 8.7 against 13.9 clocks per wave instruction on the benchmark's jittered lattice, 6.2 with rows of 64 cells; the
+// returning form costs nothing), all S^3 cells of a particle at immediate offsets of ONE base address (dense rows), and
+// the contribution is the LOW WORD of fma(w, 2^f m, 1.5 2^52) as it stands (two's complement) — one vector instruction
+// per stencil point.
+// 32 bits cannot hold a rigorous worst case (every particle of the segment in one cell) at a useful resolution, so the
+// scale is OPTIMISTIC — room for 16 times the mean density of the segment's tiles — and every add is CHECKED: the
+// atomics return the cell's previous value, the lanes OR them together, and a workgroup that has seen a value at or
+// beyond 2^30 in magnitude (contributions stay below 2^29: no sum can have wrapped unseen) deposits the tile again with
+// 32 times coarser units.  Resolution where nothing overflows: 2^-f = 32 nu m_max 2^-30 <= 3e-8 of a particle's mass at
+// nu = 1 particle per cell; after a retry the unit is <= 2^-24 of the tile's largest cell sum.  Every contribution is
+// rounded once (absolute error 2^-f-1), the region's sum is exact in integers and bit-reproducible, the float canvas
+// gets it rounded once more: inside |d| <= 2e-6 max(1, max |cell|), the tolerance of a float canvas.
+#ifndef PMX_REGION32
+#define PMX_REGION32 1
+#endif
+#ifndef PMX_PITCH32_TSC
+#define PMX_PITCH32_TSC 64
+#endif
+#ifndef PMX_PITCH32_PCS
+#define PMX_PITCH32_PCS 48
+#endif
+#ifndef PMX_TILE32_THREADS_TSC
+#define PMX_TILE32_THREADS_TSC 512
+#endif
+#ifndef PMX_TILE32_THREADS_PCS
+#define PMX_TILE32_THREADS_PCS 512
+#endif
+#ifndef PMX_PAINT32_WAVES_TSC
+#define PMX_PAINT32_WAVES_TSC 6
+#endif
+#ifndef PMX_PAINT32_WAVES_PCS
+#define PMX_PAINT32_WAVES_PCS 4
+#endif
+#ifndef PMX_HEADROOM32
+#define PMX_HEADROOM32 4          // log2 of the room above the mean density of the segment's tiles
+#endif
+#ifndef PMX_RETRY32
+#define PMX_RETRY32 5             // log2 of the coarsening per retry
+#endif
+template <int KIND> struct Tile32 {
+    static constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    static constexpr int P = S == 3 ? PMX_PITCH32_TSC : PMX_PITCH32_PCS;       // row pitch (cells) >= R2
+    static_assert(P >= Rg::R2, "row pitch of the 32-bit region");
+    static constexpr int CELLS = Rg::R0 * Rg::R1 * P;
+    static constexpr int threads = S == 3 ? PMX_TILE32_THREADS_TSC : PMX_TILE32_THREADS_PCS;
+    static constexpr int waves = S == 3 ? PMX_PAINT32_WAVES_TSC : PMX_PAINT32_WAVES_PCS;
+};
+
+// the optimistic scale of a segment: 2^f (mass bound) (weight bound) 2^HEADROOM (mean particles per cell, at least 1) <= 2^30
+__device__ __forceinline__ int fixed_exponent32(const pmx_painter &p, double mb, int64_t n, int ntiles_seg)
+{
+    double wb = 1.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+        if (p.order[d]) wb *= 2.0 * fabs(p.scale[d]) + 2.0;
+    const int e = ((mb > 0) ? ilogb(mb) + 1 : -1000) + (wb > 1.0 ? ilogb(wb) + 1 : 0);
+    const int64_t cells = (int64_t)ntiles_seg * TCELLS;
+    int lg = 0;
+    while ((cells << lg) < n && lg < 40) lg++;                        // mean density <= 2^lg
+    int f = 30 - e - PMX_HEADROOM32 - lg;
+    return f < -1020 ? -1020 : (f > 1020 ? 1020 : f);
+}
+
+// The particles [start, start + count) of a tile's list deposited into its 32-bit region; returns the OR of what the
+// cells held before each add (SIGNED: shifted by 2^30, so that bit 31 says "at or beyond 2^30 in magnitude").
+// PE = 4 / 8: the positions are dense rows of three floats / doubles (one 12-byte load, or a 16- and an 8-byte one, per
+// particle); PE = 0: any strides and element size.  !SIGNED implies a scalar mass and no differentiated axis.
+template <int PE> struct PosRow { double x[3]; };
+template <> struct PosRow<4> { float x[3]; };
+template <int PE> __device__ __forceinline__ PosRow<PE> pos_row(const DVec &pos, int64_t i)
+{
+    PosRow<PE> r;
+    if constexpr (PE == 4) {
+        // (three dwords in one instruction: rows are 4-byte aligned)
+        const float *q = (const float *)(pos.data + i * 12);
+        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
+    } else if constexpr (PE == 8) {
+        const double *q = (const double *)(pos.data + i * 24);
+        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
+    } else {
+        r.x[0] = pos.get(i, 0); r.x[1] = pos.get(i, 1); r.x[2] = pos.get(i, 2);
+    }
+    return r;
+}
+
+template <int KIND, int TTHREADS, bool SORTED, int PE, bool WHOLE, bool SIGNED>
+__device__ __forceinline__ uint32_t tile_deposit32(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
+                                                   const DVec &mass, double mass_scalar, const uint32_t *list,
+                                                   int64_t start, int count, uint32_t *lds, double scale)
+{
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, P = Tile32<KIND>::P;
+    constexpr bool SWAP = UNROLL == 2;
+    // stencil points in groups of G atomics; the values a group returns are folded into the guard behind the NEXT
+    // group's atomics: G registers of returns in flight instead of S^3 (left alone the compiler issues all S^3 first)
+    constexpr int G = S == 3 ? 9 : 8, NG = S * S * S / G;
+    uint32_t guard = 0;
+    const uint32_t *tl = list + start;
+    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+        // both list entries, then both rows: no load waits behind a branch (an entry beyond the end reads the last one)
+        bool ok[UNROLL];
+        uint32_t id[UNROLL];
+        PosRow<PE> row[UNROLL];
+        double m[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int j = j0 + u * TTHREADS;
+            ok[u] = j < count;
+            const int jc = ok[u] ? j : count - 1;
+            id[u] = SORTED ? (uint32_t)jc : tl[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            row[u] = pos_row<PE>(pos, SORTED ? start + id[u] : (int64_t)id[u]);
+            // (sorted: `id` is the list slot; a per-particle mass lives at the row the list names)
+            if (SIGNED) m[u] = mass.data ? mass.get(SORTED ? (int64_t)tl[id[u]] : (int64_t)id[u], 0) : mass_scalar;
+        }
+        if (SWAP && (threadIdx.x & 1)) {
+            // (odd lanes take their second particle first: see tile_deposit)
+            const PosRow<PE> tr = row[0]; row[0] = row[1]; row[1] = tr;
+            const bool to = ok[0]; ok[0] = ok[1]; ok[1] = to;
+            if (SIGNED) { const double tm = m[0]; m[0] = m[1]; m[1] = tm; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (!ok[u]) continue;
+            int lb[3];
+            double V[3][S];
+            const double x[3] = {(double)row[u].x[0], (double)row[u].x[1], (double)row[u].x[2]};
+            particle_setup_fast<KIND, WHOLE, double, !SIGNED>(p, g, t, x, V, lb);
+            // (a plan that no longer matches the positions must not index outside the region)
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            const double mu = (SIGNED ? m[u] : mass_scalar) * scale;
+#pragma unroll
+            for (int a = 0; a < S; a++) V[0][a] *= mu;
+            uint32_t *base = lds + (lb[0] * R1 + lb[1]) * P + lb[2];
+            uint32_t old[2][G];
+            double fb = 0;
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+#pragma unroll
+                for (int k = 0; k < G; k++) {
+                    const int q = gi * G + k, a = q / (S * S), b = (q / S) % S, c = q % S;
+                    if (c == 0) fb = V[0][a] * V[1][b];
+                    const double r = __builtin_fma(fb, V[2][c], FIXED_MAGIC);
+                    old[gi & 1][k] = atomicAdd(base + (a * R1 + b) * P + c, (uint32_t)__double_as_longlong(r));
+                }
+                if (gi > 0) {
+#pragma unroll
+                    for (int k = 0; k < G; k++) guard |= SIGNED ? old[(gi - 1) & 1][k] + 0x40000000u : old[(gi - 1) & 1][k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < G; k++) guard |= SIGNED ? old[(NG - 1) & 1][k] + 0x40000000u : old[(NG - 1) & 1][k];
+        }
+    }
+    return SIGNED ? guard & 0x80000000u : guard & 0xC0000000u;
+}
+
+// paint_tile_kernel for a float canvas with the 32-bit region: the same walk (segments of ZSEG tiles along x, the
+// x-face carried in LDS), the same owned-box stores and halo staging (halo_merge_kernel / pmx_rowfft_halo read them
+// the same way).  SIGNED: contributions of either sign (derivative weights, per-particle masses).  WHOLE (the block is the
+// whole periodic mesh: one rank) and PE (bytes of a position element) are the launcher's to know: every form of the
+// deposit loop is a kernel of its own with its own registers.
+template <int KIND, int TTHREADS, bool SORTED, bool SIGNED, bool WHOLE, int PE>
+__global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
+                                                            DVec mass, double mass_scalar,
+                                                            const uint32_t *list, const int64_t *offsets,
+                                                            const uint32_t *counts, float *halo, int overwrite,
+                                                            const double *mstats, int want_odd)
+{
+    if (!batch_is_mine(mstats, want_odd)) return;
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, P = Tile32<KIND>::P, CELLS = Tile32<KIND>::CELLS;
+    __shared__ uint32_t lds[CELLS];
+    __shared__ uint32_t flag[2];
+    constexpr bool WALK_X = walk_x(S);
+    constexpr int NCARRY = WALK_X ? (S - 1) * R1 * Rg::R2 : Rg::R0 * R1 * (S - 1);
+    constexpr int CPT = (NCARRY + TTHREADS - 1) / TTHREADS;
+    const int ntw = WALK_X ? g.nt[0] : g.nt[2];
+    const int64_t tstride = WALK_X ? (int64_t)g.nt[1] * g.nt[2] : 1;
+    const int nseg = (ntw + ZSEG - 1) / ZSEG;
+    const int64_t ncolumn = g.ntiles / ntw;
+    const int64_t nwork = ncolumn * nseg;
+    if (threadIdx.x < 2) flag[threadIdx.x] = 0;
+    int trial = 0;                              // flag[trial & 1] is the overflow word of the next deposit
+    for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+      const int64_t column = w / nseg;
+      const int seg = (int)(w - column * nseg);
+      const int t2a = seg * ZSEG, t2b = (t2a + ZSEG < ntw) ? t2a + ZSEG : ntw;
+      const int64_t tile0 = WALK_X ? column : column * ntw;
+      bool live = false;
+      int64_t nseg_part = 0;
+      for (int t2 = t2a; t2 < t2b; t2++) {
+          const uint32_t c = counts[tile0 + t2 * tstride];
+          nseg_part += c < (uint32_t)g.chunk ? c : (uint32_t)g.chunk;
+      }
+      int f = fixed_exponent32(p, mstats ? mstats[0] : fabs(mass_scalar), nseg_part, t2b - t2a);
+      for (int t2 = t2a; t2 < t2b; t2++) {
+        const int64_t tile = tile0 + t2 * tstride;
+        const bool last = (t2 == t2b - 1);
+        int t[3];
+        tile_coords(g, tile, t);
+        const int64_t start = offsets[tile];
+        const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
+        if (count == 0 && !overwrite && !live) continue;
+        constexpr bool TOUCH = !SORTED && S >= 4;
+        uint32_t touched = 0;
+        if constexpr (TOUCH) touched = list_touch(list, start, count);
+        int carry[CPT];
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < CPT; u++) {
+                const int q = threadIdx.x + u * TTHREADS;
+                if (q < NCARRY) {
+                    if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; carry[u] = (int)lds[(T0 * R1 + r) * P + c]; }
+                    else { const int c = q % (S - 1), r = q / (S - 1); carry[u] = (int)lds[r * P + T2 + c]; }
+                }
+            }
+            __syncthreads();
+        }
+        for (;;) {
+            for (int q = threadIdx.x; q < CELLS; q += TTHREADS) lds[q] = 0;
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < CPT; u++) {
+                    const int q = threadIdx.x + u * TTHREADS;
+                    if (q < NCARRY) {
+                        if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; lds[r * P + c] = (uint32_t)carry[u]; }
+                        else { const int c = q % (S - 1), r = q / (S - 1); lds[r * P + c] = (uint32_t)carry[u]; }
+                    }
+                }
+                __syncthreads();
+            }
+            if constexpr (TOUCH) list_touch_done(touched);
+            const uint32_t over = tile_deposit32<KIND, TTHREADS, SORTED, PE, WHOLE, SIGNED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, pow2(f));
+            if (over) flag[trial & 1] = 1;
+            __syncthreads();
+            const bool again = flag[trial & 1] != 0 && f > -1000;
+            trial++;
+            if (threadIdx.x == 0) flag[trial & 1] = 0;            // (the other word: read next behind two more barriers)
+            if (!again) break;
+            // some cell came within a factor 2 of the 32 bits: the tile once more in coarser units (the carried
+            // face with it, rounded to nearest)
+            f -= PMX_RETRY32;
+#pragma unroll
+            for (int u = 0; u < CPT; u++) carry[u] = (carry[u] + (1 << (PMX_RETRY32 - 1))) >> PMX_RETRY32;
+            __syncthreads();
+        }
+        const double inv = pow2(-f);
+        // owned box -> canvas, plain stores in rows of T2 cells
+        for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
+            const int c = q % T2, r = q / T2;
+            const int b = r % T1, a = r / T1;
+            int64_t goff;
+            bool in = true;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const int l = t[d] * tile_ext(d) - g.o[d] + (d == 0 ? a : (d == 1 ? b : c));
+                in = in && l >= 0 && l < p.size[d];
+            }
+            if (in && region_cell(p, g, t, a, b, c, &goff)) {
+                const float v = (float)((double)(int)lds[(a * R1 + b) * P + c] * inv);
+                float *dst = (float *)(canvas + goff);
+                if (overwrite) *dst = v;
+                else *dst += v;
+            }
+        }
+        // halo -> staging (compact numbering, contiguous writes)
+        float *hbase = halo + tile * (int64_t)Rg::HALO;
+        for (int h = threadIdx.x; h < Rg::HALO; h += TTHREADS) {
+            int a, b, c;
+            Rg::halo_decode(h, &a, &b, &c);
+            if (!last && (WALK_X ? a >= T0 : c >= T2)) continue;           // carried to the next tile instead
+            hbase[h] = (float)((double)(int)lds[(a * R1 + b) * P + c] * inv);
         }
         live = !last;
         __syncthreads();
@@ -1929,8 +2222,18 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
     }
 #define PT3(K, TT, MD, ODD, PP, CV, HL, OW) do { if (sorted) paint_tile_kernel<K, TT, TileThreads<K, TT>::paint, true, MD><<<pgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, HL, OW, mstats, ODD, dexp, p); \
                    else paint_tile_kernel<K, TT, TileThreads<K, TT>::paint, false, MD><<<pgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, HL, OW, mstats, ODD, dexp, p); } while (0)
+    // [r5] float canvases, S >= 3: the 32-bit region (paint_tile32_kernel); contributions of either sign need its SIGNED guard
+    const bool signed32 = mass.data != nullptr || ms < 0 || p.order[0] != 0 || p.order[1] != 0 || p.order[2] != 0;
+    const bool dense32 = pos.stride1 == pos.elsize && pos.stride0 == 3 * pos.elsize;      // (always so for the plan's sorted copy)
+    bool whole32 = true;
+    for (int d = 0; d < 3; d++) whole32 = whole32 && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
+#define PT32L(K, SD, SG, WH, PE_) paint_tile32_kernel<K, Tile32<K>::threads, SD, SG, WH, PE_><<<pgrid, Tile32<K>::threads, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, (float *)halo, overwrite, mstats, 0)
+#define PT32P(K, SD, SG, WH) do { if (!dense32) { if constexpr (!SD) PT32L(K, false, SG, WH, 0); } else if (pos.elsize == 8) PT32L(K, SD, SG, WH, 8); else PT32L(K, SD, SG, WH, 4); } while (0)
+#define PT32W(K, SD, SG) do { if (whole32) PT32P(K, SD, SG, true); else PT32P(K, SD, SG, false); } while (0)
+#define PT32(K, SG) do { if (sorted) PT32W(K, true, SG); else PT32W(K, false, SG); } while (0)
 #define PT(K) do { if (run_fixed && det) PT3(K, double, 2, 0, pd, pl->dscratch, dhalo, 1); \
-                   else if (run_fixed) PT3(K, T, 1, 0, p, canvas, halo, overwrite); \
+                   else if (run_fixed) { if constexpr (PMX_REGION32 && std::is_same<T, float>::value && Tuned<K>::S >= 3) { if (signed32) PT32(K, true); else PT32(K, false); } \
+                                         else PT3(K, T, 1, 0, p, canvas, halo, overwrite); } \
                    if (run_float) PT3(K, T, 0, (run_fixed ? 1 : 0), p, canvas, halo, overwrite); } while (0)
     // (a batch is served either by the fixed-point or by the floating-point kernels: the merge of the other
     // finds only zeros in its staging buffer... the deterministic one has a staging buffer of its own)
@@ -1945,6 +2248,10 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
     }
 #undef PT
 #undef PT3
+#undef PT32
+#undef PT32W
+#undef PT32P
+#undef PT32L
 #undef HM
     // the pieces of crowded tiles (none for a uniform batch: the kernel then returns at once)
     const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
