@@ -536,8 +536,12 @@ def main():
         ach = algorithmic_bytes(dom, e, pe, nu, me) * units / (single[dom] * 1e-3) / 1e9
         binned = any(e[3] for e in _window.bin_cache().entries)
         if binned:
-            kname = {'paint': 'paint_tile_kernel' if halo_deferred[0] else 'paint_tile_kernel+halo_merge_kernel',
-                     'readout': 'readout_tile_kernel', 'apply': 'transfer_kernel'}[dom]
+            # (float canvases under TSC / PCS paint through the 32-bit regions; the default readout of dense rows is
+            # the lean loop: the names rocprofv3 shows)
+            pk = 'paint_tile32_kernel' if (args.dtype == 'f4' and args.window in ('tsc', 'pcs') and not args.deterministic) else 'paint_tile_kernel'
+            kname = {'paint': pk if halo_deferred[0] else pk + '+halo_merge_kernel',
+                     'readout': 'readout_tile_lean_kernel' if (not args.host_arrays and _window.EXACT is False) else 'readout_tile_kernel',
+                     'apply': 'transfer_kernel'}[dom]
         else:
             kname = {'paint': 'paint_tuned_kernel', 'readout': 'readout_tuned_kernel',
                      'apply': 'transfer_kernel'}[dom]

@@ -440,6 +440,247 @@ __global__ void __launch_bounds__(TBLOCK) bin_block_kernel(pmx_painter p, BinGeo
     }
 }
 
+// a position row in registers: PE = 4 / 8: dense rows of three floats / doubles; 0: any strides and element size
+template <int PE> struct PosRow { double x[3]; };
+template <> struct PosRow<4> { float x[3]; };
+template <int PE> __device__ __forceinline__ PosRow<PE> pos_row(const DVec &pos, int64_t i)
+{
+    PosRow<PE> r;
+    if constexpr (PE == 4) {
+        // (three dwords in one instruction: rows are 4-byte aligned)
+        const float *q = (const float *)(pos.data + i * 12);
+        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
+    } else if constexpr (PE == 8) {
+        const double *q = (const double *)(pos.data + i * 24);
+        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
+    } else {
+        r.x[0] = pos.get(i, 0); r.x[1] = pos.get(i, 1); r.x[2] = pos.get(i, 2);
+    }
+    return r;
+}
+
+// ---- [r5] the block form of the single-pass rebuild for dense rows, as a loop of its own ----------------------------
+// bin_block_kernel above is bound by instruction issue (~250 vector + scalar instructions per 64 rows; the 3.8 GB it
+// moves would take 0.68 ms, it takes 0.95-1.0, and 0.9 for 12-byte rows that move 2.1 GB).  Most of those instructions
+// are not the binning: rows staged through LDS in 16-byte pieces behind two workgroup barriers per trip, bounds tests
+// on every piece, the element size of the rows looked up per component, the general wrap of the block on every axis.
+// Here every lane loads its own rows (PE = 4: one 12-byte load per row; PE = 8: a 16- and an 8-byte one — the 64 rows
+// of a wave are one contiguous piece of memory either way), the next trip's rows are in flight while this trip's are
+// binned, the trips need no barrier, and WHOLE (the block is the whole periodic mesh: the one-rank case) is the
+// launcher's to know.  Same table, same slots, same flags: the list is a permutation of the other form's within each tile.
+template <int PE> __device__ __forceinline__ PosRow<PE> dense_row(const char *data, int64_t i)
+{
+    PosRow<PE> r;
+    if constexpr (PE == 4) {
+        const float *q = (const float *)(data + i * 12);
+        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
+    } else {
+        const double *q = (const double *)(data + i * 24);
+        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
+    }
+    return r;
+}
+
+// bucket of a row: its tile, or g.ntiles if it touches no local cell (particle_bucket); WHOLE: every axis is the whole periodic mesh, a multiple of the tile
+template <int KIND, bool WHOLE, typename R>
+__device__ __forceinline__ int row_tile(const pmx_painter &p, const BinGeom &g, const R &row)
+{
+    if constexpr (!WHOLE) {
+        const double x[3] = {(double)row.x[0], (double)row.x[1], (double)row.x[2]};
+        return (int)particle_bucket<KIND>(p, g, x);
+    } else {
+        bool ok = true;
+        int tt[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double X = (double)row.x[d] * p.scale[d] + p.translate[d];
+            ok = ok && (fabs(X) < 1073741824.0);               // NaN / out of int range: dropped
+            int w = Tuned<KIND>::first(ok ? X : 0.0);
+            const int period = (int)p.period[d];
+            w += (w < 0) ? period : 0;
+            w -= (w >= period) ? period : 0;
+            if ((unsigned)w >= (unsigned)period) { w %= period; if (w < 0) w += period; }
+            tt[d] = (int)((unsigned)w / (unsigned)tile_ext(d));
+        }
+        const int tb = (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+        return ok ? tb : (int)g.ntiles;
+    }
+}
+
+#ifndef PMX_LEAN_U
+#define PMX_LEAN_U 4
+#endif
+template <int KIND, int PE, bool WHOLE>
+__global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
+                                                          uint32_t *counts, uint32_t *flags, const int64_t *offsets,
+                                                          uint32_t *list, uint32_t *host_flag)
+{
+    constexpr int U = PMX_LEAN_U, BLOCK_ITERS = BLOCK_ROWS / (TBLOCK * U);
+    static_assert(BLOCK_ITERS * TBLOCK * U == BLOCK_ROWS, "rows of a block");
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu, DIRECT = 0xFFu;
+    __shared__ uint32_t keys[BLOCK_HT], cnt[BLOCK_HT];
+    __shared__ int64_t first[BLOCK_HT], last[BLOCK_HT];
+    __shared__ uint32_t where[BLOCK_ITERS * U * TBLOCK];
+    const int lane = threadIdx.x & 63;
+    // row (it, u) of this lane within a trip: the U chunks of 64 rows a wave takes follow each other in memory, and its
+    // U requests reach a tile's counter back to back: the list keeps the rows of a wave in their order (with the chunks
+    // of a wave TBLOCK rows apart the tile kernels read rows 0-63, 256-319, 512-575, ... of a trip in turn: PCS readout
+    // 1.63 -> 1.84 ms at U = 4)
+    const int wave0 = (int)(threadIdx.x >> 6) * (U * 64) + lane;
+    auto lrow = [&](int u) { return wave0 + u * 64; };
+    uint32_t nbreaks = 0, nsampled = 0;
+    const char *data = pos.data;
+    for (int64_t blk = blockIdx.x; blk * BLOCK_ROWS < n; blk += gridDim.x) {
+        const int64_t row0 = blk * BLOCK_ROWS;
+        __syncthreads();
+        for (int s = threadIdx.x; s < BLOCK_HT; s += TBLOCK) { keys[s] = EMPTY; cnt[s] = 0; }
+        __syncthreads();
+        PosRow<PE> next[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = row0 + lrow(u);
+            next[u] = dense_row<PE>(data, i < n ? i : n - 1);           // (a row beyond the end reads the last one: no load behind a branch)
+        }
+#pragma unroll 1
+        for (int it = 0; it < BLOCK_ITERS; it++) {
+            const int64_t base = row0 + (int64_t)it * (TBLOCK * U);
+            PosRow<PE> row[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) row[u] = next[u];
+            if (it + 1 < BLOCK_ITERS) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t i = base + TBLOCK * U + lrow(u);
+                    next[u] = dense_row<PE>(data, i < n ? i : n - 1);
+                }
+            }
+            // the U rows of a lane side by side: their table requests travel together (two LDS round trips per trip —
+            // the claim of an entry, the add to its counter — instead of two per row: with the rows loaded leanly the
+            // chain of dependent LDS operations behind the leaders is what the trip waits for)
+            int t[U], leader[U];
+            unsigned long long same[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = base + lrow(u);
+                t[u] = i < n ? row_tile<KIND, WHOLE>(p, g, row[u]) : -1;
+#if defined(PMX_EXPERIMENT) && defined(PMX_EXP_LEANBIN)
+                // timing experiments (wrong lists): 1: no match loop, no table: the list written sequentially;
+                // 2: no list either (the tile ids summed into the coherence counter); 3: the rows summed, no tile
+                if (PMX_EXP_LEANBIN == 1) { where[(it * U + u) * TBLOCK + threadIdx.x] = t[u] >= 0 ? (uint32_t)(t[u] & 1) : EMPTY; continue; }
+                if (PMX_EXP_LEANBIN == 2) { nbreaks += (uint32_t)t[u]; where[(it * U + u) * TBLOCK + threadIdx.x] = EMPTY; continue; }
+                if (PMX_EXP_LEANBIN == 3) { nbreaks += (uint32_t)(int)((double)row[u].x[0] + (double)row[u].x[1] + (double)row[u].x[2]); where[(it * U + u) * TBLOCK + threadIdx.x] = EMPTY; continue; }
+#endif
+                // the lanes that share my tile (ballots only)
+                unsigned long long sm = 0, active = __ballot(t[u] >= 0);
+                while (active) {
+                    const int ld = __ffsll((long long)active) - 1;
+                    const int lt = __shfl(t[u], ld);
+                    const unsigned long long m = __ballot(t[u] == lt) & active;
+                    if (t[u] == lt) sm = m;
+                    active &= ~m;
+                }
+                same[u] = sm;
+                leader[u] = t[u] >= 0 ? __ffsll((long long)sm) - 1 : lane;
+                if (u == 0 && ((((uint32_t)(base / (TBLOCK * U))) * 2654435761u) >> 27) == 0) {   // coherence sample, as in bin_count_kernel
+                    const int tprev = __shfl_up(t[u], 1);
+                    nbreaks += (uint32_t)__popcll(__ballot(lane > 0 && t[u] >= 0 && t[u] != tprev));
+                    nsampled += (uint32_t)__popcll(__ballot(t[u] >= 0));
+                }
+            }
+#if defined(PMX_EXPERIMENT) && defined(PMX_EXP_LEANBIN)
+            continue;
+#endif
+            bool lead[U];
+            uint32_t h[U], k[U], e[U], w[U], bd[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                lead[u] = t[u] >= 0 && lane == leader[u];
+                h[u] = ((uint32_t)t[u] * 2654435761u) >> 25;               // 7 bits: BLOCK_HT = 128
+                k[u] = 0; w[u] = 0; bd[u] = 0; e[u] = DIRECT;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (lead[u]) k[u] = atomicCAS(&keys[h[u]], EMPTY, (uint32_t)t[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (lead[u]) {
+                    if (k[u] == EMPTY || k[u] == (uint32_t)t[u]) e[u] = h[u];
+                    else {
+                        // (the entry belongs to another tile: the next ones, as many as seven)
+                        uint32_t hh = h[u];
+                        for (int probe = 1; probe < 8; probe++) {
+                            hh = (hh + 1) & (BLOCK_HT - 1);
+                            const uint32_t kk = atomicCAS(&keys[hh], EMPTY, (uint32_t)t[u]);
+                            if (kk == EMPTY || kk == (uint32_t)t[u]) { e[u] = hh; break; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (lead[u]) {
+                    if (e[u] != DIRECT) w[u] = (e[u] << 24) | atomicAdd(&cnt[e[u]], (uint32_t)__popcll(same[u]));
+                    else {
+                        // no room in the table: this group asks the global counter itself
+                        w[u] = DIRECT << 24;
+                        bd[u] = atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) w[u] = __shfl(w[u], leader[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = base + lrow(u);
+                const uint32_t rank = (uint32_t)__popcll(same[u] & (((unsigned long long)1 << lane) - 1));
+                uint32_t wh = EMPTY;
+                if (t[u] >= 0) {
+                    if ((w[u] >> 24) == DIRECT) {
+                        // (rare) written at once: list[offsets[t] + b + rank]
+                        const uint32_t b0 = __shfl(bd[u], leader[u]);
+                        const int64_t slot = offsets[t[u]] + (int64_t)b0 + rank;
+                        if (slot < offsets[t[u] + 1]) list[slot] = (uint32_t)i;
+                        else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
+                    } else wh = w[u] + rank;
+                }
+                where[(it * U + u) * TBLOCK + threadIdx.x] = wh;
+            }
+        }
+        __syncthreads();
+        // one request per tile of the block to its global counter
+        for (int s = threadIdx.x; s < BLOCK_HT; s += TBLOCK) {
+            if (keys[s] != EMPTY) {
+                const uint32_t t = keys[s];
+                const uint32_t b = atomicAdd(&counts[t], cnt[s]);
+                first[s] = offsets[t] + b;
+                last[s] = offsets[t + 1];
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < BLOCK_ITERS; it++) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t w = where[(it * U + u) * TBLOCK + threadIdx.x];
+                if (w == EMPTY) continue;
+                const int64_t i = row0 + (int64_t)it * (TBLOCK * U) + lrow(u);
+#if defined(PMX_EXPERIMENT) && defined(PMX_EXP_LEANBIN)
+                list[i] = (uint32_t)i + (w & 1);
+                continue;
+#endif
+                const uint32_t e = w >> 24;
+                const int64_t slot = first[e] + (w & 0xFFFFFFu);
+                if (slot < last[e]) list[slot] = (uint32_t)i;
+                else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
+            }
+        }
+    }
+    if (lane == 0 && (nsampled || nbreaks == 0xFFFFFFFFu)) {
+        atomicAdd(&flags[1], nbreaks);
+        atomicAdd(&flags[2], nsampled);
+    }
+}
+
 // exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup
 static __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
                                                         unsigned long long *cursor, const uint32_t *gate)
@@ -740,6 +981,14 @@ __device__ __forceinline__ int fixed_exponent(const pmx_painter &p, double mb, i
     return f < -1020 ? -1020 : (f > 1020 ? 1020 : f);                  // (2^f and 2^-f stay normal doubles)
 }
 __device__ __forceinline__ double pow2(int f) { return __longlong_as_double((long long)(1023 + f) << 52); }
+// a wave-uniform double (loaded through a vector register) moved to scalar registers
+__device__ __forceinline__ double uniform_double(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // The particles [start, start + count) of a tile's list are deposited into its LDS region.
 // WF: double / float = the weights of the RELAXED form in that precision (fixed-point regions of the S >= 3 windows:
@@ -766,13 +1015,14 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     // benchmark's pattern from 12.1 to 8.4 clocks there — and changed nothing in this kernel: TSC f4 paint 1.65 / 1.65 ms,
     // PCS 2.77 / 2.90, with the odd-lane swap on top 1.78 / 3.22.  The kernel is not waiting for those conflicts.)
     double sink = 0;
+    const uint32_t *tl = list + start;       // (a wave-uniform base + the lane's entry: nothing per thread for the compiler to keep across tiles)
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             int j = j0 + u * TTHREADS;
-            idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
+            idx[u] = j < count ? (sorted ? start + j : (int64_t)tl[j]) : -1;
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
@@ -880,13 +1130,14 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1;
+    const uint32_t *tl = list + start;
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         int64_t idx[UNROLL];
         double x[UNROLL][3];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             int j = j0 + u * TTHREADS;
-            idx[u] = j < count ? (sorted ? start + j : (int64_t)list[start + j]) : -1;
+            idx[u] = j < count ? (sorted ? start + j : (int64_t)tl[j]) : -1;
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
@@ -1053,7 +1304,10 @@ template <int KIND, bool SORTED, int MODE = 0> constexpr int paint_min_waves()
          : (KIND == PMX_TUNED_CIC ? PMX_PAINT_WAVES_CIC : ((KIND == PMX_TUNED_PCS && !SORTED) ? PMX_PAINT_WAVES_PCS : 1));
 }
 
-template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE>
+// [r5] WHOLE (the block is the whole periodic mesh) and PE (bytes of a position element) are the launcher's to know: one
+// form of the deposit loop per kernel, with its own registers (with all four in one kernel the fixed-point TSC kernel on a
+// double canvas kept per-thread addresses of every form alive across the tile loop and spilled 28 bytes per lane)
+template <int KIND, typename T, int TTHREADS, bool SORTED, int MODE, bool WHOLE, int PE>
 __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>())) paint_tile_kernel(pmx_painter p, BinGeom g, char *canvas, DVec pos,
                                                             DVec mass, double mass_scalar,
                                                             const uint32_t *list, const int64_t *offsets,
@@ -1094,7 +1348,6 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
     const int nseg = (ntw + ZSEG - 1) / ZSEG;
     const int64_t ncolumn = g.ntiles / ntw;
     const int64_t nwork = ncolumn * nseg;
-    const bool whole = whole_mesh(pwr, g);
     for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
       const int64_t column = w / nseg;
       const int seg = (int)(w - column * nseg);
@@ -1110,7 +1363,8 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
               const uint32_t c = counts[tile0 + t2 * tstride];
               nseg_part += c < (uint32_t)g.chunk ? c : (uint32_t)g.chunk;
           }
-          const int f = MODE == 2 ? *dexp : fixed_exponent(pwr, mstats ? mstats[0] : fabs(mass_scalar), nseg_part);
+          // (the mass bound as a scalar: as a vector register it lived — and was spilled — across the whole kernel)
+          const int f = MODE == 2 ? *dexp : fixed_exponent(pwr, uniform_double(mstats ? mstats[0] : fabs(mass_scalar)), nseg_part);
           scale = pow2(f);
           inv = pow2(-f);
       }
@@ -1131,6 +1385,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
 #pragma unroll
             for (int u = 0; u < CPT; u++) {
                 int q = threadIdx.x + u * TTHREADS;
+                asm volatile("" : "+v"(q));      // (opaque: the divisions below stay inside the tile loop instead of living in registers — and spilling — across the deposit)
                 if (q < NCARRY) {
                     if (WALK_X) {
                         const int c = q % Rg::R2, r = q / Rg::R2;             // r = a R1 + b of the destination, a < S - 1
@@ -1149,6 +1404,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
 #pragma unroll
             for (int u = 0; u < CPT; u++) {
                 int q = threadIdx.x + u * TTHREADS;
+                asm volatile("" : "+v"(q));      // (opaque: the divisions below stay inside the tile loop instead of living in registers — and spilling — across the deposit)
                 if (q < NCARRY) {
                     if (WALK_X) {
                         const int c = q % Rg::R2, r = q / Rg::R2;
@@ -1162,7 +1418,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
             __syncthreads();
         }
         if constexpr (TOUCH) list_touch_done(touched);
-        tile_deposit_any<KIND, TTHREADS, SORTED, FIXED, typename DepositWeights<KIND, T, MODE>::type>(whole, pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+        tile_deposit<KIND, TTHREADS, SORTED, FIXED, PE, WHOLE, typename DepositWeights<KIND, T, MODE>::type>(pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
@@ -1187,7 +1443,9 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
         // halo -> staging (compact numbering, contiguous writes)
         if (S > 1) {
             T *hbase = halo + tile * (int64_t)Rg::HALO;
-            for (int h = threadIdx.x; h < Rg::HALO; h += TTHREADS) {
+            int h0 = threadIdx.x;
+            asm volatile("" : "+v"(h0));      // (opaque: no per-thread staging address kept — and spilled — across the tile loop)
+            for (int h = h0; h < Rg::HALO; h += TTHREADS) {
                 int a, b, c;
                 Rg::halo_decode(h, &a, &b, &c);
                 if (!last && (WALK_X ? a >= T0 : c >= T2)) continue;           // carried to the next tile instead
@@ -1272,24 +1530,6 @@ __device__ __forceinline__ int fixed_exponent32(const pmx_painter &p, double mb,
 // cells held before each add (SIGNED: shifted by 2^30, so that bit 31 says "at or beyond 2^30 in magnitude").
 // PE = 4 / 8: the positions are dense rows of three floats / doubles (one 12-byte load, or a 16- and an 8-byte one, per
 // particle); PE = 0: any strides and element size.  !SIGNED implies a scalar mass and no differentiated axis.
-template <int PE> struct PosRow { double x[3]; };
-template <> struct PosRow<4> { float x[3]; };
-template <int PE> __device__ __forceinline__ PosRow<PE> pos_row(const DVec &pos, int64_t i)
-{
-    PosRow<PE> r;
-    if constexpr (PE == 4) {
-        // (three dwords in one instruction: rows are 4-byte aligned)
-        const float *q = (const float *)(pos.data + i * 12);
-        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
-    } else if constexpr (PE == 8) {
-        const double *q = (const double *)(pos.data + i * 24);
-        r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2];
-    } else {
-        r.x[0] = pos.get(i, 0); r.x[1] = pos.get(i, 1); r.x[2] = pos.get(i, 2);
-    }
-    return r;
-}
-
 template <int KIND, int TTHREADS, bool SORTED, int PE, bool WHOLE, bool SIGNED>
 __device__ __forceinline__ uint32_t tile_deposit32(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                                    const DVec &mass, double mass_scalar, const uint32_t *list,
@@ -1298,12 +1538,18 @@ __device__ __forceinline__ uint32_t tile_deposit32(const pmx_painter &p, const B
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, P = Tile32<KIND>::P;
-    constexpr bool SWAP = UNROLL == 2;
+#ifndef PMX_SWAP32
+#define PMX_SWAP32 1
+#endif
+    constexpr bool SWAP = PMX_SWAP32 && UNROLL == 2;
     // stencil points in groups of G atomics; the values a group returns are folded into the guard behind the NEXT
     // group's atomics: G registers of returns in flight instead of S^3 (left alone the compiler issues all S^3 first)
     constexpr int G = S == 3 ? 9 : 8, NG = S * S * S / G;
     uint32_t guard = 0;
     const uint32_t *tl = list + start;
+    // ([r5] measured and dropped once more, now that this loop is bound by the LDS: the 64 list entries of a wave dealt to
+    // its lanes so that the 16 lanes the LDS serves together hold every second entry — 0.96 -> 1.07 ms on config 3, PCS
+    // 1.74 -> 1.83: the permuted 12-byte row loads cost more than the conflicts they avoid.)
     for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
         // both list entries, then both rows: no load waits behind a branch (an entry beyond the end reads the last one)
         bool ok[UNROLL];
@@ -1405,7 +1651,7 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
           const uint32_t c = counts[tile0 + t2 * tstride];
           nseg_part += c < (uint32_t)g.chunk ? c : (uint32_t)g.chunk;
       }
-      int f = fixed_exponent32(p, mstats ? mstats[0] : fabs(mass_scalar), nseg_part, t2b - t2a);
+      int f = fixed_exponent32(p, uniform_double(mstats ? mstats[0] : fabs(mass_scalar)), nseg_part, t2b - t2a);
       for (int t2 = t2a; t2 < t2b; t2++) {
         const int64_t tile = tile0 + t2 * tstride;
         const bool last = (t2 == t2b - 1);
@@ -1421,7 +1667,8 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
         if (live) {
 #pragma unroll
             for (int u = 0; u < CPT; u++) {
-                const int q = threadIdx.x + u * TTHREADS;
+                int q = threadIdx.x + u * TTHREADS;
+                    asm volatile("" : "+v"(q));      // (opaque: see paint_tile_kernel)
                 if (q < NCARRY) {
                     if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; carry[u] = (int)lds[(T0 * R1 + r) * P + c]; }
                     else { const int c = q % (S - 1), r = q / (S - 1); carry[u] = (int)lds[r * P + T2 + c]; }
@@ -1435,7 +1682,8 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
             if (live) {
 #pragma unroll
                 for (int u = 0; u < CPT; u++) {
-                    const int q = threadIdx.x + u * TTHREADS;
+                    int q = threadIdx.x + u * TTHREADS;
+                    asm volatile("" : "+v"(q));      // (opaque: see paint_tile_kernel)
                     if (q < NCARRY) {
                         if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; lds[r * P + c] = (uint32_t)carry[u]; }
                         else { const int c = q % (S - 1), r = q / (S - 1); lds[r * P + c] = (uint32_t)carry[u]; }
@@ -1444,7 +1692,11 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
                 __syncthreads();
             }
             if constexpr (TOUCH) list_touch_done(touched);
+#if defined(PMX_EXPERIMENT) && defined(PMX_EXP_NODEPOSIT32)
+            const uint32_t over = 0;        // timing experiment: everything but the deposit loop
+#else
             const uint32_t over = tile_deposit32<KIND, TTHREADS, SORTED, PE, WHOLE, SIGNED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, pow2(f));
+#endif
             if (over) flag[trial & 1] = 1;
             __syncthreads();
             const bool again = flag[trial & 1] != 0 && f > -1000;
@@ -1580,6 +1832,90 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, B
         }
         __syncthreads();
         tile_gather_any<KIND, T, TTHREADS, SORTED, RELAX>(whole, p, g, t, pos, out, list, start, count, lds);
+        __syncthreads();
+    }
+}
+
+// ---- [r5] the readout of the common case as a loop of its own -----------------------------------------------------
+// Relaxed arithmetic, positions in dense rows of three (PE = 4 / 8 bytes per element), results in a dense vector (OE),
+// the index list (no tile-ordered copy); WHOLE (the block is the whole periodic mesh) known to the launcher.  What the
+// general loop pays per trip and this one does not: a wait behind a branch between the two list entries, three
+// position loads with 64-bit strides each (one 12-byte load, or a 16- and an 8-byte one), the element size of the
+// results looked up per store.
+template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
+__device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
+                                                 char *out, const uint32_t *tl, int count, const T *lds)
+{
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, GP = Rg::template gpitch<T>();
+    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+        bool ok[UNROLL];
+        uint32_t id[UNROLL];
+        PosRow<PE> row[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int j = j0 + u * TTHREADS;
+            ok[u] = j < count;
+            id[u] = tl[ok[u] ? j : count - 1];            // (an entry beyond the end reads the last one: no load behind a branch)
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) row[u] = pos_row<PE>(pos, (int64_t)id[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (!ok[u]) continue;
+            int lb[3];
+            T W[3][S];
+            const double x[3] = {(double)row[u].x[0], (double)row[u].x[1], (double)row[u].x[2]};
+            particle_setup_fast<KIND, WHOLE, T>(p, g, t, x, W, lb);
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            const T *base = lds + (lb[0] * R1 + lb[1]) * GP + lb[2];
+            T acc = 0;
+#pragma unroll
+            for (int a = 0; a < S; a++) {
+                T plane = 0;
+#pragma unroll
+                for (int b = 0; b < S; b++) {
+                    T r = 0;
+#pragma unroll
+                    for (int c = 0; c < S; c++) r = fma_(base[(a * R1 + b) * GP + c], W[2][c], r);
+                    plane = fma_(W[1][b], r, plane);
+                }
+                acc = fma_(W[0][a], plane, acc);
+            }
+            if (OE == 8) *(double *)(out + (int64_t)id[u] * 8) = (double)acc;
+            else *(float *)(out + (int64_t)id[u] * 4) = (float)acc;
+        }
+    }
+}
+
+template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
+__global__ void __launch_bounds__(TTHREADS) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
+                                                                   DVec pos, char *out, const uint32_t *list,
+                                                                   const int64_t *offsets, const uint32_t *counts)
+{
+    constexpr int S = Tuned<KIND>::S;
+    using Rg = Region<S>;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    __shared__ T lds[Rg::template glds<T>()];
+    __shared__ int64_t tab[Rg::R0 + Rg::R1 + Rg::R2];
+    for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        const int64_t start = offsets[tile];
+        const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
+        if (count == 0) continue;
+        int t[3];
+        tile_coords(g, tile, t);
+        region_tables<S, false>(p, g, t, tab, TTHREADS);
+        __syncthreads();
+#pragma unroll 4
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
+            int c = q % R2, r = q / R2;
+            int b = r % R1, a = r / R1;
+            const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
+            lds[r * Rg::template gpitch<T>() + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;
+        }
+        __syncthreads();
+        tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + start, count, lds);
         __syncthreads();
     }
 }
@@ -2067,9 +2403,18 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                 // rows in a coherent order, no tile-ordered copy: one request per tile and block of rows
                 const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
                 const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);
+#ifndef PMX_LEAN_BIN
+#define PMX_LEAN_BIN 1
+#endif
+                bool whole_b = true;
+                for (int d = 0; d < 3; d++) whole_b = whole_b && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
+#define BL(K, PE_, WH) bin_lean_kernel<K, PE_, WH><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag)
 #define BB(K)                                                                                                   \
     do {                                                                                                        \
-        if (dense) bin_block_kernel<K, true><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag); \
+        if (dense && PMX_LEAN_BIN) {                                                                            \
+            if (whole_b) { if (dpos.elsize == 8) BL(K, 8, true); else BL(K, 4, true); }                         \
+            else { if (dpos.elsize == 8) BL(K, 8, false); else BL(K, 4, false); }                               \
+        } else if (dense) bin_block_kernel<K, true><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag); \
         else bin_block_kernel<K, false><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag); \
     } while (0)
                 switch (p.kind) {
@@ -2079,6 +2424,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                 default: BB(PMX_TUNED_PCS); break;
                 }
 #undef BB
+#undef BL
             } else
                 BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
             const uint32_t *gate = pl->flags;
@@ -2220,8 +2566,10 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
         pd.strides[2] = 8; pd.strides[1] = 8 * p.size[2]; pd.strides[0] = 8 * p.size[2] * p.size[1];
         det_scale_kernel<<<1, 1024, 0, st>>>(p, pl->counts, g.ntiles, mstats, ms, dexp);
     }
-#define PT3(K, TT, MD, ODD, PP, CV, HL, OW) do { if (sorted) paint_tile_kernel<K, TT, TileThreads<K, TT>::paint, true, MD><<<pgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, HL, OW, mstats, ODD, dexp, p); \
-                   else paint_tile_kernel<K, TT, TileThreads<K, TT>::paint, false, MD><<<pgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, HL, OW, mstats, ODD, dexp, p); } while (0)
+#define PT3L(K, TT, MD, ODD, PP, CV, HL, OW, SD, WH, PE_) paint_tile_kernel<K, TT, TileThreads<K, TT>::paint, SD, MD, WH, PE_><<<pgrid, TileThreads<K, TT>::paint, 0, st>>>(PP, g, (char *)(CV), pos, mass, ms, pl->list, pl->offsets, pl->counts, HL, OW, mstats, ODD, dexp, p)
+#define PT3P(K, TT, MD, ODD, PP, CV, HL, OW, SD, WH) do { if (pos.elsize == 8) PT3L(K, TT, MD, ODD, PP, CV, HL, OW, SD, WH, 8); else PT3L(K, TT, MD, ODD, PP, CV, HL, OW, SD, WH, 4); } while (0)
+#define PT3W(K, TT, MD, ODD, PP, CV, HL, OW, SD) do { if (whole32) PT3P(K, TT, MD, ODD, PP, CV, HL, OW, SD, true); else PT3P(K, TT, MD, ODD, PP, CV, HL, OW, SD, false); } while (0)
+#define PT3(K, TT, MD, ODD, PP, CV, HL, OW) do { if (sorted) PT3W(K, TT, MD, ODD, PP, CV, HL, OW, true); else PT3W(K, TT, MD, ODD, PP, CV, HL, OW, false); } while (0)
     // [r5] float canvases, S >= 3: the 32-bit region (paint_tile32_kernel); contributions of either sign need its SIGNED guard
     const bool signed32 = mass.data != nullptr || ms < 0 || p.order[0] != 0 || p.order[1] != 0 || p.order[2] != 0;
     const bool dense32 = pos.stride1 == pos.elsize && pos.stride0 == 3 * pos.elsize;      // (always so for the plan's sorted copy)
@@ -2248,6 +2596,9 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
     }
 #undef PT
 #undef PT3
+#undef PT3W
+#undef PT3P
+#undef PT3L
 #undef PT32
 #undef PT32W
 #undef PT32P
@@ -2423,6 +2774,38 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
 #define RT2(K, T, RX) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
                       else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)
 #define RT(K, T) do { if (relax) RT2(K, T, true); else RT2(K, T, false); } while (0)
+    // [r5] the common case — relaxed arithmetic, the index list, dense position rows, a dense result vector — has a loop of its own
+#ifndef PMX_LEAN_READOUT
+#define PMX_LEAN_READOUT 1
+#endif
+    bool whole_r = true;
+    for (int d = 0; d < 3; d++) whole_r = whole_r && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
+    const bool lean = PMX_LEAN_READOUT && relax && !sorted && dpos.stride1 == dpos.elsize && dpos.stride0 == 3 * dpos.elsize
+                      && dout.stride0 == dout.elsize;
+#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts)
+#define RLW(K, T, PE_, OE_) do { if (whole_r) RLL(K, T, PE_, OE_, true); else RLL(K, T, PE_, OE_, false); } while (0)
+#define RLO(K, T, PE_) do { if (dout.elsize == 8) RLW(K, T, PE_, 8); else RLW(K, T, PE_, 4); } while (0)
+#define RL(K, T) do { if (dpos.elsize == 8) RLO(K, T, 8); else RLO(K, T, 4); } while (0)
+    if (lean) {
+        if (p.canvas_elsize == 8) {
+            switch (p.kind) {
+            case PMX_TUNED_NNB: RL(PMX_TUNED_NNB, double); break;
+            case PMX_TUNED_CIC: RL(PMX_TUNED_CIC, double); break;
+            case PMX_TUNED_TSC: RL(PMX_TUNED_TSC, double); break;
+            default: RL(PMX_TUNED_PCS, double); break;
+            }
+        } else {
+            switch (p.kind) {
+            case PMX_TUNED_NNB: RL(PMX_TUNED_NNB, float); break;
+            case PMX_TUNED_CIC: RL(PMX_TUNED_CIC, float); break;
+            case PMX_TUNED_TSC: RL(PMX_TUNED_TSC, float); break;
+            default: RL(PMX_TUNED_PCS, float); break;
+            }
+        }
+    } else
+#undef RL
+#undef RLO
+#undef RLW
     if (p.canvas_elsize == 8) {
         switch (p.kind) {
         case PMX_TUNED_NNB: RT(PMX_TUNED_NNB, double); break;

@@ -12,7 +12,7 @@
 // naming one of their switches without it is a compile error, and pmx_build_flags() lets a caller see what a
 // library was built with (bench.py refuses to print a line for an experiment build).
 #ifndef PMX_EXPERIMENT
-#if defined(PMX_EXP_NOATOM) || defined(PMX_EXP_NOWEIGHT) || defined(PMX_EXP_NOPASS) || defined(PMX_EXP_BINFLOOR)
+#if defined(PMX_EXP_NOATOM) || defined(PMX_EXP_NOWEIGHT) || defined(PMX_EXP_NOPASS) || defined(PMX_EXP_BINFLOOR) || defined(PMX_EXP_NODEPOSIT32) || defined(PMX_EXP_LEANBIN)
 #error "PMX_EXP_* switches produce wrong results: they need -DPMX_EXPERIMENT as well"
 #endif
 #endif

@@ -88,7 +88,8 @@ def test_column_fft_budgets():
 
 def test_tile_kernel_budgets():
     t = resources('pmx_binned.hip')
-    tiles = {k: v for k, v in t.items() if 'paint_tile_kernel' in k or 'readout_tile_kernel' in k}
+    tiles = {k: v for k, v in t.items() if 'paint_tile_kernel' in k or 'readout_tile_kernel' in k
+             or 'paint_tile32_kernel' in k or 'readout_tile_lean_kernel' in k}
     assert len(tiles) >= 16
     for k, v in tiles.items():
         assert v['ScratchSize'] == 0, k
@@ -97,11 +98,21 @@ def test_tile_kernel_budgets():
     for k, v in tiles.items():
         if 'ILi5Ed' in k:
             assert v['LDS'] <= 40960 and v['Occupancy'] >= 4, (k, v)
-    # TSC (kind 6) through the index list, fixed-point regions (MODE 1): 49 KB regions allow three workgroups of
-    # 512 threads per CU only if six waves per SIMD fit the registers (80 VGPRs); at 84-90 it ran two (paint 2.23
-    # instead of 1.85 ms on config 3)
-    tsc = [v for k, v in tiles.items() if 'paint_tile_kernelILi6E' in k and 'ELb0ELi1E' in k]
-    assert len(tsc) == 2 and all(v['VGPRs'] <= 80 and v['Occupancy'] >= 6 for v in tsc), tsc
+    # TSC (kind 6) through the index list, fixed-point regions (MODE 1; double canvases — float ones take the 32-bit
+    # regions below): 49 KB regions allow three workgroups of 512 threads per CU only if six waves per SIMD fit the
+    # registers (80 VGPRs); at 84-90 it ran two (paint 2.23 instead of 1.85 ms on config 3).  One kernel per form of
+    # the deposit loop (whole mesh or not x element size of the positions)
+    tsc = [v for k, v in tiles.items() if 'paint_tile_kernelILi6Ed' in k and 'ELb0ELi1E' in k]
+    assert len(tsc) == 4 and all(v['VGPRs'] <= 80 and v['Occupancy'] >= 6 for v in tsc), tsc
+    # [r5] the 32-bit regions of float canvases: TSC 45 KB (rows of 64 cells) x three workgroups of 512 threads per CU,
+    # i.e. six waves per SIMD; PCS four waves per SIMD
+    t32 = {k: v for k, v in tiles.items() if 'paint_tile32_kernel' in k}
+    assert len(t32) >= 16
+    for k, v in t32.items():
+        if 'ILi6E' in k:
+            assert v['VGPRs'] <= 80 and v['Occupancy'] >= 6 and v['LDS'] <= 49152, (k, v)
+        else:
+            assert v['VGPRs'] <= 128 and v['Occupancy'] >= 4, (k, v)
     for k, v in t.items():
         if 'bin_count_kernel' in k:
             assert v['ScratchSize'] == 0, k
@@ -111,3 +122,9 @@ def test_tile_kernel_budgets():
     assert len(blocks) == 8
     for k, v in blocks.items():
         assert v['ScratchSize'] == 0 and v['VGPRs'] <= 96 and v['LDS'] <= 32768, (k, v)
+    # [r5] its lean form for dense rows: four rows per lane and trip plus the next trip's four in flight (96 VGPRs for
+    # 24-byte rows: five workgroups of 256 threads per CU; measured 0.75 against 1.0 ms of the form above)
+    lean = {k: v for k, v in t.items() if 'bin_lean_kernel' in k}
+    assert len(lean) == 16
+    for k, v in lean.items():
+        assert v['ScratchSize'] == 0 and v['VGPRs'] <= 96 and v['LDS'] <= 20480, (k, v)
