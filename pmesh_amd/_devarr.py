@@ -73,6 +73,19 @@ def _unwrap(a, device):
     return a
 
 
+def _store(dst, r):
+    """dst[...] = r with numpy's 'same_kind' rule: a complex result does not go into a real array (torch's copy_ would
+    drop the imaginary parts with a warning; numpy raises — and Field.apply then evaluates the callable on the host)"""
+    if isinstance(r, torch.Tensor) and r.is_complex() and not dst.is_complex():
+        raise TypeError("cannot cast a complex result into a real device array")
+    if isinstance(r, complex) and not dst.is_complex():
+        raise TypeError("cannot cast a complex result into a real device array")
+    if isinstance(r, torch.Tensor):
+        dst.copy_(r)
+    else:
+        dst[...] = r
+
+
 def _wrap(r):
     if isinstance(r, torch.Tensor):
         return DevArr(r)
@@ -192,6 +205,15 @@ class DevArr(NDArrayOperatorsMixin):
             args = [_unwrap(a, dev) for a in inputs]
             if not any(isinstance(a, torch.Tensor) for a in args):
                 raise TypeError('no device array among the operands')
+            # numpy's (NEP 50) promotion for numpy SCALARS: `x * numpy.float64(c)` with a float32 array computes in
+            # float64 — python floats are weak, numpy scalars are not (torch treats both as weak)
+            strong = [a.dtype for a in inputs if isinstance(a, numpy.generic) and a.dtype.kind in 'fc']
+            if strong:
+                have = [numpy_dtype(a.dtype) for a in args if isinstance(a, torch.Tensor) and (a.is_floating_point() or a.is_complex())]
+                if have:
+                    target = torch_dtype(numpy.result_type(*(have + strong)))
+                    args = [a.to(target) if isinstance(a, torch.Tensor) and (a.is_floating_point() or a.is_complex())
+                            and a.dtype != target and torch.promote_types(a.dtype, target) == target else a for a in args]
             if len(args) > 1 and ufunc.__name__ not in ('add', 'subtract', 'multiply', 'true_divide', 'divide', 'power'):
                 # (most binary torch functions take tensors on both sides; a 0-d tensor promotes like a python scalar)
                 args = [a if isinstance(a, torch.Tensor) else torch.as_tensor(a, device=dev) for a in args]
@@ -204,10 +226,12 @@ class DevArr(NDArrayOperatorsMixin):
                 raise TypeError('numpy.%s.reduce is not available on device arrays' % ufunc.__name__)
             axis = kwargs.pop('axis', 0)
             keepdims = kwargs.pop('keepdims', False)
-            kwargs.pop('dtype', None)
+            rdt = kwargs.pop('dtype', None)
             if kwargs.pop('initial', None) is not None or kwargs:
                 raise TypeError('reduce arguments are not available on device arrays')
             t = _unwrap(inputs[0], dev)
+            if rdt is not None:
+                t = t.to(torch_dtype(numpy.dtype(rdt)))          # (the accumulator's type, as numpy's dtype= asks)
             if axis is None:
                 r = fn(t)
                 if keepdims:
@@ -220,7 +244,7 @@ class DevArr(NDArrayOperatorsMixin):
             o = out[0] if isinstance(out, tuple) else out
             if not isinstance(o, DevArr):
                 raise TypeError('out= must be a device array')
-            o.t.copy_(r)
+            _store(o.t, r)
             return o
         return _wrap(r)
 
@@ -235,26 +259,30 @@ class DevArr(NDArrayOperatorsMixin):
         return DevArr(self.t[_index(idx, self.t.device)])
 
     def __setitem__(self, idx, value):
-        self.t[_index(idx, self.t.device)] = _unwrap(value, self.t.device)
+        v = _unwrap(value, self.t.device)
+        if not self.t.is_complex() and (isinstance(v, complex) or (isinstance(v, torch.Tensor) and v.is_complex())):
+            raise TypeError("cannot cast a complex value into a real device array")      # (numpy's 'same_kind' rule: see _store)
+        self.t[_index(idx, self.t.device)] = v
 
     def nonzero(self):
         return tuple(DevArr(x) for x in self.t.nonzero(as_tuple=True))
 
     # -- the ndarray methods transfer functions use -------------------------------------------------------------------
-    def _reduce(self, fn, axis, keepdims):
+    def _reduce(self, fn, axis, keepdims, dtype=None):
+        t = self.t if dtype is None else self.t.to(torch_dtype(numpy.dtype(dtype)))      # (numpy's dtype=: the accumulator's type)
         if axis is None:
-            r = fn(self.t)
-            return DevArr(r.reshape([1] * self.t.dim())) if keepdims else DevArr(r)
-        return DevArr(fn(self.t, dim=axis, keepdim=keepdims))
+            r = fn(t)
+            return DevArr(r.reshape([1] * t.dim())) if keepdims else DevArr(r)
+        return DevArr(fn(t, dim=axis, keepdim=keepdims))
 
     def sum(self, axis=None, dtype=None, out=None, keepdims=False):
-        return self._reduce(torch.sum, axis, keepdims)
+        return self._reduce(torch.sum, axis, keepdims, dtype)
 
     def prod(self, axis=None, dtype=None, out=None, keepdims=False):
-        return self._reduce(torch.prod, axis, keepdims)
+        return self._reduce(torch.prod, axis, keepdims, dtype)
 
     def mean(self, axis=None, dtype=None, out=None, keepdims=False):
-        return self._reduce(torch.mean, axis, keepdims)
+        return self._reduce(torch.mean, axis, keepdims, dtype)
 
     def max(self, axis=None, out=None, keepdims=False):
         return self._reduce(torch.amax, axis, keepdims)

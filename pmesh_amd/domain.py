@@ -132,6 +132,10 @@ class _Scratch(object):
 
     def get(self, name, nbytes, device):
         e = self.buffers.get(name)
+        if e is not None and isinstance(e[1], _InUse) and not e[1].released:
+            # the consumer of what an asynchronous exchange left in this buffer has not run yet (received rows whose
+            # columns are still to be extracted, results still to be added): this exchange gets memory of its own
+            return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         if e is not None and e[1] is not None:
             e[1].wait()
             e[1] = None
@@ -158,6 +162,22 @@ class _Scratch(object):
             if e[1] is not None:
                 e[1].wait()
         self.buffers = {}
+
+
+class _InUse(object):
+    """what _Scratch.busy() remembers for a buffer whose CONSUMER must have run before it is reused: the handle of the
+    exchange (waited for as before) and whether the consumer — enqueued on the stream every later use is enqueued
+    on — has been issued."""
+
+    def __init__(self, work):
+        self.work, self.released = work, False
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+
+    def release(self):
+        self.released = True
 
 
 def release_staging(comm):
@@ -473,6 +493,11 @@ class Layout(object):
                 w = self.comm.alltoallv(send, sc, recv, rc, async_op=async_op)
                 st['works'].append(w)
                 scratch.busy('send0', w)
+                if async_op:
+                    # the received rows stay in the communicator's buffer until _exchange_remote_end has taken the
+                    # columns out of them: no other exchange may receive into it in between
+                    st['hold'] = _InUse(w)
+                    scratch.busy('recv', st['hold'])
             st.update(packed=recv)
         st.update(wrong=wrong, message=message, src=src, got=got, nrecv=nrecv)
         return st
@@ -493,6 +518,8 @@ class Layout(object):
                     rb = _row_bytes(a)
                     got.append(self._column(be, st['packed'], off, rb, a.dtype, tuple(a.shape[1:])))
                     off += rb
+                if st.get('hold') is not None:
+                    st['hold'].release()
             for i, r in zip(st['missing'], got):
                 # (a weak reference to the source tensor: the memo must not keep a caller's array alive, and an
                 # address reused by another tensor must not pass for the old one)
@@ -539,26 +566,35 @@ class Layout(object):
         # get() waits for it if not — and the results are never wider than the positions)
         back = _typed(scratch.get('send0', nsend * _row_bytes(data), be.device), data.dtype, (nsend,) + tuple(data.shape[1:]))
         work = self.comm.alltoallv(data, rc, back, sc, async_op=async_op)
-        scratch.busy('send0', work)
+        # (async: what comes back lives in 'send0' until finish() has added it — a second exchange before wait(out)
+        # must not gather its rows into the same buffer)
+        hold = _InUse(work) if async_op else work
+        scratch.busy('send0', hold)
 
         def finish(target):
             if work is not None:
                 work.wait()
-            if wrong:
-                raise ValueError(message)
-            if nsend:
-                b = back if back.dtype == target.dtype else back.to(target.dtype)
-                ncol = 1
-                for s in b.shape[1:]:
-                    ncol *= s
-                # nout = 0: accumulate into `out` without clearing it (include/pmesh_amd.h)
-                if target.dtype not in (torch.float32, torch.float64):
-                    target.index_add_(0, idx.to(torch.int64), b)
-                    return target
-                be.call('scatter_add', b.data_ptr(), b.element_size(), ncol, idx.data_ptr(),
-                        idx.element_size(), nsend, target.data_ptr(), 0, be.stream())
-                touched(target)
-            return target
+            try:
+                if wrong:
+                    raise ValueError(message)
+                if nsend:
+                    b = back if back.dtype == target.dtype else back.to(target.dtype)
+                    ncol = 1
+                    for s in b.shape[1:]:
+                        ncol *= s
+                    # nout = 0: accumulate into `out` without clearing it (include/pmesh_amd.h).  pmx_scatter_add
+                    # writes a DENSE out (out[i * ncol + c]): a strided target — a column F[:, d] of a force array —
+                    # and the integer payloads take torch's strided index_add_
+                    if target.dtype not in (torch.float32, torch.float64) or not target.is_contiguous():
+                        target.index_add_(0, idx.to(torch.int64), b)
+                        return target
+                    be.call('scatter_add', b.data_ptr(), b.element_size(), ncol, idx.data_ptr(),
+                            idx.element_size(), nsend, target.data_ptr(), 0, be.stream())
+                    touched(target)
+                return target
+            finally:
+                if async_op:
+                    hold.release()
         if async_op:
             return _Pending2(finish, data)
         return finish(out)

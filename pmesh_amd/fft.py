@@ -874,7 +874,10 @@ class Plan(object):
         # array in front of an in-place transform
         oop = bool(plane) and not inplace and hasattr(be, 'rowfft_to') and be.rowfft_supported(N2, self.elsize)
         if plane and not inplace and not oop:
-            # the padded layout is only walked by the in-place kernels: transform a copy
+            # the padded layout is only walked by the in-place kernels: transform a copy — of the COMPLETE field: a halo
+            # merge that the paint left to this transform is a note on the input's storage, which the copy does not carry
+            if self.forward and getattr(bufin.storage, '_pmx_halo', None) is not None:
+                settle(bufin.storage)
             n = p.i_alloc if self.forward else 2 * p.o_alloc
             bufout.storage[:n].copy_(bufin.storage[:n])
             bufin = bufout

@@ -1489,7 +1489,10 @@ class ParticleMesh(object):
         resampler = FindResampler(self.resampler if resampler is None else resampler)
         if layout is not None and layout.comm.size == 1 and _ghosts_only(layout, resampler, transform, hsml):
             # one rank, nothing to receive: `pm.paint(x, layout=pm.decompose(x))` — how callers of the reference write
-            # every paint (examples/nbody.py:203-204) — is the paint of the caller's own array
+            # every paint (examples/nbody.py:203-204) — is the paint of the caller's own array.  The reference's
+            # exchange would have refused an array of another length than the layout was built for (domain.py:177-179)
+            if len(pos) != layout.sendlength:
+                raise ValueError('the length of data does not match that used to build the layout')
             layout = None
         fresh = out is None
         part = self._get_partition(RealField)

@@ -831,6 +831,65 @@ def case_async_ghost_exchange(be, comm):
     assert all(v[0]() is not None for v in c._memo_remote.values())
 
 
+def case_readout_into_strided_and_float_out(be, comm):
+    """RealField.readout(layout=..., out=F[:, d]) — how a force loop writes its columns — and a float32 out, on several
+    ranks: the partial sums of the ghosts land in the caller's rows whatever the stride (the contract of
+    pmx_scatter_add is a DENSE out; a strided target takes the strided add).  And two asynchronous exchanges in flight
+    on one communicator do not share their staging: a second begin before the first wait leaves the first's rows alone."""
+    from pmesh_amd import pm as PM, domain
+    N, L = 16, 8.0
+    rs = numpy.random.RandomState(70 + comm.rank)
+    npart = 301 + 17 * comm.rank
+    pos_h = rs.uniform(0, L, size=(npart, 3))
+    field = numpy.random.RandomState(6).normal(size=(N, N, N))
+    pm = PM.ParticleMesh(BoxSize=L, Nmesh=[N, N, N], comm=comm, dtype='f8', resampler='cic')
+    fld = pm.create('real', value=field[pm.create('real').slices])
+    pos = torch.from_numpy(pos_h).to(be.device)
+    layout = pm.decompose(pos)
+    want = [fld.readout(pos, layout=layout, gradient=d) for d in range(3)]
+    want = [w if torch.is_tensor(w) else torch.from_numpy(numpy.asarray(w)).to(be.device) for w in want]
+    F = torch.full((npart, 3), 7.0, dtype=torch.float64, device=be.device)
+    for d in range(3):
+        r = fld.readout(pos, layout=layout, gradient=d, out=F[:, d])
+        assert r.data_ptr() == F[:, d].data_ptr()
+    for d in range(3):
+        assert torch.allclose(F[:, d], want[d], rtol=0, atol=1e-12), d
+    F4 = torch.zeros((npart, 3), dtype=torch.float32, device=be.device)
+    o4 = torch.zeros(npart, dtype=torch.float32, device=be.device)
+    fld.readout(pos, layout=layout, gradient=1, out=F4[:, 1])
+    fld.readout(pos, layout=layout, gradient=1, out=o4)
+    assert torch.allclose(F4[:, 1].double(), want[1], rtol=0, atol=2e-6 * float(want[1].abs().max() + 1))
+    assert torch.allclose(o4.double(), want[1], rtol=0, atol=2e-6 * float(want[1].abs().max() + 1))
+    assert float(F4[:, 0].abs().max()) == 0.0 and float(F4[:, 2].abs().max()) == 0.0
+    # overlapping asynchronous handles on one communicator
+    P = comm.size
+    dcop = domain.GridND([numpy.linspace(0, 1, P + 1)], comm=comm, periodic=True)
+    rng = numpy.random.RandomState(90 + comm.rank)
+    x1 = torch.from_numpy(rng.uniform(0, 1, size=(150, 3))).to(be.device)
+    m1 = torch.from_numpy(rng.uniform(size=150)).to(be.device)
+    x2 = torch.from_numpy(rng.uniform(0, 1, size=(170, 3))).to(be.device)
+    m2 = torch.from_numpy(rng.uniform(size=170)).to(be.device)
+    la, lb = dcop.decompose(x1[:, :1], smoothing=0.08), dcop.decompose(x2[:, :1], smoothing=0.08)
+    ra = la.exchange_remote(x1, m1)
+    rb = lb.exchange_remote(x2, m2)
+    la2, lb2 = dcop.decompose(x1[:, :1], smoothing=0.08), dcop.decompose(x2[:, :1], smoothing=0.08)
+    ha = la2.exchange_remote(x1, m1, async_op=True)
+    hb = lb2.exchange_remote(x2, m2, async_op=True)          # begins before the first has been waited for
+    ga, gb = ha.wait(), hb.wait()
+    assert torch.equal(ga[0], ra[0]) and torch.equal(ga[1], ra[1])
+    assert torch.equal(gb[0], rb[0]) and torch.equal(gb[1], rb[1])
+    va, vb = ra[0][:, 0] + ra[1], rb[0][:, 1] - rb[1]
+    o1, o2 = torch.zeros(150, dtype=torch.float64, device=be.device), torch.zeros(170, dtype=torch.float64, device=be.device)
+    la.gather_remote_add(va, o1)
+    lb.gather_remote_add(vb, o2)
+    p1 = la2.gather_remote_add(va.clone(), None, async_op=True)
+    p2 = lb2.gather_remote_add(vb.clone(), None, async_op=True)      # a second begin before wait(out) of the first
+    q1, q2 = torch.zeros_like(o1), torch.zeros_like(o2)
+    p1.wait(q1)
+    p2.wait(q2)
+    assert torch.allclose(q1, o1, rtol=0, atol=1e-15) and torch.allclose(q2, o2, rtol=0, atol=1e-15)
+
+
 def case_comm_trace(be, comm):
     """the record of the data-path collectives that bench.py --gpus N reports (pmesh_amd.comm.trace):
     a slab FFT round trip moves the whole half spectrum twice, (P-1)/P of it off rank"""
@@ -855,7 +914,7 @@ def case_comm_trace(be, comm):
     assert 0.7 * full <= total <= 1.3 * full, (total, full)
 
 
-CASES = [case_comm_trace, case_async_ghost_exchange, case_length_check_is_collective, case_promote_and_pack, case_pencil,
+CASES = [case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
          case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 

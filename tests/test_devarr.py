@@ -194,3 +194,33 @@ def test_slab_loops_in_numpy_terms(be):
     assert nslabs == ck.shape[0] or nslabs == max(ck.shape)
     assert abs(total - want_total) <= 1e-12 * abs(want_total)
     assert_allclose(numpy.asarray(ck), host * numpy.exp(-0.5 * k2full), rtol=1e-13, atol=1e-15)
+
+
+def test_numpy_scalars_reductions_and_casts_follow_numpy():
+    """numpy SCALARS are strong in numpy's promotion (NEP 50: `x * numpy.float64(c)` on a float32 array computes in
+    float64; python floats are weak); `dtype=` of the reductions is the accumulator's type; a complex result does not
+    go into a real array (numpy raises — Field.apply then evaluates the callable on the host)."""
+    h = numpy.linspace(0.1, 3.0, 64, dtype='f4').reshape(4, 16)
+    a = DevArr(torch.from_numpy(h.copy()))
+    C = (numpy.array([1000.0]) / numpy.array([512]))[0]            # a numpy.float64, as (pm.BoxSize / pm.Nmesh)[d] is
+    assert isinstance(C, numpy.float64)
+    got, want = a * C, h * C
+    assert got.dtype == want.dtype == numpy.float64
+    assert_allclose(got.t.numpy(), want, rtol=0, atol=0)
+    assert (a * 2.5).dtype == (h * 2.5).dtype == numpy.float32      # python scalars stay weak
+    assert (a * numpy.float32(2.5)).dtype == numpy.float32
+    big = DevArr(torch.full((1 << 16,), 1.0e-3, dtype=torch.float32))
+    assert big.sum(dtype='f8').dtype == numpy.float64
+    assert float(big.sum(dtype='f8')) == float(numpy.full(1 << 16, 1.0e-3, dtype='f4').sum(dtype='f8'))
+    assert numpy.add.reduce(big, dtype='f8').dtype == numpy.float64
+    assert big.mean(dtype='f8').dtype == numpy.float64
+    r = DevArr(torch.zeros(8, dtype=torch.float64))
+    with pytest.raises(TypeError):
+        r[...] = DevArr(torch.ones(8, dtype=torch.complex128))
+    with pytest.raises(TypeError):
+        numpy.multiply(r, 1j, out=r)
+    with pytest.raises(TypeError):
+        r *= 1j
+    c = DevArr(torch.ones(8, dtype=torch.complex128))
+    c *= 1j                                                           # complex into complex is fine
+    assert_allclose(c.t.numpy(), numpy.full(8, 1j))
