@@ -184,6 +184,13 @@ int pmx_binplan_sorted(pmx_binplan *plan, int32_t pref, int32_t *is_sorted);
  * (particles moved a lot) and fell back to the exact two-pass build on the device.  Host
  * counter, written by the device: exact once the stream has been synchronised. */
 int pmx_binplan_overflows(pmx_binplan *plan, uint32_t *count);
+/* How many particles the tile kernels of this plan have skipped so far because their position no longer lay in
+ * the region of the tile their list entry names: the plan was built for other positions — rows rewritten in
+ * place without the caller's cache noticing (the reference has no such state: it re-reads every position on
+ * every call, pm.py:1795-1869).  Blocks that are the whole periodic mesh cannot tell (a particle's cell modulo
+ * the tile is always inside: its mass lands in the wrong cell of the right tile).  Host counter written by the
+ * device: exact once the stream has been synchronised; 0 for every correct use. */
+int pmx_binplan_stale(pmx_binplan *plan, uint32_t *count);
 /* PMX_OK if (painter, npart) can use the binned kernels */
 int pmx_binplan_supported(const pmx_painter *p, int64_t npart);
 /* bin the batch: tile id + slot per particle, per-tile counts, scan, index lists */
@@ -400,6 +407,10 @@ int pmx_apply_transfer(const pmx_transfer *t, int32_t ndim, int32_t elsize, cons
                        const int64_t *shape, const int64_t *start, const int64_t *nmesh,
                        const double *boxsize, void *stream);
 
+/* Where the master seed stream of pmx_whitenoise runs (pmesh/_whitenoise_generics.h:73-93: one RANLUX stream walked in
+ * rings over the (i, j) plane, one seed per column): 0 (default) one host core + a copy of 8 bytes per local column;
+ * 1 one device thread (no copy, no wait; a sequential chain: ~35 x slower than the host core).  Same tables bit for bit. */
+int pmx_whitenoise_master(int32_t on_device);
 /* ---- white noise (the step before the cycle: initial conditions) -------------------------
  * pmesh.whitenoise.generate for 3-d meshes (pmesh/_whitenoise.pyx:25-45,
  * _whitenoise_imp.c:75-105, _whitenoise_generics.h:29-238; pm.py:1656-1696): fills the local

@@ -76,6 +76,7 @@ PROTOTYPES = {
     'scatter_add': (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i64, _vp, _i64, _vp]),
     'apply_transfer': (C.c_int, [_P(Transfer), _i32, _i32, _vp, _P(_i64), _vp, _P(_i64),
                                  _P(_i64), _P(_i64), _P(_i64), _P(_f64), _vp]),
+    'whitenoise_master': (C.c_int, [_i32]),
     'whitenoise': (C.c_int, [C.c_uint32, _i32, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _i32, _vp, _vp]),
     'synth_uniform': (C.c_int, [_P(Vec), _i64, _f64, C.c_uint64, _i64, _i64, _vp]),
     'synth_clustered': (C.c_int, [_P(Vec), _i64, _f64, _P(_f64), _i32, _f64, _i64, _i64, _vp]),
@@ -96,6 +97,7 @@ DEVICE_ONLY = {
     'mass_stats': (C.c_int, [_P(Vec), _i64, _vp, _vp]),
     'binplan_mass_stats': (C.c_int, [_vp, _vp]),
     'binplan_overflows': (C.c_int, [_vp, _P(C.c_uint32)]),
+    'binplan_stale': (C.c_int, [_vp, _P(C.c_uint32)]),
     'binplan_sorted': (C.c_int, [_vp, _i32, _P(_i32)]),
     'binplan_supported': (C.c_int, [_P(Painter), _i64]),
     'binplan_build': (C.c_int, [_vp, _P(Painter), _P(Vec), _i64, _vp]),

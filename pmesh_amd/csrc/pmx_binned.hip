@@ -877,6 +877,15 @@ __device__ __forceinline__ bool whole_mesh(const pmx_painter &p, const BinGeom &
     return w;
 }
 
+// a list entry whose particle no longer lies in the tile's region: the plan was built for other positions (rows rewritten
+// in place behind the cache's back).  The particle is skipped — never an access outside the region — and counted where
+// the host can see it (pmx_binplan_stale; pmesh_amd.window warns).  Only blocks that are not the whole periodic mesh can
+// tell: there the local base of a particle is its cell modulo the tile (see particle_setup), always inside.
+__device__ __forceinline__ void stale_row(const BinGeom &g)
+{
+    if (g.stale) atomicAdd_system(g.stale, 1u);
+}
+
 template <int KIND, bool WHOLE = false>
 __device__ __forceinline__ void particle_setup(const pmx_painter &p, const BinGeom &g, const int *t,
                                                const double *x, double (*V)[Tuned<KIND>::S], int *lb)
@@ -1063,7 +1072,7 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
             } else particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
             // a plan that no longer matches the positions (rewritten behind the cache's back)
             // must not index outside the LDS region
-            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
             // (FIXED: the mass carries the 2^f — a power of two, so the products are those of the reference times 2^f)
             const double mu = FIXED ? m[u] * scale : m[u];
 #pragma unroll
@@ -1152,7 +1161,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
             if constexpr (RELAX) {
                 T W[3][S];
                 particle_setup_fast<KIND, WHOLE, T>(p, g, t, x[u], W, lb);
-                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
                 T acc = 0;
 #pragma unroll
                 for (int a = 0; a < S; a++) {
@@ -1172,7 +1181,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
             }
             double V[3][S];
             particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
-            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
             double value = 0;
 #pragma unroll
             for (int a = 0; a < S; a++)
@@ -1583,7 +1592,7 @@ __device__ __forceinline__ uint32_t tile_deposit32(const pmx_painter &p, const B
             const double x[3] = {(double)row[u].x[0], (double)row[u].x[1], (double)row[u].x[2]};
             particle_setup_fast<KIND, WHOLE, double, !SIGNED>(p, g, t, x, V, lb);
             // (a plan that no longer matches the positions must not index outside the region)
-            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
             const double mu = (SIGNED ? m[u] : mass_scalar) * scale;
 #pragma unroll
             for (int a = 0; a < S; a++) V[0][a] *= mu;
@@ -1868,7 +1877,7 @@ __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const Bin
             T W[3][S];
             const double x[3] = {(double)row[u].x[0], (double)row[u].x[1], (double)row[u].x[2]};
             particle_setup_fast<KIND, WHOLE, T>(p, g, t, x, W, lb);
-            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) continue;
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
             const T *base = lds + (lb[0] * R1 + lb[1]) * GP + lb[2];
             T acc = 0;
 #pragma unroll
@@ -2190,6 +2199,13 @@ extern "C" int pmx_binplan_overflows(pmx_binplan *pl, uint32_t *count)
     return PMX_OK;
 }
 
+extern "C" int pmx_binplan_stale(pmx_binplan *pl, uint32_t *count)
+{
+    PMX_REQUIRE(pl != nullptr && count != nullptr, PMX_EINVAL, "NULL argument");
+    *count = pl->host_flag ? *(volatile uint32_t *)(pl->host_flag + 1) : 0u;
+    return PMX_OK;
+}
+
 extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
 {
     if (!pl) return PMX_OK;
@@ -2256,6 +2272,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     hipStream_t st = (hipStream_t)stream;
     pmx_painter p = *p_;
     BinGeom g;
+    g.stale = nullptr;
     g.kind = p.kind;
     g.S = native_support(p.kind);
     const int T[3] = {T0, T1, T2};
@@ -2339,8 +2356,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     PMX_HIP_CHECK(hipMemsetAsync(pl->nheavy, 0, 16, st));
     if (!pl->host_flag) {
         PMX_HIP_CHECK(hipHostMalloc((void **)&pl->host_flag, 64, hipHostMallocMapped));
-        *pl->host_flag = 0;
+        pl->host_flag[0] = 0;
+        pl->host_flag[1] = 0;      // particles a tile kernel found outside the region their list entry names (pmx_binplan_stale)
     }
+    pl->g.stale = pl->host_flag + 1;
     PMX_HIP_CHECK(hipMemsetAsync(pl->flags, 0, 16, st));
     PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)nbuckets * 4, st));
     DVec dpos = dvec(pos);

@@ -16,8 +16,8 @@
 // amplitudes go through log/sqrt/sin/cos, which on the device differ from glibc in the last
 // bit (tests: <= 4 ulp).
 //
-// Mapping: the master stream is a strictly sequential chain of N0*N1 draws -> run once on the
-// host (a few ms at 512^2; the table is 2 x 4 bytes per local column).  The columns are
+// Mapping: the master stream is a strictly sequential chain of N0*N1 draws -> one host core by default (a few
+// ms at 512^2; the table is 2 x 4 bytes per local column), or one device thread (wn_master_kernel).  The columns are
 // independent: one thread per column and stream ("own" stream: every mode except the mirrored
 // planes; "mirror" stream: only the k2 = 0 and N2/2 modes of upper-half columns).  The twelve
 // state words live in registers with static indices: a refill is 16 rounds of 12 steps plus 10
@@ -25,6 +25,7 @@
 // numbers are parked in LDS ([slot][thread]) where they can be indexed dynamically.
 #include <hip/hip_runtime.h>
 #include <math.h>
+
 
 #include <vector>
 
@@ -35,13 +36,13 @@ namespace pmx {
 constexpr double ULP48 = 1.0 / 281474976710656.0;   // 2^-48
 constexpr int WN_BLOCK = 128;
 
-// ---- host: master stream and seed tables -------------------------------------------------
+// ---- the master stream and the seed tables (one thread: the stream is one sequential chain) ----
 
 struct HostRlx {
     double x[12];
     double borrow;
     int ir, ir_refill;
-    void seed(unsigned long s)
+    __host__ __device__ void seed(unsigned long s)
     {
         int bits[31];
         if (s == 0) s = 1;
@@ -63,7 +64,7 @@ struct HostRlx {
         ir = 11;
         ir_refill = 0;
     }
-    double uniform()
+    __host__ __device__ double uniform()
     {
         ir = (ir + 1) % 12;
         if (ir == ir_refill) {
@@ -144,6 +145,55 @@ struct DevRlx {
     }
 };
 
+// The master stream: N-GenIC's ring order (_whitenoise_generics.h:73-93; the mixed use of N0 / N1 in the ring corners
+// is the reference's), one 31-bit seed per column and its mirror image, written for the columns of the local block.
+struct SeedTables {
+    int N0, N1;
+    int64_t s0, s1, n0, n1;
+    uint32_t *own, *mir;
+    __host__ __device__ void assign(HostRlx &master, int i, int j) const
+    {
+        const unsigned int s = (unsigned int)(0x7fffffff * master.uniform());
+        const int ii[2] = {i, (N0 - i) % N0};
+        const int jj[2] = {j, (N1 - j) % N1};
+        for (int a = 0; a < 2; a++) {
+            // only the pairings (direct, direct) and (mirrored, mirrored) are ever read back
+            const int64_t li = ii[a] - s0, lj = jj[a] - s1;
+            if (li >= 0 && li < n0 && lj >= 0 && lj < n1) (a == 0 ? own : mir)[li * n1 + lj] = s;
+        }
+    }
+    __host__ __device__ void fill(HostRlx &master, uint32_t seed) const
+    {
+        master.seed(seed);
+        for (int i = 0; i < N0 / 2; i++) {
+            for (int j = 0; j < i; j++) assign(master, i, j);
+            for (int j = 0; j < i + 1; j++) assign(master, j, i);
+            for (int j = 0; j < i; j++) assign(master, N0 - 1 - i, j);
+            for (int j = 0; j < i + 1; j++) assign(master, N1 - 1 - j, i);
+            for (int j = 0; j < i; j++) assign(master, i, N1 - 1 - j);
+            for (int j = 0; j < i + 1; j++) assign(master, j, N0 - 1 - i);
+            for (int j = 0; j < i; j++) assign(master, N0 - 1 - i, N1 - 1 - j);
+            for (int j = 0; j < i + 1; j++) assign(master, N1 - 1 - j, N0 - 1 - i);
+        }
+    }
+};
+
+// [r5] The same on the device (pmx_whitenoise_master(1)): a strictly sequential chain of N0 * N1 draws (17 subtract-with-
+// borrow steps each, every step waiting for the borrow of the one before) on ONE thread, its twelve state words in LDS.
+// Measured on MI355X: 0.12 / 0.48 / 1.9 s at 256^2 / 512^2 / 1024^2 columns against 3 / 13 / 50 ms of one host core plus a
+// copy of 8 bytes per column — a chain with no parallelism is the host's work, which is why the host form stays the
+// default; the device form never copies or waits (the tables do not exist on the host) and is tested against the same
+// golden spectrum.  (What would parallelise it is the skip-ahead of the recurrence — Luescher's equivalent linear
+// congruential form modulo 2^576 - 2^240 + 1 — a 576-bit modular power per thread: sized, not built.)
+static __global__ void __launch_bounds__(64) wn_master_kernel(uint32_t seed, SeedTables tb)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ HostRlx master;
+    tb.fill(master, seed);
+}
+
+static int wn_master_on_device = 0;
+
 struct WnGeom {
     int64_t nmesh[3], start[3], size[3], strides[3];
     int32_t unitary, elsize;
@@ -219,6 +269,12 @@ __global__ void __launch_bounds__(WN_BLOCK) whitenoise_kernel(WnGeom g, const ui
 
 using namespace pmx;
 
+extern "C" int pmx_whitenoise_master(int32_t on_device)
+{
+    pmx::wn_master_on_device = on_device ? 1 : 0;
+    return PMX_OK;
+}
+
 extern "C" int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nmesh, const int64_t *start,
                               const int64_t *size, const int64_t *strides, int32_t elsize, void *canvas,
                               void *stream)
@@ -240,39 +296,20 @@ extern "C" int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nme
     PMX_REQUIRE(canvas != nullptr, PMX_EINVAL, "canvas is NULL");
     hipStream_t st = (hipStream_t)stream;
 
-    // ---- master stream (host): N-GenIC's ring order (_whitenoise_generics.h:73-90; the mixed
-    // use of N0 / N1 in the ring corners is the reference's), seeds for the local columns
-    std::vector<uint32_t> own((size_t)ncol, 0u), mir((size_t)ncol, 0u);
+    // ---- master stream: seeds of the local columns, on the host (default) or on the device (pmx_whitenoise_master)
     const int N0 = (int)nmesh[0], N1 = (int)nmesh[1];
-    HostRlx master;
-    master.seed(seed);
-    auto assign = [&](int i, int j) {
-        unsigned int s = (unsigned int)(0x7fffffff * master.uniform());
-        const int ii[2] = {i, (N0 - i) % N0};
-        const int jj[2] = {j, (N1 - j) % N1};
-        for (int a = 0; a < 2; a++) {
-            // only the pairings (direct, direct) and (mirrored, mirrored) are ever read back
-            int64_t li = ii[a] - start[0], lj = jj[a] - start[1];
-            if (li >= 0 && li < size[0] && lj >= 0 && lj < size[1]) (a == 0 ? own : mir)[(size_t)(li * size[1] + lj)] = s;
-        }
-    };
-    for (int i = 0; i < N0 / 2; i++) {
-        for (int j = 0; j < i; j++) assign(i, j);
-        for (int j = 0; j < i + 1; j++) assign(j, i);
-        for (int j = 0; j < i; j++) assign(N0 - 1 - i, j);
-        for (int j = 0; j < i + 1; j++) assign(N1 - 1 - j, i);
-        for (int j = 0; j < i; j++) assign(i, N1 - 1 - j);
-        for (int j = 0; j < i + 1; j++) assign(j, N0 - 1 - i);
-        for (int j = 0; j < i; j++) assign(N0 - 1 - i, N1 - 1 - j);
-        for (int j = 0; j < i + 1; j++) assign(N1 - 1 - j, N0 - 1 - i);
-    }
     uint32_t *dseed = nullptr;
-    PMX_HIP_CHECK(hipMalloc((void **)&dseed, (size_t)ncol * 8));
-    hipError_t e1 = hipMemcpyAsync(dseed, own.data(), (size_t)ncol * 4, hipMemcpyHostToDevice, st);
-    hipError_t e2 = hipMemcpyAsync(dseed + ncol, mir.data(), (size_t)ncol * 4, hipMemcpyHostToDevice, st);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-        (void)hipFree(dseed);
-        PMX_HIP_CHECK(e1 != hipSuccess ? e1 : e2);
+    PMX_HIP_CHECK(hipMallocAsync((void **)&dseed, (size_t)ncol * 8, st));
+    std::vector<uint32_t> tables;
+    if (wn_master_on_device) {
+        PMX_HIP_CHECK(hipMemsetAsync(dseed, 0, (size_t)ncol * 8, st));
+        wn_master_kernel<<<1, 64, 0, st>>>(seed, SeedTables{N0, N1, start[0], start[1], size[0], size[1], dseed, dseed + ncol});
+    } else {
+        tables.assign((size_t)ncol * 2, 0u);
+        HostRlx master;
+        SeedTables{N0, N1, start[0], start[1], size[0], size[1], tables.data(), tables.data() + ncol}.fill(master, seed);
+        hipError_t e1 = hipMemcpyAsync(dseed, tables.data(), (size_t)ncol * 8, hipMemcpyHostToDevice, st);
+        if (e1 != hipSuccess) { (void)hipFreeAsync(dseed, st); PMX_HIP_CHECK(e1); }
     }
     WnGeom g;
     for (int d = 0; d < 3; d++) { g.nmesh[d] = nmesh[d]; g.start[d] = start[d]; g.size[d] = size[d]; g.strides[d] = strides[d]; }
@@ -282,9 +319,9 @@ extern "C" int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nme
     if (full) whitenoise_kernel<<<grid, WN_BLOCK, 0, st>>>(g, dseed, dseed + ncol, (char *)canvas, -1);
     whitenoise_kernel<<<grid, WN_BLOCK, 0, st>>>(g, dseed, dseed + ncol, (char *)canvas, +1);
     hipError_t e3 = hipGetLastError();
-    // the host vectors go out of scope on return: wait for the copies and the kernel
-    hipError_t e4 = hipStreamSynchronize(st);
-    (void)hipFree(dseed);
+    (void)hipFreeAsync(dseed, st);          // (stream ordered: behind the kernels that read the tables)
+    // the host tables go out of scope on return: wait for their copy (the device form neither copies nor waits)
+    hipError_t e4 = wn_master_on_device ? hipSuccess : hipStreamSynchronize(st);
     PMX_HIP_CHECK(e3);
     PMX_HIP_CHECK(e4);
     return PMX_OK;

@@ -7,11 +7,18 @@ decomposition, large scales invariant under a change of the mesh size, Hermitian
 testing", whitenoise.py:24-41) evaluated on the host and copied into the block.
 """
 
+import os
+
 import numpy
 import torch
 
 from . import _abi, backend
 from ._arrays import is_tensor
+
+
+#: where the master seed stream runs (one sequential chain of N0 * N1 draws): False = one host core (default, a few ms at
+#: 512^2), True = one device thread (no copy, no wait, ~35 x slower; include/pmesh_amd.h: pmx_whitenoise_master)
+MASTER_ON_DEVICE = os.environ.get('PMESH_AMD_WN_MASTER', 'host') == 'device'
 
 
 def generate(complex, start, Nmesh, seed, unitary):
@@ -38,6 +45,7 @@ def generate(complex, start, Nmesh, seed, unitary):
         complex[...] = dev.cpu().numpy()
         return
     if ndim == 3:
+        be.call('whitenoise_master', 1 if MASTER_ON_DEVICE else 0)
         if not complex.is_complex():
             raise TypeError('complex must be a complex array')
         es = complex.element_size()

@@ -177,6 +177,8 @@ class _BinCache(object):
         for e in self.entries:
             if e[0] == key and e[3]:
                 e[4] = self._tick()
+                if self._warn_if_stale(be, e):
+                    break                        # (built again below)
                 be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
                 be.call('binplan_exact', e[1], int(bool(EXACT)))
                 return e[1]
@@ -201,7 +203,7 @@ class _BinCache(object):
         elif len(self.entries) < self.SLOTS:
             plan = C.c_void_p()
             be.call('binplan_create', C.byref(plan))
-            e = [None, plan, None, False, 0, None]
+            e = [None, plan, None, False, 0, None, 0]
             self.entries.append(e)
         elif same and not free:
             # every slot is taken by a live tensor: the plan of the same shape used last has the closest lists
@@ -231,6 +233,26 @@ class _BinCache(object):
                 be.call('binplan_sorted', e[1], -2, C.byref(c))
                 n += int(c.value)
         return n
+
+    def _warn_if_stale(self, be, e):
+        """A plan is reused for a tensor at the same address and version (torch counts in-place operations).  Rows
+        rewritten behind that — a kernel of the caller's own through data_ptr(), a numpy view of shared memory — leave
+        a plan built for OTHER positions: the tile kernels skip (and count) the particles they find outside the
+        region their list entry names.  The count is read without waiting for the device: what a previous use of
+        the plan has found makes this use rebuild it, and warns.  (The reference keeps no state between calls:
+        pm.py:1795-1869.)"""
+        c = C.c_uint32(0)
+        be.call('binplan_stale', e[1], C.byref(c))
+        if len(e) > 6 and int(c.value) != e[6]:
+            lost = int(c.value) - e[6]
+            e[6] = int(c.value)
+            e[3] = False                         # rebuilt by this lookup
+            import warnings
+            warnings.warn('pmesh_amd: %d particles were skipped by an earlier paint / readout because their positions '
+                          'had been changed in place without torch noticing (a stale bin plan); the plan is rebuilt '
+                          'now.  Call pmesh_amd.window.clear_bin_cache() after such an update.' % lost, RuntimeWarning)
+            return True
+        return False
 
     def overflows(self, be):
         """single-pass rebuilds of the pooled plans that had to be repaired by the two-pass

@@ -313,6 +313,37 @@ def test_plan_is_shared_and_invalidated(hip):
     assert_allclose(c2.cpu().numpy(), c3.cpu().numpy(), rtol=0, atol=1e-12 * float(c3.abs().max()))
 
 
+@pytest.mark.parametrize('name', ['cic', 'tsc'])
+def test_stale_plan_is_counted_warned_and_rebuilt(hip, oracle, name):
+    """Positions rewritten in place WITHOUT torch noticing (through `.data`: the version counter of the tensor the
+    cache keys on does not move): the plan is for other positions.  On a block that is not the whole periodic mesh the
+    tile kernels skip — and count — the particles they find outside the region their list entry names
+    (pmx_binplan_stale); the next use of the plan warns and rebuilds it, and is right again."""
+    W = windows[name]
+    window.BINNED = 'always'
+    window.clear_bin_cache()
+    shape, period, scale, translate = CASES[2]                  # a slab-local block of a bigger mesh
+    aff = Affine(3, scale=scale, translate=translate, period=period)
+    oaff = oracle.Affine(3, scale=scale, translate=translate, period=period)
+    rs = numpy.random.RandomState(77)
+    pos_h = rs.uniform(30, 60, size=(20000, 3))
+    pos = torch.from_numpy(pos_h).to(hip.device)
+    field_h = rs.normal(size=shape)
+    field = torch.from_numpy(field_h).to(hip.device)
+    a = W.readout(field, pos, transform=aff).cpu().numpy()
+    assert_binned_ran()
+    v = pos._version
+    pos.data.add_(17.0)                                         # behind the cache's back
+    assert pos._version == v
+    W.readout(field, pos, transform=aff)                        # the stale plan: skips what left its regions, memory-safe
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match='stale bin plan'):
+        b = W.readout(field, pos, transform=aff).cpu().numpy()
+    want = oracle.Window(W.kind).readout(field_h, pos_h + 17.0, transform=oaff)
+    assert_allclose(b, want, rtol=0, atol=1e-12 * abs(field_h).max() * 8)
+    assert abs(a - b).max() > 0
+
+
 @pytest.mark.parametrize('name,dt', [('cic', 'f8'), ('tsc', 'f4'), ('pcs', 'f8'), ('nnb', 'f8')])
 def test_deterministic_paint(hip, oracle, name, dt):
     """window.DETERMINISTIC (the reference's scatter is a serial loop, _window.pyx:157-165: same call, same bits):

@@ -64,7 +64,13 @@ def ulp_close(got, want):
     assert_allclose(got.imag, want.imag, rtol=0, atol=tol * max(1.0, abs(want).max()))
 
 
-def test_generate_equals_golden(be, golden):
+@pytest.mark.parametrize('master', ['host', 'device'])
+def test_generate_equals_golden(be, golden, master, monkeypatch):
+    # master: where the master seed stream runs (pmx_whitenoise_master): the same tables bit for bit either way
+    if master == 'device' and be.name != 'hip':
+        pytest.skip('the device form of the master stream needs the HIP backend')
+    from pmesh_amd import whitenoise as wn
+    monkeypatch.setattr(wn, 'MASTER_ON_DEVICE', master == 'device')
     for nmesh, start, seed, unitary, value in cases(golden):
         t = torch.zeros(value.shape, dtype=torch.complex128 if value.dtype == numpy.complex128 else torch.complex64,
                         device=be.device)
