@@ -76,7 +76,6 @@ PROTOTYPES = {
     'scatter_add': (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i64, _vp, _i64, _vp]),
     'apply_transfer': (C.c_int, [_P(Transfer), _i32, _i32, _vp, _P(_i64), _vp, _P(_i64),
                                  _P(_i64), _P(_i64), _P(_i64), _P(_f64), _vp]),
-    'whitenoise_master': (C.c_int, [_i32]),
     'whitenoise': (C.c_int, [C.c_uint32, _i32, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _i32, _vp, _vp]),
     'synth_uniform': (C.c_int, [_P(Vec), _i64, _f64, C.c_uint64, _i64, _i64, _vp]),
     'synth_clustered': (C.c_int, [_P(Vec), _i64, _f64, _P(_f64), _i32, _f64, _i64, _i64, _vp]),
@@ -89,6 +88,7 @@ DEVICE_ONLY = {
     'build_flags': (C.c_char_p, []),
     'device_count': (C.c_int, []),
     'window_set_table': (C.c_int, [_i32, _P(_f64), _i32, _f64]),
+    'whitenoise_master': (C.c_int, [_i32]),
     'binplan_create': (C.c_int, [_P(_vp)]),
     'binplan_destroy': (C.c_int, [_vp]),
     'binplan_configure': (C.c_int, [_vp, _i32]),
