@@ -78,6 +78,24 @@ typedef struct pmx_painter {
     int64_t strides[PMX_MAXDIM];  /* canvas strides in bytes */
 } pmx_painter;
 
+/* The same for meshes of 4 to PMX_MAXDIM_ND dimensions (the reference's painter takes up to 32, _window_imp.h:50-60;
+ * ParticleMesh.reshape(Nmesh=[8, 8, 8, 8]), pmesh/tests/test_pm.py:381-384): a struct of its own, because pmx_painter
+ * travels by value to the hot kernels of the 3-d path and every element costs them scalar registers.  Served by the
+ * generic per-particle kernels only (pmx_paint_nd / pmx_readout_nd; no tuned, no tile-binned path). */
+#define PMX_MAXDIM_ND 8
+typedef struct pmx_painter_nd {
+    int32_t kind;          /* pmx_window_kind */
+    int32_t support;       /* <= 0: native support */
+    int32_t ndim;          /* 1..PMX_MAXDIM_ND */
+    int32_t canvas_elsize; /* 4 (float) or 8 (double) */
+    int32_t order[PMX_MAXDIM_ND];
+    double scale[PMX_MAXDIM_ND];
+    double translate[PMX_MAXDIM_ND];
+    int64_t period[PMX_MAXDIM_ND];
+    int64_t size[PMX_MAXDIM_ND];
+    int64_t strides[PMX_MAXDIM_ND];
+} pmx_painter_nd;
+
 /* A strided per-particle column set (numpy view semantics): element (i, c) is
  * at data + i*stride0 + c*stride1 and is a float (elsize 4) or double (8).
  * Mirrors the fused postype/masstype/hsmltype arguments of _window.pyx:6-16. */
@@ -124,6 +142,13 @@ int pmx_paint(const pmx_painter *p, void *canvas, const pmx_vec *pos, const pmx_
  * lexicographic cell order, stored as float or double per out->elsize. */
 int pmx_readout(const pmx_painter *p, const void *canvas, const pmx_vec *pos, const pmx_vec *hsml,
                 const pmx_vec *out, int64_t npart, void *stream);
+/* pmx_paint / pmx_readout for meshes of up to PMX_MAXDIM_ND dimensions (_generic_paint / _generic_readout,
+ * _window_generics.h:4-142, with _fill_k, _window_imp.c:50-83: any kind, any integer support <= PMX_MAXSUPPORT,
+ * per-particle hsml).  For ndim <= 3 the same numbers as the generic path of pmx_paint / pmx_readout. */
+int pmx_paint_nd(const pmx_painter_nd *p, void *canvas, const pmx_vec *pos, const pmx_vec *mass,
+                 double mass_scalar, const pmx_vec *hsml, int64_t npart, void *stream);
+int pmx_readout_nd(const pmx_painter_nd *p, const void *canvas, const pmx_vec *pos, const pmx_vec *hsml,
+                   const pmx_vec *out, int64_t npart, void *stream);
 
 /* ---- tile-binned paint / readout (device-side acceleration structure) ---- */
 /* A bin plan orders the particles of one batch by mesh tile (an index list per

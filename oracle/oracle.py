@@ -43,7 +43,7 @@ def lib(which='oracle'):
         elif which == 'ref':
             path = os.path.join(_HERE, '_ref', 'libpmesh_ref.so')
             prefix = 'ref_'
-            table = {k: _abi.PROTOTYPES[k] for k in ('paint', 'readout', 'window_info', 'fwindow')}
+            table = {k: _abi.PROTOTYPES[k] for k in ('paint', 'readout', 'paint_nd', 'readout_nd', 'window_info', 'fwindow')}
         else:
             raise ValueError(which)
         if not os.path.exists(path):
@@ -93,7 +93,8 @@ def vec_of(a, ncol=None):
 
 
 def make_painter(kind, support, real, order, scale, translate, period):
-    p = _abi.Painter()
+    # (meshes of more than three dimensions: pmx_painter_nd and the *_nd entry points)
+    p = _abi.Painter() if real.ndim <= _abi.PMX_MAXDIM else _abi.PainterND()
     p.kind = _abi.KINDS[kind] if isinstance(kind, str) else int(kind)
     p.support = int(support)
     p.ndim = real.ndim
@@ -182,7 +183,7 @@ class Window(object):
         p = make_painter(self._k, self.support, real, order, transform.scale, transform.translate,
                          transform.period)
         pv = vec_of(pos)
-        _check(_fn(self.which, 'paint')(
+        _check(_fn(self.which, 'paint' if real.ndim <= _abi.PMX_MAXDIM else 'paint_nd')(
             C.byref(p), real.ctypes.data, C.byref(pv),
             C.byref(massv) if massv is not None else None, mass_scalar,
             C.byref(hs) if hs is not None else None, len(pos), None), 'paint')
@@ -210,7 +211,7 @@ class Window(object):
                          transform.period)
         pv = vec_of(pos)
         ov = vec_of(out)
-        _check(_fn(self.which, 'readout')(
+        _check(_fn(self.which, 'readout' if real.ndim <= _abi.PMX_MAXDIM else 'readout_nd')(
             C.byref(p), real.ctypes.data, C.byref(pv),
             C.byref(hs) if hs is not None else None, C.byref(ov), len(pos), None), 'readout')
         return out

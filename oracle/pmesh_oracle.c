@@ -460,6 +460,103 @@ int pmo_readout(const pmx_painter *p, const void *canvas, const pmx_vec *pos, co
     return PMX_OK;
 }
 
+/* ---- meshes of more than three dimensions (include/pmesh_amd.h: pmx_painter_nd) ----
+ * _generic_paint / _generic_readout (_window_generics.h:4-142) with _fill_k (_window_imp.c:50-83) for any ndim up
+ * to PMX_MAXDIM_ND; the reference's tuned fast path exists for ndim <= 3 only (_window_imp.c:486-520), so every
+ * kind takes the generic product here.  mode 0 paint. */
+static double generic_one_nd(const pmx_painter_nd *p, void *canvas, const double *pos, double weight,
+                             double hsml, int paint)
+{
+    winfo w, w0;
+    int ns = native_support(p->kind);
+    winfo_init(&w0, ns, (double)p->support);
+    winfo_init(&w, ns, w0.support * hsml);
+    kfunc kern, diff;
+    pick_kernel(p->kind, &kern, &diff);
+    int ipos[PMX_MAXDIM_ND];
+    double k[PMX_MAXDIM_ND * PMX_MAXSUPPORT];
+    if (w.support > PMX_MAXSUPPORT) return 0;
+    int nd = p->ndim;
+    for (int d = 0; d < nd; d++) {
+        double *kd = &k[w.support * d];
+        double g = pos[d] * p->scale[d] + p->translate[d];
+        ipos[d] = floor(g + w.shift) - w.left;
+        double dx = g - ipos[d];
+        for (int i = 0; i < w.support; i++) {
+            double x = (dx - i) * w.vfactor;
+            if (p->order[d] == 0) kd[i] = kern(x) * w.vfactor;
+            else kd[i] = diff(x) * p->scale[d] * w.vfactor * w.vfactor;
+        }
+    }
+    int rel[PMX_MAXDIM_ND] = {0};
+    int s2 = w.support;
+    double value = 0;
+    while (rel[0] != s2) {
+        double kernel = 1.0;
+        int64_t ind = 0;
+        int outside = 0;
+        for (int d = 0; d < nd; d++) {
+            int r = rel[d];
+            int64_t t = ipos[d] + r;
+            kernel *= k[w.support * d + r];
+            t = wrap_idx(t, p->period[d]);
+            if (t >= p->size[d] || t < 0) { outside = 1; break; }
+            ind += p->strides[d] * t;
+        }
+        if (!outside) {
+            if (paint) canvas_add(canvas, p->canvas_elsize, ind, weight * kernel);
+            else value += kernel * canvas_get(canvas, p->canvas_elsize, ind);
+        }
+        rel[nd - 1]++;
+        for (int d = nd - 1; d > 0; d--)
+            if (rel[d] == s2) { rel[d - 1]++; rel[d] = 0; }
+    }
+    return value;
+}
+
+static int check_painter_nd(const pmx_painter_nd *p)
+{
+    if (!p) return PMX_EINVAL;
+    if (p->ndim < 1 || p->ndim > PMX_MAXDIM_ND) return PMX_EUNSUPPORTED;
+    if (p->canvas_elsize != 4 && p->canvas_elsize != 8) return PMX_EINVAL;
+    if (native_support(p->kind) < 0) return PMX_EUNSUPPORTED;
+    return PMX_OK;
+}
+
+int pmo_paint_nd(const pmx_painter_nd *p, void *canvas, const pmx_vec *pos, const pmx_vec *mass,
+                 double mass_scalar, const pmx_vec *hsml, int64_t npart, void *stream)
+{
+    (void)stream;
+    int rc = check_painter_nd(p);
+    if (rc) return rc;
+    for (int64_t i = 0; i < npart; i++) {
+        double x[PMX_MAXDIM_ND];
+        for (int d = 0; d < p->ndim; d++) x[d] = vec_get(pos, i, d);
+        double m = (mass && mass->data) ? vec_get(mass, i, 0) : mass_scalar;
+        double h = (hsml && hsml->data) ? vec_get(hsml, i, 0) : 1.0;
+        generic_one_nd(p, canvas, x, m, h, 1);
+    }
+    return PMX_OK;
+}
+
+int pmo_readout_nd(const pmx_painter_nd *p, const void *canvas, const pmx_vec *pos, const pmx_vec *hsml,
+                   const pmx_vec *out, int64_t npart, void *stream)
+{
+    (void)stream;
+    int rc = check_painter_nd(p);
+    if (rc) return rc;
+    for (int64_t i = 0; i < npart; i++) {
+        double x[PMX_MAXDIM_ND];
+        for (int d = 0; d < p->ndim; d++) x[d] = vec_get(pos, i, d);
+        double h = (hsml && hsml->data) ? vec_get(hsml, i, 0) : 1.0;
+        double v = generic_one_nd(p, (void *)canvas, x, 0.0, h, 0);
+        char *o = (char *)out->data + i * out->stride0;
+        if (out->elsize == 8) *(double *)o = v;
+        else *(float *)o = (float)v;
+    }
+    return PMX_OK;
+}
+
 /* ------------------------------------------------------------- decomposition */
 
 /* numpy's float remainder (npy_divmod): result carries the sign of b */

@@ -135,3 +135,61 @@ int ref_fwindow(int32_t kind, int32_t support, const double *w, int64_t n, doubl
     for (int64_t i = 0; i < n; i++) out[i] = pmesh_painter_get_fwindow(painter, w[i]);
     return 0;
 }
+
+/* ---- meshes of more than three dimensions: the same loop around the reference's entry points with the geometry of a
+ * pmx_painter_nd (the reference's painter holds up to 32 dimensions, _window_imp.h:50-60) */
+static void setup_nd(PMeshPainter *painter, const pmx_painter_nd *p, void *canvas)
+{
+    memset(painter, 0, sizeof(*painter));
+    painter->support = p->support;
+    painter->type = (PMeshPainterType)ref_type(p->kind);
+    painter->ndim = 0;
+    painter->canvas_dtype_elsize = 0;
+    pmesh_painter_init(painter);
+    painter->ndim = p->ndim;
+    painter->canvas = canvas;
+    painter->canvas_dtype_elsize = p->canvas_elsize;
+    for (int d = 0; d < p->ndim; d++) {
+        painter->order[d] = p->order[d];
+        painter->Nmesh[d] = p->period[d];
+        painter->scale[d] = p->scale[d];
+        painter->translate[d] = p->translate[d];
+        painter->size[d] = p->size[d];
+        painter->strides[d] = p->strides[d];
+    }
+    pmesh_painter_init(painter);
+}
+
+int ref_paint_nd(const pmx_painter_nd *p, void *canvas, const pmx_vec *pos, const pmx_vec *mass,
+                 double mass_scalar, const pmx_vec *hsml, int64_t npart, void *stream)
+{
+    (void)stream;
+    PMeshPainter painter[1];
+    setup_nd(painter, p, canvas);
+    for (int64_t i = 0; i < npart; i++) {
+        double x[32];
+        for (int d = 0; d < p->ndim; d++) x[d] = ld(pos, i, d);
+        double m = (mass && mass->data) ? ld(mass, i, 0) : mass_scalar;
+        double h = (hsml && hsml->data) ? ld(hsml, i, 0) : 1.0;
+        pmesh_painter_paint(painter, x, m, h);
+    }
+    return 0;
+}
+
+int ref_readout_nd(const pmx_painter_nd *p, const void *canvas, const pmx_vec *pos, const pmx_vec *hsml,
+                   const pmx_vec *out, int64_t npart, void *stream)
+{
+    (void)stream;
+    PMeshPainter painter[1];
+    setup_nd(painter, p, (void *)canvas);
+    for (int64_t i = 0; i < npart; i++) {
+        double x[32];
+        for (int d = 0; d < p->ndim; d++) x[d] = ld(pos, i, d);
+        double h = (hsml && hsml->data) ? ld(hsml, i, 0) : 1.0;
+        double v = pmesh_painter_readout(painter, x, h);
+        char *o = (char *)out->data + i * out->stride0;
+        if (out->elsize == 8) *(double *)o = v;
+        else *(float *)o = (float)v;
+    }
+    return 0;
+}

@@ -37,6 +37,21 @@ class Painter(C.Structure):
     ]
 
 
+PMX_MAXDIM_ND = 8
+
+
+class PainterND(C.Structure):
+    """pmx_painter_nd (include/pmesh_amd.h): meshes of 4 .. PMX_MAXDIM_ND dimensions, generic kernels only"""
+    _fields_ = [
+        ('kind', C.c_int32), ('support', C.c_int32), ('ndim', C.c_int32),
+        ('canvas_elsize', C.c_int32),
+        ('order', C.c_int32 * PMX_MAXDIM_ND),
+        ('scale', C.c_double * PMX_MAXDIM_ND), ('translate', C.c_double * PMX_MAXDIM_ND),
+        ('period', C.c_int64 * PMX_MAXDIM_ND), ('size', C.c_int64 * PMX_MAXDIM_ND),
+        ('strides', C.c_int64 * PMX_MAXDIM_ND),
+    ]
+
+
 class Vec(C.Structure):
     _fields_ = [
         ('data', C.c_void_p), ('elsize', C.c_int32), ('ncol', C.c_int32),
@@ -69,6 +84,8 @@ PROTOTYPES = {
     'fwindow': (C.c_int, [_i32, _i32, _P(_f64), _i64, _P(_f64)]),
     'paint': (C.c_int, [_P(Painter), _vp, _P(Vec), _P(Vec), _f64, _P(Vec), _i64, _vp]),
     'readout': (C.c_int, [_P(Painter), _vp, _P(Vec), _P(Vec), _P(Vec), _i64, _vp]),
+    'paint_nd': (C.c_int, [_P(PainterND), _vp, _P(Vec), _P(Vec), _f64, _P(Vec), _i64, _vp]),
+    'readout_nd': (C.c_int, [_P(PainterND), _vp, _P(Vec), _P(Vec), _P(Vec), _i64, _vp]),
     'decompose_count': (C.c_int, [_P(Grid), _P(Vec), _P(_f64), _P(_f64), _i64, _vp, _vp, _vp]),
     'decompose_fill': (C.c_int, [_i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     'take_rows': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i64, _vp, _vp]),

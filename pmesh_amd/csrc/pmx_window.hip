@@ -250,8 +250,10 @@ __device__ double tuned_dispatch(const pmx_painter &p, char *canvas, const doubl
 // hsml; tuned kinds take their fast path per particle when the integer support
 // equals the native one (quirk Q6).  p.support holds the effective integer
 // support of the window object (pmesh_painter_init, _window_imp.c:456-458).
-template <typename T, bool PAINT>
-__global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canvas, DVec pos,
+// P: pmx_painter (1..3 dimensions, MAXD = PMX_MAXDIM) or pmx_painter_nd (up to PMX_MAXDIM_ND: pmx_paint_nd /
+// pmx_readout_nd; no tuned fast path there: the reference's own is for ndim <= 3, _window_imp.c:486-520)
+template <typename T, bool PAINT, typename P = pmx_painter, int MAXD = PMX_MAXDIM>
+__global__ void __launch_bounds__(256) general_kernel(P p, char *canvas, DVec pos,
                                                       DVec mass, double mass_scalar, DVec hsml,
                                                       DVec out, int64_t n, TableD tab)
 {
@@ -260,22 +262,27 @@ __global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canva
     const bool tuned = p.kind >= PMX_TUNED_NNB && p.kind <= PMX_TUNED_PCS;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        double x[PMX_MAXDIM];
+        double x[MAXD];
         for (int d = 0; d < nd; d++) x[d] = pos.get(i, d);
         double m = PAINT ? (mass.data ? mass.get(i, 0) : mass_scalar) : 0.0;
         double h = hsml.data ? hsml.get(i, 0) : 1.0;
         WInfo w = winfo_init(ns, p.support * h);
         double value = 0;
-        if (tuned && w.support == ns) {
-            value = tuned_dispatch<T, PAINT>(p, canvas, x, m);
-        } else {
+        bool done = false;
+        if constexpr (MAXD == PMX_MAXDIM) {
+            if (tuned && w.support == ns) {
+                value = tuned_dispatch<T, PAINT>(p, canvas, x, m);
+                done = true;
+            }
+        }
+        if (!done) {
             // weights are tabulated per particle up to PMX_MAXSUPPORT points per axis and
             // evaluated on the fly beyond (the reference sizes its table dynamically,
             // _window_generics.h:24; test_lanczos_resize uses support 400)
             const bool cached = w.support <= PMX_MAXSUPPORT;
-            int ipos[PMX_MAXDIM];
-            double dxs[PMX_MAXDIM];
-            double k[PMX_MAXDIM][PMX_MAXSUPPORT];
+            int ipos[MAXD];
+            double dxs[MAXD];
+            double k[MAXD][PMX_MAXSUPPORT];
             bool finite = true;
             auto weight = [&](int d, int j) -> double {
                 double xx = (dxs[d] - j) * w.vfactor;
@@ -295,7 +302,8 @@ __global__ void __launch_bounds__(256) general_kernel(pmx_painter p, char *canva
                     for (int j = 0; j < w.support; j++) k[d][j] = weight(d, j);
             }
             if (finite) {
-                int rel[PMX_MAXDIM] = {0, 0, 0};
+                int rel[MAXD];
+                for (int d = 0; d < MAXD; d++) rel[d] = 0;
                 const int s2 = w.support;
                 while (rel[0] != s2) {
                     double kernel = 1.0;
@@ -544,6 +552,78 @@ extern "C" int pmx_readout(const pmx_painter *p_, const void *canvas, const pmx_
         else
             general_kernel<float, false><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart, tab);
     }
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- meshes of more than three dimensions (include/pmesh_amd.h: pmx_painter_nd) --------------------------------------
+static int check_painter_nd(const pmx_painter_nd *p)
+{
+    PMX_REQUIRE(p != nullptr, PMX_EINVAL, "painter is NULL");
+    PMX_REQUIRE(p->ndim >= 1 && p->ndim <= PMX_MAXDIM_ND, PMX_EUNSUPPORTED, "ndim must be 1..PMX_MAXDIM_ND");
+    PMX_REQUIRE(p->canvas_elsize == 4 || p->canvas_elsize == 8, PMX_EINVAL,
+                "canvas must be float or double (_window.pyx:135)");
+    PMX_REQUIRE(native_support(p->kind) > 0, PMX_EUNSUPPORTED, "window kind not built");
+    return PMX_OK;
+}
+
+static bool canvas_empty_nd(const pmx_painter_nd &p)
+{
+    for (int d = 0; d < p.ndim; d++)
+        if (p.size[d] == 0) return true;
+    return false;
+}
+
+extern "C" int pmx_paint_nd(const pmx_painter_nd *p_, void *canvas, const pmx_vec *pos,
+                            const pmx_vec *mass, double mass_scalar, const pmx_vec *hsml,
+                            int64_t npart, void *stream)
+{
+    int rc = check_painter_nd(p_);
+    if (rc) return rc;
+    if (npart == 0) return PMX_OK;
+    if (canvas_empty_nd(*p_)) return PMX_OK;
+    PMX_REQUIRE(canvas != nullptr, PMX_EINVAL, "canvas is NULL");
+    PMX_REQUIRE(vec_ok(pos) && pos->ncol >= p_->ndim, PMX_EINVAL, "pos must be (n, >=ndim) f4/f8");
+    PMX_REQUIRE(!mass || !mass->data || vec_ok(mass), PMX_EINVAL, "mass must be f4/f8");
+    PMX_REQUIRE(!hsml || !hsml->data || vec_ok(hsml), PMX_EINVAL, "hsml must be f4/f8");
+    pmx_painter_nd p = *p_;
+    p.support = winfo_init(native_support(p.kind), (double)p.support).support;
+    hipStream_t st = (hipStream_t)stream;
+    DVec dpos = dvec(pos), dmass = dvec(mass), dh = dvec(hsml), none = dvec(nullptr);
+    TableD tab;
+    rc = lookup_table(p.kind, &tab);
+    if (rc) return rc;
+    dim3 block(256), grid(grid_for(npart, 256));
+    if (p.canvas_elsize == 8)
+        general_kernel<double, true, pmx_painter_nd, PMX_MAXDIM_ND><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart, tab);
+    else
+        general_kernel<float, true, pmx_painter_nd, PMX_MAXDIM_ND><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, dmass, mass_scalar, dh, none, npart, tab);
+    PMX_HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_readout_nd(const pmx_painter_nd *p_, const void *canvas, const pmx_vec *pos,
+                              const pmx_vec *hsml, const pmx_vec *out, int64_t npart, void *stream)
+{
+    int rc = check_painter_nd(p_);
+    if (rc) return rc;
+    if (npart == 0) return PMX_OK;
+    PMX_REQUIRE(canvas != nullptr || canvas_empty_nd(*p_), PMX_EINVAL, "canvas is NULL");
+    PMX_REQUIRE(vec_ok(pos) && pos->ncol >= p_->ndim, PMX_EINVAL, "pos must be (n, >=ndim) f4/f8");
+    PMX_REQUIRE(vec_ok(out), PMX_EINVAL, "out must be f4/f8");
+    PMX_REQUIRE(!hsml || !hsml->data || vec_ok(hsml), PMX_EINVAL, "hsml must be f4/f8");
+    pmx_painter_nd p = *p_;
+    p.support = winfo_init(native_support(p.kind), (double)p.support).support;
+    hipStream_t st = (hipStream_t)stream;
+    DVec dpos = dvec(pos), dh = dvec(hsml), dout = dvec(out), none = dvec(nullptr);
+    TableD tab;
+    rc = lookup_table(p.kind, &tab);
+    if (rc) return rc;
+    dim3 block(256), grid(grid_for(npart, 256));
+    if (p.canvas_elsize == 8)
+        general_kernel<double, false, pmx_painter_nd, PMX_MAXDIM_ND><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart, tab);
+    else
+        general_kernel<float, false, pmx_painter_nd, PMX_MAXDIM_ND><<<grid, block, 0, st>>>(p, (char *)canvas, dpos, none, 0.0, dh, dout, npart, tab);
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }

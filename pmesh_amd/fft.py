@@ -103,6 +103,8 @@ class Partition(object):
         self.is_c2c = bool(is_c2c)
         if nd == 1 and P > 1:
             raise ValueError("Running 1d transforms on multiple ranks is not supported")
+        if nd > 3 and P > 1:
+            raise NotImplementedError('meshes of more than 3 dimensions are transformed on one rank only')
         self.nproc = P
         # (a 2-d process mesh [P, 1] IS the slab: axis 0 of the real field distributed, axis 1 of the transposed spectrum;
         # [1, P] distributes axes 1 and 2, as PFFT lays it out: the pencil schedule with a first group of one)
@@ -849,6 +851,8 @@ class Plan(object):
         settle(bufin.storage)
         if transfer is not None:
             raise NotImplementedError('fused transfer needs the column-FFT path')
+        if p.ndim > 3:
+            return self._execute_local_nd(be, bufin, bufout, inplace)
 
         def make():
             if self.forward:
@@ -858,6 +862,60 @@ class Plan(object):
                                  p.i_strides, p.i_alloc, 1, 1.0, inplace)
         plan = self._native(('local', inplace), make)
         be.fft_execute(plan, bufin.storage, bufout.storage)
+
+    def _execute_local_nd(self, be, bufin, bufout, inplace):
+        """Meshes of more than three dimensions on one rank (pfft transforms any number; ParticleMesh.reshape(Nmesh=
+        [8, 8, 8, 8]), pmesh/tests/test_pm.py:381-384): rocFFT plans hold up to three, so the last three axes are ONE
+        batched 3-d plan (real-to-complex or complex; the leading axes, dense among themselves, are its batch) and
+        every leading axis a strided 1-d complex plan over the contiguous run behind it — in place in the output
+        buffer (an out-of-place call copies first: a rare path, not a hot one)."""
+        p = self.partition
+        nd = p.ndim
+        n = [int(x) for x in p.Nmesh]
+        lead = nd - 3
+        norm = 1.0 / float(numpy.prod(p.Nmesh, dtype='f8'))
+        work = bufout.storage
+        if not inplace:
+            cnt = (p.i_alloc if self.forward else 2 * p.o_alloc) if not p.is_c2c else 2 * max(p.i_alloc, p.o_alloc)
+            work[:cnt].copy_(bufin.storage[:cnt])
+        istr = [int(x) for x in p.i_strides]
+        ostr = [int(x) for x in p.o_strides]
+        nbatch = 1
+        for x in n[:lead]:
+            nbatch *= x
+        if p.is_c2c:
+            k3f, k3b = _abi.PMX_FFT_C2C_FWD, _abi.PMX_FFT_C2C_BWD
+        else:
+            k3f, k3b = _abi.PMX_FFT_R2C, _abi.PMX_FFT_C2R
+
+        def inner():
+            if self.forward:
+                plan = self._native(('nd3',), lambda: be.fft_create(k3f, self.elsize, n[lead:], istr[lead:], istr[lead - 1],
+                                                                   ostr[lead:], ostr[lead - 1], nbatch, norm, True))
+            else:
+                plan = self._native(('nd3',), lambda: be.fft_create(k3b, self.elsize, n[lead:], ostr[lead:], ostr[lead - 1],
+                                                                   istr[lead:], istr[lead - 1], nbatch, 1.0, True))
+            be.fft_execute(plan, work, work)
+
+        def leading():
+            kind = _abi.PMX_FFT_C2C_FWD if self.forward else _abi.PMX_FFT_C2C_BWD
+            for d in range(lead):
+                run = ostr[d]                               # complex elements behind axis d: contiguous
+                plan = self._native(('nd1', d), lambda: be.fft_create(kind, self.elsize, [n[d]], [run], 1, [run], 1,
+                                                                      run, 1.0, True))
+                outer = 1
+                for x in n[:d]:
+                    outer *= x
+                for j in range(outer):
+                    off = 2 * j * n[d] * run                # in reals: the storage is a real tensor
+                    be.fft_execute(plan, work[off:], work[off:])
+
+        if self.forward:
+            inner()
+            leading()
+        else:
+            leading()
+            inner()
 
     def _execute_local_hybrid(self, be, bufin, bufout, inplace, transfer):
         """3-d transform on one rank: rocFFT along the contiguous axis, column FFTs along
@@ -1291,6 +1349,9 @@ class Plan(object):
         kind = _abi.PMX_FFT_C2C_FWD if self.forward else _abi.PMX_FFT_C2C_BWD
         scale = norm if self.forward else 1.0
         same = bufin.storage.data_ptr() == bufout.storage.data_ptr()
+        if p.nproc == 1 and p.ndim > 3:
+            settle(bufin.storage)
+            return self._execute_local_nd(be, bufin, bufout, same)
         if p.nproc == 1:
             def make():
                 return be.fft_create(kind, self.elsize, n, p.i_strides, p.i_alloc, p.o_strides, p.o_alloc, 1,

@@ -28,7 +28,7 @@ import numpy
 import torch
 from numpy.lib.mixins import NDArrayOperatorsMixin as NDArrayLike
 
-from . import backend, domain
+from . import _abi, backend, domain
 from . import fft as _fft
 from ._arrays import to_device, is_tensor, torch_dtype, numpy_dtype, to_numpy
 from ._devarr import DevArr, unwrap as _dev_unwrap
@@ -1185,8 +1185,8 @@ class ParticleMesh(object):
         rdtype = numpy.dtype('f%d' % (dtype.itemsize // 2)) if is_c2c else dtype
         self.Nmesh = numpy.array(Nmesh, dtype='i8')
         self.ndim = len(self.Nmesh)
-        if self.ndim > 3:
-            raise NotImplementedError('meshes of more than 3 dimensions')
+        if self.ndim > _abi.PMX_MAXDIM_ND:
+            raise NotImplementedError('meshes of more than %d dimensions' % _abi.PMX_MAXDIM_ND)
         self.BoxSize = numpy.empty(len(Nmesh), dtype='f8')
         self.BoxSize[:] = BoxSize
         self.dtype = dtype
@@ -1301,6 +1301,10 @@ class ParticleMesh(object):
             BoxSize = [BoxSize for i in range(len(Nmesh))]
         if len(BoxSize) != len(Nmesh):
             raise ValueError("Dimension of BoxSize (%d) doesn't agree with Nmesh (%d); provide BoxSize explicitly." % (len(BoxSize), len(Nmesh)))
+        if len(self.np) > len(Nmesh):
+            # the reference hands its process mesh on (pm.py:1568-1573) and PFFT refuses one of more dimensions than
+            # the mesh: pm.reshape(Nmesh=[8]) of a mesh made with np=[1, 1] raises (pmesh/tests/test_pm.py:376-379)
+            raise ValueError("a process mesh of %d dimensions cannot decompose a mesh of %d" % (len(self.np), len(Nmesh)))
         return ParticleMesh(BoxSize=BoxSize, Nmesh=Nmesh, dtype=self.dtype, comm=self.comm,
                             resampler=self.resampler, np=self.np if len(Nmesh) == self.ndim else None)
 

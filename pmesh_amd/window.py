@@ -329,7 +329,7 @@ def _mass_stats(be, m, mv):
 
 
 def _binned_ok(be, painter, pos, n, hs):
-    if BINNED == 'never' or be.name != 'hip' or hs is not None:
+    if BINNED == 'never' or be.name != 'hip' or hs is not None or isinstance(painter, _abi.PainterND):
         return False
     if BINNED == 'auto' and not DETERMINISTIC:
         if n < BINNED_MIN_PARTICLES:
@@ -425,7 +425,8 @@ class ResampleWindow(object):
 
     # ------------------------------------------------------------------
     def _painter(self, real, order, transform):
-        p = _abi.Painter()
+        # (meshes of more than three dimensions: pmx_painter_nd, served by pmx_paint_nd / pmx_readout_nd)
+        p = _abi.Painter() if real.dim() <= _abi.PMX_MAXDIM else _abi.PainterND()
         p.kind = self._k
         p.support = self.support
         p.ndim = real.dim()
@@ -559,7 +560,7 @@ class ResampleWindow(object):
         else:
             if _overwrite:
                 canvas.zero_()
-            be.call('paint', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv), mass_scalar,
+            be.call('paint' if canvas.dim() <= _abi.PMX_MAXDIM else 'paint_nd', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(mv), mass_scalar,
                     vec_ref(hv), n, be.stream())
         touched(canvas)
         if writeback is not None:
@@ -616,7 +617,7 @@ class ResampleWindow(object):
             be.call('readout_binned', plan, C.byref(p), canvas.data_ptr(), C.byref(pv), C.byref(ov),
                     be.stream())
         else:
-            be.call('readout', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(hv), C.byref(ov), n,
+            be.call('readout' if canvas.dim() <= _abi.PMX_MAXDIM else 'readout_nd', C.byref(p), canvas.data_ptr(), C.byref(pv), vec_ref(hv), C.byref(ov), n,
                     be.stream())
         touched(dout)
         if host_out is not None:

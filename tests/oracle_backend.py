@@ -38,7 +38,7 @@ class OracleBackend(object):
     def call(self, name, *args):
         if name in ('window_set_table', 'whitenoise_master'):
             return                      # the reference library has its tables compiled in; one form of the master stream
-        if name in ('paint', 'readout', 'window_info', 'fwindow'):
+        if name in ('paint', 'readout', 'paint_nd', 'readout_nd', 'window_info', 'fwindow'):
             kind = args[0] if name in ('window_info', 'fwindow') else args[0]._obj.kind
             if kind >= 8:               # table-driven kinds: only the compiled reference has them
                 if not O.have_ref():

@@ -353,3 +353,27 @@ def test_synthetic_inputs(oracle):
     d = (c - q + 500.0) % 1000.0 - 500.0
     rms = numpy.sqrt((d ** 2).sum(axis=1).mean())
     assert 1.5 * 125 < rms < 4.5 * 125
+
+
+@pytest.mark.parametrize('kind', ['nearest', 'linear', 'quadratic', 'cubic', 'tunednnb', 'tunedcic', 'tunedtsc', 'tunedpcs'])
+@pytest.mark.parametrize('shape,period', [((6, 5, 7, 4), (6, 5, 7, 0)), ((4, 3, 5, 4, 3), (4, 3, 5, 4, 3))])
+def test_more_than_three_dimensions_equal_compiled_reference(oracle, kind, shape, period):
+    """pmo_paint_nd / pmo_readout_nd (meshes of 4 .. 8 dimensions: the reference's generic product, its tuned kernels
+    stop at three, _window_imp.c:486-520) == the reference's own _window_imp.c compiled where it lies (oracle/_ref),
+    bit for bit: anisotropic affine, a non-periodic axis, gradients, per-particle hsml, f4 / f8 canvases."""
+    if not oracle.have_ref():
+        pytest.skip('oracle/_ref (compiled reference) is not available')
+    nd = len(shape)
+    rs = numpy.random.RandomState(31 + nd)
+    pos = rs.uniform(-3, 9, size=(300, nd))
+    mass = rs.uniform(0.5, 1.5, size=300)
+    hs = rs.uniform(0.8, 1.6, size=300)
+    aff = oracle.Affine(nd, scale=[1.0, 0.5, 1.5, 1.0, 0.7][:nd], translate=[0.2, 0, -0.3, 0.1, 0][:nd], period=period)
+    for dt in ('f8', 'f4'):
+        for diffdir in (None, 2):
+            a, b = numpy.zeros(shape, dtype=dt), numpy.zeros(shape, dtype=dt)
+            oracle.Window(kind).paint(a, pos, mass=mass, transform=aff, diffdir=diffdir)
+            oracle.Window(kind, which='ref').paint(b, pos, mass=mass, transform=aff, diffdir=diffdir)
+            assert_array_equal(a, b)
+            assert_array_equal(oracle.Window(kind).readout(a, pos, hsml=hs, transform=aff, diffdir=diffdir),
+                               oracle.Window(kind, which='ref').readout(a, pos, hsml=hs, transform=aff, diffdir=diffdir))

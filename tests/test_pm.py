@@ -797,3 +797,72 @@ def test_pack_arrays():
     assert_array_equal(s[s.dtype.names[1]], b)
     with pytest.raises(ValueError):
         pack_arrays([a, b[:3]])
+
+
+def test_reshape(be):                         # test_pm.py:372-389
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='f8', np=[1, 1])
+    pm2d = pm.reshape(Nmesh=[8, 8])
+    assert pm2d.ndim == 2
+    with pytest.raises(ValueError):
+        pm.reshape(Nmesh=[8])                  # a 2-d process mesh cannot decompose a 1-d mesh
+    pm4d = pm.reshape(Nmesh=[8, 8, 8, 8], BoxSize=8.0)
+    assert pm4d.ndim == 4 and tuple(pm4d.Nmesh) == (8, 8, 8, 8)
+    with pytest.raises(ValueError):
+        pm.reshape(Nmesh=[8, 8, 8, 8])         # BoxSize of another dimension
+    pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], dtype='f8', np=[1, ])
+    assert pm.reshape(Nmesh=[8, 8]).ndim == 2
+
+
+def _host(x):
+    """a field value / result as a numpy array whichever backend made it"""
+    return x.cpu().numpy() if hasattr(x, 'cpu') else numpy.asarray(x)
+
+
+@pytest.mark.parametrize('Nmesh,dtype,tol', [([8, 6, 4, 8], 'f8', 1e-13), ([4, 6, 2, 4, 6], 'f8', 1e-13), ([8, 6, 4, 8], 'f4', 5e-6),
+                                             ([4, 6, 5, 4], 'c16', 1e-13)])
+def test_meshes_of_more_than_three_dimensions(be, oracle, Nmesh, dtype, tol):
+    """The reference's ParticleMesh takes any number of dimensions (PFFT transforms them, the generic window kernels
+    loop over them: _window_imp.h:50-60; pm.reshape(Nmesh=[8, 8, 8, 8]), test_pm.py:381).  Here: transforms against
+    numpy.fft under the contract of pm.py:692, paint / readout of every kind of window (there is no tuned kernel
+    beyond three dimensions in the reference either) against the oracle, which tests/test_oracle.py pins to the
+    compiled reference; apply with coordinates; decompose on one rank."""
+    nd = len(Nmesh)
+    pm = ParticleMesh(BoxSize=[8.0, 6.0, 4.0, 8.0, 5.0][:nd], Nmesh=Nmesh, dtype=dtype)
+    rs = numpy.random.RandomState(11)
+    real = pm.create('real')
+    v = rs.normal(size=real.shape)
+    if dtype == 'c16':
+        v = v + 1j * rs.normal(size=real.shape)
+    real[...] = v
+    cplx = real.r2c()
+    want = (numpy.fft.fftn(v) if dtype == 'c16' else numpy.fft.rfftn(v)) / v.size
+    assert_allclose(_host(cplx.value), want, rtol=0, atol=tol * abs(want).max() * 10)
+    back = cplx.c2r()
+    assert_allclose(_host(back.value), v, rtol=0, atol=tol * abs(v).max() * 10)
+    real.r2c(out=Ellipsis).c2r(out=Ellipsis)           # in place
+    assert_allclose(_host(real.value), v, rtol=0, atol=tol * abs(v).max() * 10)
+    if dtype == 'c16':
+        return
+    pos = rs.uniform(-2.0, 10.0, size=(400, nd))
+    mass = rs.uniform(0.5, 1.5, size=400)
+    aff = oracle.Affine(nd, scale=pm.Nmesh / pm.BoxSize, period=pm.Nmesh)
+    names = {'nnb': 'tunednnb', 'cic': 'tunedcic', 'tsc': 'tunedtsc', 'pcs': 'tunedpcs'}
+    for res in ('nnb', 'cic', 'tsc', 'pcs', 'linear', 'quadratic', 'cubic'):
+        f = pm.paint(pos, mass=mass, resampler=res)
+        a = numpy.zeros(tuple(pm.Nmesh), dtype=dtype)
+        oracle.Window(names.get(res, res)).paint(a, pos, mass=mass, transform=aff)
+        assert_allclose(_host(f.value), a, rtol=0, atol=(1e-12 if dtype == 'f8' else 2e-6) * max(1.0, abs(a).max()))
+        assert abs(f.csum() - mass.sum()) < (1e-9 if dtype == 'f8' else 1e-3) * mass.sum()
+        for gradient in (None, nd - 1):
+            r = f.readout(pos, resampler=res, gradient=gradient)
+            rr = oracle.Window(names.get(res, res)).readout(_host(f.value), pos, diffdir=gradient, transform=aff)
+            assert_allclose(_host(r), rr, rtol=0, atol=(1e-12 if dtype == 'f8' else 1e-5) * max(1.0, abs(rr).max()))
+    layout = pm.decompose(pos)
+    f2 = pm.paint(pos, mass=mass, layout=layout)
+    assert_allclose(_host(f2.value), _host(pm.paint(pos, mass=mass).value), rtol=0, atol=1e-12 if dtype == 'f8' else 2e-6)
+    smooth = real.r2c().apply(lambda k, v: v * numpy.exp(-0.5 * sum(ki ** 2 for ki in k)))
+    kk = sum(numpy.meshgrid(*[2 * numpy.pi * numpy.fft.fftfreq(n, d=L / n) if i < nd - 1 else
+                              2 * numpy.pi * numpy.fft.rfftfreq(n, d=L / n)
+                              for i, (n, L) in enumerate(zip(pm.Nmesh, pm.BoxSize))], indexing='ij', sparse=True)[i] ** 2 for i in range(nd))
+    assert_allclose(_host(smooth.value), numpy.fft.rfftn(v) / v.size * numpy.exp(-0.5 * kk), rtol=0,
+                    atol=tol * 10 * abs(want).max())
