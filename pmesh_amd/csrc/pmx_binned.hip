@@ -1430,6 +1430,19 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
         tile_deposit<KIND, TTHREADS, SORTED, FIXED, PE, WHOLE, typename DepositWeights<KIND, T, MODE>::type>(pwr, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
         __syncthreads();
         // owned box -> canvas, plain stores in rows of T2 cells
+        if constexpr (WHOLE && MODE != 2) {
+            // [r5] the block is the whole periodic mesh, a multiple of the tile on every axis: no wraps, no bounds
+            char *tbase = canvas + (int64_t)t[0] * T0 * p.strides[0] + (int64_t)t[1] * T1 * p.strides[1] + (int64_t)t[2] * T2 * p.strides[2];
+            const int s0 = (int)p.strides[0], s1 = (int)p.strides[1], s2 = (int)p.strides[2];
+            for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
+                const int c = q % T2, r = q / T2;
+                const int b = r % T1, a = r / T1;
+                const T v = (T)cell_value<MODE>(lds[Rg::dat(a * R1 + b, c)], inv);
+                T *dst = (T *)(tbase + ((int64_t)a * s0 + b * s1 + c * s2));
+                if (overwrite) *dst = v;
+                else *dst += v;
+            }
+        } else
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
             int c = q % T2, r = q / T2;
             int b = r % T1, a = r / T1;
@@ -1686,7 +1699,9 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
             __syncthreads();
         }
         for (;;) {
-            for (int q = threadIdx.x; q < CELLS; q += TTHREADS) lds[q] = 0;
+            // (16 bytes per store: the region is a multiple of four cells)
+            static_assert(CELLS % 4 == 0, "32-bit region in 16-byte pieces");
+            for (int q = threadIdx.x; q < CELLS / 4; q += TTHREADS) ((uint4 *)lds)[q] = make_uint4(0, 0, 0, 0);
             __syncthreads();
             if (live) {
 #pragma unroll
@@ -1721,6 +1736,20 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
         }
         const double inv = pow2(-f);
         // owned box -> canvas, plain stores in rows of T2 cells
+        if constexpr (WHOLE) {
+            // the block is the whole periodic mesh, a multiple of the tile on every axis (pmx_binplan_supported): the
+            // owned box lies inside it, cell (a, b, c) at a fixed offset from the tile's first — no wraps, no bounds
+            char *tbase = canvas + (int64_t)t[0] * T0 * p.strides[0] + (int64_t)t[1] * T1 * p.strides[1] + (int64_t)t[2] * T2 * p.strides[2];
+            const int s0 = (int)p.strides[0], s1 = (int)p.strides[1], s2 = (int)p.strides[2];
+            for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
+                const int c = q % T2, r = q / T2;
+                const int b = r % T1, a = r / T1;
+                const float v = (float)((double)(int)lds[(a * R1 + b) * P + c] * inv);
+                float *dst = (float *)(tbase + ((int64_t)a * s0 + b * s1 + c * s2));
+                if (overwrite) *dst = v;
+                else *dst += v;
+            }
+        } else
         for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
             const int c = q % T2, r = q / T2;
             const int b = r % T1, a = r / T1;
