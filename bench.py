@@ -97,6 +97,9 @@ def parse():
                          'fastpm caller passes them: every paint / readout stages them over PCIe (diagnostic: '
                          'the reported rate then is PCIe inclusive and is NOT the headline metric); 2: the same with '
                          'the position arrays registered once (ParticleMesh.stage) and refreshed once per cycle')
+    ap.add_argument('--cold-plan', type=int, default=0,
+                    help='1: the bin plans are destroyed before every cycle (diagnostic: every build is the first build of a '
+                         'plan — allocation, the exact two-pass build, no slot ranges of a previous step to reuse)')
     ap.add_argument('--out-field', type=int, default=0,
                     help='0: pm.paint(pos) returns a new field every cycle, as the callers of the reference write it '
                          '(fastpm: pm.paint(x, layout=layout)) — on one rank the halo merge of the tile kernels then rides '
@@ -438,7 +441,10 @@ def main():
         layout = layouts[ncycle[0] % len(psets)]
         ncycle[0] += 1
         # a new time step: positions are "new", nothing binned or exchanged is reused
-        _window.clear_bin_cache()
+        if args.cold_plan:
+            _window.bin_cache().destroy(be)
+        else:
+            _window.clear_bin_cache()
         if layout is not None:
             layout._memo = None
             layout._memo_remote = None
@@ -592,6 +598,11 @@ def main():
             'drift_cells': args.drift,
             'host_arrays': bool(args.host_arrays), 'deterministic_paint': bool(args.deterministic),
             'bin_overflows': _window.bin_cache().overflows(be),
+            # what the `bin` stage is: the plan is rebuilt in EVERY cycle (the cache is cleared: a time-stepping caller's
+            # positions are new), by the single pass into the slot ranges of the previous cycle's build — whose positions
+            # differ by N(0, drift_cells) per axis — unless --cold-plan; a build whose ranges overflow is repaired by the exact
+            # two-pass build on the device (bin_overflows counts those over the whole run, warm-up included)
+            'bin_rebuilds_per_step': 1.0, 'cold_plan': bool(args.cold_plan),
             'tile_order_ms': round(1e3 * t_order, 3),
             # every stage against the same roofline: its algorithmic bytes (the fused apply is
             # charged to c2r) over its measured time, as a fraction of the HBM peak

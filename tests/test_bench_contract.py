@@ -39,12 +39,15 @@ def test_bench_line_has_what_the_driver_reads():
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['unit'] == 'particles/s' and c['sample']
     assert c['value'] is None or c['value'] > 0
     assert 'PMX_EXP' not in d['build_flags']
+    # what the bin stage is, said in the line: a rebuild per step over positions moved by drift_cells
+    assert d['bin_rebuilds_per_step'] == 1.0 and d['cold_plan'] is False and d['drift_cells'] > 0
     # the stages add up to the step (events on the stream)
     assert abs(sum(d['stages_ms'].values()) - d['ms_per_step']) <= 0.25 * d['ms_per_step']
 
 
 def test_bench_other_forms_run():
     for args in (['--mesh', '128', '--window', 'tsc', '--dtype', 'f4', '--gradient', '0'],
-                 ['--mesh', '128', '--out-field', '1'], ['--mesh', '128', '--data', 'clustered', '--window', 'pcs']):
+                 ['--mesh', '128', '--out-field', '1'], ['--mesh', '128', '--data', 'clustered', '--window', 'pcs'],
+                 ['--mesh', '128', '--cold-plan', '1'], ['--mesh', '128', '--drift', '2.0']):
         d = run_bench('--steps', '2', '--warmup', '1', '--no-cpu-baseline', *args)
-        assert d['value'] > 0 and d['bin_overflows'] == 0
+        assert d['value'] > 0 and (d['bin_overflows'] == 0 or '--drift' in args)
