@@ -1491,11 +1491,15 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
 // 32 bits cannot hold a rigorous worst case (every particle of the segment in one cell) at a useful resolution, so the
 // scale is OPTIMISTIC — room for 16 times the mean density of the segment's tiles — and every add is CHECKED: the
 // atomics return the cell's previous value, the lanes OR them together, and a workgroup that has seen a value at or
-// beyond 2^30 in magnitude (contributions stay below 2^29: no sum can have wrapped unseen) deposits the tile again with
-// 32 times coarser units.  Resolution where nothing overflows: 2^-f = 32 nu m_max 2^-30 <= 3e-8 of a particle's mass at
-// nu = 1 particle per cell; after a retry the unit is <= 2^-24 of the tile's largest cell sum.  Every contribution is
-// rounded once (absolute error 2^-f-1), the region's sum is exact in integers and bit-reproducible, the float canvas
-// gets it rounded once more: inside |d| <= 2e-6 max(1, max |cell|), the tolerance of a float canvas.
+// beyond 2^30 in magnitude (contributions stay below 2^29: no sum can have wrapped unseen) deposits the tile again IN
+// TWO PARTS at the same scale: the high parts v >> sh of all contributions into one zeroed region, flushed, then the
+// low parts v & (2^sh - 1) into another, added on top.  (A first version retried in 32 times coarser units: thousands
+// of IDENTICAL contributions on one cell — their roundings do not cancel — then left 5e-5 of the cell's sum, outside
+// the tolerance; tests/test_binned.py::test_float_canvas_regions_retry_on_overflow.)  Resolution, always: 2^-f =
+// 32 nu m_max 2^-30 <= 3e-8 of the largest mass at nu = 1 particle per cell.  Every contribution is rounded once
+// (absolute error 2^-f-1), the region's sum is exact in integers, the float canvas gets it rounded once more (twice
+// for a tile in two parts): inside |d| <= 2e-6 max(1, max |cell|), the tolerance of a float canvas.
+// The face carried from tile to tile of a segment is kept in 64 bits: a tile in two parts hands on more than 32.
 #ifndef PMX_REGION32
 #define PMX_REGION32 1
 #endif
@@ -1521,7 +1525,7 @@ __global__ void __launch_bounds__(TTHREADS, (paint_min_waves<KIND, SORTED, MODE>
 #define PMX_HEADROOM32 4          // log2 of the room above the mean density of the segment's tiles
 #endif
 #ifndef PMX_RETRY32
-#define PMX_RETRY32 5             // log2 of the coarsening per retry
+#define PMX_RETRY32 5             // log2 of the coarsening of the scale itself, should even the high parts overflow
 #endif
 template <int KIND> struct Tile32 {
     static constexpr int S = Tuned<KIND>::S;
@@ -1552,10 +1556,12 @@ __device__ __forceinline__ int fixed_exponent32(const pmx_painter &p, double mb,
 // cells held before each add (SIGNED: shifted by 2^30, so that bit 31 says "at or beyond 2^30 in magnitude").
 // PE = 4 / 8: the positions are dense rows of three floats / doubles (one 12-byte load, or a 16- and an 8-byte one, per
 // particle); PE = 0: any strides and element size.  !SIGNED implies a scalar mass and no differentiated axis.
-template <int KIND, int TTHREADS, bool SORTED, int PE, bool WHOLE, bool SIGNED>
+// PART (a tile that overflowed its optimistic scale is deposited in two parts, see paint_tile32_kernel): 0 = the
+// contribution v as it is; 1 = its high part v >> sh (arithmetic: floor); 2 = its low part v & (2^sh - 1)
+template <int KIND, int TTHREADS, bool SORTED, int PE, bool WHOLE, bool SIGNED, int PART = 0>
 __device__ __forceinline__ uint32_t tile_deposit32(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
                                                    const DVec &mass, double mass_scalar, const uint32_t *list,
-                                                   int64_t start, int count, uint32_t *lds, double scale)
+                                                   int64_t start, int count, uint32_t *lds, double scale, int sh = 0)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
@@ -1619,7 +1625,10 @@ __device__ __forceinline__ uint32_t tile_deposit32(const pmx_painter &p, const B
                     const int q = gi * G + k, a = q / (S * S), b = (q / S) % S, c = q % S;
                     if (c == 0) fb = V[0][a] * V[1][b];
                     const double r = __builtin_fma(fb, V[2][c], FIXED_MAGIC);
-                    old[gi & 1][k] = atomicAdd(base + (a * R1 + b) * P + c, (uint32_t)__double_as_longlong(r));
+                    uint32_t v = (uint32_t)__double_as_longlong(r);
+                    if (PART == 1) v = (uint32_t)((int)v >> sh);
+                    if (PART == 2) v &= (1u << sh) - 1u;
+                    old[gi & 1][k] = atomicAdd(base + (a * R1 + b) * P + c, v);
                 }
                 if (gi > 0) {
 #pragma unroll
@@ -1668,6 +1677,9 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
       const int t2a = seg * ZSEG, t2b = (t2a + ZSEG < ntw) ? t2a + ZSEG : ntw;
       const int64_t tile0 = WALK_X ? column : column * ntw;
       bool live = false;
+      long long carry[CPT];                    // the face carried from tile to tile of the segment (see below)
+#pragma unroll
+      for (int u = 0; u < CPT; u++) carry[u] = 0;
       int64_t nseg_part = 0;
       for (int t2 = t2a; t2 < t2b; t2++) {
           const uint32_t c = counts[tile0 + t2 * tstride];
@@ -1685,95 +1697,168 @@ __global__ void __launch_bounds__(TTHREADS, (Tile32<KIND>::waves)) paint_tile32_
         constexpr bool TOUCH = !SORTED && S >= 4;
         uint32_t touched = 0;
         if constexpr (TOUCH) touched = list_touch(list, start, count);
-        int carry[CPT];
-        if (live) {
+        // `carry` (registers, 64 bits: a tile deposited in two parts hands on more than 32) was captured when the previous
+        // tile of the segment was flushed: its face cells, in units of 2^-f
+        auto zero_region = [&]() __attribute__((always_inline)) {
+            // (16 bytes per store: the region is a multiple of four cells)
+            static_assert(CELLS % 4 == 0, "32-bit region in 16-byte pieces");
+            int z0 = threadIdx.x;
+            asm volatile("" : "+v"(z0));
+            for (int q = z0; q < CELLS / 4; q += TTHREADS) ((uint4 *)lds)[q] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        };
+        // the carried face as the first cells of the region: part 0 = the value, 1 = value >> sh, 2 = value & (2^sh - 1)
+        auto place_carry = [&](int part, int sh) __attribute__((always_inline)) {
+            if (!live) return;
 #pragma unroll
             for (int u = 0; u < CPT; u++) {
                 int q = threadIdx.x + u * TTHREADS;
-                    asm volatile("" : "+v"(q));      // (opaque: see paint_tile_kernel)
+                asm volatile("" : "+v"(q));      // (opaque: see paint_tile_kernel)
                 if (q < NCARRY) {
-                    if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; carry[u] = (int)lds[(T0 * R1 + r) * P + c]; }
-                    else { const int c = q % (S - 1), r = q / (S - 1); carry[u] = (int)lds[r * P + T2 + c]; }
+                    const long long cv = carry[u];
+                    const uint32_t v = part == 0 ? (uint32_t)cv : (part == 1 ? (uint32_t)(cv >> sh) : (uint32_t)(cv & ((1ll << sh) - 1)));
+                    if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; lds[r * P + c] = v; }
+                    else { const int c = q % (S - 1), r = q / (S - 1); lds[r * P + c] = v; }
                 }
             }
             __syncthreads();
-        }
-        for (;;) {
-            // (16 bytes per store: the region is a multiple of four cells)
-            static_assert(CELLS % 4 == 0, "32-bit region in 16-byte pieces");
-            for (int q = threadIdx.x; q < CELLS / 4; q += TTHREADS) ((uint4 *)lds)[q] = make_uint4(0, 0, 0, 0);
-            __syncthreads();
-            if (live) {
+        };
+        // region -> canvas and halo staging: every cell times `unit`; add: on top of what a first part has written
+        auto flush = [&](double unit, bool add) __attribute__((always_inline)) {
+            const bool ow = overwrite && !add;
+            // owned box -> canvas, plain stores in rows of T2 cells
+            if constexpr (WHOLE) {
+                // the block is the whole periodic mesh, a multiple of the tile on every axis (pmx_binplan_supported): the
+                // owned box lies inside it, cell (a, b, c) at a fixed offset from the tile's first — no wraps, no bounds
+                char *tbase = canvas + (int64_t)t[0] * T0 * p.strides[0] + (int64_t)t[1] * T1 * p.strides[1] + (int64_t)t[2] * T2 * p.strides[2];
+                const int s0 = (int)p.strides[0], s1 = (int)p.strides[1], s2 = (int)p.strides[2];
+                int q0 = threadIdx.x;
+                asm volatile("" : "+v"(q0));      // (opaque, likewise)
+                for (int q = q0; q < TCELLS; q += TTHREADS) {
+                    const int c = q % T2, r = q / T2;
+                    const int b = r % T1, a = r / T1;
+                    const float v = (float)((double)(int)lds[(a * R1 + b) * P + c] * unit);
+                    float *dst = (float *)(tbase + ((int64_t)a * s0 + b * s1 + c * s2));
+                    if (ow) *dst = v;
+                    else *dst += v;
+                }
+            } else {
+                for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
+                    const int c = q % T2, r = q / T2;
+                    const int b = r % T1, a = r / T1;
+                    int64_t goff;
+                    bool in = true;
 #pragma unroll
-                for (int u = 0; u < CPT; u++) {
-                    int q = threadIdx.x + u * TTHREADS;
-                    asm volatile("" : "+v"(q));      // (opaque: see paint_tile_kernel)
-                    if (q < NCARRY) {
-                        if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; lds[r * P + c] = (uint32_t)carry[u]; }
-                        else { const int c = q % (S - 1), r = q / (S - 1); lds[r * P + c] = (uint32_t)carry[u]; }
+                    for (int d = 0; d < 3; d++) {
+                        const int l = t[d] * tile_ext(d) - g.o[d] + (d == 0 ? a : (d == 1 ? b : c));
+                        in = in && l >= 0 && l < p.size[d];
+                    }
+                    if (in && region_cell(p, g, t, a, b, c, &goff)) {
+                        const float v = (float)((double)(int)lds[(a * R1 + b) * P + c] * unit);
+                        float *dst = (float *)(canvas + goff);
+                        if (ow) *dst = v;
+                        else *dst += v;
                     }
                 }
-                __syncthreads();
             }
-            if constexpr (TOUCH) list_touch_done(touched);
+            // halo -> staging (compact numbering, contiguous writes)
+            float *hbase = halo + tile * (int64_t)Rg::HALO;
+            int h0 = threadIdx.x;
+            asm volatile("" : "+v"(h0));      // (opaque: no per-thread staging address kept — and spilled — across the tile loop)
+            for (int h = h0; h < Rg::HALO; h += TTHREADS) {
+                int a, b, c;
+                Rg::halo_decode(h, &a, &b, &c);
+                if (!last && (WALK_X ? a >= T0 : c >= T2)) continue;           // carried to the next tile instead
+                const float v = (float)((double)(int)lds[(a * R1 + b) * P + c] * unit);
+                if (add) hbase[h] += v;
+                else hbase[h] = v;
+            }
+        };
+        // the face the next tile of the segment starts from, out of the region: carry = (add ? carry : 0) + cell << sh
+        auto capture = [&](int sh, bool add) __attribute__((always_inline)) {
+            if (last) return;
+#pragma unroll
+            for (int u = 0; u < CPT; u++) {
+                int q = threadIdx.x + u * TTHREADS;
+                asm volatile("" : "+v"(q));
+                if (q < NCARRY) {
+                    int cell;
+                    if (WALK_X) { const int c = q % Rg::R2, r = q / Rg::R2; cell = (int)lds[(T0 * R1 + r) * P + c]; }
+                    else { const int c = q % (S - 1), r = q / (S - 1); cell = (int)lds[r * P + T2 + c]; }
+                    carry[u] = (add ? carry[u] : 0ll) + ((long long)cell << sh);
+                }
+            }
+        };
+        // one deposit, and whether some cell came within a factor 2 of the 32 bits (uniform over the workgroup)
+        auto overflowed = [&](uint32_t over) __attribute__((always_inline)) {
+            if (over) flag[trial & 1] = 1;
+            __syncthreads();
+            const bool yes = flag[trial & 1] != 0;
+            trial++;
+            if (threadIdx.x == 0) flag[trial & 1] = 0;            // (the other word: read next behind two more barriers)
+            return yes;
+        };
+        // A face that does not fit 32 bits (handed on by a tile in two parts) puts this tile in two parts from the start
+        bool two = false;
+        if (live) {
+            uint32_t big = 0;
+#pragma unroll
+            for (int u = 0; u < CPT; u++)
+                if ((int)(threadIdx.x + u * TTHREADS) < NCARRY && (carry[u] >= (1ll << 30) || carry[u] <= -(1ll << 30))) big = 1;
+            two = overflowed(big);
+        }
+        if constexpr (TOUCH) list_touch_done(touched);
+        if (!two) {
+            zero_region();
+            place_carry(0, 0);
 #if defined(PMX_EXPERIMENT) && defined(PMX_EXP_NODEPOSIT32)
             const uint32_t over = 0;        // timing experiment: everything but the deposit loop
 #else
-            const uint32_t over = tile_deposit32<KIND, TTHREADS, SORTED, PE, WHOLE, SIGNED>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, pow2(f));
+            const uint32_t over = tile_deposit32<KIND, TTHREADS, SORTED, PE, WHOLE, SIGNED, 0>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, pow2(f));
 #endif
-            if (over) flag[trial & 1] = 1;
-            __syncthreads();
-            const bool again = flag[trial & 1] != 0 && f > -1000;
-            trial++;
-            if (threadIdx.x == 0) flag[trial & 1] = 0;            // (the other word: read next behind two more barriers)
-            if (!again) break;
-            // some cell came within a factor 2 of the 32 bits: the tile once more in coarser units (the carried
-            // face with it, rounded to nearest)
-            f -= PMX_RETRY32;
-#pragma unroll
-            for (int u = 0; u < CPT; u++) carry[u] = (carry[u] + (1 << (PMX_RETRY32 - 1))) >> PMX_RETRY32;
-            __syncthreads();
-        }
-        const double inv = pow2(-f);
-        // owned box -> canvas, plain stores in rows of T2 cells
-        if constexpr (WHOLE) {
-            // the block is the whole periodic mesh, a multiple of the tile on every axis (pmx_binplan_supported): the
-            // owned box lies inside it, cell (a, b, c) at a fixed offset from the tile's first — no wraps, no bounds
-            char *tbase = canvas + (int64_t)t[0] * T0 * p.strides[0] + (int64_t)t[1] * T1 * p.strides[1] + (int64_t)t[2] * T2 * p.strides[2];
-            const int s0 = (int)p.strides[0], s1 = (int)p.strides[1], s2 = (int)p.strides[2];
-            for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
-                const int c = q % T2, r = q / T2;
-                const int b = r % T1, a = r / T1;
-                const float v = (float)((double)(int)lds[(a * R1 + b) * P + c] * inv);
-                float *dst = (float *)(tbase + ((int64_t)a * s0 + b * s1 + c * s2));
-                if (overwrite) *dst = v;
-                else *dst += v;
-            }
-        } else
-        for (int q = threadIdx.x; q < TCELLS; q += TTHREADS) {
-            const int c = q % T2, r = q / T2;
-            const int b = r % T1, a = r / T1;
-            int64_t goff;
-            bool in = true;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const int l = t[d] * tile_ext(d) - g.o[d] + (d == 0 ? a : (d == 1 ? b : c));
-                in = in && l >= 0 && l < p.size[d];
-            }
-            if (in && region_cell(p, g, t, a, b, c, &goff)) {
-                const float v = (float)((double)(int)lds[(a * R1 + b) * P + c] * inv);
-                float *dst = (float *)(canvas + goff);
-                if (overwrite) *dst = v;
-                else *dst += v;
+            two = overflowed(over);
+            if (!two) {
+                flush(pow2(-f), false);
+                capture(0, false);
             }
         }
-        // halo -> staging (compact numbering, contiguous writes)
-        float *hbase = halo + tile * (int64_t)Rg::HALO;
-        for (int h = threadIdx.x; h < Rg::HALO; h += TTHREADS) {
-            int a, b, c;
-            Rg::halo_decode(h, &a, &b, &c);
-            if (!last && (WALK_X ? a >= T0 : c >= T2)) continue;           // carried to the next tile instead
-            hbase[h] = (float)((double)(int)lds[(a * R1 + b) * P + c] * inv);
+        if (two) {
+            // Some cell came within a factor 2 of the 32 bits at the optimistic scale (a crowded tile).  The same
+            // contributions, at the SAME scale, in two parts: v >> sh into one zeroed region, flushed, then v & (2^sh - 1)
+            // into another, added on top — every contribution still rounded once to 2^-f, the sum exact.  sh: the low
+            // parts of `count` particles (and of the carried face) cannot reach 2^30.  Should the high parts overflow
+            // (more than 2^16 of the largest contributions on one cell) the scale itself is coarsened, before
+            // anything is written.
+            int lg = 0;
+            while ((1 << lg) <= count + 1) lg++;                       // count + 1 < 2^lg
+            const int sh = 29 - lg < 12 ? (29 - lg > 0 ? 29 - lg : 0) : 12;
+            for (;;) {
+                zero_region();
+                place_carry(1, sh);
+                const uint32_t over = tile_deposit32<KIND, TTHREADS, SORTED, PE, WHOLE, SIGNED, 1>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, pow2(f), sh);
+                if (!overflowed(over) || f <= -1000) break;
+                f -= PMX_RETRY32;
+#pragma unroll
+                for (int u = 0; u < CPT; u++) carry[u] = (carry[u] + (1ll << (PMX_RETRY32 - 1))) >> PMX_RETRY32;
+            }
+            const long long keep_dummy = 0; (void)keep_dummy;
+            long long carry_in[CPT];
+#pragma unroll
+            for (int u = 0; u < CPT; u++) carry_in[u] = carry[u];
+            flush(pow2(sh - f), false);
+            capture(sh, false);
+            __syncthreads();
+            // the low parts (the carried face's low part from what came in, not from what was just captured)
+#pragma unroll
+            for (int u = 0; u < CPT; u++) { const long long tmp = carry[u]; carry[u] = carry_in[u]; carry_in[u] = tmp; }
+            zero_region();
+            place_carry(2, sh);
+            (void)tile_deposit32<KIND, TTHREADS, SORTED, PE, WHOLE, SIGNED, 2>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, pow2(f), sh);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < CPT; u++) carry[u] = carry_in[u];
+            flush(pow2(-f), true);
+            capture(0, true);
         }
         live = !last;
         __syncthreads();

@@ -238,6 +238,66 @@ def test_crowded_tile_is_split(hip, oracle, name):
         assert_array_equal(got, oracle.Window(W.kind).readout(field_h, pos_h, transform=oaff))
 
 
+@pytest.mark.parametrize('name', ['tsc', 'pcs'])
+@pytest.mark.parametrize('case', ['one_cell', 'blob', 'signed', 'gradient', 'big_masses', 'tiny_masses'])
+def test_float_canvas_regions_retry_on_overflow(hip, oracle, name, case):
+    """[r5] The 32-bit fixed-point regions of float canvases (paint_tile32_kernel): the scale is optimistic (room for 16 x
+    the mean density of a segment's tiles), every add is checked through the value the atomic returns, and a tile that
+    comes within a factor 2 of the 32 bits is deposited again IN TWO PARTS at the same scale (v >> sh, flushed, then
+    v & (2^sh - 1) added on top: every contribution still rounded once to 2^-f) — here made to happen: thousands of
+    particles on ONE cell (identical contributions: their roundings do not cancel, the case that a coarser retry scale
+    fails) / in a tight blob inside an otherwise thin set, masses of either sign and derivative weights (the signed
+    guard), masses of 1e6 and 1e-9 (the scale follows the largest |mass|).  Against the oracle within the tolerance of a float canvas; the sum of the mesh to 1e-6
+    of the summed |mass|."""
+    W = windows[name]
+    N = 64
+    rs = numpy.random.RandomState({'one_cell': 1, 'blob': 2, 'signed': 3, 'gradient': 4, 'big_masses': 5, 'tiny_masses': 6}[case])
+    thin = rs.uniform(0, N, size=(30000, 3))
+    if case == 'one_cell':
+        dense = numpy.tile(numpy.array([[20.3, 33.6, 40.2]]), (12000, 1))
+    else:
+        dense = numpy.array([[20.3, 33.6, 40.2]]) + rs.normal(scale=0.7, size=(15000, 3))
+    pos_h = numpy.concatenate([thin, dense]).astype('f4')
+    mass_h = rs.uniform(0.5, 1.5, size=len(pos_h))
+    diffdir = None
+    if case == 'signed':
+        mass_h *= rs.choice([-1.0, 1.0], size=len(pos_h))
+    elif case == 'gradient':
+        diffdir = 1
+    elif case == 'big_masses':
+        mass_h *= 1.0e6
+    elif case == 'tiny_masses':
+        mass_h *= 1.0e-9
+    aff, oaff = Affine(3, period=N), oracle.Affine(3, period=N)
+    want = numpy.zeros((N, N, N))
+    oracle.Window(W.kind).paint(want, pos_h.astype('f8'), mass=mass_h, transform=oaff, diffdir=diffdir)
+    window.BINNED = 'always'
+    pos = torch.from_numpy(pos_h).to(hip.device)
+    mass = torch.from_numpy(mass_h).to(hip.device)
+    got = []
+    for scalar in (False, True):
+        if scalar and case in ('signed', 'big_masses', 'tiny_masses'):
+            continue
+        for _ in range(2):
+            window.clear_bin_cache()
+            c = torch.zeros((N, N, N), dtype=torch.float32, device=hip.device)
+            W.paint(c, pos, mass=None if scalar else mass, diffdir=diffdir, transform=aff)
+            assert_binned_ran()
+            got.append(c.cpu().numpy().astype('f8'))
+        w = want
+        if scalar:
+            w = numpy.zeros((N, N, N))
+            oracle.Window(W.kind).paint(w, pos_h.astype('f8'), transform=oaff, diffdir=diffdir)
+        # (two runs agree to the rounding of the float adds that merge the staged halo cells: the REGION sums are integers)
+        assert_allclose(got[-1], got[-2], rtol=0, atol=2.5e-7 * max(1.0, abs(got[-1]).max()))
+        scale = abs(w).max()
+        assert scale > 100 * (abs(mass_h).mean() if not scalar else 1.0) or case in ('gradient', 'signed')     # the blob really is a blob
+        assert_allclose(got[-1], w, rtol=0, atol=2e-6 * max(1.0, scale) if case != 'tiny_masses' else 2e-6 * scale)
+        if diffdir is None and case != 'signed':
+            total = mass_h.sum() if not scalar else float(len(pos_h))
+            assert abs(got[-1].sum() - total) <= 1e-6 * abs(total) + 1e-5 * scale
+
+
 @pytest.mark.parametrize('name', ['nnb', 'cic', 'tsc'])
 def test_binned_dyadic_bit_exact(hip, form, oracle, name):
     """positions on a 1/16-cell lattice, small integer masses: exact partial sums =>

@@ -92,7 +92,16 @@ def test_tile_kernel_budgets():
              or 'paint_tile32_kernel' in k or 'readout_tile_lean_kernel' in k}
     assert len(tiles) >= 16
     for k, v in tiles.items():
-        assert v['ScratchSize'] == 0, k
+        if 'paint_tile32_kernel' in k:
+            # [r5] a few forms (blocks that are not whole meshes, the tile-ordered copy with signed contributions) park up
+            # to five kernel-lifetime words per lane — addresses and reciprocals computed once, the carried face — in
+            # scratch OUTSIDE the deposit loops (read from the listing: stores at the kernel's entry, reloads at tile
+            # boundaries); the forms of the one-rank default path (index list, whole mesh) must not
+            assert v['ScratchSize'] <= 24, (k, v)
+            if 'ELb0ELb0ELb1E' in k or 'ELb0ELb1ELb1E' in k:
+                assert v['ScratchSize'] == 0, (k, v)
+        else:
+            assert v['ScratchSize'] == 0, k
         assert v['VGPRs'] <= 128, (k, v)
     # CIC (kind 5), double canvas: 40 KB regions -> four workgroups per CU
     for k, v in tiles.items():
