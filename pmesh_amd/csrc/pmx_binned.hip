@@ -2402,7 +2402,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         // list entries of a tile that its own workgroup takes: four times the mean population, at
         // least 16384; what a crowded tile holds beyond that is cut into pieces of the same size
         int64_t mean = g.ntiles > 0 ? npart / g.ntiles : 0;
-        int64_t ch = 4 * mean > 16384 ? 4 * mean : 16384;
+#ifndef PMX_MIN_CHUNK
+#define PMX_MIN_CHUNK 16384
+#endif
+        int64_t ch = 4 * mean > PMX_MIN_CHUNK ? 4 * mean : PMX_MIN_CHUNK;
         g.chunk = (int32_t)(ch < (1 << 30) ? ch : (1 << 30));
     }
     PMX_REQUIRE(g.ntiles < 2147483647ll, PMX_EUNSUPPORTED, "more than 2^31 buckets");
