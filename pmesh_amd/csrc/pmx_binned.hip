@@ -2405,7 +2405,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #ifndef PMX_MIN_CHUNK
 #define PMX_MIN_CHUNK 16384
 #endif
-        int64_t ch = 4 * mean > PMX_MIN_CHUNK ? 4 * mean : PMX_MIN_CHUNK;
+#ifndef PMX_CHUNK_FACTOR
+#define PMX_CHUNK_FACTOR 4
+#endif
+        int64_t ch = PMX_CHUNK_FACTOR * mean > PMX_MIN_CHUNK ? PMX_CHUNK_FACTOR * mean : PMX_MIN_CHUNK;
         g.chunk = (int32_t)(ch < (1 << 30) ? ch : (1 << 30));
     }
     PMX_REQUIRE(g.ntiles < 2147483647ll, PMX_EUNSUPPORTED, "more than 2^31 buckets");
