@@ -280,8 +280,14 @@ def main():
     torch.cuda.set_device(0 if share else local_rank)
     launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ      # under torch.distributed.run
     if world > 1 or launched:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group(os.environ.get('PMESH_AMD_DIST_BACKEND', 'nccl'))
+        # a rank that dies must not leave the others in an all-to-all for ever: collectives time out (default 5 min)
+        # and, with RCCL's asynchronous error handling, a timed-out rank's process exits non-zero — the launcher
+        # (torch.distributed.run) then ends the job.  (Never re-exec a process that has touched the GPU.)
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
+        dist.init_process_group(os.environ.get('PMESH_AMD_DIST_BACKEND', 'nccl'),
+                                timeout=datetime.timedelta(seconds=int(os.environ.get('PMESH_AMD_COLLECTIVE_TIMEOUT_S', '300'))))
 
     from pmesh_amd import backend
     from pmesh_amd._arrays import vec

@@ -33,11 +33,14 @@ def setup():
     use_hip = os.environ.get('PMESH_MP_BACKEND', 'double') == 'hip'
     if use_hip:
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-        dist.init_process_group('nccl')
+        import datetime
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
+        dist.init_process_group('nccl', timeout=datetime.timedelta(seconds=300))      # (a dead rank ends the job, see bench.py)
         from pmesh_amd import backend
         be = backend.get()
     else:
-        dist.init_process_group('gloo')
+        import datetime
+        dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
         from tests import oracle_backend
         be = oracle_backend.install()
     from pmesh_amd.comm import TorchComm
