@@ -18,7 +18,7 @@ for row in csv.DictReader(open(f[0])):
     n[(k, row['Counter_Name'])] += 1
 with open(out + '/sq_summary.txt', 'w') as o:
     for k, c in acc.items():
-        if 'walk' not in k and 'tile_kernel' not in k and 'halo' not in k and 'bin_count' not in k and 'fft' not in k: continue
+        if 'tile' not in k and 'halo' not in k and 'bin_' not in k and 'fft' not in k: continue
         wc = c.get('SQ_WAVE_CYCLES', 0) or 1
         line = '%-62s ' % k + ' '.join('%s=%.3f' % (name.replace('SQ_', ''), c[name] / wc) for name in sorted(c) if name != 'SQ_WAVE_CYCLES')
         print(line); o.write(line + '\n')
