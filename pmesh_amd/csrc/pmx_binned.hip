@@ -2012,20 +2012,42 @@ __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const Bin
     }
 }
 
+// The kernel also does what the general readout leaves to two launches of their own: the particles that touch no local
+// cell read 0 (zero_dropped_kernel), and the pieces of crowded tiles beyond g.chunk entries (readout_heavy_kernel) are
+// work units behind the tiles — a readout is read-only on the canvas, nothing orders them.  (Two launches of ~4.5 us per
+// readout: nothing at 512^3 on one GPU, 2 % of a rank's particle kernels at 8 ranks.)
 template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
 __global__ void __launch_bounds__(TTHREADS) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                                    DVec pos, char *out, const uint32_t *list,
-                                                                   const int64_t *offsets, const uint32_t *counts)
+                                                                   const int64_t *offsets, const uint32_t *counts,
+                                                                   const uint64_t *items, const uint32_t *nitems, uint32_t cap)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
     constexpr int R1 = Rg::R1, R2 = Rg::R2;
     __shared__ T lds[Rg::template glds<T>()];
     __shared__ int64_t tab[Rg::R0 + Rg::R1 + Rg::R2];
-    for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        const int64_t start = offsets[tile];
-        const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
-        if (count == 0) continue;
+    {
+        // entries of `out` for particles that are in no tile (the common case: none)
+        const int64_t nd = counts[g.ntiles];
+        const uint32_t *dl = list + offsets[g.ntiles];
+        for (int64_t j = blockIdx.x * (int64_t)TTHREADS + threadIdx.x; j < nd; j += (int64_t)gridDim.x * TTHREADS) {
+            if (OE == 8) *(double *)(out + (int64_t)dl[j] * 8) = 0.0;
+            else *(float *)(out + (int64_t)dl[j] * 4) = 0.0f;
+        }
+    }
+    const int64_t nh = *nitems < cap ? *nitems : cap;
+    for (int64_t unit = blockIdx.x; unit < g.ntiles + nh; unit += gridDim.x) {
+        int64_t tile = unit, first = 0;
+        if (unit >= g.ntiles) {
+            const uint64_t it = items[unit - g.ntiles];
+            tile = (int64_t)(it >> 20);
+            first = (int64_t)(it & 0xFFFFF) * g.chunk;
+        }
+        const int64_t start = offsets[tile] + first;
+        const int64_t left = (int64_t)counts[tile] - first;
+        const int count = left < g.chunk ? (int)left : g.chunk;
+        if (count <= 0) continue;
         int t[3];
         tile_coords(g, tile, t);
         region_tables<S, false>(p, g, t, tab, TTHREADS);
@@ -2325,10 +2347,9 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (!pl) return PMX_OK;
     if (pl->tid) (void)hipFree(pl->tid);
     if (pl->list) (void)hipFree(pl->list);
-    if (pl->counts) (void)hipFree(pl->counts);
+    if (pl->ctl) (void)hipFree(pl->ctl);          // (flags, nheavy and counts live in it)
     if (pl->offsets) (void)hipFree(pl->offsets);
     if (pl->cursor) (void)hipFree(pl->cursor);
-    if (pl->flags) (void)hipFree(pl->flags);
     if (pl->host_flag) (void)hipHostFree(pl->host_flag);
     if (pl->halo) (void)hipFree(pl->halo);
     if (pl->pos_copy) (void)hipFree(pl->pos_copy);
@@ -2339,7 +2360,6 @@ extern "C" int pmx_binplan_destroy(pmx_binplan *pl)
     if (pl->dscratch) (void)hipFree(pl->dscratch);
     if (pl->dhalo) (void)hipFree(pl->dhalo);
     if (pl->heavy_items) (void)hipFree(pl->heavy_items);
-    if (pl->nheavy) (void)hipFree(pl->nheavy);
     delete pl;
     return PMX_OK;
 }
@@ -2455,33 +2475,31 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     }
     if ((size_t)(nbuckets + 1) > pl->cap_tiles) {
         size_t c1 = 0, c2 = 0, c3 = 0;
-        if (pl->counts) (void)hipFree(pl->counts);
+        if (pl->ctl) (void)hipFree(pl->ctl);
         if (pl->offsets) (void)hipFree(pl->offsets);
         if (pl->cursor) (void)hipFree(pl->cursor);
-        pl->counts = nullptr; pl->offsets = nullptr; pl->cursor = nullptr; pl->cap_tiles = 0;
-        rc = plan_ensure((void **)&pl->counts, &c1, (size_t)(nbuckets + 1) * 4); if (rc) return rc;
+        pl->ctl = nullptr; pl->counts = nullptr; pl->flags = nullptr; pl->nheavy = nullptr;
+        pl->offsets = nullptr; pl->cursor = nullptr; pl->cap_tiles = 0;
+        rc = plan_ensure((void **)&pl->ctl, &c1, 32 + (size_t)(nbuckets + 1) * 4); if (rc) return rc;
+        pl->flags = pl->ctl; pl->nheavy = pl->ctl + 4; pl->counts = pl->ctl + 8;
         rc = plan_ensure((void **)&pl->offsets, &c2, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
         rc = plan_ensure((void **)&pl->cursor, &c3, (size_t)(nbuckets + 1) * 8); if (rc) return rc;
         pl->cap_tiles = (size_t)(nbuckets + 1);
         reuse = false;
     }
-    if (!pl->flags) PMX_HIP_CHECK(hipMalloc((void **)&pl->flags, 16));
-    if (!pl->nheavy) PMX_HIP_CHECK(hipMalloc((void **)&pl->nheavy, 16));
     {
         size_t cb = pl->cap_heavy * 8;
         rc = plan_ensure((void **)&pl->heavy_items, &cb, (np1 / (size_t)g.chunk + 16) * 8);
         if (rc) return rc;
         pl->cap_heavy = cb / 8;
     }
-    PMX_HIP_CHECK(hipMemsetAsync(pl->nheavy, 0, 16, st));
     if (!pl->host_flag) {
         PMX_HIP_CHECK(hipHostMalloc((void **)&pl->host_flag, 64, hipHostMallocMapped));
         pl->host_flag[0] = 0;
         pl->host_flag[1] = 0;      // particles a tile kernel found outside the region their list entry names (pmx_binplan_stale)
     }
     pl->g.stale = pl->host_flag + 1;
-    PMX_HIP_CHECK(hipMemsetAsync(pl->flags, 0, 16, st));
-    PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)nbuckets * 4, st));
+    PMX_HIP_CHECK(hipMemsetAsync(pl->ctl, 0, 32 + (size_t)nbuckets * 4, st));      // flags, nheavy, counts: one fill
     DVec dpos = dvec(pos);
     if (npart > 0) {
         const unsigned full_grid = grid_for((npart + 3) / 4, TBLOCK);
@@ -2906,22 +2924,23 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
         dout.data = (const char *)pl->out_sorted;
         dout.stride0 = 8; dout.stride1 = 0; dout.elsize = 8;
     }
-    zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
     const bool relax = pl->exact == 0;
+    // [r5] the common case — relaxed arithmetic, the index list, dense position rows, a dense result vector — has a loop of its
+    // own, which also zeroes the dropped particles and takes the pieces of crowded tiles (one launch instead of three)
+#ifndef PMX_LEAN_READOUT
+#define PMX_LEAN_READOUT 1
+#endif
+    const bool lean = PMX_LEAN_READOUT && relax && !sorted && dpos.stride1 == dpos.elsize && dpos.stride0 == 3 * dpos.elsize
+                      && dout.stride0 == dout.elsize;
+    if (!lean) zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
     // (NNB: one cell, weight 1 — the same bits either way; the lean per-particle setup of the relaxed form is what it takes)
 #define RT2(K, T, RX) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
                       else readout_tile_kernel<K, T, TileThreads<K, T>::readout, false, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); } while (0)
 #define RT(K, T) do { if (relax) RT2(K, T, true); else RT2(K, T, false); } while (0)
-    // [r5] the common case — relaxed arithmetic, the index list, dense position rows, a dense result vector — has a loop of its own
-#ifndef PMX_LEAN_READOUT
-#define PMX_LEAN_READOUT 1
-#endif
     bool whole_r = true;
     for (int d = 0; d < 3; d++) whole_r = whole_r && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
-    const bool lean = PMX_LEAN_READOUT && relax && !sorted && dpos.stride1 == dpos.elsize && dpos.stride0 == 3 * dpos.elsize
-                      && dout.stride0 == dout.elsize;
-#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts)
+#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy)
 #define RLW(K, T, PE_, OE_) do { if (whole_r) RLL(K, T, PE_, OE_, true); else RLL(K, T, PE_, OE_, false); } while (0)
 #define RLO(K, T, PE_) do { if (dout.elsize == 8) RLW(K, T, PE_, 8); else RLW(K, T, PE_, 4); } while (0)
 #define RL(K, T) do { if (dpos.elsize == 8) RLO(K, T, 8); else RLO(K, T, 4); } while (0)
@@ -2962,7 +2981,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     }
 #undef RT
 #undef RT2
-    {
+    if (!lean) {
         const unsigned hgrid = (unsigned)(pl->cap_heavy < 1024 ? pl->cap_heavy : 1024);
 #define RH2(K, T, RX) do { if (sorted) readout_heavy_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); \
                       else readout_heavy_kernel<K, T, TileThreads<K, T>::readout, false, RX><<<hgrid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy); } while (0)

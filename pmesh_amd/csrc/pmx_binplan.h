@@ -135,7 +135,8 @@ struct pmx_binplan {
     uint32_t *list = nullptr;   // particle indices, tile major
     size_t cap_part = 0;
     size_t cap_list = 0;        // entries of `list`: npart + slack (see slot_capacity)
-    uint32_t *counts = nullptr; // particles per tile; entry [ntiles] = particles that touch no local cell
+    uint32_t *ctl = nullptr;    // ONE allocation for what every build clears: [flags: 4 words][nheavy: 4 words][counts ...] (one memset per build instead of three)
+    uint32_t *counts = nullptr; // particles per tile; entry [ntiles] = particles that touch no local cell (= ctl + 8)
     int64_t *offsets = nullptr; // first list slot of every tile (ntiles + 2 entries): tile t owns
                                 // slots [offsets[t], offsets[t+1]), of which counts[t] are used
     unsigned long long *cursor = nullptr;   // next free slot per tile while scattering
