@@ -461,7 +461,7 @@ def main():
             pm.resampler.prebin(rho.value, getattr(pos, 'tensor', pos), pm.affine)      # tile binning, shared by paint+readout
         mark(1)
         # (includes the zero fill)
-        painted = pm.paint(pos, mass=mass, hold=False, layout=layout, out=rho if (args.out_field or layout is not None) else None)
+        painted = pm.paint(pos, mass=mass, hold=False, layout=layout, out=rho if args.out_field else None)
         halo_deferred[0] = getattr(painted._base.storage, '_pmx_halo', None) is not None
         mark(2)
         rhok = painted.r2c(out=Ellipsis)

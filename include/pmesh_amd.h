@@ -247,7 +247,8 @@ int pmx_paint_binned_defer(pmx_binplan *plan, const pmx_painter *p, void *canvas
 int pmx_halo_merge(pmx_binplan *plan, const pmx_painter *p, void *canvas, void *stream);
 /* what pmx_rowfft_halo reads: the staging buffer of the plan's last deferred paint (elements of the canvas type,
  * ntiles x the halo cells of a tile region in the compact numbering of csrc/pmx_binplan.h), the window support S and
- * the tiles per axis nt[3]; PMX_EINVAL unless `canvas` / `elsize` are those of that paint.  consume != 0 releases the
+ * nt[4]: the tiles per axis, then the plane of tile space the block starts at along axis 0 (0: one rank's whole mesh;
+ * S - 1: a slab rank's block of planes); PMX_EINVAL unless `canvas` / `elsize` are those of that paint.  consume != 0 releases the
  * plan (the staged values are moot: the canvas is gone or about to be overwritten as a whole). */
 int pmx_binplan_halo_source(pmx_binplan *plan, const void *canvas, int32_t elsize, const void **halo,
                             int32_t *S, int32_t *nt, int32_t consume);

@@ -83,19 +83,26 @@ __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const B
     return ok ? (int64_t)tb : g.ntiles;
 }
 
+template <int NT>
+__device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor);
+
 // MODE 0: count pass of the two-pass build: tid[i] = tile, counts[tile]++.
 // MODE 1: single-pass build into the slot ranges of the previous build: the wave-aggregated
 //         atomic returns the first free slot of the group; particle i goes to
 //         list[offsets[tile] + slot] unless the tile's range is full (-> flags[0], host_flag).
+// MODE 3: the repair after a single pass that overflowed, ONE launch: every single-pass form adds to counts[] before
+//         it looks at the range, so the counts are exact; workgroup 0 lays the new ranges out from them (offsets,
+//         cursor) and raises flags[3], the others wait for that (the grid is small enough to be resident at once),
+//         then every group of rows takes its slots from cursor[tile].
 // Particles that touch no local cell go to bucket `ntiles`.  gate != NULL: do nothing unless
-// *gate != 0 (the fallback launches after a single-pass build are always enqueued and only
-// run if it overflowed — no host synchronisation).
+// *gate != 0 (the repair after a single-pass build is always enqueued and only
+// runs if it overflowed — no host synchronisation).
 template <int KIND, bool DENSE, int MODE, bool SORTP>
 __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
                                                            int32_t *tid, uint32_t *counts, uint32_t *flags,
                                                            const int64_t *offsets, uint32_t *list,
                                                            uint32_t *host_flag, const uint32_t *gate, uint32_t *inv_,
-                                                           void *copy_)
+                                                           void *copy_, unsigned long long *cursor)
 {
     // SORTP: the plan keeps a tile-ordered copy of the positions: the inverse list is recorded, and
     constexpr bool noagg = SORTP && MODE == 1;
@@ -108,6 +115,20 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
     constexpr int U = MODE == 1 ? PMX_ONEPASS_U : 4;
     const int lane = threadIdx.x & 63;
     if (gate != nullptr && *gate == 0) return;
+    if (MODE == 3) {
+        if (blockIdx.x == 0) {
+            scan_ranges<TBLOCK>(counts, g.ntiles + 1, const_cast<int64_t *>(offsets), cursor);
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) atomicExch(&flags[3], 1u);
+        } else {
+            if (threadIdx.x == 0) {
+                while (atomicAdd(&flags[3], 0u) == 0) __builtin_amdgcn_s_sleep(16);
+                __threadfence();
+            }
+            __syncthreads();
+        }
+    }
     __shared__ __align__(16) unsigned char stage[DENSE ? U * TBLOCK * 24 : 16];
     // Workgroups that run at the same time take chunks that are far apart in the array: rows in
     // lattice order put neighbouring chunks into the same few tiles, and the ~7000 resident
@@ -194,6 +215,25 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
                 const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
                 if (t[u] >= 0 && lane == leader) atomicAdd(&counts[t[u]], (uint32_t)__popcll(same[u]));
                 if (i < n) tid[i] = t[u];
+            }
+        } else if (MODE == 3) {
+            unsigned long long b[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+                b[u] = 0;
+                if (t[u] >= 0 && lane == leader) b[u] = atomicAdd(&cursor[t[u]], (unsigned long long)__popcll(same[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = base + u * TBLOCK + threadIdx.x;
+                const int leader = t[u] >= 0 ? __ffsll((long long)same[u]) - 1 : lane;
+                const unsigned long long bb = __shfl(b[u], leader);
+                if (t[u] >= 0) {
+                    const unsigned long long slot = bb + (unsigned long long)__popcll(same[u] & (((unsigned long long)1 << lane) - 1));
+                    list[slot] = (uint32_t)i;
+                    if (inv) inv[i] = (uint32_t)slot;
+                }
             }
         } else {
             uint32_t b[U];
@@ -681,22 +721,21 @@ __global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom
     }
 }
 
-// exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup
-static __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
-                                                        unsigned long long *cursor, const uint32_t *gate)
+// exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup of NT threads
+template <int NT>
+__device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor)
 {
-    __shared__ int64_t sh[1024];
+    __shared__ int64_t sh[NT];
     __shared__ int64_t carry;
-    if (gate != nullptr && *gate == 0) return;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int64_t base = 0; base < ntiles; base += 1024) {
+    for (int64_t base = 0; base < ntiles; base += NT) {
         int64_t i = base + threadIdx.x;
         int64_t v = i < ntiles ? slot_capacity(counts[i]) : 0;
         sh[threadIdx.x] = v;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int64_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        for (int off = 1; off < NT; off <<= 1) {
+            int64_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
             __syncthreads();
             sh[threadIdx.x] += t;
             __syncthreads();
@@ -707,10 +746,17 @@ static __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *c
             cursor[i] = (unsigned long long)(carry + incl - v);
         }
         __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
+        if (threadIdx.x == NT - 1) carry += incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) offsets[ntiles] = carry;
+}
+
+static __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
+                                                        unsigned long long *cursor, const uint32_t *gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    scan_ranges<1024>(counts, ntiles, offsets, cursor);
 }
 
 static __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
@@ -808,13 +854,6 @@ static __global__ void __launch_bounds__(TBLOCK) unsort_kernel(const double *sor
         for (int u = 0; u < 4; u++)
             if (i0 + u * stride < n) out.set(i0 + u * stride, 0, v[u]);
     }
-}
-
-static __global__ void __launch_bounds__(TBLOCK) bin_zero_kernel(uint32_t *counts, int64_t nbuckets, const uint32_t *gate)
-{
-    if (*gate == 0) return;
-    for (int64_t i = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; i < nbuckets; i += (int64_t)gridDim.x * TBLOCK)
-        counts[i] = 0;
 }
 
 __device__ __forceinline__ void tile_coords(const BinGeom &g, int64_t tile, int *t)
@@ -2066,10 +2105,14 @@ __global__ void __launch_bounds__(TTHREADS) readout_tile_lean_kernel(pmx_painter
 }
 
 // ---- crowded tiles ------------------------------------------------------------------------
-// work items (tile, piece >= 1) for what the tiles hold beyond `chunk` list entries
+// work items (tile, piece >= 1) for what the tiles hold beyond `chunk` list entries; the last kernel of every build,
+// so it also hands the build's measurement of the row order (flags[1..2]) to the host's mapped slot (no copy node)
 static __global__ void __launch_bounds__(TBLOCK) heavy_items_kernel(const uint32_t *counts, int64_t ntiles, int chunk,
-                                                             uint64_t *items, uint32_t *nitems, uint32_t cap)
+                                                             uint64_t *items, uint32_t *nitems, uint32_t cap,
+                                                             const uint32_t *flags, uint32_t *host_measure)
 {
+    if (host_measure != nullptr && blockIdx.x == 0 && threadIdx.x < 2)
+        __hip_atomic_store(&host_measure[threadIdx.x], flags[1 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int64_t tile = blockIdx.x * (int64_t)TBLOCK + threadIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * TBLOCK) {
         const uint32_t c = counts[tile];
         if (c > (uint32_t)chunk) {
@@ -2497,7 +2540,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         PMX_HIP_CHECK(hipHostMalloc((void **)&pl->host_flag, 64, hipHostMallocMapped));
         pl->host_flag[0] = 0;
         pl->host_flag[1] = 0;      // particles a tile kernel found outside the region their list entry names (pmx_binplan_stale)
+        pl->host_flag[2] = 0;      // [2..3]: the last finished build's measurement of the row order (heavy_items_kernel)
+        pl->host_flag[3] = 0;
     }
+    uint32_t *measure_out = nullptr;
     pl->g.stale = pl->host_flag + 1;
     PMX_HIP_CHECK(hipMemsetAsync(pl->ctl, 0, 32 + (size_t)nbuckets * 4, st));      // flags, nheavy, counts: one fill
     DVec dpos = dvec(pos);
@@ -2510,9 +2556,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #define BC2(K, MODE, GRID, GATE, SP)                                                                              \
     do {                                                                                                        \
         if (dense) bin_count_kernel<K, true, MODE, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts, \
-                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp);                             \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp, pl->cursor);                 \
         else bin_count_kernel<K, false, MODE, SP><<<GRID, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->tid, pl->counts,  \
-                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp);                             \
+                pl->flags, pl->offsets, pl->list, pl->host_flag, GATE, inv, copyp, pl->cursor);                 \
     } while (0)
 #define BC(K, MODE, GRID, GATE)                                                                                 \
     do {                                                                                                        \
@@ -2537,6 +2583,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             pl->host_groups[0] = 0;                 // breaks of the tile sequence among ...
             pl->host_groups[1] = 0;                 // ... this many sampled rows of the last build
             pl->host_groups[2] = 0;                 // particles of that build
+        }
+        if (pl->have_measure) {                     // what the last finished build left in the mapped slot
+            pl->host_groups[0] = *(volatile uint32_t *)(pl->host_flag + 2);
+            pl->host_groups[1] = *(volatile uint32_t *)(pl->host_flag + 3);
         }
         // breaks of the tile sequence per 64 consecutive rows above which the row order counts as
         // incoherent (lattice order: a handful; random order: 63)
@@ -2584,11 +2634,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #undef BL
             } else
                 BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
+            // the repair, one launch that returns at once unless a tile overflowed (measured: the four gated launches
+            // it replaces, zero / count / scan / scatter, cost a slab rank 20 us per build)
             const uint32_t *gate = pl->flags;
-            bin_zero_kernel<<<64, TBLOCK, 0, st>>>(pl->counts, nbuckets, gate);
-            BCK(0, small_grid, gate);
-            bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, gate);
-            bin_scatter_kernel<<<small_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, gate, inv);
+            BCK(3, small_grid, gate);
         } else {
             BCK(0, full_grid, nogate);
             // How coherent is the row order?  Every build leaves its measurement in host_groups
@@ -2626,8 +2675,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #undef BC
 #undef BC2
         if (pl->sort_pref < 0 && npart >= (1 << 16)) {
-            // what this build saw of the row order, read by the NEXT build (stale at worst: a hint)
-            PMX_HIP_CHECK(hipMemcpyAsync(pl->host_groups, pl->flags + 1, 8, hipMemcpyDeviceToHost, st));
+            // what this build saw of the row order, read by the NEXT build (stale at worst: a hint); the build's last
+            // kernel stores it into the mapped slot
+            measure_out = pl->host_flag + 2;
             pl->host_groups[2] = (uint32_t)npart;
             pl->have_measure = true;
         }
@@ -2643,7 +2693,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     }
     if (npart > 0)
         heavy_items_kernel<<<grid_for(g.ntiles, TBLOCK, 1024), TBLOCK, 0, st>>>(pl->counts, g.ntiles, g.chunk, pl->heavy_items,
-                                                                               pl->nheavy, (uint32_t)pl->cap_heavy);
+                                                                               pl->nheavy, (uint32_t)pl->cap_heavy, pl->flags, measure_out);
     PMX_HIP_CHECK(hipGetLastError());
     pl->built = true;
     pl->have_history = npart > 0;
@@ -2807,15 +2857,18 @@ extern "C" int pmx_mass_stats(const pmx_vec *mass, int64_t n, double *stats, voi
     return PMX_OK;
 }
 
-// can the halo merge of a paint be left to the forward row pass of r2c (pmx_rowfft_halo)?  One rank's whole periodic
-// mesh (every tile a full one, halos wrap onto tiles), every cell written by the paint (overwrite), dense rows of a
-// power-of-two length the row kernel gathers for, floating-point staging.
+// can the halo merge of a paint be left to the forward row pass of r2c (pmx_rowfft_halo)?  Whole periodic axes 1 and 2
+// (every tile a full one, halos wrap onto tiles); along axis 0 either the same (one rank's mesh) or [r5] a block of
+// planes of a larger period (a slab rank: tile space starts S - 1 planes below the block, nothing wraps, what a region
+// holds outside the block is dropped by whoever merges); every cell written by the paint (overwrite), dense rows of
+// a power-of-two length the row kernel gathers for, floating-point staging.
 static bool halo_deferrable(const pmx_binplan *pl, const pmx_painter &p, int overwrite)
 {
     const BinGeom &g = pl->g;
     if (!overwrite || pl->deterministic || g.S < 2) return false;
-    for (int d = 0; d < 3; d++)
+    for (int d = 1; d < 3; d++)
         if (g.o[d] != 0 || p.period[d] != p.size[d]) return false;
+    if (!((g.o[0] == 0 && p.period[0] == p.size[0]) || g.o[0] == g.S - 1)) return false;
     if (p.strides[2] != p.canvas_elsize) return false;
     return pmx_rowfft_halo_supported(p.size[2], p.canvas_elsize) == PMX_OK;
 }
@@ -2887,6 +2940,7 @@ extern "C" int pmx_binplan_halo_source(pmx_binplan *pl, const void *canvas, int3
     *halo = pl->halo;
     *S = pl->g.S;
     for (int d = 0; d < 3; d++) nt[d] = pl->g.nt[d];
+    nt[3] = pl->g.o[0];          // plane 0 of the block in tile space (0: the whole mesh of one rank)
     if (consume) pl->halo_pending = 0;
     return PMX_OK;
 }

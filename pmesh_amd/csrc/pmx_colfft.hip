@@ -1687,14 +1687,17 @@ extern "C" int pmx_rowfft_halo(int32_t elsize, void *data, void *dst, int64_t nr
     PMX_REQUIRE(rows_per_plane % (128 / (2 * elsize)) == 0, PMX_EUNSUPPORTED,
                 "rows_per_plane must be a multiple of the rows of a tile");
     HaloSrc hs;
-    int32_t nt[3];
+    int32_t nt[4];
     rc = pmx_binplan_halo_source(plan, canvas, elsize, &hs.halo, &hs.S, nt, last);
     if (rc) return rc;
     hs.nt0 = nt[0]; hs.nt1 = nt[1]; hs.nt2 = nt[2];
-    hs.x0 = (int)x0;
+    // planes are counted in tile space: a slab rank's block starts nt[3] = S - 1 planes into it (plane 0 of tile
+    // layer 0 lies below the block and nothing wraps along that axis: the first planes of the block are then never
+    // the first of a tile layer, so the gather never looks for a layer before the first)
+    hs.x0 = (int)x0 + nt[3];
     PMX_REQUIRE(nrows % rows_per_plane == 0, PMX_EINVAL, "whole planes only");
     PMX_REQUIRE(rows_per_plane == (int64_t)nt[1] * T1 && n == (int64_t)nt[2] * T2 && x0 >= 0 &&
-                x0 * rows_per_plane + nrows <= (int64_t)nt[0] * T0 * rows_per_plane, PMX_EINVAL,
+                (x0 + nt[3]) * rows_per_plane + nrows <= (int64_t)nt[0] * T0 * rows_per_plane, PMX_EINVAL,
                 "rows do not match the mesh the plan's tiles cover");
     const int64_t plane_extra = plane_pitch - rows_per_plane * pitch;
     if (nrows == 0) return PMX_OK;

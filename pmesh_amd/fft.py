@@ -469,7 +469,10 @@ class Plan(object):
             # halos inside its row pass (_execute_local_hybrid); anything else needs the finished mesh first
             mine = (self.forward and p.nproc == 1 and not getattr(p, 'is_c2c', False) and p.ndim == 3 and
                     not (getattr(p, 'pencil', False) and not p.transposed))
-            if not mine:
+            # slab ranks: the row pass of the local stage does the same for the block of planes (_slab_row_forward)
+            slab = (self.forward and p.nproc > 1 and not getattr(p, 'is_c2c', False) and p.ndim == 3 and
+                    not getattr(p, 'pencil', False) and p.transposed and bufin.storage is bufout.storage)
+            if not (mine or slab):
                 settle(bufin.storage)
         pend = getattr(bufin.storage, '_pmx_pending', None)
         if pend is not None:
@@ -1163,6 +1166,20 @@ class Plan(object):
         pend.fused(transfer)
         return True
 
+    def _slab_row_forward(self, be, X, nrows, N1, N2, pi):
+        """the forward row pass of a slab rank's block, in place on X.  A paint that left its halo merge to this
+        transform (window._HaloDebt on X) is paid here: the staged halos are added to the rows as they are loaded"""
+        debt = getattr(X, '_pmx_halo', None)
+        if debt is not None:
+            if (hasattr(be, 'rowfft_halo') and debt.open and debt.canvas_ptr == X.data_ptr() and nrows and
+                    be.lib.pmx_rowfft_halo_supported(N2, self.elsize) == 0):
+                be.rowfft_halo(self.elsize, X, nrows, N2, pi, N1, N1 * pi, debt.plan, debt.canvas_ptr, 0, True)
+                debt.taken()
+                return
+            settle(X)
+        if nrows:
+            be.rowfft(self.elsize, False, X, nrows, N2, pi)
+
     def _execute_slab(self, bufin, bufout, transfer=None):
         """Slab-decomposed 3-D (or 2-D) transform with one global transpose."""
         be = backend.get()
@@ -1202,6 +1219,10 @@ class Plan(object):
 
         same = bufin.storage.data_ptr() == bufout.storage.data_ptr()
         own = self._slab_own(be)
+        if not (own and self.forward and same):
+            settle_halo = getattr(bufin.storage, '_pmx_halo', None)
+            if settle_halo is not None:
+                settle(bufin.storage)           # only the in-place forward row pass of the LDS kernels pays it itself
         if transfer is not None and (not own or self.forward):
             raise NotImplementedError('fused transfer needs the column-FFT path of c2r')
         if own:
@@ -1228,8 +1249,8 @@ class Plan(object):
                 fuse_pack = (hasattr(be, 'colfft_split') and n1loc * P == N1 and
                              n1loc & (n1loc - 1) == 0 and all(e1[r + 1] - e1[r] == n1loc for r in range(P)))
                 assert fuse_pack or pi == N2c               # padded rows only with the fused pack
+                self._slab_row_forward(be, X, n0loc * N1, N1, N2, pi)
                 if n0loc:
-                    be.rowfft(self.elsize, False, X, n0loc * N1, N2, pi)
                     if fuse_pack:
                         be.colfft_split(self.elsize, False, X, W1, n0loc, N1, N2c, n1loc, scale=norm,
                                         plain_pitch=pi)
@@ -1447,7 +1468,7 @@ class Plan(object):
                 nreal = n0loc * N1 * 2 * pi
                 W0[:nreal].copy_(bufin.storage[:nreal])     # r2c preserves its input
                 X = W0
-            be.rowfft(es, False, X, n0loc * N1, N2, pi)
+            self._slab_row_forward(be, X, n0loc * N1, N1, N2, pi)
             for (b0, cw), o in zip(chunks, offs):
                 n = 2 * n0loc * N1 * cw
                 be.colfft_split(es, False, X[2 * b0:], W1[o:o + n], n0loc, N1, cw, n1loc, scale=norm, plain_pitch=pi)

@@ -1500,7 +1500,8 @@ class ParticleMesh(object):
             layout = None
         fresh = out is None
         part = self._get_partition(RealField)
-        if fresh and layout is None and not hold and not getattr(part, 'is_c2c', False) and backend.get().name == 'hip':
+        ghosts = layout is not None and _ghosts_only(layout, resampler, transform, hsml)
+        if fresh and (layout is None or ghosts) and not hold and not getattr(part, 'is_c2c', False) and backend.get().name == 'hip':
             # a field of this call's own making that the paint overwrites cell by cell: no zero fill of the buffer
             # (complex-to-complex meshes: the paint writes the real parts only, the imaginary ones must read 0)
             out = RealField(self, base=torch.empty(part.alloc_reals, dtype=torch_dtype(self._rdtype),
@@ -1518,7 +1519,7 @@ class ParticleMesh(object):
             resampler.paint(out.value, pos, hsml=hsml, mass=mass, transform=transform, diffdir=gradient,
                             _overwrite=not hold, _defer_to=defer)
             return out
-        if _ghosts_only(layout, resampler, transform, hsml):
+        if ghosts:
             # the caller's own particles are painted where they lie (those whose window misses
             # the local block fall under the drop-outside rule, _window_generics.h:144-167);
             # only the ghosts received from other ranks are exchanged
@@ -1536,15 +1537,23 @@ class ParticleMesh(object):
                     handle = layout.exchange_remote(dpos, async_op=True)
                 else:
                     handle = layout.exchange_remote(dpos, dmass, async_op=True)
+            # HALO_DEFER as on one rank: the merge of the tile kernels' halos is left to the row pass of the forward
+            # transform (fft.Plan._slab_row_forward).  What the ghosts add afterwards are atomic adds to the same
+            # cells: the order does not matter, so they go into the field as it is (`_value`: no settling)
+            defer = None
+            if not hold and (HALO_DEFER == 'always' or (HALO_DEFER == 'fresh' and fresh)):
+                defer = out._base.storage
             resampler.paint(out.value, dpos, mass=dmass, transform=transform, diffdir=gradient,
-                            _overwrite=not hold)
+                            _overwrite=not hold, _defer_to=defer)
             if remote:
                 if _is_scalar(mass):
                     rpos, rmass = handle.wait(), dmass
                 else:
                     rpos, rmass = handle.wait()
                 if len(rpos):
-                    resampler.paint(out.value, rpos, mass=rmass, transform=transform, diffdir=gradient)
+                    owed = getattr(out._base.storage, '_pmx_halo', None) is not None
+                    resampler.paint(out._value if owed else out.value, rpos, mass=rmass, transform=transform,
+                                    diffdir=gradient)
             return out
         localpos = layout.exchange(pos)
         localmass = exchange(layout, mass)

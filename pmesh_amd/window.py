@@ -137,7 +137,7 @@ class _HaloDebt(object):
         """the canvas is gone or about to be overwritten as a whole: the staged halos are moot"""
         if not self.open:
             return
-        halo, S, nt = C.c_void_p(), C.c_int32(), (C.c_int32 * 3)()
+        halo, S, nt = C.c_void_p(), C.c_int32(), (C.c_int32 * 4)()
         self.be.call('binplan_halo_source', self.plan, C.c_void_p(self.canvas_ptr), int(self.painter.canvas_elsize),
                      C.byref(halo), C.byref(S), nt, 1)
         self._close()

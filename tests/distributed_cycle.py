@@ -55,6 +55,7 @@ def parse(argv=None):
                     help='1: every particle moves to the rank that owns its cell first, once (bench.py --gpus N does: what a '
                          'time-stepping code does after its first decompose); 0: the ranks keep their slabs of lattice ids and '
                          'on a pencil mesh three quarters of the rows travel as "ghosts" in every cycle')
+    ap.add_argument('--out-field', type=int, default=0, help='1: paint into a field the caller keeps across cycles')
     ap.add_argument('--oracle-planes', type=int, default=0,
                     help='K > 0: the first K planes of rank 0 painted block against the CPU oracle')
     return ap.parse_args(argv)
@@ -124,7 +125,7 @@ def run(args):
             from pmesh_amd.domain import release_staging
             release_staging(comm)
         T = Transfer.dx1(0)
-        rho = pm.create('real')
+        rho0 = pm.create('real')
         layout = pm.decompose(pos)
         result = torch.empty(len(pos), dtype=torch.float64, device=be.device)      # lives across cycles, as a caller keeps it
 
@@ -132,7 +133,9 @@ def run(args):
             _window.clear_bin_cache()
             layout._memo = None
             layout._memo_remote = None
-            pm.paint(pos, mass=mass, layout=layout, out=rho)
+            # as the one-rank cycle of bench.py: a field of the paint's own making (no fill, and the merge of the tile
+            # halos left to the row pass of r2c), unless --out-field 1 hands it the caller's
+            rho = pm.paint(pos, mass=mass, layout=layout, out=rho0 if args.out_field else None)
             if keep_block and r == 0 and args.oracle_planes:
                 block0['value'] = rho.value[:args.oracle_planes].clone().cpu().numpy()
                 block0['start'] = [int(x) for x in rho.start]

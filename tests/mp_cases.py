@@ -139,6 +139,69 @@ def case_paint_distributed_equals_serial(be, comm):
         assert_allclose(g1, w1, rtol=0, atol=1e-12 * abs(w1).max())
 
 
+def case_halo_merge_left_to_the_slab_row_pass(be, comm):
+    """pm.paint(pos, layout=...) on slab ranks returns a field of its own making whose tile halos are still staged
+    (pm.HALO_DEFER, as on one rank: tests/test_halo_defer.py); the ghosts are added to it as it is, the row pass of
+    r2c pays the debt (fft.Plan._slab_row_forward), every other reader merges first.  Spectrum and values equal the
+    eager paint's (reference: pm.py:1795-1869 then pm.py:655-694; only the order of the additions differs)."""
+    from pmesh_amd import pm as PM, window as W
+    if comm.size > 4:
+        return                       # (blocks of fewer planes than a tile region: nothing new)
+    N, L = (128, 64, 128), 100.0
+    rs = numpy.random.RandomState(31 + comm.rank)
+    npart = 150000 + 1000 * comm.rank
+    pos0 = rs.uniform(-0.2 * L, 1.2 * L, size=(npart, 3))
+    mass0 = rs.uniform(0.5, 1.5, size=npart)
+    old = (W.BINNED, PM.HALO_DEFER, W.BINNED_MIN_PARTICLES)
+    try:
+        # the rank's own particles through the tile kernels, the thin ghost band through the direct ones, as at full
+        # size (a ghost batch that is itself binned needs the plan and pays the debt first: correct, nothing saved)
+        comm.Barrier()
+        W.BINNED, W.BINNED_MIN_PARTICLES = 'auto', 50000
+        comm.Barrier()
+        for resampler in ('cic', 'tsc', 'pcs'):
+            for dtype in ('f8', 'f4'):
+                pm = PM.ParticleMesh(BoxSize=L, Nmesh=N, comm=comm, dtype=dtype, resampler=resampler, np=[comm.size])     # slabs
+                # every particle on the rank that holds its cell, as a time-stepping caller keeps them: what arrives
+                # from other ranks in the paint is the thin band of ghosts
+                home = pm.decompose(pos0, smoothing=0)
+                pos, mass = home.exchange(pos0), home.exchange(mass0)
+                layout = pm.decompose(pos)
+                comm.Barrier()               # (thread ranks share the module's switches)
+                PM.HALO_DEFER = 'never'
+                comm.Barrier()
+                eager = pm.paint(pos, mass=mass, layout=layout)
+                assert getattr(eager._base.storage, '_pmx_halo', None) is None
+                ev = numpy.array(numpy.asarray(eager))
+                ek = numpy.array(numpy.asarray(eager.r2c(out=Ellipsis)))
+                comm.Barrier()
+                PM.HALO_DEFER = 'fresh'
+                comm.Barrier()
+                lazy = pm.paint(pos, mass=mass, layout=layout)
+                owed = getattr(lazy._base.storage, '_pmx_halo', None) is not None
+                if be.name == 'hip' and ev.shape[0] >= 16:
+                    assert owed, 'the paint did not leave its halo merge to the transform (%s %s, %d own rows, %d from other ranks)' % (
+                        resampler, dtype, len(pos), layout.remote_recvlength)
+                lk = numpy.array(numpy.asarray(lazy.r2c(out=Ellipsis)))
+                assert getattr(lazy._base.storage, '_pmx_halo', None) is None
+                tol = 1e-13 if dtype == 'f8' else 2e-6
+                scale = comm.allreduce(float(abs(ek).max()) if ek.size else 0.0, op='max')
+                assert float(abs(lk - ek).max()) <= tol * scale if ek.size else True
+                # a reader in between: the values are those of the eager paint
+                lazy = pm.paint(pos, mass=mass, layout=layout)
+                lv = numpy.array(numpy.asarray(lazy))
+                assert getattr(lazy._base.storage, '_pmx_halo', None) is None
+                assert float(abs(lv - ev).max()) <= tol * 8 * float(abs(ev).max())
+                # a caller's field is complete when the call returns
+                mine = pm.create('real')
+                pm.paint(pos, mass=mass, layout=layout, out=mine)
+                assert getattr(mine._base.storage, '_pmx_halo', None) is None
+    finally:
+        comm.Barrier()
+        W.BINNED, PM.HALO_DEFER, W.BINNED_MIN_PARTICLES = old
+        W.clear_bin_cache()
+
+
 def case_ghosts_only_equals_literal(be, comm):
     """paint/readout with a layout: own particles in place + ghosts only (pm._ghosts_only) gives
     the same field / values as the reference's literal exchange -> local op -> gather
@@ -918,7 +981,7 @@ def case_comm_trace(be, comm):
 
 
 CASES = [case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
-         case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial,
+         case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial, case_halo_merge_left_to_the_slab_row_pass,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 
