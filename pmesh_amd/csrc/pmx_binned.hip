@@ -184,17 +184,22 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
             if (i < n) t[u] = (int)particle_bucket<KIND>(p, g, xin[u]);
             // wave-aggregated counting: find the lanes that share my tile (ballots only)
             same[u] = 0;
-            if (noagg) {
-                if (t[u] >= 0) same[u] = 1ull << lane;
-            } else {
+            {
+                // noagg: at most NOAGG_ROUNDS groups are looked for, the lanes left over add for themselves.  (None
+                // at all was the first form: 15.5 ms instead of ~1 for rows that are only PARTLY out of order — a
+                // lattice with 2 cells of jitter, which the coherence measure already calls incoherent: up to 64
+                // lanes of a wave, and every wave of the neighbourhood, queue on the same few tile counters.)
+                constexpr int NOAGG_ROUNDS = 8;
                 unsigned long long active = __ballot(t[u] >= 0);
-                while (active) {
+                int rounds = noagg ? NOAGG_ROUNDS : 64;
+                while (active && rounds-- > 0) {
                     int leader = __ffsll((long long)active) - 1;
                     int lt = __shfl(t[u], leader);
                     unsigned long long m = __ballot(t[u] == lt) & active;
                     if (t[u] == lt) same[u] = m;
                     active &= ~m;
                 }
+                if (noagg && t[u] >= 0 && same[u] == 0) same[u] = 1ull << lane;
             }
         }
         // coherence of the row order (flags[1]), sampled on one chunk in 32 (pseudo-randomly chosen): lanes whose tile differs
@@ -2589,10 +2594,15 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             pl->host_groups[1] = *(volatile uint32_t *)(pl->host_flag + 3);
         }
         // breaks of the tile sequence per 64 consecutive rows above which the row order counts as
-        // incoherent (lattice order: a handful; random order: 63)
-        auto incoherent = [&](double breaks, double rows) { return breaks * 64.0 > 24.0 * rows; };
+        // incoherent (lattice order: a handful; random order: 63).  [r5] ~60, not 24: measured at 512^3 with the plan's
+        // form forced both ways (scripts/r05/order_threshold.sh; cycle in ms without / with the tile-ordered copy): a
+        // lattice with N(0, 1 / 2 / 4 / 8) cells of jitter per row (~15 / 28 / 47 / 59 breaks) 5.44 / 5.83 / 7.01 /
+        // 9.50 against 7.06 / 7.67 / 10.58 / 11.04; only rows in no order at all (63) gain: 22.8 against 14.4.
+        // Two thresholds: a plan takes the copy above 61.5 and gives it up below 58 (position sets on either side of ONE
+        // threshold made the plan start over every step: 11.1 ms at 8 cells of jitter against 9.5 in either form).
+        auto incoherent = [&](double breaks, double rows, bool has_copy) { return breaks * 64.0 > (has_copy ? 58.0 : 61.5) * rows; };
         if (reuse && pl->sort_pref < 0 && pl->host_groups[2] == (uint32_t)npart && pl->host_groups[1] > 4096 &&
-            incoherent(pl->host_groups[0], (double)pl->host_groups[1]) != pl->sorted)
+            incoherent(pl->host_groups[0], (double)pl->host_groups[1], pl->sorted) != pl->sorted)
             reuse = false;       // the order of the rows changed its character since the plan was built: start over
         if (!reuse) pl->sorted = false;
         pl->last_reuse = reuse;
@@ -2656,7 +2666,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                     pl->host_groups[2] = (uint32_t)npart;
                     pl->have_measure = true;
                 }
-                want = pl->host_groups[1] > 0 && incoherent(pl->host_groups[0], (double)pl->host_groups[1]);
+                want = pl->host_groups[1] > 0 && incoherent(pl->host_groups[0], (double)pl->host_groups[1], false);
             }
             if (want) {
                 const size_t es = (size_t)pos->elsize;
