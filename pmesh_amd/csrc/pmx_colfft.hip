@@ -348,10 +348,17 @@ struct NoLoadOp {
     static constexpr bool active = false;
     template <typename V> __device__ __forceinline__ V operator()(int, V x) const { return x; }
 };
-template <typename T, bool INV, int R, int RB, bool HALFTW, int N, int NS, int TPC, int TWS, bool ROT, typename LOP = NoLoadOp>
+// IO (register passes, [r5]): bit 0 — the legs of this pass are already in `io` (io[q + r per] = row tj + (q + r per) TPC:
+// for the FIRST pass of a transform, NS = 1, these are exactly the RPT = R per lines tj + u TPC a column kernel's thread
+// has loaded from memory); bit 1 — the results stay in `io` in the same numbering (for the LAST pass, NS = N / R, the
+// rows a Stockham pass writes, j + r NS, are again the thread's own lines tj + u TPC).  Same operations in the same
+// order as through LDS: the same bits; what is saved is a sweep of the tile through LDS each way and its barriers.
+template <typename T, bool INV, int R, int RB, bool HALFTW, int N, int NS, int TPC, int TWS, bool ROT, typename LOP = NoLoadOp, int IO = 0>
 __device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj,
-                                                 const LOP &lop = LOP())
+                                                 const LOP &lop = LOP(), cpx<T> *io = nullptr)
 {
+    static_assert(!(IO & 1) || NS == 1, "register legs: the first pass only");
+    static_assert(!(IO & 2) || NS * R == N, "register results: the last pass only");
     constexpr int nb = N / R;
     constexpr int per = nb / TPC;
     static_assert((N & (N - 1)) == 0 && (TPC & (TPC - 1)) == 0 && nb % TPC == 0 && per >= 1 && per <= 4,
@@ -363,7 +370,7 @@ __device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, 
         const int k = j & (NS - 1);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            cpx<T> x = buf[lds_at<T, RB, ROT>(tb, q * TPC + r * nb)];
+            cpx<T> x = (IO & 1) ? io[q + r * per] : buf[lds_at<T, RB, ROT>(tb, q * TPC + r * nb)];
             if (LOP::active) x = lop(tj + q * TPC + r * nb, x);
             if (r > 0 && NS > 1) {
                 const int m = r * k * (N / (NS * R));
@@ -380,6 +387,15 @@ __device__ __forceinline__ void stockham_pass_p2(cpx<T> *buf, const cpx<T> *tw, 
             v[q][r] = x;
         }
         fftR<T, INV, R>(v[q]);
+    }
+    if (IO & 2) {
+        // (rows j + r NS with NS = nb = per TPC: line q + r per of this thread; nothing is written: no barrier — the
+        // next pass that writes the tile waits for this one's reads itself)
+#pragma unroll
+        for (int q = 0; q < per; q++)
+#pragma unroll
+            for (int r = 0; r < R; r++) io[q + r * per] = v[q][r];
+        return;
     }
     __syncthreads();
 #pragma unroll
@@ -539,6 +555,16 @@ template <typename T, int LOGN, int RB> struct ColPipe {
 #ifndef PMX_ROUND_PIPE2
 #define PMX_ROUND_PIPE2 0
 #endif
+#ifndef PMX_ROUND_REGS
+#define PMX_ROUND_REGS 1
+#endif
+// (where the compiler keeps both transforms' registers and the transfer arithmetic inside 128 VGPRs: lengths up to 512
+// in double; the others spill 16-140 bytes per lane in this form and keep the LDS round trips)
+#ifndef PMX_COL_REGS
+#define PMX_COL_REGS 1
+#endif
+template <typename T, int LOGN, bool APPLY, bool REMAP> struct ColRegs { static constexpr bool value = PMX_COL_REGS != 0; };
+template <typename T, int LOGN> struct RoundRegs { static constexpr bool value = PMX_ROUND_REGS != 0 && sizeof(T) == 8 && LOGN <= 9; };
 template <typename T, int LOGN, int RB> struct RoundPipe2 {
     static constexpr bool value = PMX_ROUND_PIPE2 && LOGN < 16 && !ColPipe<T, LOGN, RB>::value && ColPipe<T, LOGN, RB>::bytes > 53 * 1024;
 };
@@ -547,16 +573,18 @@ template <typename T, int LOGN, int RB> struct RoundPipe {
 };
 
 // the Stockham passes of an N-point transform over the LDS-resident tile (compile-time radices)
-template <typename T, int LOGN, bool INV, int RB, bool HT, int TPC, int TWS, bool ROT, int I, int NS, typename LOP = NoLoadOp>
+// REGIO: the first pass takes its legs from `io`, the last leaves its results there (stockham_pass_p2: IO)
+template <typename T, int LOGN, bool INV, int RB, bool HT, int TPC, int TWS, bool ROT, int I, int NS, typename LOP = NoLoadOp, bool REGIO = false>
 __device__ __forceinline__ void run_passes_p2(cpx<T> *buf, const cpx<T> *tw, const RowBase<T, RB> &tb, int col, int tj,
-                                              const LOP &lop = LOP())
+                                              const LOP &lop = LOP(), cpx<T> *io = nullptr)
 {
     using Rd = Radices<LOGN>;
     if constexpr (I < Rd::n) {
+        constexpr int IO = REGIO ? ((I == 0 ? 1 : 0) | (I == Rd::n - 1 ? 2 : 0)) : 0;
         // (the load operation belongs to the first pass only)
-        if constexpr (I == 0) stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT, LOP>(buf, tw, tb, col, tj, lop);
-        else stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT>(buf, tw, tb, col, tj);
-        run_passes_p2<T, LOGN, INV, RB, HT, TPC, TWS, ROT, I + 1, NS * Rd::r[I]>(buf, tw, tb, col, tj);
+        if constexpr (I == 0) stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT, LOP, IO>(buf, tw, tb, col, tj, lop, io);
+        else stockham_pass_p2<T, INV, Rd::r[I], RB, HT, Len<LOGN>::N, NS, TPC, TWS, ROT, NoLoadOp, IO>(buf, tw, tb, col, tj, NoLoadOp(), io);
+        run_passes_p2<T, LOGN, INV, RB, HT, TPC, TWS, ROT, I + 1, NS * Rd::r[I], NoLoadOp, REGIO>(buf, tw, tb, col, tj, NoLoadOp(), io);
     }
 }
 
@@ -681,6 +709,31 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         const int lcol = REMAP ? 0 : col;
         ColK ck = {0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
+        // [r5] REGS (stockham_pass_p2: IO): the loaded lines are the legs of the first pass, the results of the last
+        // pass are the lines to store — the tile goes through LDS 4 times instead of 8, behind 4 barriers instead of
+        // 8; the same bits.  (No barrier at the top: the first pass that writes the tile waits for the last reads of the
+        // tile before it, and for the twiddles, itself.)
+        constexpr bool REGS = ColRegs<T, LOGN, APPLY, REMAP>::value && P2 && !PIPE;
+        if constexpr (REGS) {
+            cpx<T> *othread = obase + (line_offset(g.out, tj) + lcol);
+            load_tile(tile, ld);
+            if (APPLY && colok) {
+#pragma unroll
+                for (int u = 0; u < RPT; u++) ld[u] = apply_simple<T>(g, tj + u * TPC, ck, ld[u]);
+            }
+            run_passes_p2<T, LOGN, INV, RB, HT, TPC, 1, false, 0, 1, NoLoadOp, true>(buf, tw, tb, col, tj, NoLoadOp(), ld);
+            const T sc = (T)g.scale;
+            if (colok) {
+#pragma unroll
+                for (int u = 0; u < RPT; u++) {
+                    cpx<T> v = ld[u];
+                    v.x *= sc;
+                    v.y *= sc;
+                    othread[line_offset(g.out, u * TPC)] = v;
+                }
+            }
+            return;
+        }
         __syncthreads();
         cpx<T> *othread = obase + (line_offset(g.out, tj) + lcol);
         if (!PIPE) load_tile(tile, ld);
@@ -820,6 +873,37 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
         ColK ck = {0, 0};
         if (APPLY && colok) ck = column_k(g, b0 + col);
         cpx<T> *othread = data + b0 + ((int64_t)tj * g.out.sn + col);
+        // [r5] REGS (power-of-two lengths, one tile per workgroup): the lines a thread loads are the legs of its first
+        // forward butterflies, what its last forward pass produces are the legs of its first inverse butterflies, and
+        // what its last inverse pass produces are the lines it stores (stockham_pass_p2: IO) — the tile goes through
+        // LDS 8 times per round trip instead of 13, behind 8 barriers instead of 13; the same bits.
+        constexpr bool REGS = RoundRegs<T, LOGN>::value && P2 && !PIPE;
+        if constexpr (REGS) {
+            const T sc = (T)g.scale;
+            const bool force_form = APPLY && !(sizeof(T) == 4 && LOGN == 11) && g.t.laplace_pow == -1 && g.t.grad_dir >= 0;
+            __syncthreads();
+            load_tile(tile, ld);
+            run_passes_p2<T, LOGN, false, RB, HT, TPC, 1, false, 0, 1, NoLoadOp, true>(buf, tw, tb, col, tj, NoLoadOp(), ld);
+            // what the forward pass would have stored and the inverse pass loaded: the mode times the forward scale, then
+            // the transfer function
+            if (force_form) {
+                const RoundOp<T, APPLY, 1> op{g, ck, sc, colok};
+                // (one line at a time: interleaved, the double-precision transfer arithmetic of all RPT lines beside the
+                // tile's registers spills 44-112 bytes per lane at every length but 512 in double)
+#pragma unroll
+                for (int u = 0; u < RPT; u++) { ld[u] = op(tj + u * TPC, ld[u]); if (APPLY) __builtin_amdgcn_sched_barrier(0); }
+            } else {
+                const RoundOp<T, APPLY, 0> op{g, ck, sc, colok};
+#pragma unroll
+                for (int u = 0; u < RPT; u++) { ld[u] = op(tj + u * TPC, ld[u]); if (APPLY) __builtin_amdgcn_sched_barrier(0); }
+            }
+            run_passes_p2<T, LOGN, true, RB, HT, TPC, 1, false, 0, 1, NoLoadOp, true>(buf, tw, tb, col, tj, NoLoadOp(), ld);
+            if (colok) {
+#pragma unroll
+                for (int u = 0; u < RPT; u++) othread[(int64_t)(u * TPC) * g.out.sn] = ld[u];
+            }
+            return;
+        }
         __syncthreads();
         if (!PIPE) load_tile(tile, ld);
 #pragma unroll
