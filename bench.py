@@ -439,10 +439,12 @@ def main():
     ncycle = [0]
     halo_deferred = [False]       # the last paint left its halo merge to the row pass of r2c (pm.HALO_DEFER)
 
+    cur_stream = torch.cuda.current_stream()         # (Event.record() without a stream looks it up: ~10 us of host time per mark)
+
     def cycle(marks=None):
         def mark(i):
             if marks is not None:
-                marks[i].record()
+                marks[i].record(cur_stream)
         pos = psets[ncycle[0] % len(psets)]
         layout = layouts[ncycle[0] % len(psets)]
         ncycle[0] += 1
