@@ -17,6 +17,8 @@ run headline_nodrift --drift 0
 run headline_drift05 --drift 0.5
 run headline_drift1 --drift 1.0
 run headline_drift2 --drift 2.0
+run headline_drift4 --drift 4.0
+run headline_drift8 --drift 8.0
 run headline_cold_plan --cold-plan 1 --steps 5
 run clustered --data clustered
 run config2_256 --mesh 256
