@@ -18,7 +18,7 @@ for row in csv.DictReader(open(f[0])):
     n[(k, row['Counter_Name'])] += 1
 with open(out + '/inst_summary.txt', 'w') as o:
     for k, c in acc.items():
-        if 'tile' not in k and 'bin_' not in k: continue
+        if 'tile' not in k and 'bin_' not in k and 'fft' not in k: continue
         launches = n[(k, 'SQ_WAVES')]
         w = c.get('SQ_WAVES', 0) or 1
         line = '%-58s launches %d waves/launch %.0f  per wave: ' % (k, launches, w / launches) + ' '.join(

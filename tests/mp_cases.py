@@ -145,8 +145,6 @@ def case_halo_merge_left_to_the_slab_row_pass(be, comm):
     r2c pays the debt (fft.Plan._slab_row_forward), every other reader merges first.  Spectrum and values equal the
     eager paint's (reference: pm.py:1795-1869 then pm.py:655-694; only the order of the additions differs)."""
     from pmesh_amd import pm as PM, window as W
-    if comm.size > 4:
-        return                       # (blocks of fewer planes than a tile region: nothing new)
     N, L = (128, 64, 128), 100.0
     rs = numpy.random.RandomState(31 + comm.rank)
     npart = 150000 + 1000 * comm.rank
@@ -157,7 +155,7 @@ def case_halo_merge_left_to_the_slab_row_pass(be, comm):
         # the rank's own particles through the tile kernels, the thin ghost band through the direct ones, as at full
         # size (a ghost batch that is itself binned needs the plan and pays the debt first: correct, nothing saved)
         comm.Barrier()
-        W.BINNED, W.BINNED_MIN_PARTICLES = 'auto', 50000
+        W.BINNED, W.BINNED_MIN_PARTICLES = 'auto', 100000
         comm.Barrier()
         for resampler in ('cic', 'tsc', 'pcs'):
             for dtype in ('f8', 'f4'):
@@ -179,7 +177,7 @@ def case_halo_merge_left_to_the_slab_row_pass(be, comm):
                 comm.Barrier()
                 lazy = pm.paint(pos, mass=mass, layout=layout)
                 owed = getattr(lazy._base.storage, '_pmx_halo', None) is not None
-                if be.name == 'hip' and ev.shape[0] >= 16:
+                if be.name == 'hip' and ev.shape[0] >= 16:     # (8 ranks: blocks of 16 planes, two layers of tiles and the offset)
                     assert owed, 'the paint did not leave its halo merge to the transform (%s %s, %d own rows, %d from other ranks)' % (
                         resampler, dtype, len(pos), layout.remote_recvlength)
                 lk = numpy.array(numpy.asarray(lazy.r2c(out=Ellipsis)))
