@@ -704,7 +704,9 @@ class Plan(object):
         """[(first plane, planes)] of the local axis-0 range if both transposes of the pencil transform
         can be pipelined over chunks of planes: the fused axis-1 pass, equal plane ranges on all ranks
         (the chunk boundaries must agree) and asynchronous exchanges on both sub-communicators"""
-        C = _overlap_chunks(2 * self.elsize * int(numpy.prod(p.local_o_shape, dtype='i8')))
+        # (every rank must come to the same answer — the probe below and the chunked exchanges are collective: the size
+        # that decides is the mean block, not this rank's own, which differs from rank to rank on uneven meshes)
+        C = _overlap_chunks(2 * self.elsize * int(numpy.prod(p.cshape_o, dtype='i8')) // max(1, int(p.nproc)))
         if C < 2 or not fuse1 or n0l * P0 != N0 or n0l < 2 * C:
             return None
         if not (hasattr(rowc, 'alltoall_views') and hasattr(colc, 'alltoall_views')):
@@ -1431,14 +1433,18 @@ class Plan(object):
         """[(first column, width)] of the last axis if the transposes can be pipelined: equal
         power-of-two blocks on both sides and enough columns; widths are multiples of 8 columns
         (128-byte lines of complex128) except for the last chunk"""
+        # Every rank must come to the same answer (the probe and the chunked exchanges are collective): first what all
+        # ranks see alike — equal blocks on both sides — then the size, which is then the same everywhere.  (The size
+        # of a rank's OWN block came first until round 5: on uneven slabs near the threshold some ranks ran the probe
+        # and the others did not — scripts/halo_fuzz_slabs.py, 3 ranks on a 192 x 128 x 512 mesh.)
+        if any(e1[r + 1] - e1[r] != e1[1] - e1[0] for r in range(P)) or any(e0[r + 1] - e0[r] != e0[1] - e0[0] for r in range(P)):
+            return None
+        if n1loc * P != N1 or n1loc & (n1loc - 1) or n0loc * P != N0 or n0loc == 0:
+            return None
         C = _overlap_chunks(2 * self.elsize * N0 * n1loc * N2c)
         if C < 2 or not hasattr(be, 'colfft_chunk') or N2c < 64:
             return None
         if not _async_exchange_works(p.procmesh.comm):
-            return None
-        if n1loc * P != N1 or n1loc & (n1loc - 1) or n0loc * P != N0 or n0loc == 0:
-            return None
-        if any(e1[r + 1] - e1[r] != n1loc for r in range(P)) or any(e0[r + 1] - e0[r] != n0loc for r in range(P)):
             return None
         w = -(-N2c // C)
         w = -(-w // 8) * 8

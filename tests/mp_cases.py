@@ -321,6 +321,37 @@ def case_pipelined_equals_single_exchange(be, comm):
             assert_allclose(a, b, rtol=0, atol=1e-13 * max(1.0, abs(b).max()))
 
 
+def case_uneven_blocks_decide_alike(be, comm):
+    """Whether a transform pipelines its transposes is decided by every rank for itself — and the decision leads to
+    collectives (the probe of asynchronous exchanges, the chunked all-to-alls): all ranks must decide alike.  On
+    uneven blocks the ranks' own block sizes differ; with a minimum chunk size between them, ranks that looked at
+    their own size disagreed (found by scripts/halo_fuzz_slabs.py: three slab ranks, a 192 x 128 x 512 mesh)."""
+    from pmesh_amd import fft as _fft
+    from pmesh_amd.pm import ParticleMesh
+    if comm.size != 3:
+        return
+    old = (_fft.OVERLAP_MIN_CHUNK_BYTES, _fft.OVERLAP_CHUNKS)
+    comm.Barrier()
+    try:
+        for Nmesh, np_ in (([64, 64, 128], [3]), ([128, 64, 256], [3]), ([64, 64, 128], [3, 1])):      # (lengths the LDS kernels take)
+            pm = ParticleMesh(BoxSize=1.0, Nmesh=Nmesh, comm=comm, dtype='f8', np=np_)
+            sizes = comm.allgather(16 * int(numpy.prod(pm.create('complex').shape)))
+            comm.Barrier()
+            # a threshold that half of the largest block passes and half of the smallest does not (or all do)
+            _fft.OVERLAP_MIN_CHUNK_BYTES, _fft.OVERLAP_CHUNKS = (max(sizes) // 2 + min(sizes) // 2) // 2 + 1, 2
+            comm.Barrier()
+            pm.procmesh.comm._pmx_async_ok = None
+            data = numpy.random.RandomState(3).normal(size=Nmesh)
+            real = pm.create('real', value=data[pm.create('real').slices])
+            back = real.r2c().c2r()
+            assert_allclose(numpy.asarray(back), numpy.asarray(real), rtol=0, atol=1e-12)
+            comm.Barrier()
+    finally:
+        comm.Barrier()
+        _fft.OVERLAP_MIN_CHUNK_BYTES, _fft.OVERLAP_CHUNKS = old
+        comm.Barrier()
+
+
 def case_fused_transfer_slab(be, comm):
     """c2r(transfer=T) on a slab decomposition (T folded into the first column pass of the
     inverse transform) == apply(T).c2r(), and leaves the complex field untouched out of place"""
@@ -980,7 +1011,7 @@ def case_comm_trace(be, comm):
 
 CASES = [case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
          case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial, case_halo_merge_left_to_the_slab_row_pass,
-         case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
+         case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_uneven_blocks_decide_alike, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 
 def main():

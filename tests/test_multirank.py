@@ -52,7 +52,7 @@ def test_multirank_rccl():
     assert 'ok case_cycle' in out
 
 
-@pytest.mark.parametrize('nproc', [2, 4, 8])
+@pytest.mark.parametrize('nproc', [2, 3, 4, 8])
 def test_multirank_threads(be, nproc):
     """The same cases with the ranks as threads of this process (tests/thread_comm.py).
     Under -m gpu this drives the real HIP kernels and the rocFFT stage plans of the slab
