@@ -232,8 +232,10 @@ int pmx_readout_binned(pmx_binplan *plan, const pmx_painter *p, const void *canv
  * read-modify-write of a quarter (CIC) to two thirds (PCS) of the mesh on top of the paint itself.  In the PM cycle
  * the next reader of the mesh is the forward row pass of r2c (pm.py:1795-1869 -> pm.py:655-694), which can add the
  * staged values while it loads the rows: no pass of their own, no atomics.
- * pmx_paint_binned_defer : as pmx_paint_binned; *deferred = 1 if the merge was left out (one rank's whole periodic
- *                          mesh, overwrite != 0, not deterministic, a row length pmx_rowfft_halo gathers for), else 0
+ * pmx_paint_binned_defer : as pmx_paint_binned; *deferred = 1 if the merge was left out (axes 1 and 2 whole and
+ *                          periodic; axis 0 the same — one rank's mesh — or [r5] a block of planes of a larger
+ *                          period, a slab rank of domain.py:561-652; overwrite != 0, not deterministic, a row
+ *                          length pmx_rowfft_halo gathers for), else 0
  *                          and the call is pmx_paint_binned.  While a plan holds staged halos it refuses to build or
  *                          paint (PMX_EINVAL): one of the next two calls comes first.
  * pmx_halo_merge         : the merge pmx_paint_binned would have run (no-op if nothing is staged).
