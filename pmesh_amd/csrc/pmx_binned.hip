@@ -531,8 +531,22 @@ template <int KIND, bool WHOLE, typename R>
 __device__ __forceinline__ int row_tile(const pmx_painter &p, const BinGeom &g, const R &row)
 {
     if constexpr (!WHOLE) {
-        const double x[3] = {(double)row.x[0], (double)row.x[1], (double)row.x[2]};
-        return (int)particle_bucket<KIND>(p, g, x);
+        // blocks of any shape (slab / pencil ranks): particle_bucket without the weights it computes on the way — the
+        // first cell of the stencil is all a tile id needs (12-byte rows: 0.69 -> ... ms per 512^3 rows, the whole-mesh
+        // form 0.59)
+        bool ok = true;
+        int tt[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double X = (double)row.x[d] * p.scale[d] + p.translate[d];
+            ok = ok && (fabs(X) < 1073741824.0);               // NaN / out of int range: dropped
+            const int I0 = Tuned<KIND>::first(ok ? X : 0.0);
+            int i0w = 0;
+            ok = ok && local_base<KIND>(p, d, I0, &i0w);
+            tt[d] = (int)((unsigned)(i0w + g.o[d]) / (unsigned)tile_ext(d));
+        }
+        const int tb = (tt[0] * g.nt[1] + tt[1]) * g.nt[2] + tt[2];
+        return ok ? tb : (int)g.ntiles;
     } else {
         bool ok = true;
         int tt[3];
@@ -2060,8 +2074,11 @@ __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const Bin
 // cell read 0 (zero_dropped_kernel), and the pieces of crowded tiles beyond g.chunk entries (readout_heavy_kernel) are
 // work units behind the tiles — a readout is read-only on the canvas, nothing orders them.  (Two launches of ~4.5 us per
 // readout: nothing at 512^3 on one GPU, 2 % of a rank's particle kernels at 8 ranks.)
+// (768 threads — PCS on double canvases, an 81 KB region: TWO workgroups per CU need 6 waves per SIMD, i.e. at most 80
+// VGPRs.  The form for blocks of any shape came to 83 and ran ONE: 2.62 ms against 1.75 at 512^3 — every pencil rank
+// of config 5 runs that form.  The bound makes the compiler hold it.)
 template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
-__global__ void __launch_bounds__(TTHREADS) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
+__global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? 6 : 1)) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                                    DVec pos, char *out, const uint32_t *list,
                                                                    const int64_t *offsets, const uint32_t *counts,
                                                                    const uint64_t *items, const uint32_t *nitems, uint32_t cap)
@@ -2625,6 +2642,9 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #endif
                 bool whole_b = true;
                 for (int d = 0; d < 3; d++) whole_b = whole_b && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
+#ifdef PMX_GENERAL_FORMS_ONLY
+    whole_b = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
+#endif
 #define BL(K, PE_, WH) bin_lean_kernel<K, PE_, WH><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag)
 #define BB(K)                                                                                                   \
     do {                                                                                                        \
@@ -2792,6 +2812,9 @@ int paint_binned_t(pmx_binplan *pl, const pmx_painter &p, void *canvas, DVec pos
     const bool dense32 = pos.stride1 == pos.elsize && pos.stride0 == 3 * pos.elsize;      // (always so for the plan's sorted copy)
     bool whole32 = true;
     for (int d = 0; d < 3; d++) whole32 = whole32 && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
+#ifdef PMX_GENERAL_FORMS_ONLY
+    whole32 = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
+#endif
 #define PT32L(K, SD, SG, WH, PE_) paint_tile32_kernel<K, Tile32<K>::threads, SD, SG, WH, PE_><<<pgrid, Tile32<K>::threads, 0, st>>>(p, g, (char *)canvas, pos, mass, ms, pl->list, pl->offsets, pl->counts, (float *)halo, overwrite, mstats, 0)
 #define PT32P(K, SD, SG, WH) do { if (!dense32) { if constexpr (!SD) PT32L(K, false, SG, WH, 0); } else if (pos.elsize == 8) PT32L(K, SD, SG, WH, 8); else PT32L(K, SD, SG, WH, 4); } while (0)
 #define PT32W(K, SD, SG) do { if (whole32) PT32P(K, SD, SG, true); else PT32P(K, SD, SG, false); } while (0)
@@ -3004,6 +3027,9 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
 #define RT(K, T) do { if (relax) RT2(K, T, true); else RT2(K, T, false); } while (0)
     bool whole_r = true;
     for (int d = 0; d < 3; d++) whole_r = whole_r && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
+#ifdef PMX_GENERAL_FORMS_ONLY
+    whole_r = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
+#endif
 #define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy)
 #define RLW(K, T, PE_, OE_) do { if (whole_r) RLL(K, T, PE_, OE_, true); else RLL(K, T, PE_, OE_, false); } while (0)
 #define RLO(K, T, PE_) do { if (dout.elsize == 8) RLW(K, T, PE_, 8); else RLW(K, T, PE_, 4); } while (0)

@@ -100,6 +100,14 @@ def test_tile_kernel_budgets():
             assert v['ScratchSize'] <= 24, (k, v)
             if 'ELb0ELb0ELb1E' in k or 'ELb0ELb1ELb1E' in k:
                 assert v['ScratchSize'] == 0, (k, v)
+        elif 'readout_tile_lean_kernelILi7EdLi768' in k:
+            # [r5] PCS on double canvases, 768 threads, an 81 KB region: TWO workgroups per CU need six waves per SIMD,
+            # <= 80 VGPRs.  The form for blocks of any shape came to 83 and ran ONE workgroup per CU (2.62 ms against
+            # 1.75 at 512^3: every pencil rank of config 5); held to 80 by its launch bound it parks one 8-byte address
+            # per lane in scratch, stored at the kernel's entry and reloaded once per TILE (read from the listing:
+            # outside the gather loops) — 1.91 ms
+            assert v['VGPRs'] <= 80 and v['Occupancy'] >= 6, (k, v)
+            assert v['ScratchSize'] <= (16 if 'ELb0EEEv' in k else 0), (k, v)
         else:
             assert v['ScratchSize'] == 0, k
         assert v['VGPRs'] <= 128, (k, v)
