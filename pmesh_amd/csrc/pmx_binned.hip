@@ -1982,8 +1982,11 @@ static __global__ void __launch_bounds__(TBLOCK) zero_dropped_kernel(const uint3
         out.set(sorted ? start + j : (int64_t)list[start + j], 0, 0.0);
 }
 
+#ifndef PMX_READOUT768_WAVES
+#define PMX_READOUT768_WAVES 6      // (waves per SIMD the 768-thread readouts are held to: two workgroups per CU; see readout_tile_lean_kernel)
+#endif
 template <int KIND, typename T, int TTHREADS, bool SORTED, bool RELAX>
-__global__ void __launch_bounds__(TTHREADS) readout_tile_kernel(pmx_painter p, BinGeom g, const char *canvas,
+__global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WAVES : 1)) readout_tile_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                               DVec pos, DVec out, const uint32_t *list,
                                                               const int64_t *offsets, const uint32_t *counts)
 {
@@ -2078,7 +2081,7 @@ __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const Bin
 // VGPRs.  The form for blocks of any shape came to 83 and ran ONE: 2.62 ms against 1.75 at 512^3 — every pencil rank
 // of config 5 runs that form.  The bound makes the compiler hold it.)
 template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
-__global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? 6 : 1)) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
+__global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WAVES : 1)) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                                    DVec pos, char *out, const uint32_t *list,
                                                                    const int64_t *offsets, const uint32_t *counts,
                                                                    const uint64_t *items, const uint32_t *nitems, uint32_t cap)

@@ -108,6 +108,11 @@ def test_tile_kernel_budgets():
             # outside the gather loops) — 1.91 ms
             assert v['VGPRs'] <= 80 and v['Occupancy'] >= 6, (k, v)
             assert v['ScratchSize'] <= (16 if 'ELb0EEEv' in k else 0), (k, v)
+        elif 'readout_tile_kernelILi7EdLi768' in k:
+            # the same budget for the forms behind the tile-ordered copy (rows in random order) and the exact arithmetic:
+            # 83-85 VGPRs unbounded, one workgroup per CU; held to 80 they spill up to ten words per lane and are still
+            # 12 % faster (512^3 PCS readout of shuffled rows 7.02 -> 6.16 ms, scripts/r05/readout768_ab.sh)
+            assert v['VGPRs'] <= 80 and v['Occupancy'] >= 6 and v['ScratchSize'] <= 48, (k, v)
         else:
             assert v['ScratchSize'] == 0, k
         assert v['VGPRs'] <= 128, (k, v)
