@@ -100,6 +100,9 @@ def parse():
     ap.add_argument('--cold-plan', type=int, default=0,
                     help='1: the bin plans are destroyed before every cycle (diagnostic: every build is the first build of a '
                          'plan — allocation, the exact two-pass build, no slot ranges of a previous step to reuse)')
+    ap.add_argument('--count-jitter', type=float, default=0.0,
+                    help='a diagnostic (one rank, scalar mass): the k-th of the position sets has this fraction times k '
+                         'FEWER rows than the first — a rank whose particle count changes from step to step (migration)')
     ap.add_argument('--out-field', type=int, default=0,
                     help='0: pm.paint(pos) returns a new field every cycle, as the callers of the reference write it '
                          '(fastpm: pm.paint(x, layout=layout)) — on one rank the halo merge of the tile kernels then rides '
@@ -391,6 +394,10 @@ def main():
             step = torch.randn(pos.shape, dtype=tdt, device=be.device, generator=gen) * (args.drift * L / N)
             psets.append(psets[-1] + step)
             del step
+        if args.count_jitter > 0:
+            if world > 1 or args.exchange or args.mass == 'array' or args.host_arrays:
+                raise SystemExit('--count-jitter is a single-GPU diagnostic with a scalar mass')
+            psets = [q[:int(nloc * (1.0 - k * args.count_jitter))].contiguous() for k, q in enumerate(psets)]
     if args.host_arrays:
         if world > 1 or args.exchange:
             raise SystemExit('--host-arrays is a single-GPU diagnostic')
@@ -475,7 +482,7 @@ def main():
         mark(5)
         # the result goes into a buffer that lives across cycles, as a time-stepping caller keeps it:
         # a fresh 1 GB tensor per cycle occasionally costs a hipMalloc (~20 ms) inside the timed loop
-        f = back.readout(pos, gradient=args.gradient, layout=layout, out=result)
+        f = back.readout(pos, gradient=args.gradient, layout=layout, out=result[:len(pos)] if args.count_jitter > 0 else result)
         mark(6)
         return f
 
@@ -604,6 +611,7 @@ def main():
             'value_with_decompose': ntot / (elapsed / args.steps + t_decompose),
             'comm': comm_line,
             'drift_cells': args.drift,
+            'count_jitter': args.count_jitter,
             'host_arrays': bool(args.host_arrays), 'deterministic_paint': bool(args.deterministic),
             'bin_overflows': _window.bin_cache().overflows(be),
             # what the `bin` stage is: the plan is rebuilt in EVERY cycle (the cache is cleared: a time-stepping caller's

@@ -216,6 +216,10 @@ int pmx_binplan_overflows(pmx_binplan *plan, uint32_t *count);
  * the tile is always inside: its mass lands in the wrong cell of the right tile).  Host counter written by the
  * device: exact once the stream has been synchronised; 0 for every correct use. */
 int pmx_binplan_stale(pmx_binplan *plan, uint32_t *count);
+/* [r5] builds of this plan so far with npart > 0: in ONE pass into the slot ranges of the build before (same geometry,
+ * a particle count within an eighth of the previous one: a time-stepping caller, also one whose particles migrate
+ * between ranks) / in two passes (the first build, another geometry or count, the back-off after an overflow). */
+int pmx_binplan_builds(pmx_binplan *plan, uint32_t *single_pass, uint32_t *two_pass);
 /* PMX_OK if (painter, npart) can use the binned kernels */
 int pmx_binplan_supported(const pmx_painter *p, int64_t npart);
 /* bin the batch: tile id + slot per particle, per-tile counts, scan, index lists */

@@ -189,6 +189,7 @@ struct pmx_binplan {
     uint32_t seen_overflows = 0;
     int distrust = 0, skip = 0;  // back-off after an overflow
     bool last_reuse = false;     // the previous build was a single-pass (history) build
+    uint32_t builds[2] = {0, 0}; // builds of this plan so far: single pass into the previous ranges / two passes (pmx_binplan_builds)
 };
 
 namespace pmx {

@@ -182,12 +182,15 @@ class _BinCache(object):
                 be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
                 be.call('binplan_exact', e[1], int(bool(EXACT)))
                 return e[1]
-        # a plan that last served the same geometry and particle count rebuilds in a single
-        # pass over the positions (csrc/pmx_binned.hip: slot ranges of the previous build)
-        shape = key[2:] + (n,)
+        # a plan that last served the same geometry and about as many particles rebuilds in a single
+        # pass over the positions (csrc/pmx_binned.hip: slot ranges of the previous build; "about": within an eighth —
+        # on several ranks the particles migrate and a rank's count changes a little with every step)
+        shape = (key[2][1:],) + key[3:] + (n,)
         # free: invalidated entries and those built for an older version of this very tensor
         free = [e for e in self.entries if not e[3] or (e[0] is not None and e[0][0] == key[0])]
-        same = [e for e in self.entries if e[5] == shape]
+        same = [e for e in self.entries if e[5] is not None and e[5][:-1] == shape[:-1] and
+                abs(e[5][-1] - n) * 8 <= e[5][-1]]
+        best = lambda cands: max(cands, key=lambda q: (-abs(q[5][-1] - n), q[4]))      # the closest count, then the one used last
         like = [e for e in same if any(e is q for q in free)]
         # entries of the same shape whose tensor nobody else holds any more: a time-stepping caller that
         # makes a new position tensor every step and dropped the old one.  The new tensor takes over that
@@ -197,9 +200,9 @@ class _BinCache(object):
         dead = [e for e in same if e[2] is not None and sys.getrefcount(e[2]) <= 2]
         if like:
             # the one used last: its lists are the closest to these positions
-            e = max(like, key=lambda q: q[4])
+            e = best(like)
         elif dead:
-            e = max(dead, key=lambda q: q[4])
+            e = best(dead)
         elif len(self.entries) < self.SLOTS:
             plan = C.c_void_p()
             be.call('binplan_create', C.byref(plan))
@@ -207,7 +210,7 @@ class _BinCache(object):
             self.entries.append(e)
         elif same and not free:
             # every slot is taken by a live tensor: the plan of the same shape used last has the closest lists
-            e = max(same, key=lambda q: q[4])
+            e = best(same)
         else:
             e = min(free or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape

@@ -350,6 +350,51 @@ def test_sorted_copy_is_chosen_for_incoherent_rows(hip, oracle):
     assert torch.equal(res[0][1][perm], res[1][1])              # readout: bit-identical, row by row
 
 
+def test_plan_survives_a_changing_particle_count(hip, oracle):
+    """A rank of a time-stepping run gains and loses a few particles every step (they migrate between ranks): a new
+    position tensor of a slightly different length takes over the plan of the previous step and rebuilds it in ONE
+    pass (pmx_binplan_builds), as long as the count stays within an eighth of the previous one; a jump starts over.
+    Results are those of the direct kernels every time.  (The reference keeps no state between calls: pm.py:1795-1869.)"""
+    import ctypes as C
+    W = windows['cic']
+    window.BINNED = 'always'
+    window.clear_bin_cache()
+    window.bin_cache().destroy(hip)
+    N = 64
+    aff = Affine(3, period=N)
+    rs = numpy.random.RandomState(12)
+    allpos = torch.from_numpy(rs.uniform(0, N, size=(260000, 3))).to(hip.device)
+    field = torch.from_numpy(rs.normal(size=(N, N, N))).to(hip.device)
+
+    def builds():
+        tot = [0, 0]
+        for e in window.bin_cache().entries:
+            a, b = C.c_uint32(0), C.c_uint32(0)
+            hip.call('binplan_builds', e[1], C.byref(a), C.byref(b))
+            tot[0] += int(a.value)
+            tot[1] += int(b.value)
+        return tot
+    counts = [200000, 200700, 199100, 203000, 215000, 260000, 259000]
+    want_single = [False, True, True, True, True, False, True]          # (260000 is 21 % more than 215000: starts over)
+    for n, single in zip(counts, want_single):
+        before = builds()
+        pos = (allpos[:n] + 0.01).contiguous()            # a new tensor every step, the old one dropped
+        c = torch.zeros((N, N, N), dtype=torch.float64, device=hip.device)
+        W.paint(c, pos, transform=aff)
+        got = W.readout(field, pos, transform=aff)
+        after = builds()
+        assert (after[0] - before[0], after[1] - before[1]) == ((1, 0) if single else (0, 1)), (n, before, after)
+        window.BINNED = 'never'
+        c2 = torch.zeros((N, N, N), dtype=torch.float64, device=hip.device)
+        W.paint(c2, pos, transform=aff)
+        want = W.readout(field, pos, transform=aff)
+        window.BINNED = 'always'
+        assert float((c - c2).abs().max()) <= 1e-12 * float(c2.abs().max())
+        assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+        del pos
+    assert len(window.bin_cache().entries) <= 2          # (the jump opened a second plan; the steps around it reuse theirs)
+
+
 def test_plan_is_shared_and_invalidated(hip):
     """paint and readout on the same position tensor share one plan; an in-place change of
     the positions (version counter) rebuilds it."""
