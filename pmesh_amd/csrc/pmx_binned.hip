@@ -84,7 +84,8 @@ __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const B
 }
 
 template <int NT>
-__device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor);
+__device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor,
+                                            uint32_t *zero);
 
 // MODE 0: count pass of the two-pass build: tid[i] = tile, counts[tile]++.
 // MODE 1: single-pass build into the slot ranges of the previous build: the wave-aggregated
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
     if (gate != nullptr && *gate == 0) return;
     if (MODE == 3) {
         if (blockIdx.x == 0) {
-            scan_ranges<TBLOCK>(counts, g.ntiles + 1, const_cast<int64_t *>(offsets), cursor);
+            scan_ranges<TBLOCK>(counts, g.ntiles + 1, const_cast<int64_t *>(offsets), cursor, nullptr);
             __threadfence();
             __syncthreads();
             if (threadIdx.x == 0) atomicExch(&flags[3], 1u);
@@ -697,9 +698,11 @@ __global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom
                     if ((w[u] >> 24) == DIRECT) {
                         // (rare) written at once: list[offsets[t] + b + rank]
                         const uint32_t b0 = __shfl(bd[u], leader[u]);
-                        const int64_t slot = offsets[t[u]] + (int64_t)b0 + rank;
-                        if (slot < offsets[t[u] + 1]) list[slot] = (uint32_t)i;
-                        else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
+                        if (list != nullptr) {
+                            const int64_t slot = offsets[t[u]] + (int64_t)b0 + rank;
+                            if (slot < offsets[t[u] + 1]) list[slot] = (uint32_t)i;
+                            else if (atomicOr(&flags[0], 1u) == 0) atomicAdd_system(host_flag, 1u);
+                        }
                     } else wh = w[u] + rank;
                 }
                 where[(it * U + u) * TBLOCK + threadIdx.x] = wh;
@@ -711,10 +714,13 @@ __global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom
             if (keys[s] != EMPTY) {
                 const uint32_t t = keys[s];
                 const uint32_t b = atomicAdd(&counts[t], cnt[s]);
-                first[s] = offsets[t] + b;
-                last[s] = offsets[t + 1];
+                if (list != nullptr) {
+                    first[s] = offsets[t] + b;
+                    last[s] = offsets[t + 1];
+                }
             }
         }
+        if (list == nullptr) continue;        // (the count pass of a two-pass build: no ranges yet, nothing to write)
         __syncthreads();
 #pragma unroll 2
         for (int it = 0; it < BLOCK_ITERS; it++) {
@@ -742,7 +748,8 @@ __global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom
 
 // exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup of NT threads
 template <int NT>
-__device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor)
+__device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor,
+                                            uint32_t *zero)
 {
     __shared__ int64_t sh[NT];
     __shared__ int64_t carry;
@@ -751,6 +758,7 @@ __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntil
     for (int64_t base = 0; base < ntiles; base += NT) {
         int64_t i = base + threadIdx.x;
         int64_t v = i < ntiles ? slot_capacity(counts[i]) : 0;
+        if (zero != nullptr && i < ntiles) zero[i] = 0;       // (the counters start the pass that fills the ranges from 0)
         sh[threadIdx.x] = v;
         __syncthreads();
         for (int off = 1; off < NT; off <<= 1) {
@@ -772,10 +780,10 @@ __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntil
 }
 
 static __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
-                                                        unsigned long long *cursor, const uint32_t *gate)
+                                                        unsigned long long *cursor, const uint32_t *gate, uint32_t *zero = nullptr)
 {
     if (gate != nullptr && *gate == 0) return;
-    scan_ranges<1024>(counts, ntiles, offsets, cursor);
+    scan_ranges<1024>(counts, ntiles, offsets, cursor, zero);
 }
 
 static __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
@@ -2642,6 +2650,37 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             incoherent(pl->host_groups[0], (double)pl->host_groups[1], pl->sorted) != pl->sorted)
             reuse = false;       // the order of the rows changed its character since the plan was built: start over
         if (!reuse) pl->sorted = false;
+#ifndef PMX_LEAN_BIN
+#define PMX_LEAN_BIN 1
+#endif
+        // the block form of the pass (bin_lean_kernel for dense rows, else bin_block_kernel): into the ranges `offsets`
+        // names — or, list_arg == NULL (lean form only), the counts alone
+        auto block_pass = [&](uint32_t *list_arg) {
+            const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
+            const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);
+            bool whole_b = true;
+            for (int d = 0; d < 3; d++) whole_b = whole_b && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
+#ifdef PMX_GENERAL_FORMS_ONLY
+            whole_b = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
+#endif
+#define BL(K, PE_, WH) bin_lean_kernel<K, PE_, WH><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, list_arg, pl->host_flag)
+#define BB(K)                                                                                                   \
+    do {                                                                                                        \
+        if (dense && PMX_LEAN_BIN) {                                                                            \
+            if (whole_b) { if (dpos.elsize == 8) BL(K, 8, true); else BL(K, 4, true); }                         \
+            else { if (dpos.elsize == 8) BL(K, 8, false); else BL(K, 4, false); }                               \
+        } else if (dense) bin_block_kernel<K, true><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, list_arg, pl->host_flag); \
+        else bin_block_kernel<K, false><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, list_arg, pl->host_flag); \
+    } while (0)
+            switch (p.kind) {
+            case PMX_TUNED_NNB: BB(PMX_TUNED_NNB); break;
+            case PMX_TUNED_CIC: BB(PMX_TUNED_CIC); break;
+            case PMX_TUNED_TSC: BB(PMX_TUNED_TSC); break;
+            default: BB(PMX_TUNED_PCS); break;
+            }
+#undef BB
+#undef BL
+        };
         pl->last_reuse = reuse;
         pl->builds[reuse ? 0 : 1]++;
         if (reuse) {
@@ -2656,33 +2695,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             // 3.76, clustered 0.96 vs 1.27, 12-byte rows 0.90 vs 0.96, config 3 0.86 vs 1.08, 256^3 0.17 vs 0.20)
             if (inv == nullptr && pl->form != 2) {
                 // rows in a coherent order, no tile-ordered copy: one request per tile and block of rows
-                const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
-                const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);
-#ifndef PMX_LEAN_BIN
-#define PMX_LEAN_BIN 1
-#endif
-                bool whole_b = true;
-                for (int d = 0; d < 3; d++) whole_b = whole_b && g.o[d] == 0 && (int)p.period[d] == (int)p.size[d];      // (whole_mesh())
-#ifdef PMX_GENERAL_FORMS_ONLY
-    whole_b = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
-#endif
-#define BL(K, PE_, WH) bin_lean_kernel<K, PE_, WH><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag)
-#define BB(K)                                                                                                   \
-    do {                                                                                                        \
-        if (dense && PMX_LEAN_BIN) {                                                                            \
-            if (whole_b) { if (dpos.elsize == 8) BL(K, 8, true); else BL(K, 4, true); }                         \
-            else { if (dpos.elsize == 8) BL(K, 8, false); else BL(K, 4, false); }                               \
-        } else if (dense) bin_block_kernel<K, true><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag); \
-        else bin_block_kernel<K, false><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->list, pl->host_flag); \
-    } while (0)
-                switch (p.kind) {
-                case PMX_TUNED_NNB: BB(PMX_TUNED_NNB); break;
-                case PMX_TUNED_CIC: BB(PMX_TUNED_CIC); break;
-                case PMX_TUNED_TSC: BB(PMX_TUNED_TSC); break;
-                default: BB(PMX_TUNED_PCS); break;
-                }
-#undef BB
-#undef BL
+                block_pass(pl->list);
             } else
                 BCK(1, grid_for((npart + PMX_ONEPASS_U - 1) / PMX_ONEPASS_U, TBLOCK), nogate);
             // the repair, one launch that returns at once unless a tile overflowed (measured: the four gated launches
@@ -2690,7 +2703,18 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             const uint32_t *gate = pl->flags;
             BCK(3, small_grid, gate);
         } else {
-            BCK(0, full_grid, nogate);
+            // [r5] Dense rows count through the block form too (list == NULL: counts only) and fill their ranges with
+            // the same pass a rebuild uses, instead of one device atomic per wave and tile in both passes: nothing
+            // for uniform rows (1.6 ms either way at 512^3), but on clustered rows the waves queue on the counters of
+            // the crowded tiles — 18.6 + 19.6 ms for the 2.7e8 rows of a config-5 rank against 1.1 ms per block pass.
+            // (Rows in no order, which get the tile-ordered copy, need a tile id per row and the inverse list: they
+            // are counted again by the per-wave kernel below.)
+#ifndef PMX_LEAN_TWOPASS
+#define PMX_LEAN_TWOPASS 1
+#endif
+            const bool lean2 = PMX_LEAN_TWOPASS && dense && PMX_LEAN_BIN && pl->form != 2 && pl->sort_pref != 1;
+            if (lean2) block_pass(nullptr);
+            else BCK(0, full_grid, nogate);
             // How coherent is the row order?  Every build leaves its measurement in host_groups
             // (asynchronous copy, below); a two-pass build of about as many rows as that one (within an
             // eighth: ghost batches change their size from step to step, overflow repairs, reallocations)
@@ -2719,8 +2743,17 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                 pl->copy_elsize = (int)es;
                 inv = pl->inv;
             }
-            bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate);
-            bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate, inv);
+            if (lean2 && !want) {
+                bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate, pl->counts);
+                block_pass(pl->list);
+            } else {
+                if (lean2) {
+                    PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)nbuckets * 4, st));
+                    BCK(0, full_grid, nogate);
+                }
+                bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate);
+                bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate, inv);
+            }
         }
 #undef BCK
 #undef BC
