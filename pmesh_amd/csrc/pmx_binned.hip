@@ -571,9 +571,9 @@ __device__ __forceinline__ int row_tile(const pmx_painter &p, const BinGeom &g, 
 #define PMX_LEAN_U 4
 #endif
 template <int KIND, int PE, bool WHOLE>
-__global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
-                                                          uint32_t *counts, uint32_t *flags, const int64_t *offsets,
-                                                          uint32_t *list, uint32_t *host_flag)
+__device__ __forceinline__ void lean_blocks(const pmx_painter &p, const BinGeom &g, const DVec &pos, int64_t n,
+                                            uint32_t *counts, uint32_t *flags, const int64_t *offsets,
+                                            uint32_t *list, uint32_t *host_flag)
 {
     constexpr int U = PMX_LEAN_U, BLOCK_ITERS = BLOCK_ROWS / (TBLOCK * U);
     static_assert(BLOCK_ITERS * TBLOCK * U == BLOCK_ROWS, "rows of a block");
@@ -744,6 +744,45 @@ __global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom
         atomicAdd(&flags[1], nbreaks);
         atomicAdd(&flags[2], nsampled);
     }
+}
+
+template <int KIND, int PE, bool WHOLE>
+__global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
+                                                          uint32_t *counts, uint32_t *flags, const int64_t *offsets,
+                                                          uint32_t *list, uint32_t *host_flag)
+{
+    lean_blocks<KIND, PE, WHOLE>(p, g, pos, n, counts, flags, offsets, list, host_flag);
+}
+
+template <int NT>
+__device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor,
+                                            uint32_t *zero);
+
+// [r5] The repair of a single pass that overflowed, for the rows the lean form takes: ONE gated launch of a grid small
+// enough to be resident at once.  The counts are exact (every single-pass form adds before it looks at the range):
+// workgroup 0 lays the new ranges out from them, zeroes the counters and raises flags[3]; the others wait for that;
+// then all of them fill the ranges block by block like any rebuild.  (bin_count_kernel<MODE 3>, which does the same
+// with one cursor request per wave and tile, took 9.7 ms for the 512^3 rows where this takes 2.6: scripts/overflow_probe.py.)
+template <int KIND, int PE, bool WHOLE>
+__global__ void __launch_bounds__(TBLOCK) bin_repair_lean_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
+                                                                 uint32_t *counts, uint32_t *flags, int64_t *offsets,
+                                                                 unsigned long long *cursor, uint32_t *list,
+                                                                 uint32_t *host_flag, const uint32_t *gate)
+{
+    if (*gate == 0) return;
+    if (blockIdx.x == 0) {
+        scan_ranges<TBLOCK>(counts, g.ntiles + 1, offsets, cursor, counts);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) atomicExch(&flags[3], 1u);
+    } else {
+        if (threadIdx.x == 0) {
+            while (atomicAdd(&flags[3], 0u) == 0) __builtin_amdgcn_s_sleep(16);
+            __threadfence();
+        }
+        __syncthreads();
+    }
+    lean_blocks<KIND, PE, WHOLE>(p, g, pos, n, counts, flags, offsets, list, host_flag);
 }
 
 // exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup of NT threads
@@ -2653,9 +2692,12 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #ifndef PMX_LEAN_BIN
 #define PMX_LEAN_BIN 1
 #endif
+#ifndef PMX_REPAIR_GRID
+#define PMX_REPAIR_GRID 512      // workgroups of the gated repair, resident at once (measured 128 / 256 / 512: the launch that returns at once 4.7 us each; the repair of 512^3 rows 5.3 / 3.4 / 2.6 ms)
+#endif
         // the block form of the pass (bin_lean_kernel for dense rows, else bin_block_kernel): into the ranges `offsets`
         // names — or, list_arg == NULL (lean form only), the counts alone
-        auto block_pass = [&](uint32_t *list_arg) {
+        auto block_pass = [&](uint32_t *list_arg, const uint32_t *repair_gate = nullptr) {
             const int64_t nblocks = (npart + BLOCK_ROWS - 1) / BLOCK_ROWS;
             const unsigned bgrid = (unsigned)(nblocks < 65535 * 8 ? nblocks : 65535 * 8);
             bool whole_b = true;
@@ -2663,7 +2705,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
 #ifdef PMX_GENERAL_FORMS_ONLY
             whole_b = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
 #endif
-#define BL(K, PE_, WH) bin_lean_kernel<K, PE_, WH><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, list_arg, pl->host_flag)
+#define BL(K, PE_, WH) do { if (repair_gate) bin_repair_lean_kernel<K, PE_, WH><<<(bgrid < PMX_REPAIR_GRID ? bgrid : PMX_REPAIR_GRID), TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, pl->cursor, list_arg, pl->host_flag, repair_gate); \
+                             else bin_lean_kernel<K, PE_, WH><<<bgrid, TBLOCK, 0, st>>>(p, g, dpos, npart, pl->counts, pl->flags, pl->offsets, list_arg, pl->host_flag); } while (0)
 #define BB(K)                                                                                                   \
     do {                                                                                                        \
         if (dense && PMX_LEAN_BIN) {                                                                            \
@@ -2701,7 +2744,8 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             // the repair, one launch that returns at once unless a tile overflowed (measured: the four gated launches
             // it replaces, zero / count / scan / scatter, cost a slab rank 20 us per build)
             const uint32_t *gate = pl->flags;
-            BCK(3, small_grid, gate);
+            if (inv == nullptr && pl->form != 2 && dense && PMX_LEAN_BIN && PMX_REPAIR_GRID > 0) block_pass(pl->list, gate);
+            else BCK(3, small_grid, gate);
         } else {
             // [r5] Dense rows count through the block form too (list == NULL: counts only) and fill their ranges with
             // the same pass a rebuild uses, instead of one device atomic per wave and tile in both passes: nothing
