@@ -103,6 +103,9 @@ def parse():
     ap.add_argument('--count-jitter', type=float, default=0.0,
                     help='a diagnostic (one rank, scalar mass): the k-th of the position sets has this fraction times k '
                          'FEWER rows than the first — a rank whose particle count changes from step to step (migration)')
+    ap.add_argument('--pos-columns', type=int, default=3,
+                    help='a diagnostic (one rank): > 3: the positions are the first three columns of an array with this many '
+                         '(a phase-space array: rows with a pitch, not dense)')
     ap.add_argument('--out-field', type=int, default=0,
                     help='0: pm.paint(pos) returns a new field every cycle, as the callers of the reference write it '
                          '(fastpm: pm.paint(x, layout=layout)) — on one rank the halo merge of the tile kernels then rides '
@@ -394,6 +397,13 @@ def main():
             step = torch.randn(pos.shape, dtype=tdt, device=be.device, generator=gen) * (args.drift * L / N)
             psets.append(psets[-1] + step)
             del step
+        if args.pos_columns > 3:
+            if world > 1 or args.exchange or args.host_arrays:
+                raise SystemExit('--pos-columns is a single-GPU diagnostic')
+            wide = [torch.zeros((len(q), args.pos_columns), dtype=q.dtype, device=q.device) for q in psets]
+            for w, q in zip(wide, psets):
+                w[:, :3] = q
+            psets = [w[:, :3] for w in wide]
         if args.count_jitter > 0:
             if world > 1 or args.exchange or args.mass == 'array' or args.host_arrays:
                 raise SystemExit('--count-jitter is a single-GPU diagnostic with a scalar mass')

@@ -21,6 +21,7 @@ run headline_drift4 --drift 4.0
 run headline_drift8 --drift 8.0
 run headline_cold_plan --cold-plan 1 --steps 5
 run headline_count_jitter --count-jitter 0.01
+run headline_pos_columns6 --pos-columns 6
 run clustered --data clustered
 run config2_256 --mesh 256
 run config3_tsc_f4_grad --window tsc --dtype f4 --gradient 0
