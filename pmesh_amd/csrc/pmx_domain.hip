@@ -272,6 +272,112 @@ __global__ void __launch_bounds__(DBLOCK) classify_kernel(GridD g, DVec pos, F3 
         atomicAdd(&counts[threadIdx.x], (unsigned long long)tcount[threadIdx.x]);
 }
 
+// [r5] The lean form for what ParticleMesh.decompose sends: dense rows of 3 floats or doubles, a periodic grid whose
+// tables fit the LDS.  On P ranks every step of a time-stepping caller classifies its particles again
+// (examples/nbody.py:199-204) and classify_kernel was the largest kernel of such a cycle (238 us per 1.7e7 rows, 14
+// ps per row, against 108 us for the bin pass over the same rows): its loop carries the general patch enumeration, the
+// three remainders and binary searches of the slow path and the strided element loads in every trip.  Here a lane loads
+// its row in one piece, only the axes that are split are looked at, and the fast path — the coordinate inside the box,
+// its smoothing interval inside ONE domain: all but the particles within s of a domain face — is a guess, at most a
+// correction against the edges, and two table reads; any other row takes the general functions as before (whole waves
+// do, for rows in a coherent order).  Same masks, same counts (tests/test_domain.py).
+template <int PE>
+__global__ void __launch_bounds__(DBLOCK) classify_lean_kernel(GridD g, const char *data, F3 scale, F3 smoothing,
+                                                               int64_t n, uint64_t *masks,
+                                                               unsigned long long *counts, int64_t nchunks,
+                                                               int64_t *chunk_counts)
+{
+    __shared__ unsigned int lcount[PMX_MAXRANKS];
+    __shared__ unsigned int tcount[PMX_MAXRANKS];
+    constexpr int MAXE = 80, MAXCELLS = 256;
+    __shared__ double s_edges[3][MAXE];
+    __shared__ int32_t s_assign[MAXCELLS];
+    __shared__ int16_t s_degenerate[PMX_MAXRANKS];
+    double invw[3], box[3];
+    int stride[3];
+    {
+        int cells = 1;
+        for (int j = 2; j >= 0; j--) { stride[j] = cells; cells *= g.shape[j]; }
+        for (int j = 0; j < 3; j++) {
+            box[j] = g.edges[j][g.shape[j]];
+            invw[j] = (double)g.shape[j] / box[j];
+            for (int q = threadIdx.x; q <= g.shape[j]; q += DBLOCK) s_edges[j][q] = g.edges[j][q];
+        }
+        for (int q = threadIdx.x; q < cells; q += DBLOCK) s_assign[q] = g.assign[q];
+        for (int q = threadIdx.x; q < g.nranks; q += DBLOCK) s_degenerate[q] = g.degenerate[q];
+        for (int j = 0; j < 3; j++) g.edges[j] = s_edges[j];
+        g.assign = s_assign;
+        g.degenerate = s_degenerate;
+    }
+    if (threadIdx.x < PMX_MAXRANKS) tcount[threadIdx.x] = 0;
+    constexpr int ROW = 3 * PE;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x < PMX_MAXRANKS) lcount[threadIdx.x] = 0;
+        __syncthreads();
+        // (the next sub-batch's row is in flight while this one is classified)
+        auto load = [&](int k, double *x) __attribute__((always_inline)) {
+            const int64_t i = chunk * DCHUNK + k * DBLOCK + threadIdx.x;
+            const int64_t il = i < n ? i : n - 1;                   // (a row beyond the end reads the last one: no load behind a branch)
+            if (PE == 4) { const float *q = (const float *)(data + il * ROW); x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; }
+            else { const double *q = (const double *)(data + il * ROW); x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; }
+        };
+        double xn[3];
+        load(0, xn);
+#pragma unroll 2
+        for (int k = 0; k < DSUB; k++) {
+            const int64_t i = chunk * DCHUNK + k * DBLOCK + threadIdx.x;
+            double x[3] = {xn[0], xn[1], xn[2]};
+            if (k + 1 < DSUB) load(k + 1, xn);
+            bool fast = true;
+            int target = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (g.shape[j] == 1) continue;                      // (uniform: an axis that is not split resolves to its one domain)
+                const double X = scale.v[j] * x[j];                 // transform0 (pm.py:1788-1790): scale * x in double
+                const double s = smoothing.v[j];
+                int kk = (int)(X * invw[j]);
+                kk = max(0, min(kk, g.shape[j] - 1));
+                while (kk > 0 && X < s_edges[j][kk]) kk--;
+                while (kk < g.shape[j] - 1 && X >= s_edges[j][kk + 1]) kk++;
+                fast = fast && X >= 0 && X < box[j] && X - s >= s_edges[j][kk] && X + s < s_edges[j][kk + 1];
+                target += kk * stride[j];
+                x[j] = X;
+            }
+            uint64_t m = 0;
+            if (i < n) {
+                if (fast) {
+                    const int rank = s_assign[target];
+                    m = s_degenerate[rank] ? 0 : (uint64_t)1 << rank;
+                } else {
+                    int sil[PMX_MAXDIM], sir[PMX_MAXDIM];
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        classify_axis(g, j, g.shape[j] == 1 ? x[j] : x[j], smoothing.v[j], &sil[j], &sir[j], invw[j]);
+                    m = particle_targets<3>(g, sil, sir);
+                }
+                masks[i] = m;
+            }
+            const uint64_t m0 = __shfl(m, 0);
+            if (__ballot(m != m0) == 0 && (m0 & (m0 - 1)) == 0) {
+                if ((threadIdx.x & 63) == 0 && m0) atomicAdd(&lcount[__ffsll((long long)m0) - 1], 64u);
+            } else {
+                for (int r = 0; r < g.nranks; r++) {
+                    unsigned long long b = __ballot((m >> r) & 1);
+                    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&lcount[r], (unsigned)__popcll(b));
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < g.nranks) {
+            chunk_counts[(int64_t)threadIdx.x * nchunks + chunk] = lcount[threadIdx.x];
+            tcount[threadIdx.x] += lcount[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < g.nranks && tcount[threadIdx.x])
+        atomicAdd(&counts[threadIdx.x], (unsigned long long)tcount[threadIdx.x]);
+}
+
 // per-chunk (DCHUNK particles), per-rank counts from the masks alone (when the classification
 // was not run by this library instance just before, see pmx_decompose_fill)
 __global__ void __launch_bounds__(DBLOCK) chunk_count_kernel(const uint64_t *masks, int64_t n,
@@ -491,9 +597,25 @@ extern "C" int pmx_decompose_count(const pmx_grid *g, const pmx_vec *pos, const 
     int rc = g_scratch.ensure(sizeof(int64_t) * nchunks * g->nranks);
     if (rc) return rc;
     unsigned grid = (unsigned)(nchunks < 256 * 16 ? nchunks : 256 * 16);
-    auto classify = gd.ndim == 3 ? classify_kernel<3> : (gd.ndim == 2 ? classify_kernel<2> : classify_kernel<1>);      // (PMX_MAXDIM = 3)
-    classify<<<grid, DBLOCK, 0, st>>>(gd, dvec(pos), sc, sm, npart, masks, (unsigned long long *)counts,
-                                             nchunks, (int64_t *)g_scratch.ptr);
+#ifndef PMX_LEAN_CLASSIFY
+#define PMX_LEAN_CLASSIFY 1
+#endif
+    // the lean form: 3-d, periodic, tables that fit its LDS copies, dense rows of 3 elements
+    bool lean = PMX_LEAN_CLASSIFY && gd.ndim == 3 && gd.periodic && pos->ncol == 3 && pos->stride1 == pos->elsize &&
+                pos->stride0 == 3 * (int64_t)pos->elsize && (int64_t)gd.shape[0] * gd.shape[1] * gd.shape[2] <= 256;
+    for (int d = 0; d < 3 && lean; d++) lean = gd.shape[d] + 1 <= 80;
+    if (lean) {
+        if (pos->elsize == 8)
+            classify_lean_kernel<8><<<grid, DBLOCK, 0, st>>>(gd, (const char *)pos->data, sc, sm, npart, masks,
+                                                             (unsigned long long *)counts, nchunks, (int64_t *)g_scratch.ptr);
+        else
+            classify_lean_kernel<4><<<grid, DBLOCK, 0, st>>>(gd, (const char *)pos->data, sc, sm, npart, masks,
+                                                             (unsigned long long *)counts, nchunks, (int64_t *)g_scratch.ptr);
+    } else {
+        auto classify = gd.ndim == 3 ? classify_kernel<3> : (gd.ndim == 2 ? classify_kernel<2> : classify_kernel<1>);      // (PMX_MAXDIM = 3)
+        classify<<<grid, DBLOCK, 0, st>>>(gd, dvec(pos), sc, sm, npart, masks, (unsigned long long *)counts,
+                                          nchunks, (int64_t *)g_scratch.ptr);
+    }
     PMX_HIP_CHECK(hipGetLastError());
     g_chunk_tag.masks = masks;
     g_chunk_tag.npart = npart;

@@ -55,6 +55,7 @@ def parse(argv=None):
                     help='1: every particle moves to the rank that owns its cell first, once (bench.py --gpus N does: what a '
                          'time-stepping code does after its first decompose); 0: the ranks keep their slabs of lattice ids and '
                          'on a pencil mesh three quarters of the rows travel as "ghosts" in every cycle')
+    ap.add_argument('--decompose', type=int, default=0, help='1: pm.decompose inside every cycle, as a time-stepping caller writes it (examples/nbody.py:199-204)')
     ap.add_argument('--out-field', type=int, default=0, help='1: paint into a field the caller keeps across cycles')
     ap.add_argument('--oracle-planes', type=int, default=0,
                     help='K > 0: the first K planes of rank 0 painted block against the CPU oracle')
@@ -126,13 +127,17 @@ def run(args):
             release_staging(comm)
         T = Transfer.dx1(0)
         rho0 = pm.create('real')
-        layout = pm.decompose(pos)
+        layout0 = pm.decompose(pos)
         result = torch.empty(len(pos), dtype=torch.float64, device=be.device)      # lives across cycles, as a caller keeps it
 
         def cycle(keep_block=False):
             _window.clear_bin_cache()
-            layout._memo = None
-            layout._memo_remote = None
+            if args.decompose:
+                layout = pm.decompose(pos)
+            else:
+                layout = layout0
+                layout._memo = None
+                layout._memo_remote = None
             # as the one-rank cycle of bench.py: a field of the paint's own making (no fill, and the merge of the tile
             # halos left to the row pass of r2c), unless --out-field 1 hands it the caller's
             rho = pm.paint(pos, mass=mass, layout=layout, out=rho0 if args.out_field else None)
@@ -156,7 +161,7 @@ def run(args):
             f = cycle()
         sync()
         comm.Barrier()
-        results[r] = (time.perf_counter() - t0, float(f.sum()), int(layout.remote_recvlength))
+        results[r] = (time.perf_counter() - t0, float(f.sum()), int(layout0.remote_recvlength))
         from pmesh_amd.domain import _scratch_of
         staging[r] = _scratch_of(comm).nbytes()
         if args.check or args.oracle_planes:
