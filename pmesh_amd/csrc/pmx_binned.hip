@@ -2075,7 +2075,7 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
 // results looked up per store.
 template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
 __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
-                                                 char *out, const uint32_t *tl, int count, const T *lds)
+                                                 char *out, const uint32_t *tl, int count, const T *lds, int ostride)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
@@ -2114,8 +2114,9 @@ __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const Bin
                 }
                 acc = fma_(W[0][a], plane, acc);
             }
-            if (OE == 8) *(double *)(out + (int64_t)id[u] * 8) = (double)acc;
-            else *(float *)(out + (int64_t)id[u] * 4) = (float)acc;
+            // (ostride: bytes from one result to the next — OE for a dense vector, more for a column of the caller's array)
+            if (OE == 8) *(double *)(out + (int64_t)id[u] * ostride) = (double)acc;
+            else *(float *)(out + (int64_t)id[u] * ostride) = (float)acc;
         }
     }
 }
@@ -2131,7 +2132,8 @@ template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
 __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WAVES : 1)) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                                    DVec pos, char *out, const uint32_t *list,
                                                                    const int64_t *offsets, const uint32_t *counts,
-                                                                   const uint64_t *items, const uint32_t *nitems, uint32_t cap)
+                                                                   const uint64_t *items, const uint32_t *nitems, uint32_t cap,
+                                                                   int ostride)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
@@ -2143,8 +2145,8 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
         const int64_t nd = counts[g.ntiles];
         const uint32_t *dl = list + offsets[g.ntiles];
         for (int64_t j = blockIdx.x * (int64_t)TTHREADS + threadIdx.x; j < nd; j += (int64_t)gridDim.x * TTHREADS) {
-            if (OE == 8) *(double *)(out + (int64_t)dl[j] * 8) = 0.0;
-            else *(float *)(out + (int64_t)dl[j] * 4) = 0.0f;
+            if (OE == 8) *(double *)(out + (int64_t)dl[j] * ostride) = 0.0;
+            else *(float *)(out + (int64_t)dl[j] * ostride) = 0.0f;
         }
     }
     const int64_t nh = *nitems < cap ? *nitems : cap;
@@ -2171,7 +2173,7 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
             lds[r * Rg::template gpitch<T>() + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;
         }
         __syncthreads();
-        tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + start, count, lds);
+        tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + start, count, lds, ostride);
         __syncthreads();
     }
 }
@@ -3117,7 +3119,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
 #define PMX_LEAN_READOUT 1
 #endif
     const bool lean = PMX_LEAN_READOUT && relax && !sorted && dpos.stride1 == dpos.elsize && dpos.stride0 == 3 * dpos.elsize
-                      && dout.stride0 == dout.elsize;
+                      && dout.stride0 >= dout.elsize && dout.stride0 % dout.elsize == 0 && dout.stride0 < (1 << 20);      // (a dense vector, or a column of the caller's array: F[:, d])
     if (!lean) zero_dropped_kernel<<<256, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, g.ntiles, dout, sorted);
     // (NNB: one cell, weight 1 — the same bits either way; the lean per-particle setup of the relaxed form is what it takes)
 #define RT2(K, T, RX) do { if (sorted) readout_tile_kernel<K, T, TileThreads<K, T>::readout, true, RX><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, dout, pl->list, pl->offsets, pl->counts); \
@@ -3128,7 +3130,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
 #ifdef PMX_GENERAL_FORMS_ONLY
     whole_r = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
 #endif
-#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy)
+#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, (int)dout.stride0)
 #define RLW(K, T, PE_, OE_) do { if (whole_r) RLL(K, T, PE_, OE_, true); else RLL(K, T, PE_, OE_, false); } while (0)
 #define RLO(K, T, PE_) do { if (dout.elsize == 8) RLW(K, T, PE_, 8); else RLW(K, T, PE_, 4); } while (0)
 #define RL(K, T) do { if (dpos.elsize == 8) RLO(K, T, 8); else RLO(K, T, 4); } while (0)

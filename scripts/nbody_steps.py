@@ -34,7 +34,11 @@ def force(X, fused):
     layout = pm.decompose(X)
     rho = pm.paint(X, layout=layout)
     rhok = rho.r2c(out=Ellipsis)
-    F = torch.empty_like(X)
+    # fused == 2: the components of the force one after the other in memory (a (3, n) array, used as its (n, 3) view):
+    # a column of an (n, 3) array is written in 8-byte pieces 24 bytes apart — every 64-byte piece of the array is read,
+    # patched and written back by the memory system, 1.4 ms more per readout at 512^3 than a dense vector, whichever
+    # kernel writes it (measured: scripts/r05/nbody_kstats.sh, 2.54 against 1.12 ms)
+    F = torch.empty((3, len(X)), dtype=X.dtype, device=X.device).t() if fused == 2 else torch.empty_like(X)
     for d in range(3):
         # (the result goes straight into its column of the force array: readout's `out`, window.py:165-221)
         if fused:
@@ -44,7 +48,7 @@ def force(X, fused):
     return F
 
 
-for fused in (False, True):
+for fused in (False, True, 2):
     x, v = X.clone(), V.clone()
     F = force(x, fused)
 
@@ -66,5 +70,5 @@ for fused in (False, True):
           % (st1['num_device_alloc'] - st0['num_device_alloc'], st1['num_device_free'] - st0['num_device_free'],
              st1['reserved_bytes.all.current'] / 1e9), flush=True)
     print('N=%d: %s: %.2f ms per step (one paint, one r2c, three c2r + readout; %d particles), |F| max %.3e'
-          % (N, 'fused Transfer.force on c2r' if fused else "the caller's numpy-style force_transfer on device arrays",
+          % (N, ('fused Transfer.force on c2r' + (', force components contiguous' if fused == 2 else '')) if fused else "the caller's numpy-style force_transfer on device arrays",
              ms, len(x), float(F.abs().max())), flush=True)
