@@ -542,6 +542,17 @@ __device__ __forceinline__ int row_tile(const pmx_painter &p, const BinGeom &g, 
             const double X = (double)row.x[d] * p.scale[d] + p.translate[d];
             ok = ok && (fabs(X) < 1073741824.0);               // NaN / out of int range: dropped
             const int I0 = Tuned<KIND>::first(ok ? X : 0.0);
+            const int period = (int)p.period[d];
+            if (g.o[d] == 0 && period == (int)p.size[d]) {
+                // (uniform: an axis that IS the whole periodic mesh — two of three on a slab rank — wraps as in the
+                // whole-mesh form and cannot miss the block)
+                int w = I0;
+                w += (w < 0) ? period : 0;
+                w -= (w >= period) ? period : 0;
+                if ((unsigned)w >= (unsigned)period) { w %= period; if (w < 0) w += period; }
+                tt[d] = (int)((unsigned)w / (unsigned)tile_ext(d));
+                continue;
+            }
             int i0w = 0;
             ok = ok && local_base<KIND>(p, d, I0, &i0w);
             tt[d] = (int)((unsigned)(i0w + g.o[d]) / (unsigned)tile_ext(d));
