@@ -200,10 +200,15 @@ int pmx_binplan_mass_stats(pmx_binplan *plan, const double *stats);
  * through the index list a sector of its own.  A plan can instead carry a copy of the positions
  * in tile order (one gather per build): paint and readout stream it, readout writes its results
  * in tile order and pulls them back through the inverse list.  pref: -1 (default) = decided by
- * the first build of a geometry from the measured coherence of the row order (more than 24
- * changes of tile per 64 consecutive rows), 0 = never, 1 = always, -2 = leave unchanged.
+ * every build of a geometry from the measured coherence of the row order: a plan without the
+ * copy takes it above PMX_SORTED_TAKE_BREAKS changes of tile per 64 consecutive rows, a plan
+ * with it gives it up below PMX_SORTED_DROP_BREAKS (two thresholds, so that position sets on
+ * either side of one do not restart the plan every step; lattice order shows a handful of
+ * breaks, random order 63), 0 = never, 1 = always, -2 = leave unchanged.
  * is_sorted (optional): whether the plan as built carries the copy.  Results do not depend on it
  * (readout bit-identical, paint up to the order of the additions). */
+#define PMX_SORTED_TAKE_BREAKS 61.5
+#define PMX_SORTED_DROP_BREAKS 58.0
 int pmx_binplan_sorted(pmx_binplan *plan, int32_t pref, int32_t *is_sorted);
 /* How many builds of this plan so far found the slot ranges of their previous build too small
  * (particles moved a lot) and fell back to the exact two-pass build on the device.  Host

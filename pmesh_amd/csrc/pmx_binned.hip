@@ -2697,7 +2697,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         // 9.50 against 7.06 / 7.67 / 10.58 / 11.04; only rows in no order at all (63) gain: 22.8 against 14.4.
         // Two thresholds: a plan takes the copy above 61.5 and gives it up below 58 (position sets on either side of ONE
         // threshold made the plan start over every step: 11.1 ms at 8 cells of jitter against 9.5 in either form).
-        auto incoherent = [&](double breaks, double rows, bool has_copy) { return breaks * 64.0 > (has_copy ? 58.0 : 61.5) * rows; };
+        auto incoherent = [&](double breaks, double rows, bool has_copy) { return breaks * 64.0 > (has_copy ? PMX_SORTED_DROP_BREAKS : PMX_SORTED_TAKE_BREAKS) * rows; };
         if (reuse && pl->sort_pref < 0 && pl->host_groups[2] == (uint32_t)npart && pl->host_groups[1] > 4096 &&
             incoherent(pl->host_groups[0], (double)pl->host_groups[1], pl->sorted) != pl->sorted)
             reuse = false;       // the order of the rows changed its character since the plan was built: start over

@@ -129,12 +129,15 @@ class _Scratch(object):
 
     def __init__(self):
         self.buffers = {}      # name -> [uint8 tensor, handle of the exchange that uses it or None]
+        self.private = {}      # name -> whether the last get() handed out memory of the caller's own
 
     def get(self, name, nbytes, device):
         e = self.buffers.get(name)
+        self.private[name] = False
         if e is not None and isinstance(e[1], _InUse) and not e[1].released:
             # the consumer of what an asynchronous exchange left in this buffer has not run yet (received rows whose
             # columns are still to be extracted, results still to be added): this exchange gets memory of its own
+            self.private[name] = True
             return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         if e is not None and e[1] is not None:
             e[1].wait()
@@ -149,8 +152,15 @@ class _Scratch(object):
         return e[0][:nbytes]
 
     def busy(self, name, work):
-        if work is not None and name in self.buffers:
-            self.buffers[name][1] = work
+        # (an exchange that was given memory of its own has nothing of the pool to protect — and the hold of the
+        # exchange that still owns the pooled buffer must stay: replaced by this one's, a THIRD exchange would be
+        # handed the buffer the first has not read yet)
+        if work is None or name not in self.buffers or self.private.get(name):
+            return
+        e = self.buffers[name]
+        if isinstance(e[1], _InUse) and not e[1].released and e[1] is not work:
+            return
+        e[1] = work
 
     def nbytes(self):
         return sum(e[0].numel() for e in self.buffers.values() if e[0] is not None)
@@ -276,15 +286,13 @@ class Layout(object):
         default, as in the reference): the rows of all arrays travel in ONE all-to-all-v, packed
         side by side as bytes; pack=False: one exchange per array.
         """
-        if pack and len(args) > 1 and self.comm.size > 1:
-            r = self._exchange_packed(args)
-        else:
-            r = tuple([self._exchange(arg) for arg in args])
-        if len(args) == 0:
+        if not args:
             return None
         if len(args) == 1:
-            return r[0]
-        return r
+            return self._exchange(args[0])
+        if pack and self.comm.size > 1:
+            return self._exchange_packed(args)
+        return tuple(self._exchange(a) for a in args)
 
     def _exchange(self, data):
         be = backend.get()
@@ -506,20 +514,23 @@ class Layout(object):
         memo, keys = st['memo'], st['keys']
         if st['missing']:
             be = backend.get()
-            for w in st['works']:
-                if w is not None:
-                    w.wait()
-            if st['wrong']:
-                raise ValueError(st['message'])
             got = st['got']
-            if st['packed'] is not None:
-                off = 0
-                for a in st['src']:
-                    rb = _row_bytes(a)
-                    got.append(self._column(be, st['packed'], off, rb, a.dtype, tuple(a.shape[1:])))
-                    off += rb
-                if st.get('hold') is not None:
-                    st['hold'].release()
+            try:
+                for w in st['works']:
+                    if w is not None:
+                        w.wait()
+                if st['wrong']:
+                    raise ValueError(st['message'])
+                if st['packed'] is not None:
+                    off = 0
+                    for a in st['src']:
+                        rb = _row_bytes(a)
+                        got.append(self._column(be, st['packed'], off, rb, a.dtype, tuple(a.shape[1:])))
+                        off += rb
+            finally:
+                # (also when the lengths were wrong: a hold never released would make every later exchange
+                # allocate memory of its own)
+                _drop_hold(st.get('hold'))
             for i, r in zip(st['missing'], got):
                 # (a weak reference to the source tensor: the memo must not keep a caller's array alive, and an
                 # address reused by another tensor must not pass for the old one)
@@ -596,7 +607,7 @@ class Layout(object):
                 if async_op:
                     hold.release()
         if async_op:
-            return _Pending2(finish, data)
+            return _Pending2(finish, data, hold)
         return finish(out)
 
     def gather(self, data, mode='sum', out=None):
@@ -677,6 +688,11 @@ class Layout(object):
         raise NotImplementedError
 
 
+def _drop_hold(hold):
+    if hold is not None:
+        hold.release()          # (the next get() of the buffer waits for the exchange itself)
+
+
 class _RemoteExchange(object):
     """handle of Layout.exchange_remote(async_op=True)"""
     def __init__(self, layout, state):
@@ -685,14 +701,27 @@ class _RemoteExchange(object):
     def wait(self):
         return self.layout._exchange_remote_end(self.state)
 
+    def __del__(self):
+        # a handle dropped without wait(): the staging goes back to the pool
+        try:
+            _drop_hold(self.state.get('hold'))
+        except Exception:
+            pass
+
 
 class _Pending2(object):
     """handle of Layout.gather_remote_add(async_op=True): wait(out) adds what came back into `out`"""
-    def __init__(self, finish, keepalive):
-        self.finish, self.keepalive = finish, keepalive
+    def __init__(self, finish, keepalive, hold=None):
+        self.finish, self.keepalive, self.hold = finish, keepalive, hold
 
     def wait(self, out):
         return self.finish(out)
+
+    def __del__(self):
+        try:
+            _drop_hold(self.hold)
+        except Exception:
+            pass
 
 
 class _Finished(object):
@@ -718,23 +747,21 @@ class GridND(object):
 
     @classmethod
     def uniform(cls, BoxSize, comm=None, periodic=True):
-        if comm is None:
-            comm = default_comm()
-        ndim = len(BoxSize)
-        # compute a optimal shape where each domain is as cubical as possible
-        r = (1.0 * comm.size / numpy.prod(BoxSize) * min(BoxSize)) ** (1.0 / ndim)
-        shape = [r * (BoxSize[i] / min(BoxSize)) for i in range(ndim)]
-        shape = numpy.array(shape)
-        imax = shape.argmax()
-        shape = numpy.int32(shape)
-        shape[shape < 1] = 1
-        shape[imax] = 1
-        shape[imax] = comm.size // numpy.prod(shape)
+        """ a grid over the box [0, BoxSize) with about one domain per rank, the domains as close to cubes as the
+        rank count allows (domain.py:340-360): per axis `side x (BoxSize[d] / min BoxSize)` domains, rounded down,
+        where side^ndim x the box's aspect = comm.size; the axis with the most domains then takes every rank the
+        others leave. """
+        comm = default_comm() if comm is None else comm
+        box = [float(b) for b in BoxSize]
+        shortest = min(box)
+        side = (1.0 * comm.size / numpy.prod(BoxSize) * shortest) ** (1.0 / len(box))
+        wanted = numpy.array([side * (b / shortest) for b in box])
+        longest = int(wanted.argmax())
+        shape = numpy.maximum(numpy.int32(wanted), 1)
+        shape[longest] = 1
+        shape[longest] = comm.size // numpy.prod(shape)
         assert numpy.prod(shape) <= comm.size
-        edges = []
-        for i in range(ndim):
-            edges.append(numpy.linspace(0, BoxSize[i], shape[i] + 1, endpoint=True))
-        return cls(edges, comm, periodic)
+        return cls([numpy.linspace(0, b, n + 1, endpoint=True) for b, n in zip(BoxSize, shape)], comm, periodic)
 
     def __init__(self, edges, comm=None, periodic=True, DomainAssign=None):
         """ DomainAssign records each domain is assigned to which rank """

@@ -43,6 +43,24 @@ def is_inplace(out):
     return out is Ellipsis
 
 
+def _deprecated(message, replacement, *args):
+    warnings.warn(message, DeprecationWarning, stacklevel=3)
+    return replacement(*args)
+
+
+def _position_gradient_target(out_pos, pos, gradient):
+    """where readout_vjp / paint_vjp put the gradient with respect to the positions (pm.py:820-826, 1908-1914): a new
+    array, or — out_pos=Ellipsis or the position array itself — over the positions, which are then read from a
+    copy.  Returns (out_pos, pos to read)."""
+    if gradient is not None:
+        raise ValueError("gradient of gradient is not yet supported")
+    if out_pos is None:
+        return _zeros_like(pos), pos
+    if is_inplace(out_pos) or out_pos is pos:
+        return pos, _copy(pos)
+    return out_pos, pos
+
+
 # numpy ufunc -> torch function, so that `rho1[...] *= fac`, `field + 1`, abs(field) ...
 # stay on the device (Field.__array_ufunc__, pm.py:169-208)
 _UFUNCS = {
@@ -57,67 +75,65 @@ _UFUNCS = {
 
 
 class xslab(list):
-    """list of broadcastable coordinate arrays with the p-norm helper (pm.py:122-136)."""
+    """the broadcastable coordinate arrays of one slab; normp() is their p-norm (pm.py:122-136)."""
     def normp(self, p=2, zeromode=None):
-        kk = (sum([abs(ki) ** p for ki in self]))
+        total = None
+        for coord in self:
+            term = abs(coord) ** p
+            total = term if total is None else total + term
         if zeromode is not None:
-            kk[kk == 0] = zeromode
-        return kk
+            total[total == 0] = zeromode
+        return total
+
+
+def _slab_cut(field):
+    """how a slab iteration cuts `field`: (axis iterated over, number of slabs, function that brings that axis to
+    the front of an array with the field's dimensions).  The axis is the one with the largest stride — slabs are
+    then contiguous pieces of the buffer; a 2-d field is one slab (pm.py:90-104)."""
+    if field.ndim == 2:
+        return 2, 1, (lambda t: t[None, ...])
+    strides = field.value.stride()
+    order = sorted(range(field.ndim), key=lambda d: (strides[d], d), reverse=True)
+    return order[0], int(field.shape[order[0]]), (lambda t: t.permute(order))
 
 
 class slabiter(object):
     """ iterate over the slowest-varying axis of a field to gain locality, yielding the
         slab values with their sparse coordinates attached (pm.py:87-120). """
     def __init__(self, field, value):
-        if field.ndim == 2:
-            axis = 2
-            self.optimized_view = value[None, ...]
-            self.nslabs = 1
-            self.optx = [xx[None, ...] for xx in field.x]
-            self.opti = [ii[None, ...] for ii in field.i]
-        else:
-            strides = numpy.array(field.value.stride())
-            axissort = [int(a) for a in numpy.argsort(strides, kind='stable')[::-1]]
-            axis = axissort[0]
-            self.optimized_view = value.permute(axissort)
-            self.nslabs = field.shape[axis]
-            self.optx = [xx.permute(axissort) for xx in field.x]
-            self.opti = [ii.permute(axissort) for ii in field.i]
-        self.axis = axis
-        self.Nmesh = field.Nmesh
-        self.BoxSize = field.BoxSize
-        self.x = xslabiter(self, axis, self.nslabs, self.optx)
-        self.i = xslabiter(self, axis, self.nslabs, self.opti)
+        self.axis, self.nslabs, front = _slab_cut(field)
+        self._values = front(value)
+        self._coords = {'x': [front(c) for c in field.x], 'i': [front(c) for c in field.i]}
+        self.Nmesh, self.BoxSize = field.Nmesh, field.BoxSize
+        self.x = xslabiter(self, 'x')
+        self.i = xslabiter(self, 'i')
+
+    def _coords_of(self, which, irow):
+        # every axis but the iterated one keeps its single broadcast entry
+        return [DevArr(c[irow if d == self.axis else 0]) for d, c in enumerate(self._coords[which])]
 
     def __iter__(self):
         # (the slabs are numpy-flavoured handles on views of the field, _devarr.DevArr, as the arguments of an apply
         # callable are: `numpy.abs(slab) ** 2`, `slab[...] *= w` work on the device and write through to the field;
         # `slab.t` is the tensor)
         for irow in range(self.nslabs):
-            s = DevArr(self.optimized_view[irow])
-            kk = [DevArr(x[0] if d != self.axis else x[irow]) for d, x in enumerate(self.optx)]
-            ii = [DevArr(x[0] if d != self.axis else x[irow]) for d, x in enumerate(self.opti)]
-            s.x = kk
-            s.i = ii
-            s.BoxSize = self.BoxSize
-            s.Nmesh = self.Nmesh
+            s = DevArr(self._values[irow])
+            s.x, s.i = self._coords_of('x', irow), self._coords_of('i', irow)
+            s.Nmesh, s.BoxSize = self.Nmesh, self.BoxSize
             yield s
 
 
-class xslabiter(slabiter):
+class xslabiter(object):
     """ the coordinate side of a slab iteration: per slab, the broadcastable coordinate arrays
     with the iteration axis cut down to that slab (pm.py:138-153) """
-    def __init__(self, slabiter, axis, nslabs, optx):
-        self.axis, self.nslabs, self.optx = axis, nslabs, optx
-        self.BoxSize, self.Nmesh = slabiter.BoxSize, slabiter.Nmesh
-
-    def _coords_of(self, irow):
-        # every axis but the iterated one keeps its single broadcast entry
-        return [DevArr(x[irow if d == self.axis else 0]) for d, x in enumerate(self.optx)]
+    def __init__(self, slabs, which):
+        self._slabs, self._which = slabs, which
+        self.axis, self.nslabs = slabs.axis, slabs.nslabs
+        self.BoxSize, self.Nmesh = slabs.BoxSize, slabs.Nmesh
 
     def __iter__(self):
         for irow in range(self.nslabs):
-            slab = xslab(self._coords_of(irow))
+            slab = xslab(self._slabs._coords_of(self._which, irow))
             slab.BoxSize, slab.Nmesh = self.BoxSize, self.Nmesh
             yield slab
 
@@ -134,9 +150,9 @@ class Field(NDArrayLike):
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         out = kwargs.get('out', ())
-        for x in inputs + out:
-            if not isinstance(x, self._HANDLED_TYPES + (Field,)):
-                return NotImplemented
+        known = self._HANDLED_TYPES + (Field,)
+        if not all(isinstance(x, known) for x in tuple(inputs) + tuple(out)):
+            return NotImplemented
         dev = self.value.device
 
         def unwrap(x):
@@ -184,15 +200,15 @@ class Field(NDArrayLike):
             return self
         return self.pm.create(_gettype(self), value=result)
 
-    def _check_compatible(self, other):
-        if isinstance(other, Field):
-            if not isinstance(other, _gettype(self)):
-                raise TypeError("type of two operands of cdot must be the same type")
-        else:
-            assert all(numpy.shape(other) == self.shape)
-
     def copy(self):
         return self.pm.create(_gettype(self), value=self.value)
+
+    def _check_compatible(self, other):
+        # two fields must be of one kind; anything else only has to have this field's local shape (pm.py:210-216)
+        if not isinstance(other, Field):
+            assert tuple(numpy.shape(other)) == tuple(int(n) for n in self.shape)
+        elif not isinstance(other, _gettype(self)):
+            raise TypeError("type of two operands of cdot must be the same type")
 
     def __init__(self, pm, base=None):
         """ bind a local buffer of `pm`'s partition and mirror the attributes callers read off a
@@ -366,13 +382,12 @@ class Field(NDArrayLike):
             g = g * int(self.cshape[d]) + idx.reshape([-1 if dd == d else 1 for dd in range(self.ndim)])
         return g
 
+    # the deprecated spellings of ravel / unravel (pm.py:381-387)
     def sort(self, out=None):
-        warnings.warn("Use ravel instead of sort", DeprecationWarning, stacklevel=2)
-        return self.ravel(out)
+        return _deprecated("Use ravel instead of sort", self.ravel, out)
 
     def unsort(self, flatiter):
-        warnings.warn("Use pm.unravel instead of unsort", DeprecationWarning, stacklevel=2)
-        return self.unravel(flatiter)
+        return _deprecated("Use pm.unravel instead of unsort", self.unravel, flatiter)
 
     def ravel(self, out=None):
         """ Ravel the field to 'C'-order, partitioned by ranks: rank r receives the next
@@ -470,39 +485,23 @@ class Field(NDArrayLike):
 
             Nmesh : desired Nmesh of the result or None; axes : axes to preserve;
             method : "upsample" | "downsample" | None (by the direction of the change). """
-        if axes is None:
-            axes = range(self.ndim)
-        if not hasattr(axes, '__iter__'):
-            axes = (axes,)
-        else:
-            axes = list(axes)
-        if isinstance(self, BaseComplexField):
-            self = self.c2r()
+        keep = list(range(self.ndim)) if axes is None else (list(axes) if hasattr(axes, '__iter__') else [axes])
+        field = self.c2r() if isinstance(self, BaseComplexField) else self
         if Nmesh is not None:
-            Nmesh = numpy.ones(self.ndim, dtype='intp') * numpy.asarray(Nmesh)
-            if all(Nmesh == self.Nmesh):
-                Nmesh = None
-        if Nmesh is not None:
-            pm = self.pm.reshape(Nmesh)
-            if method is None:
-                method = 'downsample' if any(Nmesh < self.Nmesh) else 'upsample'
-            if method == 'downsample':
-                out = pm.downsample(self, resampler=resampler, keep_mean=True)
-            elif method == 'upsample':
-                out = pm.upsample(self, resampler=resampler, keep_mean=True)
-            else:
-                raise ValueError("method can only be downsample or upsample")
-        else:
-            out = self
-        result = numpy.zeros([out.cshape[i] for i in axes], dtype=out.dtype)
-        local_slice = tuple([out.slices[i] for i in axes])
-        value = out.value
-        if len(axes) != self.ndim:
-            removeaxes = [d for d in range(self.ndim) if d not in axes]
-            value = value.permute(list(axes) + removeaxes).sum(dim=tuple(range(len(axes), self.ndim)))
-        else:
-            value = value.permute(list(axes))
-        result[local_slice] += value.cpu().numpy()
+            want = numpy.ones(self.ndim, dtype='intp') * numpy.asarray(Nmesh)
+            if not all(want == field.Nmesh):
+                if method is None:
+                    method = 'downsample' if any(want < field.Nmesh) else 'upsample'
+                if method not in ('downsample', 'upsample'):
+                    raise ValueError("method can only be downsample or upsample")
+                field = getattr(field.pm.reshape(want), method)(field, resampler=resampler, keep_mean=True)
+        # project on the device (sum over the axes that go), then every rank adds its block into the global image
+        gone = [d for d in range(self.ndim) if d not in keep]
+        image = field.value.permute(keep + gone)
+        if gone:
+            image = image.sum(dim=tuple(range(len(keep), self.ndim)))
+        result = numpy.zeros([field.cshape[d] for d in keep], dtype=field.dtype)
+        result[tuple(field.slices[d] for d in keep)] += image.cpu().numpy()
         return numpy.asarray(self.pm.comm.allreduce(result))
 
     def cast(self, type=None, out=None):
@@ -649,10 +648,8 @@ class RealField(Field):
             # (one rank, LDS kernels: the first pass of the out-of-place transform writes the whole result)
             out = (_blank(TransposedComplexField, self.pm) if self.pm.plans['forwardT'].fills_output()
                    else TransposedComplexField(self.pm))
-        if is_inplace(out):
-            out = self
-        if out is self:
-            out = TransposedComplexField(self.pm, base=self._base)
+        elif is_inplace(out) or out is self:
+            out = TransposedComplexField(self.pm, base=self._base)         # the spectrum over this field's own buffer
         assert isinstance(out, (BaseComplexField,))
         inplace = self._base in out._base and out._base in self._base
         T = 'U' if isinstance(out, UntransposedComplexField) else 'T'
@@ -694,11 +691,8 @@ class RealField(Field):
         default pm.resampler; layout : domain decomposition — positions are first routed to
         the ranks that hold the cells and the partial results are summed on the way back.
         """
-        if not transform:
-            transform = self.pm.affine
-        if resampler is None:
-            resampler = self.pm.resampler
-        resampler = FindResampler(resampler)
+        transform = transform or self.pm.affine
+        resampler = FindResampler(self.pm.resampler if resampler is None else resampler)
         if layout is None:
             return resampler.readout(self.value, pos, hsml=hsml, out=out, transform=transform, diffdir=gradient)
         if _ghosts_only(layout, resampler, transform, hsml):
@@ -739,22 +733,12 @@ class RealField(Field):
                     out_self=None, out_pos=None, layout=None):
         """ back-propagate the gradient of readout (pm.py:793-846). """
         if out_pos is not False:
-            if gradient is not None:
-                raise ValueError("gradient of gradient is not yet supported")
-            if out_pos is None:
-                out_pos = _zeros_like(pos)
-            if is_inplace(out_pos):
-                out_pos = pos
-            if out_pos is pos:
-                pos = _copy(pos)
+            out_pos, pos = _position_gradient_target(out_pos, pos, gradient)
             for d in range(pos.shape[1]):
                 r = self.readout(pos, resampler=resampler, transform=transform, gradient=d, layout=layout)
                 out_pos[:, d] = _mul(r, v)
         if out_self is not False:
-            if out_self is None:
-                out_self = RealField(self.pm)
-            if is_inplace(out_self):
-                out_self = self
+            out_self = RealField(self.pm) if out_self is None else (self if is_inplace(out_self) else out_self)
             self.pm.paint(pos, mass=v, resampler=resampler, transform=transform, gradient=gradient,
                           hold=False, layout=layout, out=out_self)
         return out_self, out_pos
@@ -797,8 +781,6 @@ class RealField(Field):
 
 
 class BaseComplexField(Field):
-    def __init__(self, pm, base=None):
-        Field.__init__(self, pm, base)
 
     def _hermitian_weight(self):
         """ 2 for modes whose conjugate is not stored, 1 otherwise (pm.py:908-918). """
@@ -856,10 +838,8 @@ class BaseComplexField(Field):
         oop = self.pm.plans['backward' + T].fills_output()
         if out is None:
             out = _blank(RealField, self.pm) if oop and self.pm.comm.size == 1 else RealField(self.pm)
-        if is_inplace(out):
-            out = self
-        if out is self:
-            out = RealField(self.pm, self._base)
+        elif is_inplace(out) or out is self:
+            out = RealField(self.pm, self._base)                           # the real field over this spectrum's buffer
         assert isinstance(out, RealField)
         inplace = out._base in self._base and self._base in out._base
         src = self
@@ -1084,36 +1064,36 @@ def _typestr_to_type(typestr):
     return cls
 
 
+def _block_coords(starts, shapes, Nmesh, BoxSize, dtype, device, spectral):
+    """ per axis the global indices of a rank's block and their coordinates, each shaped to broadcast along its own
+    axis: positions `i L / N` of the real side (pm.py:1178-1198) or wavenumbers `2 pi i / L` of the spectral side
+    (pm.py:1200-1226) — indices at and beyond N // 2 count as negative, so the Nyquist mode is reported negative.
+    Returns (coordinates, indices) as lists of device tensors; the arithmetic is done on the host in `dtype` with the
+    reference's sequence of roundings. """
+    ndim = len(shapes)
+    coords, indices = [], []
+    for d in range(ndim):
+        n, first = int(shapes[d]), starts[d]
+        along = [n if dd == d else 1 for dd in range(ndim)]
+        index = numpy.arange(n, dtype='intp') + first
+        signed = numpy.arange(n, dtype=dtype) + first
+        signed[signed >= Nmesh[d] // 2] -= Nmesh[d]
+        if spectral:
+            signed *= (2 * numpy.pi / Nmesh[d])                     # radians per cell first, as the reference does
+            c = (signed * Nmesh[d] / BoxSize[d]).astype(dtype)
+        else:
+            c = signed * BoxSize[d] / Nmesh[d]
+        indices.append(torch.from_numpy(index.reshape(along)).to(device))
+        coords.append(torch.from_numpy(numpy.ascontiguousarray(c.reshape(along))).to(device))
+    return coords, indices
+
+
 def _init_i_coords(partition, Nmesh, BoxSize, dtype, device):
-    """ pm.py:1178-1198 """
-    x, i_ind = [], []
-    for d in range(partition.ndim):
-        t = numpy.ones(partition.ndim, dtype='intp')
-        t[d] = partition.local_i_shape[d]
-        i_indi = numpy.arange(t[d], dtype='intp') + partition.local_i_start[d]
-        ri = numpy.arange(t[d], dtype=dtype) + partition.local_i_start[d]
-        ri[ri >= Nmesh[d] // 2] -= Nmesh[d]
-        xi = ri * BoxSize[d] / Nmesh[d]
-        i_ind.append(torch.from_numpy(i_indi.reshape(t)).to(device))
-        x.append(torch.from_numpy(numpy.ascontiguousarray(xi.reshape(t))).to(device))
-    return x, i_ind
+    return _block_coords(partition.local_i_start, partition.local_i_shape, Nmesh, BoxSize, dtype, device, False)
 
 
 def _init_o_coords(partition, Nmesh, BoxSize, dtype, device):
-    """ pm.py:1200-1226: wavenumbers; the Nyquist is reported negative """
-    k, o_ind = [], []
-    for d in range(partition.ndim):
-        s = numpy.ones(partition.ndim, dtype='intp')
-        s[d] = partition.local_o_shape[d]
-        o_indi = numpy.arange(s[d], dtype='intp') + partition.local_o_start[d]
-        wi = numpy.arange(s[d], dtype=dtype) + partition.local_o_start[d]
-        wi[wi >= Nmesh[d] // 2] -= Nmesh[d]
-        wi *= (2 * numpy.pi / Nmesh[d])
-        ki = wi * Nmesh[d] / BoxSize[d]
-        ki_type = ki.astype(dtype)
-        o_ind.append(torch.from_numpy(o_indi.reshape(s)).to(device))
-        k.append(torch.from_numpy(numpy.ascontiguousarray(ki_type.reshape(s))).to(device))
-    return k, o_ind
+    return _block_coords(partition.local_o_start, partition.local_o_shape, Nmesh, BoxSize, dtype, device, True)
 
 
 # ParticleMesh objects by (Nmesh, communicator, process mesh, dtype, plan method): a new object that
@@ -1285,20 +1265,15 @@ class ParticleMesh(object):
     def partition(self):
         return self.plans['partitionT']
 
-    def resize(self, Nmesh):
-        warnings.warn("ParticleMesh.resize method is deprecated. Use reshape method with full Nmesh as a tuple.", DeprecationWarning, stacklevel=2)
-        return self.reshape(Nmesh=Nmesh)
-
     def reshape(self, Nmesh=None, BoxSize=None):
         """ a ParticleMesh of a different resolution, or even dimension (pm.py:1541-1573) """
-        if Nmesh is None:
-            Nmesh = self.Nmesh
-        elif numpy.isscalar(Nmesh):
-            Nmesh = [Nmesh for i in range(self.ndim)]
-        if BoxSize is None:
-            BoxSize = self.BoxSize[:len(Nmesh)]
-        elif numpy.isscalar(BoxSize):
-            BoxSize = [BoxSize for i in range(len(Nmesh))]
+        def per_axis(value, default, ndim):
+            # None: what this mesh has; a scalar: the same on every axis
+            if value is None:
+                return default
+            return [value] * ndim if numpy.isscalar(value) else value
+        Nmesh = per_axis(Nmesh, self.Nmesh, self.ndim)
+        BoxSize = per_axis(BoxSize, self.BoxSize[:len(Nmesh)], len(Nmesh))
         if len(BoxSize) != len(Nmesh):
             raise ValueError("Dimension of BoxSize (%d) doesn't agree with Nmesh (%d); provide BoxSize explicitly." % (len(BoxSize), len(Nmesh)))
         if len(self.np) > len(Nmesh):
@@ -1307,6 +1282,11 @@ class ParticleMesh(object):
             raise ValueError("a process mesh of %d dimensions cannot decompose a mesh of %d" % (len(self.np), len(Nmesh)))
         return ParticleMesh(BoxSize=BoxSize, Nmesh=Nmesh, dtype=self.dtype, comm=self.comm,
                             resampler=self.resampler, np=self.np if len(Nmesh) == self.ndim else None)
+
+    def resize(self, Nmesh):
+        # the older spelling (pm.py:1533-1539)
+        warnings.warn("ParticleMesh.resize method is deprecated. Use reshape method with full Nmesh as a tuple.", DeprecationWarning, stacklevel=2)
+        return self.reshape(Nmesh=Nmesh)
 
     def respawn(self, comm, np=None):
         """ the same geometry on a new communicator (pm.py:1575-1600) """
@@ -1565,15 +1545,14 @@ class ParticleMesh(object):
                   gradient=None, layout=None, out=None):
         """ A_q = W_qi M_i (pm.py:1872-1888) """
         assert gradient is None  # second order is not supported yet
-        if out is None:
-            out = self.create(type=RealField)
+        out = self.create(type=RealField) if out is None else out
         out[...] = 0
-        if v_pos is not None:
-            for d in range(pos.shape[1]):
-                self.paint(pos, mass=_mul(v_pos[..., d], mass), resampler=resampler, transform=transform,
-                           gradient=d, hold=True, layout=layout, out=out)
+        # one held paint per tangent: the position tangents through the window's derivative, the mass tangent plainly
+        terms = [] if v_pos is None else [(_mul(v_pos[..., d], mass), d) for d in range(pos.shape[1])]
         if v_mass is not None:
-            self.paint(pos, mass=v_mass, resampler=resampler, transform=transform, gradient=None,
+            terms.append((v_mass, None))
+        for weight, direction in terms:
+            self.paint(pos, mass=weight, resampler=resampler, transform=transform, gradient=direction,
                        hold=True, layout=layout, out=out)
         return out
 
@@ -1581,14 +1560,7 @@ class ParticleMesh(object):
                   out_pos=None, out_mass=None, layout=None):
         """ back-propagate the gradient of paint from v (pm.py:1890-1935). """
         if out_pos is not False:
-            if gradient is not None:
-                raise ValueError("gradient of gradient is not yet supported")
-            if out_pos is None:
-                out_pos = _zeros_like(pos)
-            if is_inplace(out_pos):
-                out_pos = pos
-            if out_pos is pos:
-                pos = _copy(pos)
+            out_pos, pos = _position_gradient_target(out_pos, pos, gradient)
             for d in range(pos.shape[1]):
                 r = v.readout(pos, resampler=resampler, transform=transform, gradient=d, layout=layout)
                 out_pos[..., d] = _mul(r, mass) if not numpy.isscalar(mass) else r * mass

@@ -36,23 +36,16 @@ def _mkarr(var, shape, dtype):
 class Affine(object):
     """ Defines an affine Transformation, used by ResampleWindow (window.py:18-55).
 
-        Parameters
-        ----------
-            translate : array_like, in integer mesh units.
-            period : array_like in integer mesh units.
-            scale : factor that multiples on position to obtain mesh units.
+        mesh coordinate = position x scale + translate, wrapped by period where period > 0:
+            scale : factor (or one per axis) that takes positions to mesh units;
+            translate, period : in integer mesh units, scalars or one per axis.
     """
     def __init__(self, ndim, scale=None, translate=None, period=None):
-        if scale is None:
-            scale = 1.0
-        if translate is None:
-            translate = 0
-        if period is None:
-            period = 0
-        self.scale = _mkarr(scale, ndim, 'f8')
-        self.period = _mkarr(period, ndim, 'intp')
-        self.translate = _mkarr(translate, ndim, 'f8')
+        # the identity unless told otherwise; scalars are repeated along the axes
         self.ndim = ndim
+        self.scale = _mkarr(1.0 if scale is None else scale, ndim, 'f8')
+        self.translate = _mkarr(0 if translate is None else translate, ndim, 'f8')
+        self.period = _mkarr(0 if period is None else period, ndim, 'intp')
 
     def rescale(self, amount):
         """ Returns a new Affine where the scale is multipled by amount. """
@@ -401,12 +394,12 @@ class ResampleWindow(object):
         """ Return a function that compensates the resampling window by deconvolving in
             Fourier space; usable as an argument of ComplexField.apply with kind='circular'
             (window.py:65-80). """
-        def function(w, v):
-            tf = 1.0
+        def deconvolve(w, v):
+            # the window's transform is separable: one factor per axis
             for wi in w:
-                tf = tf * self.get_fwindow(wi)
-            return v / tf
-        return function
+                v = v / self.get_fwindow(wi)
+            return v
+        return deconvolve
 
     def get_fwindow(self, w):
         """ 1d fourier space window T(w) at circular frequencies w (window.py:82-104);
@@ -638,30 +631,18 @@ def FindResampler(window):
     return window
 
 
-windows = dict(
-    LANCZOS2=ResampleWindow(kind="lanczos2"), LANCZOS3=ResampleWindow(kind="lanczos3"),
-    LANCZOS4=ResampleWindow(kind="lanczos4"), LANCZOS5=ResampleWindow(kind="lanczos5"),
-    LANCZOS6=ResampleWindow(kind="lanczos6"),
-    ACG2=ResampleWindow(kind="acg2"), ACG3=ResampleWindow(kind="acg3"), ACG4=ResampleWindow(kind="acg4"),
-    ACG5=ResampleWindow(kind="acg5"), ACG6=ResampleWindow(kind="acg6"),
-    DB6=ResampleWindow(kind="db6"), DB12=ResampleWindow(kind="db12"), DB20=ResampleWindow(kind="db20"),
-    SYM6=ResampleWindow(kind="sym6"), SYM12=ResampleWindow(kind="sym12"), SYM20=ResampleWindow(kind="sym20"),
-    NEAREST=ResampleWindow(kind="nearest"),
-    LINEAR=ResampleWindow(kind="linear"),
-    NNB=ResampleWindow(kind="tunednnb"),
-    CIC=ResampleWindow(kind="tunedcic"),
-    TSC=ResampleWindow(kind="tunedtsc"),
-    PCS=ResampleWindow(kind="tunedpcs"),
-    QUADRATIC=ResampleWindow(kind="quadratic"),
-    CUBIC=ResampleWindow(kind="cubic"),
-)
-for _k in _UNBUILT:
-    windows[_k.upper()] = ResampleWindow(kind=_k)
-
-for m, p in list(windows.items()):
-    windows[m.lower()] = p
-    globals()[m] = p
+#: the registry (window.py:231-263): every kind under its upper-case name, its lower-case name, and as a module
+#: attribute (`window.CIC`); the tuned kinds go by their short names
+_REGISTRY_NAMES = dict(
+    [(k.upper(), k) for k in ('nearest', 'linear', 'quadratic', 'cubic')]
+    + [(k.upper(), 'tuned' + k) for k in ('nnb', 'cic', 'tsc', 'pcs')]
+    + [('%s%d' % (fam.upper(), n), '%s%d' % (fam, n)) for fam, orders in
+       (('lanczos', (2, 3, 4, 5, 6)), ('acg', (2, 3, 4, 5, 6)), ('db', (6, 12, 20)), ('sym', (6, 12, 20))) for n in orders]
+    + [(k.upper(), k) for k in _UNBUILT])
+windows = {}
+for _name, _kind in _REGISTRY_NAMES.items():
+    windows[_name] = windows[_name.lower()] = globals()[_name] = ResampleWindow(kind=_kind)
+del _name, _kind
 
 # compatible.
 methods = windows
-del m, p

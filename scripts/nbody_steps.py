@@ -19,15 +19,14 @@ X = (Q + 0.3 * torch.randn(Q.shape, generator=g, dtype=Q.dtype, device=Q.device)
 V = torch.zeros_like(X)
 
 
-def force_transfer(direction):            # examples/nbody.py:162-171
-    def filter(k, v):
-        k2 = sum(ki ** 2 for ki in k)
-        k2[k2 == 0] = 1.0
-        C = (v.BoxSize / v.Nmesh)[direction]
-        w = k[direction] * C
-        kfinite = 1.0 / C * 1 / 6.0 * (8 * numpy.sin(w) - numpy.sin(2 * w))
-        return 1j * kfinite / k2 * v
-    return filter
+def force_transfer(direction):            # the four-point finite-difference force kernel of examples/nbody.py:162-171
+    def kernel(k, v):
+        ksq = k[0] ** 2 + k[1] ** 2 + k[2] ** 2
+        ksq[ksq == 0] = 1.0
+        cell = (v.BoxSize / v.Nmesh)[direction]
+        phase = k[direction] * cell
+        return 1j * ((8 * numpy.sin(phase) - numpy.sin(2 * phase)) / (6.0 * cell)) / ksq * v
+    return kernel
 
 
 def force(X, fused):

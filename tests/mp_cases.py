@@ -983,6 +983,44 @@ def case_readout_into_strided_and_float_out(be, comm):
     p1.wait(q1)
     p2.wait(q2)
     assert torch.allclose(q1, o1, rtol=0, atol=1e-15) and torch.allclose(q2, o2, rtol=0, atol=1e-15)
+    # THREE in flight, the first waited for last: the second must not take the first's hold on the pooled buffer
+    # away (the third would then receive into the rows the first has not read yet)
+    x3 = torch.from_numpy(rng.uniform(0, 1, size=(190, 3))).to(be.device)
+    m3 = torch.from_numpy(rng.uniform(size=190)).to(be.device)
+    lc = dcop.decompose(x3[:, :1], smoothing=0.08)
+    rc = lc.exchange_remote(x3, m3)
+    la3, lb3, lc3 = [dcop.decompose(x[:, :1], smoothing=0.08) for x in (x1, x2, x3)]
+    ha = la3.exchange_remote(x1, m1, async_op=True)
+    hb = lb3.exchange_remote(x2, m2, async_op=True)
+    gb = hb.wait()
+    hc = lc3.exchange_remote(x3, m3, async_op=True)
+    gc = hc.wait()
+    ga = ha.wait()
+    for g, r in ((ga, ra), (gb, rb), (gc, rc)):
+        assert torch.equal(g[0], r[0]) and torch.equal(g[1], r[1])
+    vc = rc[0][:, 2] * rc[1]
+    o3 = torch.zeros(190, dtype=torch.float64, device=be.device)
+    lc.gather_remote_add(vc, o3)
+    p1 = la3.gather_remote_add(va.clone(), None, async_op=True)
+    p2 = lb3.gather_remote_add(vb.clone(), None, async_op=True)
+    q2 = torch.zeros_like(o2)
+    p2.wait(q2)
+    p3 = lc3.gather_remote_add(vc.clone(), None, async_op=True)
+    q3 = torch.zeros_like(o3)
+    p3.wait(q3)
+    q1 = torch.zeros_like(o1)
+    p1.wait(q1)
+    assert torch.allclose(q1, o1, rtol=0, atol=1e-15) and torch.allclose(q2, o2, rtol=0, atol=1e-15)
+    assert torch.allclose(q3, o3, rtol=0, atol=1e-15)
+    # a handle dropped without wait() gives the staging back: the pool serves the next exchange again
+    ld = dcop.decompose(x1[:, :1], smoothing=0.08)
+    hd = ld.exchange_remote(x1, m1, async_op=True)
+    del hd
+    scratch = domain._scratch_of(comm)
+    le = dcop.decompose(x2[:, :1], smoothing=0.08)
+    ge = le.exchange_remote(x2, m2)
+    assert torch.equal(ge[0], rb[0]) and torch.equal(ge[1], rb[1])
+    assert not any(scratch.private.values()), scratch.private
 
 
 def case_comm_trace(be, comm):

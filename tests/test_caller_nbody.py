@@ -1,7 +1,10 @@
-"""The canonical caller of the PM cycle, examples/nbody.py:162-171 and 199-218 of the reference, restated
-line for line on *numpy* inputs against pmesh_amd's drop-in surface (B4 of SURVEY.md 8b): the only
-edit a user makes is the import.  Expected values: tests/golden/caller_nbody.npz, computed from the
-reference's own window kernels + numpy.fft (tests/golden/make_caller_fixture.py).
+"""A time-stepping caller's force evaluation on *numpy* inputs, through pmesh_amd's drop-in surface (B4 of SURVEY.md
+8b): the sequence of calls the reference's N-body example makes per step (examples/nbody.py:199-218 — create,
+decompose with the window's support as smoothing, paint, normalise to the mean density, r2c, one `apply` of a Python
+transfer callable + c2r + readout per direction), written here as this repository's own caller of that API; the
+finite-difference force kernel is the one the fixture was generated with (examples/nbody.py:162-171).  Expected
+values: tests/golden/caller_nbody.npz, computed from the reference's own window kernels + numpy.fft
+(tests/golden/make_caller_fixture.py).
 
 `-m gpu`: the HIP library; `-m "not gpu"`: the same host code over the CPU oracle double.
 """
@@ -11,44 +14,42 @@ import numpy
 import pytest
 from numpy.testing import assert_allclose
 
-from pmesh_amd.pm import ParticleMesh     # reference: from pmesh.pm import ParticleMesh
+from pmesh_amd.pm import ParticleMesh
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OMEGA_M = 0.31                             # the fixture's cosmology (only the matter density enters the force)
 
 
-class pt:                                  # the cosmology object of examples/nbody.py (only Om0 is used here)
-    Om0 = 0.31
+class LongRangeForce(object):
+    """`apply` callable: -grad of the inverse Laplacian along one axis, the gradient as the four-point finite
+    difference D(w) = (8 sin w - sin 2w) / 6 per cell of that axis."""
+    def __init__(self, axis):
+        self.axis = axis
+
+    def __call__(self, k, v):
+        ksq = k[0] ** 2
+        for kd in k[1:]:
+            ksq = ksq + kd ** 2
+        ksq[ksq == 0] = 1.0                # (the mean mode: its numerator is zero anyway)
+        cell = (v.BoxSize / v.Nmesh)[self.axis]
+        phase = k[self.axis] * cell
+        stencil = (8 * numpy.sin(phase) - numpy.sin(2 * phase)) * (1.0 / cell * 1 / 6.0)
+        return 1j * stencil / ksq * v
 
 
-def force_transfer(direction):             # examples/nbody.py:162-171
-    def filter(k, v):
-        k2 = sum(ki ** 2 for ki in k)
-        k2[k2 == 0] = 1.0
-        C = (v.BoxSize / v.Nmesh)[direction]
-        w = k[direction] * C
-        kfinite = 1.0 / C * 1 / 6.0 * (8 * numpy.sin(w) - numpy.sin(2 * w))
-        return 1j * kfinite / k2 * v
-    return filter
-
-
-def force(pm, Q, S):                       # examples/nbody.py:199-218
-    rho1 = pm.create('real')
-    X = S + Q
-    layout = pm.decompose(X, smoothing=1.0 * pm.resampler.support)
-    rho1.paint(X, layout=layout, hold=False)
-
-    N = pm.comm.allreduce(len(X))
-    fac = 1.0 * pm.Nmesh.prod() / N
-    rho1[...] *= fac
-    rhok1 = rho1.r2c()
-
-    rhok = rhok1
-
-    F = numpy.empty_like(Q)
-    for d in range(pm.ndim):
-        F[..., d] = rhok.apply(force_transfer(d)) \
-                  .c2r().readout(X, layout=layout)
-    return 1.5 * pt.Om0 * F
+def pm_force(pm, lattice, displacement):
+    """the particle-mesh force on particles at lattice + displacement, (n, ndim) numpy array"""
+    positions = displacement + lattice
+    routes = pm.decompose(positions, smoothing=1.0 * pm.resampler.support)
+    density = pm.create('real')
+    density.paint(positions, layout=routes, hold=False)
+    density[...] *= 1.0 * pm.Nmesh.prod() / pm.comm.allreduce(len(positions))     # mean density 1
+    spectrum = density.r2c()
+    force = numpy.empty_like(lattice)
+    for axis in range(pm.ndim):
+        component = spectrum.apply(LongRangeForce(axis)).c2r()
+        force[..., axis] = component.readout(positions, layout=routes)
+    return 1.5 * OMEGA_M * force
 
 
 @pytest.fixture(scope='module')
@@ -62,7 +63,7 @@ def test_force_of_nbody_example_on_numpy_inputs(be, fixture, tag, resampler):
     N = int(N)
     Q, S, want = fixture[tag + '_Q'], fixture[tag + '_S'], fixture[tag + '_F']
     pm = ParticleMesh(BoxSize=BoxSize, Nmesh=[N, N, N], dtype='f8', resampler=resampler)
-    F = force(pm, Q, S)
+    F = pm_force(pm, Q, S)
     assert isinstance(F, numpy.ndarray) and F.dtype == numpy.dtype('f8') and F.shape == Q.shape
     scale = abs(want).max()
     assert_allclose(F, want, rtol=0, atol=1e-11 * scale)

@@ -84,22 +84,20 @@ def test_fft_contract_vs_numpy(be, dtype, tol, Nmesh):
     assert rel_l2(cu.c2r(), data) < 4 * tol
 
 
-def test_inplace_fft(be):                     # test_pm.py:167-192
+def test_inplace_fft(be):                     # the case of test_pm.py:167-192
+    """out=Ellipsis transforms over the field's own buffer and gives what the out-of-place transform gives"""
     pm = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
-    Npar = 100
-    pos = 1.0 * (numpy.arange(Npar * len(pm.Nmesh))).reshape(-1, len(pm.Nmesh)) * (7, 7)
-    pos %= (pm.Nmesh + 1)
-    layout = pm.decompose(pos)
-    npos = layout.exchange(pos)
-    real = pm.paint(npos)
-    complex = real.r2c()
-    complex2 = real.r2c(out=Ellipsis)
-    assert real._base in complex2._base
-    assert_almost_equal(numpy.asarray(complex), numpy.asarray(complex2), decimal=7)
-    real = complex2.c2r()
-    real2 = complex2.c2r(out=Ellipsis)
-    assert real2._base in complex2._base
-    assert_almost_equal(numpy.asarray(real), numpy.asarray(real2), decimal=7)
+    ndim = len(pm.Nmesh)
+    pos = (1.0 * numpy.arange(100 * ndim).reshape(-1, ndim) * (7, 7)) % (pm.Nmesh + 1)
+    density = pm.paint(pm.decompose(pos).exchange(pos))
+    spectrum = density.r2c()
+    spectrum_ip = density.r2c(out=Ellipsis)
+    assert density._base in spectrum_ip._base
+    assert_almost_equal(numpy.asarray(spectrum), numpy.asarray(spectrum_ip), decimal=7)
+    back = spectrum_ip.c2r()
+    back_ip = spectrum_ip.c2r(out=Ellipsis)
+    assert back_ip._base in spectrum_ip._base
+    assert_almost_equal(numpy.asarray(back), numpy.asarray(back_ip), decimal=7)
 
 
 def test_decompose_paint_equals_serial(be):   # test_pm.py:230-264
@@ -393,16 +391,17 @@ def test_c2r_with_fused_transfer(be, dtype, tol):
         assert rel_l2(got2, want) < 10 * tol
 
 
-def test_real_resample(be):                   # test_pm.py:458-470
-    pmh = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
-    pml = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f8')
-    reall = pml.create(type='real')
-    reall.apply(lambda i, v: (i[0] % 2) * (i[1] % 2), kind='index', out=Ellipsis)
+def test_real_resample(be):                   # the case of test_pm.py:458-470
+    fine = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8], dtype='f8')
+    coarse = ParticleMesh(BoxSize=8.0, Nmesh=[4, 4], dtype='f8')
+    checker = coarse.create(type='real')
+    checker.apply(lambda i, v: (i[0] % 2) * (i[1] % 2), kind='index', out=Ellipsis)
+    total = checker.csum()
     for resampler in ['nearest', 'cic', 'tsc', 'cubic']:
-        realh = pmh.upsample(reall, resampler=resampler, keep_mean=False)
-        reall2 = pml.downsample(realh, resampler=resampler)
-        assert_almost_equal(reall.csum(), realh.csum())
-        assert_almost_equal(reall.csum(), reall2.csum())
+        up = fine.upsample(checker, resampler=resampler, keep_mean=False)
+        assert_almost_equal(total, up.csum())
+        assert_almost_equal(total, coarse.downsample(up, resampler=resampler).csum())
+    reall, pmh = checker, fine
     # nearest up then down is the identity on the coarse mesh
     realh = pmh.upsample(reall, resampler='nearest', keep_mean=True)
     assert_allclose(numpy.asarray(realh)[::2, ::2], numpy.asarray(reall))

@@ -172,21 +172,15 @@ def test_cubic_hsml(be):          # test_window.py:264
     assert_array_equal(real1, real2)
 
 
-def test_cic_tuned(be):           # test_window.py:311
-    assert CIC.support == 2
-    assert LINEAR.support == 2
+def test_cic_tuned(be):           # the case of test_window.py:311-330
+    """the tuned CIC kernel == the generic linear window, values and every derivative, bit for bit"""
+    assert CIC.support == 2 and LINEAR.support == 2
     pos = [[1.1, 1.3, 2.5]]
-    real = numpy.zeros((4, 4, 4))
-    CIC.paint(real, pos)
-    real2 = numpy.zeros((4, 4, 4))
-    LINEAR.paint(real2, pos)
-    assert_array_equal(real, real2)
-    for d in range(3):
-        d1 = numpy.zeros((4, 4, 4))
-        d2 = numpy.zeros((4, 4, 4))
-        CIC.paint(d1, pos, diffdir=d)
-        LINEAR.paint(d2, pos, diffdir=d)
-        assert_array_equal(d1, d2)
+    for diffdir in (None, 0, 1, 2):
+        tuned, generic = numpy.zeros((4, 4, 4)), numpy.zeros((4, 4, 4))
+        CIC.paint(tuned, pos, diffdir=diffdir)
+        LINEAR.paint(generic, pos, diffdir=diffdir)
+        assert_array_equal(tuned, generic)
 
 
 def test_tsc_tuned(be):           # test_window.py:332
