@@ -33,17 +33,28 @@ def library_path():
     return os.environ.get('PMESH_AMD_LIBRARY') or os.path.join(_HERE, LIBNAME)
 
 
-def load_library(path=None):
-    """dlopen the C ABI and declare every prototype; raises if it is missing
-    or lacks a symbol that include/pmesh_amd.h declares."""
+def load_library(path=None, binding=None):
+    """Load the C ABI and bind every entry point of include/pmesh_amd.h; raises if the library is missing or lacks a
+    symbol the header declares.  The binding is the Cython shim `pmesh_amd._pmx` (generated from the header by
+    csrc/gen_pyx.py, built by the same `make`): the returned object has one callable `pmx_<name>` per entry point.
+    PMESH_AMD_BINDING=ctypes binds the same library through the ctypes table of _abi.py instead (the binding the
+    tests' CPU double uses; ~10 us slower per call) — a debugging aid, never a fallback: a missing shim raises."""
     path = path or library_path()
     if not os.path.exists(path):
         raise ImportError(
             '%s not found: build it with `make -C pmesh_amd/csrc` (hipcc, gfx950). '
             'There is no CPU fallback.' % path)
-    lib = C.CDLL(path)
-    missing = _abi.declare(lib, 'pmx_', _abi.PROTOTYPES)
-    missing += _abi.declare(lib, 'pmx_', _abi.DEVICE_ONLY)
+    binding = binding or os.environ.get('PMESH_AMD_BINDING', 'cython')
+    if binding == 'ctypes':
+        lib = C.CDLL(path)
+        missing = _abi.declare(lib, 'pmx_', _abi.PROTOTYPES)
+        missing += _abi.declare(lib, 'pmx_', _abi.DEVICE_ONLY)
+    else:
+        try:
+            from . import _pmx as lib
+        except ImportError as e:
+            raise ImportError('the Cython shim pmesh_amd/_pmx is not built (`make -C pmesh_amd/csrc`): %s' % e)
+        missing = lib.bind(path)
     if missing:
         raise ImportError('%s lacks symbols declared in include/pmesh_amd.h: %s' % (path, missing))
     return lib
