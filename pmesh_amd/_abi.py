@@ -166,15 +166,27 @@ def declare(lib, prefix, table):
     return missing
 
 
+_ARRAY_MEMO = {}
+
+
+def _memo_array(ctype, conv, seq, n):
+    """small constant argument arrays (mesh shapes, starts, box sizes) are asked for again on every launch: one ctypes
+    array per distinct content, built once (the library only reads them)"""
+    key = (ctype, tuple(seq), n)
+    arr = _ARRAY_MEMO.get(key)
+    if arr is None:
+        vals = [conv(x) for x in seq]
+        if n is not None:
+            vals = vals + [conv(0)] * (n - len(vals))
+        if len(_ARRAY_MEMO) > 4096:
+            _ARRAY_MEMO.clear()
+        arr = _ARRAY_MEMO[key] = (ctype * len(vals))(*vals)
+    return arr
+
+
 def i64arr(seq, n=None):
-    seq = [int(x) for x in seq]
-    if n is not None:
-        seq = seq + [0] * (n - len(seq))
-    return (C.c_int64 * len(seq))(*seq)
+    return _memo_array(C.c_int64, int, seq, n)
 
 
 def f64arr(seq, n=None):
-    seq = [float(x) for x in seq]
-    if n is not None:
-        seq = seq + [0.0] * (n - len(seq))
-    return (C.c_double * len(seq))(*seq)
+    return _memo_array(C.c_double, float, seq, n)

@@ -12,6 +12,10 @@ import numpy
 import torch
 
 from . import _abi
+try:
+    from . import _pmx
+except ImportError:
+    _pmx = None
 
 _FLOATS = (torch.float32, torch.float64)
 
@@ -175,6 +179,11 @@ def vec(t):
     if t is None:
         return v
     es = t.element_size()
+    if _pmx is not None:
+        nd = t.dim()
+        _pmx.fill_vec(v, t.data_ptr(), es, t.shape[1] if nd > 1 else 1, t.stride(0) * es if nd else 0,
+                      t.stride(1) * es if nd > 1 else 0)
+        return v
     v.data = t.data_ptr()
     v.elsize = es
     if t.dim() == 0:

@@ -111,3 +111,37 @@ def address(o):
 def bound():
     """path of the library the entry points are bound to, or None"""
     return _bound
+
+
+def fill_painter(p, int kind, int support, int elsize, shape, strides, order,
+                 const double[::1] scale, const double[::1] translate, period):
+    """pmx_painter at `p` (a Struct or a ctypes Painter) <- window kind / support, the canvas block (shape, strides in
+    ELEMENTS, element size) and the affine transform (the fields of window.Affine): what ResampleWindow._painter does
+    with ~30 ctypes attribute stores, as one typed call.  Three dimensions at most (pmx_painter_nd is filled by the
+    Python path)."""
+    cdef pmx_painter *q = <pmx_painter *>_ptr(p)
+    cdef int d, nd = len(shape)
+    if nd > 3 or q == NULL:
+        raise ValueError('fill_painter: 1 to 3 dimensions')
+    memset(q, 0, sizeof(pmx_painter))
+    q.kind = kind
+    q.support = support
+    q.ndim = nd
+    q.canvas_elsize = elsize
+    for d in range(nd):
+        q.order[d] = <int32_t>order[d]
+        q.scale[d] = scale[d]
+        q.translate[d] = translate[d]
+        q.period[d] = <int64_t>period[d]
+        q.size[d] = <int64_t>shape[d]
+        q.strides[d] = <int64_t>strides[d] * elsize
+
+
+def fill_vec(v, size_t data, int elsize, int ncol, long long stride0, long long stride1):
+    """pmx_vec at `v` <- a strided per-particle column set"""
+    cdef pmx_vec *q = <pmx_vec *>_ptr(v)
+    q.data = <void *>data
+    q.elsize = elsize
+    q.ncol = ncol
+    q.stride0 = stride0
+    q.stride1 = stride1

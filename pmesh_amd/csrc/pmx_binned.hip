@@ -1115,6 +1115,139 @@ __device__ __forceinline__ double uniform_double(double x)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// ---- [r6] PCS on fixed-point regions: FOUR LANES PER PARTICLE ----------------------------------------------------------
+// One lane per particle puts 64 DIFFERENT particles into every ds_add_u64 instruction of the deposit: neighbours of the
+// list — neighbours in space — which meet on cells and banks (scripts/deposit_quad_model.hip, the loop with its
+// arithmetic, clocks per particle and CU: a perfect lattice 8.8, the benchmark's jittered lattice 10.7, rows in random
+// order 12.7, a clustered set — half of a tile's particles in 27 cells — 23.2; the 10.7 IS the 2.3 ms of the PCS
+// paint at 512^3).  Here the four lanes of a quad serve ONE particle: lane q owns the stencil index q along z (the four
+// cells of a quad are 32 contiguous bytes) and walks the 16 (x, y) rows; an instruction then holds 16 particles, a
+// 16-lane group of the LDS 4.  The quad's particles reach its lanes through DPP quad_perm moves (no LDS, no
+// readlane): every lane prepares ITS particle as before (cell, x and y weights times the mass, the z offset), then in
+// four sub-trips the quad takes the particle of its lane 0, 1, 2, 3; a lane evaluates only the z weight of its own
+// index, from per-lane polynomial coefficients.  Model, same patterns: 9.1 / 9.8 / 11.1 / 13.5 clocks — the conflicts of
+// a clustered set cost 4 instead of 14 clocks per particle, the vector work 6.2 instead of 5.0.  Same cells (the index
+// arithmetic is untouched), same fixed-point sums up to the z weight's rounding (a cubic in Horner form instead of the
+// factored one: absolute difference <= 2^-52 of the particle's mass per cell, far inside the contract's 1e-12).
+#ifndef PMX_QUAD_PCS
+#define PMX_QUAD_PCS 1
+#endif
+#ifndef PMX_QUAD_STRIDE8
+#define PMX_QUAD_STRIDE8 1
+#endif
+#ifndef PMX_QUAD_MIN_DEFAULT
+#define PMX_QUAD_MIN_DEFAULT (9 * TCELLS / 8)
+#endif
+template <int CTRL> __device__ __forceinline__ int quad_take(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ double quad_take(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = quad_take<CTRL>((int)b), hi = quad_take<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int TTHREADS, bool SORTED, int PE, bool WHOLE, typename WF>
+__device__ __forceinline__ void tile_deposit_quadz(const pmx_painter &p, const BinGeom &g, const int *t, const DVec &pos,
+                                                   const DVec &mass, double mass_scalar, const uint32_t *list,
+                                                   int64_t start, int count, double *lds, double scale)
+{
+    constexpr int KIND = PMX_TUNED_PCS, S = 4;
+    using Rg = Region<S>;
+    static_assert(!Rg::SPLIT, "dense rows: the four z cells of a quad are one address + its lane");
+    constexpr int R1 = Rg::R1, P2 = Rg::P2;
+    const int q = threadIdx.x & 3;
+    // W_q(d) = k0 + d (k1 + d (k2 + d k3)): Fast<PCS>::axis expanded in d (d = X - the second cell, in [0, 1)); the
+    // derivative form (order 1) carries no scale factor (quirk Q1)
+    double k0, k1, k2, k3;
+    if (p.order[2] == 0) {
+        k0 = q == 0 ? 1.0 / 6.0 : (q == 1 ? 2.0 / 3.0 : (q == 2 ? 1.0 / 6.0 : 0.0));
+        k1 = q == 0 ? -0.5 : (q == 2 ? 0.5 : 0.0);
+        k2 = q == 0 ? 0.5 : (q == 1 ? -1.0 : (q == 2 ? 0.5 : 0.0));
+        k3 = q == 0 ? -1.0 / 6.0 : (q == 1 ? 0.5 : (q == 2 ? -0.5 : 1.0 / 6.0));
+    } else {
+        k0 = q == 0 ? -0.5 : (q == 2 ? 0.5 : 0.0);
+        k1 = q == 0 ? 1.0 : (q == 1 ? -2.0 : (q == 2 ? 1.0 : 0.0));
+        k2 = q == 0 ? -0.5 : (q == 1 ? 1.5 : (q == 2 ? -1.5 : 0.5));
+        k3 = 0.0;
+    }
+    const uint32_t *tl = list + start;
+    // (a uniform trip count: the lanes of a quad serve each other's particles, so all of them stay in the loop)
+    for (int jb = 0; jb < count; jb += TTHREADS * UNROLL) {
+        int64_t idx[UNROLL];
+        double x[UNROLL][3], m[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+#if PMX_QUAD_STRIDE8
+            // a wave holds 128 CONSECUTIVE entries, the quad k of it entries 8k .. 8k + 7 (lane q: 8k + q and 8k + 4 + q):
+            // the 16 particles of an instruction are then 8 entries apart — neighbouring quads' z runs of four cells
+            // do not overlap up to two particles per cell (4 apart they did on a lattice of 2 per cell: 5.5 against
+            // 4.4 ms), and the loads still cover whole lines
+            static_assert(UNROLL == 2, "two entries per lane");
+            const int j = jb + ((int)threadIdx.x >> 6) * 128 + 2 * ((int)threadIdx.x & 63) - q + 4 * u;
+#else
+            const int j = jb + u * TTHREADS + (int)threadIdx.x;
+#endif
+            idx[u] = j < count ? (SORTED ? start + j : (int64_t)tl[j]) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (idx[u] >= 0) {
+                x[u][0] = pos_get<PE>(pos, idx[u], 0); x[u][1] = pos_get<PE>(pos, idx[u], 1); x[u][2] = pos_get<PE>(pos, idx[u], 2);
+                m[u] = mass.data ? mass.get(SORTED ? (int64_t)list[idx[u]] : idx[u], 0) : mass_scalar;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            // this lane's particle: first cell in the region, x weights (times mass and 2^f) and y weights, z offset
+            int base = -1;
+            double Wx[S], Wy[S], dz = 0;
+            if (idx[u] >= 0) {
+                int lb[3];
+                double off[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double X = x[u][d] * p.scale[d] + p.translate[d];
+                    const int I0 = Tuned<KIND>::first(X);
+                    off[d] = X - (double)(I0 + Fast<KIND, double>::REF);
+                    const int per = (int)p.period[d], siz = (int)p.size[d];
+                    if (WHOLE || (g.o[d] == 0 && per == siz)) { lb[d] = I0 & (tile_ext(d) - 1); continue; }
+                    const int w = wrap_fast(I0, per);
+                    lb[d] = ((per > 0 && w >= siz) ? w - per : w) + g.o[d] - t[d] * tile_ext(d);
+                }
+                WF wx[S], wy[S];
+                Fast<KIND, WF>::axis((WF)off[0], p.order[0], (WF)p.scale[0], wx);
+                Fast<KIND, WF>::axis((WF)off[1], p.order[1], (WF)p.scale[1], wy);
+                const double mu = m[u] * scale;
+#pragma unroll
+                for (int a = 0; a < S; a++) { Wx[a] = (double)wx[a] * mu; Wy[a] = (double)wy[a]; }
+                dz = off[2];
+                // a plan that no longer matches the positions must not index outside the LDS region
+                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) stale_row(g);
+                else base = (lb[0] * R1 + lb[1]) * P2 + lb[2];
+            }
+#define PMX_QUAD_SUBTRIP(CT) {                                                                                   \
+                const int qb = quad_take<CT>(base);                                                              \
+                const double zd = quad_take<CT>(dz);                                                             \
+                double ax[S], ay[S];                                                                             \
+                _Pragma("unroll") for (int a = 0; a < S; a++) { ax[a] = quad_take<CT>(Wx[a]); ay[a] = quad_take<CT>(Wy[a]); } \
+                if (qb >= 0) {                                                                                   \
+                    const double wz = __builtin_fma(__builtin_fma(__builtin_fma(k3, zd, k2), zd, k1), zd, k0);   \
+                    double *cellp = lds + qb + q;                                                                \
+                    _Pragma("unroll") for (int b = 0; b < S; b++) {                                              \
+                        const double fz = ay[b] * wz;                                                            \
+                        _Pragma("unroll") for (int a = 0; a < S; a++) {                                          \
+                            const double r = __builtin_fma(ax[a], fz, FIXED_MAGIC);                              \
+                            atomicAdd((unsigned long long *)(cellp + (a * R1 + b) * P2),                         \
+                                      (unsigned long long)(__double_as_longlong(r) - FIXED_MAGIC_BITS));         \
+                        }                                                                                        \
+                    }                                                                                            \
+                }                                                                                                \
+            }
+            PMX_QUAD_SUBTRIP(0x00) PMX_QUAD_SUBTRIP(0x55) PMX_QUAD_SUBTRIP(0xaa) PMX_QUAD_SUBTRIP(0xff)
+#undef PMX_QUAD_SUBTRIP
+        }
+    }
+}
+
 // The particles [start, start + count) of a tile's list are deposited into its LDS region.
 // WF: double / float = the weights of the RELAXED form in that precision (fixed-point regions of the S >= 3 windows:
 // the sum is rounded to 2^-f anyway, and to the canvas type once more for float canvases); void = the reference's
@@ -1125,6 +1258,13 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
                                              const DVec &mass, double mass_scalar, const uint32_t *list,
                                              int64_t start, int count, double *lds, double scale = 1.0)
 {
+    if constexpr (PMX_QUAD_PCS && KIND == PMX_TUNED_PCS && FIXED && !std::is_same<WF, void>::value) {
+        // (uniform per workgroup: `count` is the tile's)
+        if (SORTED || count >= g.quad_min) {
+            tile_deposit_quadz<TTHREADS, SORTED, PE, WHOLE, WF>(p, g, t, pos, mass, mass_scalar, list, start, count, lds, scale);
+            return;
+        }
+    }
     constexpr bool sorted = SORTED;
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
@@ -2552,6 +2692,21 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         g.o[d] = full ? 0 : g.S - 1;
         g.nt[d] = (int32_t)((p.size[d] + g.o[d] + T[d] - 1) / T[d]);
         g.ntiles *= g.nt[d];
+    }
+    {
+        // [r6] which tiles of a PCS paint on a fixed-point region are deposited four lanes per particle
+        // (tile_deposit_quadz): those of plans with the tile-ordered copy (rows in no order: always) and the tiles that
+        // hold more than 9/8 particles per cell — the crowded tiles of a clustered set, where the particles of a wave
+        // share cells whatever order they come in.  Measured with both forms forced (scripts/r06/quad_forced.sh,
+        // profiles/r06_quad/; paint in ms, one lane / four lanes per particle): config 5's per-GPU load 44.3 / 38.9, a
+        // Zel'dovich set at 512^3 2.90 / 2.70, at 256^3 0.545 / 0.424, white-noise steps of 1 cell 2.69 / 2.58, a
+        // lattice of 2 particles per cell 4.42 / 4.47 — but the benchmark's jittered lattice at one particle per cell
+        // 2.30 / 2.58 (its lanes rarely meet; the quad form's extra vector work shows) and steps of 4 cells 2.74 / 2.78:
+        // tiles at the mean density of a uniform set keep the lane-per-particle loop.  (A criterion from the row order
+        // the bin pass measures was tried first: a clustered set displaces neighbours together — 4 changes of tile per
+        // 64 rows, like a lattice — and does not stand out there.)  PMX_QUAD_MIN: experiments.
+        static const int quad_min = [] { const char *e = getenv("PMX_QUAD_MIN"); return e ? atoi(e) : (int)(PMX_QUAD_MIN_DEFAULT); }();
+        g.quad_min = quad_min;
     }
     g.chunk = 1 << 30;
     {

@@ -408,15 +408,19 @@ class LocalBuffer(object):
 
     def view_input(self):
         p = self.partition
+        shape = getattr(p, '_i_shape_list', None)
+        if shape is None:
+            shape = p._i_shape_list = [int(x) for x in p.local_i_shape]
         if getattr(p, 'is_c2c', False):
-            c = torch.view_as_complex(self.storage.view(-1, 2))
-            return torch.as_strided(c, [int(x) for x in p.local_i_shape], p.i_strides)
-        return torch.as_strided(self.storage, [int(x) for x in p.local_i_shape], p.i_strides)
+            return torch.as_strided(torch.view_as_complex(self.storage.view(-1, 2)), shape, p.i_strides)
+        return torch.as_strided(self.storage, shape, p.i_strides)
 
     def view_output(self):
         p = self.partition
-        c = torch.view_as_complex(self.storage.view(-1, 2))
-        return torch.as_strided(c, [int(x) for x in p.local_o_shape], p.o_strides)
+        shape = getattr(p, '_o_shape_list', None)
+        if shape is None:
+            shape = p._o_shape_list = [int(x) for x in p.local_o_shape]
+        return torch.as_strided(torch.view_as_complex(self.storage.view(-1, 2)), shape, p.o_strides)
 
     def view_raw(self):
         return self.storage

@@ -217,19 +217,32 @@ class Field(NDArrayLike):
             raise TypeError("Only RealField and ComplexField. No more subclassing")
         self.pm = pm
         self.BoxSize, self.Nmesh, self.ndim = pm.BoxSize, pm.Nmesh, len(pm.Nmesh)
-        part = self._partition = pm._get_partition(type(self))
-        buf = self._base = _fft.LocalBuffer(part, pm._rdtype, base=base)
-        if isinstance(self, RealField):
-            self._value, self.start, edges = buf.view_input(), part.local_i_start, part.i_edges
+        # what depends only on the mesh and the kind of field is worked out once per ParticleMesh (a time-stepping
+        # caller makes two or three field objects per step)
+        meta = pm._field_meta.get(type(self))
+        if meta is None:
+            meta = pm._field_meta[type(self)] = self._describe(pm)
+        (self._partition, real, self.start, self.cshape, self.csize, self.shape, self.size, self.dtype, self.slices) = meta
+        buf = self._base = _fft.LocalBuffer(self._partition, pm._rdtype, base=base)
+        self._value = buf.view_input() if real else buf.view_output()
+
+    @classmethod
+    def _describe(cls, pm):
+        """(partition, real?, start, cshape, csize, shape, size, dtype, slices) of this kind of field on `pm`"""
+        part = pm._get_partition(cls)
+        real = issubclass(cls, RealField)
+        start, edges, shape = ((part.local_i_start, part.i_edges, part.local_i_shape) if real else
+                               (part.local_o_start, part.o_edges, part.local_o_shape))
+        shape = tuple(int(n) for n in shape)
+        cshape = numpy.array([e[-1] for e in edges], dtype='intp')       # the collective shape
+        if real and not getattr(part, 'is_c2c', False):
+            dtype = numpy.dtype(pm._rdtype)
         else:
-            self._value, self.start, edges = buf.view_output(), part.local_o_start, part.o_edges
-        self.cshape = numpy.array([e[-1] for e in edges], dtype='intp')       # the collective shape
-        self.csize = int(numpy.prod(self.cshape, dtype='i8'))
-        self.shape = tuple(self._value.shape)
-        self.size = int(numpy.prod(self.shape, dtype='i8'))
-        self.dtype = numpy_dtype(self._value.dtype)
+            dtype = numpy.dtype('c16' if numpy.dtype(pm._rdtype).itemsize == 8 else 'c8')
         # where the local block sits in the collective array
-        self.slices = tuple(slice(int(a), int(a) + int(n)) for a, n in zip(self.start, self.shape))
+        slices = tuple(slice(int(a), int(a) + int(n)) for a, n in zip(start, shape))
+        return (part, real, start, cshape, int(numpy.prod(cshape, dtype='i8')), shape,
+                int(numpy.prod(shape, dtype='i8')), dtype, slices)
 
     # `value` is the view of the local block (pm.py:234-242).  A forward transform on one rank may have left its
     # last pass for the inverse transform that usually follows at once (fft.DEFER_LAST_PASS): whoever looks at
@@ -1235,6 +1248,7 @@ class ParticleMesh(object):
         self.resampler = FindResampler(resampler)
         self.plans = plans
         self._coords = {}
+        self._field_meta = {}
 
     def _get_partition(self, field_type):
         if issubclass(field_type, RealField):

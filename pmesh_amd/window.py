@@ -20,6 +20,10 @@ import numpy
 import torch
 
 from . import _abi, backend
+try:
+    from . import _pmx          # the Cython shim (csrc/gen_pyx.py); without it the structs are filled field by field
+except ImportError:             # (not a compute path: the backend itself refuses to run without the shim)
+    _pmx = None
 from ._arrays import to_device, vec, vec_ref, real_view, is_tensor, touched, upload, to_numpy, version_of
 
 
@@ -422,6 +426,12 @@ class ResampleWindow(object):
     # ------------------------------------------------------------------
     def _painter(self, real, order, transform):
         # (meshes of more than three dimensions: pmx_painter_nd, served by pmx_paint_nd / pmx_readout_nd)
+        if _pmx is not None and real.dim() <= _abi.PMX_MAXDIM:
+            # (the struct filled by one typed call of the Cython shim instead of ~30 ctypes attribute stores)
+            p = _abi.Painter()
+            _pmx.fill_painter(p, self._k, self.support, real.element_size(), real.shape, real.stride(), order,
+                              transform.scale, transform.translate, transform.period)
+            return p
         p = _abi.Painter() if real.dim() <= _abi.PMX_MAXDIM else _abi.PainterND()
         p.kind = self._k
         p.support = self.support
