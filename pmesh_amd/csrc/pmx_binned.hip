@@ -91,10 +91,9 @@ __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntil
 // MODE 1: single-pass build into the slot ranges of the previous build: the wave-aggregated
 //         atomic returns the first free slot of the group; particle i goes to
 //         list[offsets[tile] + slot] unless the tile's range is full (-> flags[0], host_flag).
-// MODE 3: the repair after a single pass that overflowed, ONE launch: every single-pass form adds to counts[] before
-//         it looks at the range, so the counts are exact; workgroup 0 lays the new ranges out from them (offsets,
-//         cursor) and raises flags[3], the others wait for that (the grid is small enough to be resident at once),
-//         then every group of rows takes its slots from cursor[tile].
+// MODE 3: the repair after a single pass that overflowed: every single-pass form adds to counts[] before it looks at
+//         the range, so the counts are exact; a gated bin_scan_kernel in front of this launch lays the new ranges out
+//         from them (offsets, cursor), then every group of rows takes its slots from cursor[tile].
 // Particles that touch no local cell go to bucket `ntiles`.  gate != NULL: do nothing unless
 // *gate != 0 (the repair after a single-pass build is always enqueued and only
 // runs if it overflowed — no host synchronisation).
@@ -116,20 +115,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_count_kernel(pmx_painter p, BinGeo
     constexpr int U = MODE == 1 ? PMX_ONEPASS_U : 4;
     const int lane = threadIdx.x & 63;
     if (gate != nullptr && *gate == 0) return;
-    if (MODE == 3) {
-        if (blockIdx.x == 0) {
-            scan_ranges<TBLOCK>(counts, g.ntiles + 1, const_cast<int64_t *>(offsets), cursor, nullptr);
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0) atomicExch(&flags[3], 1u);
-        } else {
-            if (threadIdx.x == 0) {
-                while (atomicAdd(&flags[3], 0u) == 0) __builtin_amdgcn_s_sleep(16);
-                __threadfence();
-            }
-            __syncthreads();
-        }
-    }
+    // (MODE 3: the ranges were laid out from the exact counts by the gated bin_scan_kernel in front of this launch)
     __shared__ __align__(16) unsigned char stage[DENSE ? U * TBLOCK * 24 : 16];
     // Workgroups that run at the same time take chunks that are far apart in the array: rows in
     // lattice order put neighbouring chunks into the same few tiles, and the ~7000 resident
@@ -769,10 +755,9 @@ template <int NT>
 __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor,
                                             uint32_t *zero);
 
-// [r5] The repair of a single pass that overflowed, for the rows the lean form takes: ONE gated launch of a grid small
-// enough to be resident at once.  The counts are exact (every single-pass form adds before it looks at the range):
-// workgroup 0 lays the new ranges out from them, zeroes the counters and raises flags[3]; the others wait for that;
-// then all of them fill the ranges block by block like any rebuild.  (bin_count_kernel<MODE 3>, which does the same
+// [r5] The repair of a single pass that overflowed, for the rows the lean form takes.  The counts are exact (every
+// single-pass form adds before it looks at the range): a gated bin_scan_kernel lays the new ranges out from them and
+// zeroes the counters, then this gated launch fills the ranges block by block like any rebuild.  (bin_count_kernel<MODE 3>, which does the same
 // with one cursor request per wave and tile, took 9.7 ms for the 512^3 rows where this takes 2.6: scripts/overflow_probe.py.)
 template <int KIND, int PE, bool WHOLE>
 __global__ void __launch_bounds__(TBLOCK) bin_repair_lean_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
@@ -780,19 +765,10 @@ __global__ void __launch_bounds__(TBLOCK) bin_repair_lean_kernel(pmx_painter p, 
                                                                  unsigned long long *cursor, uint32_t *list,
                                                                  uint32_t *host_flag, const uint32_t *gate)
 {
+    // ([r6] the new ranges are laid out — and the counters zeroed — by a gated bin_scan_kernel launched in front of
+    // this one: until round 5 workgroup 0 did it here while the others spun on a flag, which is only safe if workgroup 0
+    // is resident whenever they are; nothing guarantees that on a device shared with other streams or ranks)
     if (*gate == 0) return;
-    if (blockIdx.x == 0) {
-        scan_ranges<TBLOCK>(counts, g.ntiles + 1, offsets, cursor, counts);
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) atomicExch(&flags[3], 1u);
-    } else {
-        if (threadIdx.x == 0) {
-            while (atomicAdd(&flags[3], 0u) == 0) __builtin_amdgcn_s_sleep(16);
-            __threadfence();
-        }
-        __syncthreads();
-    }
     lean_blocks<KIND, PE, WHOLE>(p, g, pos, n, counts, flags, offsets, list, host_flag);
 }
 
@@ -1417,7 +1393,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
             if constexpr (RELAX) {
                 T W[3][S];
                 particle_setup_fast<KIND, WHOLE, T>(p, g, t, x[u], W, lb);
-                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
+                if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); out.set(idx[u], 0, 0.0); continue; }    // (a row the plan no longer matches reads 0, not what was in `out`)
                 T acc = 0;
 #pragma unroll
                 for (int a = 0; a < S; a++) {
@@ -1437,7 +1413,7 @@ __device__ __forceinline__ void tile_gather(const pmx_painter &p, const BinGeom 
             }
             double V[3][S];
             particle_setup<KIND, WHOLE>(p, g, t, x[u], V, lb);
-            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); out.set(idx[u], 0, 0.0); continue; }    // (a row the plan no longer matches reads 0, not what was in `out`)
             double value = 0;
 #pragma unroll
             for (int a = 0; a < S; a++)
@@ -2218,6 +2194,9 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
     }
 }
 
+#ifndef PMX_READOUT_ZWALK
+#define PMX_READOUT_ZWALK 8      // most tiles per z segment of readout_tile_lean_kernel (0: one tile per workgroup, every face fetched)
+#endif
 // ---- [r5] the readout of the common case as a loop of its own -----------------------------------------------------
 // Relaxed arithmetic, positions in dense rows of three (PE = 4 / 8 bytes per element), results in a dense vector (OE),
 // the index list (no tile-ordered copy); WHOLE (the block is the whole periodic mesh) known to the launcher.  What the
@@ -2250,7 +2229,12 @@ __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const Bin
             T W[3][S];
             const double x[3] = {(double)row[u].x[0], (double)row[u].x[1], (double)row[u].x[2]};
             particle_setup_fast<KIND, WHOLE, T>(p, g, t, x, W, lb);
-            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) { stale_row(g); continue; }
+            if ((unsigned)lb[0] >= (unsigned)T0 || (unsigned)lb[1] >= (unsigned)T1 || (unsigned)lb[2] >= (unsigned)T2) {
+                stale_row(g);                          // (a row the plan no longer matches reads 0, not what was in `out`)
+                if (OE == 8) *(double *)(out + (int64_t)id[u] * ostride) = 0.0;
+                else *(float *)(out + (int64_t)id[u] * ostride) = 0.0f;
+                continue;
+            }
             const T *base = lds + (lb[0] * R1 + lb[1]) * GP + lb[2];
             T acc = 0;
 #pragma unroll
@@ -2284,11 +2268,11 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
                                                                    DVec pos, char *out, const uint32_t *list,
                                                                    const int64_t *offsets, const uint32_t *counts,
                                                                    const uint64_t *items, const uint32_t *nitems, uint32_t cap,
-                                                                   int ostride)
+                                                                   int ostride, int rseg)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
-    constexpr int R1 = Rg::R1, R2 = Rg::R2;
+    constexpr int R1 = Rg::R1;
     __shared__ T lds[Rg::template glds<T>()];
     __shared__ int64_t tab[Rg::R0 + Rg::R1 + Rg::R2];
     {
@@ -2301,6 +2285,95 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
         }
     }
     const int64_t nh = *nitems < cap ? *nitems : cap;
+    constexpr int GP = Rg::template gpitch<T>();
+    // the rows of the region, c < T2 (whole lines of the canvas: T2 cells are 128 / 256 bytes) ...
+    auto load_rows = [&]() {
+#pragma unroll 4
+        for (int q = threadIdx.x; q < Rg::R0 * R1 * T2; q += TTHREADS) {
+            const int c = q % T2, r = q / T2;
+            const int b = r % R1, a = r / R1;
+            const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
+            lds[r * GP + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;      // outside the block reads as 0
+        }
+    };
+    // ... and its z face, c >= T2: S - 1 cells per row, each the first cells of another line
+    auto load_face = [&]() {
+        if constexpr (S > 1) {
+            for (int q = threadIdx.x; q < Rg::R0 * R1 * (S - 1); q += TTHREADS) {
+                const int c = T2 + q % (S - 1), r = q / (S - 1);
+                const int b = r % R1, a = r / R1;
+                const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
+                lds[r * GP + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;
+            }
+        }
+    };
+#if PMX_READOUT_ZWALK
+    // [r6] A workgroup walks a segment of up to RSEG tiles DOWN the z axis (the tile index runs fastest along z) and
+    // keeps the first S - 1 cells of every row of the tile it has just served: they are the z face of the tile below.
+    // The face is what made a tile's rows cost a line more than they hold — T2 + S - 1 cells are 264 bytes of a double
+    // canvas (3 lines fetched for 2.06), 136 bytes of a float one (2 for 1.06): measured as 0.6 GB of the headline
+    // readout's 6.7, and a third of config 3's mesh traffic.  Now one tile in RSEG fetches its face.
+    const int RSEG = rseg > 0 ? rseg : 1;          // (the launcher's: long segments only where they leave every CU its workgroups)
+    constexpr int NC = S > 1 ? Rg::R0 * R1 * (S - 1) : 1;
+    constexpr int CPT = (NC + TTHREADS - 1) / TTHREADS;
+    const int nt2 = g.nt[2];
+    const int nseg = (nt2 + RSEG - 1) / RSEG;
+    const int64_t nwork = (g.ntiles / nt2) * nseg;
+    for (int64_t unit = blockIdx.x; unit < nwork + nh; unit += gridDim.x) {
+        if (unit >= nwork) {
+            // a piece of a crowded tile beyond g.chunk entries: a work unit of its own, the whole region from the canvas
+            const uint64_t it = items[unit - nwork];
+            const int64_t tile = (int64_t)(it >> 20);
+            const int64_t first = (int64_t)(it & 0xFFFFF) * g.chunk;
+            const int64_t left = (int64_t)counts[tile] - first;
+            const int count = left < g.chunk ? (int)left : g.chunk;
+            if (count <= 0) continue;
+            int t[3];
+            tile_coords(g, tile, t);
+            region_tables<S, false>(p, g, t, tab, TTHREADS);
+            __syncthreads();
+            load_rows();
+            load_face();
+            __syncthreads();
+            tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + offsets[tile] + first, count, lds, ostride);
+            __syncthreads();
+            continue;
+        }
+        const int64_t column = unit / nseg;
+        const int seg = (int)(unit - column * nseg);
+        const int t2a = seg * RSEG, t2b = t2a + RSEG < nt2 ? t2a + RSEG : nt2;
+        bool live = false;                        // the region holds the tile above: its first cells are this tile's face
+        for (int t2 = t2b - 1; t2 >= t2a; t2--) {
+            const int64_t tile = column * nt2 + t2;
+            const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
+            if (count <= 0) { live = false; continue; }        // (uniform per workgroup)
+            int t[3];
+            tile_coords(g, tile, t);
+            T carry[CPT];
+            if (S > 1 && live) {
+#pragma unroll
+                for (int u = 0; u < CPT; u++) {
+                    const int q = threadIdx.x + u * TTHREADS;
+                    if (q < NC) carry[u] = lds[(q / (S - 1 > 0 ? S - 1 : 1)) * GP + q % (S - 1 > 0 ? S - 1 : 1)];
+                }
+            }
+            region_tables<S, false>(p, g, t, tab, TTHREADS);
+            __syncthreads();
+            load_rows();
+            if (S > 1 && live) {
+#pragma unroll
+                for (int u = 0; u < CPT; u++) {
+                    const int q = threadIdx.x + u * TTHREADS;
+                    if (q < NC) lds[(q / (S - 1 > 0 ? S - 1 : 1)) * GP + T2 + q % (S - 1 > 0 ? S - 1 : 1)] = carry[u];
+                }
+            } else load_face();
+            __syncthreads();
+            tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + offsets[tile], count, lds, ostride);
+            __syncthreads();
+            live = true;
+        }
+    }
+#else
     for (int64_t unit = blockIdx.x; unit < g.ntiles + nh; unit += gridDim.x) {
         int64_t tile = unit, first = 0;
         if (unit >= g.ntiles) {
@@ -2316,17 +2389,13 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
         tile_coords(g, tile, t);
         region_tables<S, false>(p, g, t, tab, TTHREADS);
         __syncthreads();
-#pragma unroll 4
-        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
-            int c = q % R2, r = q / R2;
-            int b = r % R1, a = r / R1;
-            const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
-            lds[r * Rg::template gpitch<T>() + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;
-        }
+        load_rows();
+        load_face();
         __syncthreads();
         tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + start, count, lds, ostride);
         __syncthreads();
     }
+#endif
 }
 
 // ---- crowded tiles ------------------------------------------------------------------------
@@ -2912,7 +2981,11 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             // the repair, one launch that returns at once unless a tile overflowed (measured: the four gated launches
             // it replaces, zero / count / scan / scatter, cost a slab rank 20 us per build)
             const uint32_t *gate = pl->flags;
-            if (inv == nullptr && pl->form != 2 && dense && PMX_LEAN_BIN && PMX_REPAIR_GRID > 0) block_pass(pl->list, gate);
+            // ([r6] two launches, both returning at once unless a tile overflowed: the scan of the exact counts into
+            // new ranges as a workgroup of its own — the stream orders it before the fill; no workgroup waits for another)
+            const bool lean_repair = inv == nullptr && pl->form != 2 && dense && PMX_LEAN_BIN && PMX_REPAIR_GRID > 0;
+            bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles + 1, pl->offsets, pl->cursor, gate, lean_repair ? pl->counts : nullptr);
+            if (lean_repair) block_pass(pl->list, gate);
             else BCK(3, small_grid, gate);
         } else {
             // [r5] Dense rows count through the block form too (list == NULL: counts only) and fill their ranges with
@@ -3279,6 +3352,14 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     }
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
     const bool relax = pl->exact == 0;
+    // (the lean kernel's units are z segments of tiles: readout_tile_lean_kernel)
+    // segments of up to PMX_READOUT_ZWALK tiles, shorter where longer ones would leave fewer than ~4096 work units (a
+    // 256^3 mesh has 2048 tiles: one per workgroup as before)
+    int rseg = 1;
+    while (PMX_READOUT_ZWALK && rseg * 2 <= PMX_READOUT_ZWALK && rseg * 2 <= g.nt[2] && g.ntiles / (rseg * 2) >= 4096) rseg *= 2;
+    if (const char *e = getenv("PMX_READOUT_RSEG")) rseg = atoi(e) > 0 ? atoi(e) : 1;        // (experiments)
+    const int64_t lean_units = (g.ntiles / (g.nt[2] > 0 ? g.nt[2] : 1)) * ((g.nt[2] + rseg - 1) / rseg);
+    const unsigned lean_grid = (unsigned)(lean_units < 65535 * 8 ? (lean_units > 0 ? lean_units : 1) : 65535 * 8);
     // [r5] the common case — relaxed arithmetic, the index list, dense position rows, a dense result vector — has a loop of its
     // own, which also zeroes the dropped particles and takes the pieces of crowded tiles (one launch instead of three)
 #ifndef PMX_LEAN_READOUT
@@ -3296,7 +3377,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
 #ifdef PMX_GENERAL_FORMS_ONLY
     whole_r = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
 #endif
-#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, (int)dout.stride0)
+#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<lean_grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, (int)dout.stride0, rseg)
 #define RLW(K, T, PE_, OE_) do { if (whole_r) RLL(K, T, PE_, OE_, true); else RLL(K, T, PE_, OE_, false); } while (0)
 #define RLO(K, T, PE_) do { if (dout.elsize == 8) RLW(K, T, PE_, 8); else RLW(K, T, PE_, 4); } while (0)
 #define RL(K, T) do { if (dpos.elsize == 8) RLO(K, T, 8); else RLO(K, T, 4); } while (0)

@@ -192,7 +192,9 @@ static __global__ void __launch_bounds__(64) wn_master_kernel(uint32_t seed, See
     tb.fill(master, seed);
 }
 
-static int wn_master_on_device = 0;
+// per host thread (ranks that run as threads of one process — the tests' thread ranks, a multi-threaded caller — set and
+// read their own switch; pmx_whitenoise reads it ONCE at entry)
+static thread_local int wn_master_on_device = 0;
 
 struct WnGeom {
     int64_t nmesh[3], start[3], size[3], strides[3];
@@ -301,8 +303,10 @@ extern "C" int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nme
     uint32_t *dseed = nullptr;
     PMX_HIP_CHECK(hipMallocAsync((void **)&dseed, (size_t)ncol * 8, st));
     std::vector<uint32_t> tables;
-    if (wn_master_on_device) {
-        PMX_HIP_CHECK(hipMemsetAsync(dseed, 0, (size_t)ncol * 8, st));
+    const bool on_device = wn_master_on_device != 0;
+    if (on_device) {
+        hipError_t e0 = hipMemsetAsync(dseed, 0, (size_t)ncol * 8, st);
+        if (e0 != hipSuccess) { (void)hipFreeAsync(dseed, st); PMX_HIP_CHECK(e0); }
         wn_master_kernel<<<1, 64, 0, st>>>(seed, SeedTables{N0, N1, start[0], start[1], size[0], size[1], dseed, dseed + ncol});
     } else {
         tables.assign((size_t)ncol * 2, 0u);
@@ -321,7 +325,7 @@ extern "C" int pmx_whitenoise(uint32_t seed, int32_t unitary, const int64_t *nme
     hipError_t e3 = hipGetLastError();
     (void)hipFreeAsync(dseed, st);          // (stream ordered: behind the kernels that read the tables)
     // the host tables go out of scope on return: wait for their copy (the device form neither copies nor waits)
-    hipError_t e4 = wn_master_on_device ? hipSuccess : hipStreamSynchronize(st);
+    hipError_t e4 = on_device ? hipSuccess : hipStreamSynchronize(st);
     PMX_HIP_CHECK(e3);
     PMX_HIP_CHECK(e4);
     return PMX_OK;

@@ -1546,8 +1546,11 @@ class ParticleMesh(object):
                     rpos, rmass = handle.wait()
                 if len(rpos):
                     owed = getattr(out._base.storage, '_pmx_halo', None) is not None
+                    # (a halo merge left to r2c's row pass stays owed: the ghosts go into the field as it is, through
+                    # the direct kernels — a bin plan for a large ghost batch would settle the debt in its lookup and
+                    # the deferral would be lost exactly where it saves most)
                     resampler.paint(out._value if owed else out.value, rpos, mass=rmass, transform=transform,
-                                    diffdir=gradient)
+                                    diffdir=gradient, _direct=owed)
             return out
         localpos = layout.exchange(pos)
         localmass = exchange(layout, mass)

@@ -217,6 +217,12 @@ class _BinCache(object):
         be.call('binplan_sorted', e[1], _SORTS[SORTED], None)
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
         e[3] = True
+        # what the plan's counter of skipped rows shows NOW belongs to the positions it served before (the counter is
+        # per plan object and never reset): the next lookup compares against this, not against what another tensor left
+        c = C.c_uint32(0)
+        be.call('binplan_stale', e[1], C.byref(c))
+        if len(e) > 6:
+            e[6] = int(c.value)
         e[4] = self._tick()
         return e[1]
 
@@ -502,7 +508,8 @@ class ResampleWindow(object):
         bin_cache().lookup(be, pos, p, vec(pos), n)
         return True
 
-    def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None, _overwrite=False, _defer_to=None):
+    def paint(self, real, pos, hsml=None, mass=None, diffdir=None, transform=None, _overwrite=False, _defer_to=None,
+              _direct=False):
         """
             paint to a field (window.py:106-163).
 
@@ -543,7 +550,7 @@ class ResampleWindow(object):
         p = self._painter(canvas, order, transform)
         pv = vec(pos)
         hv = vec(hs) if hs is not None else None
-        if n and _binned_ok(be, p, pos, n, hs):
+        if n and not _direct and _binned_ok(be, p, pos, n, hs):
             plan = bin_cache().lookup(be, pos, p, pv, n)
             # a caller's mass TENSOR: its statistics are found once per tensor and version, so the kernels need
             # no pass over the masses in front of every paint (numpy masses make a new device copy per call: the

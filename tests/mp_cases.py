@@ -185,6 +185,20 @@ def case_halo_merge_left_to_the_slab_row_pass(be, comm):
                 tol = 1e-13 if dtype == 'f8' else 2e-6
                 scale = comm.allreduce(float(abs(ek).max()) if ek.size else 0.0, op='max')
                 assert float(abs(lk - ek).max()) <= tol * scale if ek.size else True
+                # ... also when the ghost batch is itself large enough for the tile kernels (their plan lookup would
+                # settle the debt: the ghosts of a field that owes its merge take the direct kernels instead)
+                comm.Barrier()
+                W.BINNED_MIN_PARTICLES = 64
+                comm.Barrier()
+                many = pm.paint(pos, mass=mass, layout=layout)
+                if owed and layout.remote_recvlength >= 64:
+                    assert getattr(many._base.storage, '_pmx_halo', None) is not None, \
+                        'a ghost batch above BINNED_MIN_PARTICLES undid the deferral (%d ghosts)' % layout.remote_recvlength
+                mk = numpy.array(numpy.asarray(many.r2c(out=Ellipsis)))
+                assert float(abs(mk - ek).max()) <= tol * scale if ek.size else True
+                comm.Barrier()
+                W.BINNED_MIN_PARTICLES = 100000
+                comm.Barrier()
                 # a reader in between: the values are those of the eager paint
                 lazy = pm.paint(pos, mass=mass, layout=layout)
                 lv = numpy.array(numpy.asarray(lazy))
