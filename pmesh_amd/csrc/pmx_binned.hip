@@ -2194,9 +2194,6 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
     }
 }
 
-#ifndef PMX_READOUT_ZWALK
-#define PMX_READOUT_ZWALK 8      // most tiles per z segment of readout_tile_lean_kernel (0: one tile per workgroup, every face fetched)
-#endif
 // ---- [r5] the readout of the common case as a loop of its own -----------------------------------------------------
 // Relaxed arithmetic, positions in dense rows of three (PE = 4 / 8 bytes per element), results in a dense vector (OE),
 // the index list (no tile-ordered copy); WHOLE (the block is the whole periodic mesh) known to the launcher.  What the
@@ -2268,11 +2265,11 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
                                                                    DVec pos, char *out, const uint32_t *list,
                                                                    const int64_t *offsets, const uint32_t *counts,
                                                                    const uint64_t *items, const uint32_t *nitems, uint32_t cap,
-                                                                   int ostride, int rseg)
+                                                                   int ostride)
 {
     constexpr int S = Tuned<KIND>::S;
     using Rg = Region<S>;
-    constexpr int R1 = Rg::R1;
+    constexpr int R1 = Rg::R1, R2 = Rg::R2;
     __shared__ T lds[Rg::template glds<T>()];
     __shared__ int64_t tab[Rg::R0 + Rg::R1 + Rg::R2];
     {
@@ -2285,95 +2282,6 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
         }
     }
     const int64_t nh = *nitems < cap ? *nitems : cap;
-    constexpr int GP = Rg::template gpitch<T>();
-    // the rows of the region, c < T2 (whole lines of the canvas: T2 cells are 128 / 256 bytes) ...
-    auto load_rows = [&]() {
-#pragma unroll 4
-        for (int q = threadIdx.x; q < Rg::R0 * R1 * T2; q += TTHREADS) {
-            const int c = q % T2, r = q / T2;
-            const int b = r % R1, a = r / R1;
-            const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
-            lds[r * GP + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;      // outside the block reads as 0
-        }
-    };
-    // ... and its z face, c >= T2: S - 1 cells per row, each the first cells of another line
-    auto load_face = [&]() {
-        if constexpr (S > 1) {
-            for (int q = threadIdx.x; q < Rg::R0 * R1 * (S - 1); q += TTHREADS) {
-                const int c = T2 + q % (S - 1), r = q / (S - 1);
-                const int b = r % R1, a = r / R1;
-                const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
-                lds[r * GP + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;
-            }
-        }
-    };
-#if PMX_READOUT_ZWALK
-    // [r6] A workgroup walks a segment of up to RSEG tiles DOWN the z axis (the tile index runs fastest along z) and
-    // keeps the first S - 1 cells of every row of the tile it has just served: they are the z face of the tile below.
-    // The face is what made a tile's rows cost a line more than they hold — T2 + S - 1 cells are 264 bytes of a double
-    // canvas (3 lines fetched for 2.06), 136 bytes of a float one (2 for 1.06): measured as 0.6 GB of the headline
-    // readout's 6.7, and a third of config 3's mesh traffic.  Now one tile in RSEG fetches its face.
-    const int RSEG = rseg > 0 ? rseg : 1;          // (the launcher's: long segments only where they leave every CU its workgroups)
-    constexpr int NC = S > 1 ? Rg::R0 * R1 * (S - 1) : 1;
-    constexpr int CPT = (NC + TTHREADS - 1) / TTHREADS;
-    const int nt2 = g.nt[2];
-    const int nseg = (nt2 + RSEG - 1) / RSEG;
-    const int64_t nwork = (g.ntiles / nt2) * nseg;
-    for (int64_t unit = blockIdx.x; unit < nwork + nh; unit += gridDim.x) {
-        if (unit >= nwork) {
-            // a piece of a crowded tile beyond g.chunk entries: a work unit of its own, the whole region from the canvas
-            const uint64_t it = items[unit - nwork];
-            const int64_t tile = (int64_t)(it >> 20);
-            const int64_t first = (int64_t)(it & 0xFFFFF) * g.chunk;
-            const int64_t left = (int64_t)counts[tile] - first;
-            const int count = left < g.chunk ? (int)left : g.chunk;
-            if (count <= 0) continue;
-            int t[3];
-            tile_coords(g, tile, t);
-            region_tables<S, false>(p, g, t, tab, TTHREADS);
-            __syncthreads();
-            load_rows();
-            load_face();
-            __syncthreads();
-            tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + offsets[tile] + first, count, lds, ostride);
-            __syncthreads();
-            continue;
-        }
-        const int64_t column = unit / nseg;
-        const int seg = (int)(unit - column * nseg);
-        const int t2a = seg * RSEG, t2b = t2a + RSEG < nt2 ? t2a + RSEG : nt2;
-        bool live = false;                        // the region holds the tile above: its first cells are this tile's face
-        for (int t2 = t2b - 1; t2 >= t2a; t2--) {
-            const int64_t tile = column * nt2 + t2;
-            const int count = counts[tile] < (uint32_t)g.chunk ? (int)counts[tile] : g.chunk;
-            if (count <= 0) { live = false; continue; }        // (uniform per workgroup)
-            int t[3];
-            tile_coords(g, tile, t);
-            T carry[CPT];
-            if (S > 1 && live) {
-#pragma unroll
-                for (int u = 0; u < CPT; u++) {
-                    const int q = threadIdx.x + u * TTHREADS;
-                    if (q < NC) carry[u] = lds[(q / (S - 1 > 0 ? S - 1 : 1)) * GP + q % (S - 1 > 0 ? S - 1 : 1)];
-                }
-            }
-            region_tables<S, false>(p, g, t, tab, TTHREADS);
-            __syncthreads();
-            load_rows();
-            if (S > 1 && live) {
-#pragma unroll
-                for (int u = 0; u < CPT; u++) {
-                    const int q = threadIdx.x + u * TTHREADS;
-                    if (q < NC) lds[(q / (S - 1 > 0 ? S - 1 : 1)) * GP + T2 + q % (S - 1 > 0 ? S - 1 : 1)] = carry[u];
-                }
-            } else load_face();
-            __syncthreads();
-            tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + offsets[tile], count, lds, ostride);
-            __syncthreads();
-            live = true;
-        }
-    }
-#else
     for (int64_t unit = blockIdx.x; unit < g.ntiles + nh; unit += gridDim.x) {
         int64_t tile = unit, first = 0;
         if (unit >= g.ntiles) {
@@ -2389,13 +2297,17 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
         tile_coords(g, tile, t);
         region_tables<S, false>(p, g, t, tab, TTHREADS);
         __syncthreads();
-        load_rows();
-        load_face();
+#pragma unroll 4
+        for (int q = threadIdx.x; q < Rg::CELLS; q += TTHREADS) {
+            int c = q % R2, r = q / R2;
+            int b = r % R1, a = r / R1;
+            const int64_t o0 = tab[a], o1 = tab[Rg::R0 + b], o2 = tab[Rg::R0 + R1 + c];
+            lds[r * Rg::template gpitch<T>() + c] = (o0 | o1 | o2) >= 0 ? *(const T *)(canvas + (o0 + o1 + o2)) : (T)0;
+        }
         __syncthreads();
         tile_gather_lean<KIND, T, TTHREADS, PE, OE, WHOLE>(p, g, t, pos, out, list + start, count, lds, ostride);
         __syncthreads();
     }
-#endif
 }
 
 // ---- crowded tiles ------------------------------------------------------------------------
@@ -3352,14 +3264,6 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
     }
     unsigned grid = (unsigned)(g.ntiles < 65535 * 8 ? g.ntiles : 65535 * 8);
     const bool relax = pl->exact == 0;
-    // (the lean kernel's units are z segments of tiles: readout_tile_lean_kernel)
-    // segments of up to PMX_READOUT_ZWALK tiles, shorter where longer ones would leave fewer than ~4096 work units (a
-    // 256^3 mesh has 2048 tiles: one per workgroup as before)
-    int rseg = 1;
-    while (PMX_READOUT_ZWALK && rseg * 2 <= PMX_READOUT_ZWALK && rseg * 2 <= g.nt[2] && g.ntiles / (rseg * 2) >= 4096) rseg *= 2;
-    if (const char *e = getenv("PMX_READOUT_RSEG")) rseg = atoi(e) > 0 ? atoi(e) : 1;        // (experiments)
-    const int64_t lean_units = (g.ntiles / (g.nt[2] > 0 ? g.nt[2] : 1)) * ((g.nt[2] + rseg - 1) / rseg);
-    const unsigned lean_grid = (unsigned)(lean_units < 65535 * 8 ? (lean_units > 0 ? lean_units : 1) : 65535 * 8);
     // [r5] the common case — relaxed arithmetic, the index list, dense position rows, a dense result vector — has a loop of its
     // own, which also zeroes the dropped particles and takes the pieces of crowded tiles (one launch instead of three)
 #ifndef PMX_LEAN_READOUT
@@ -3377,7 +3281,7 @@ extern "C" int pmx_readout_binned(pmx_binplan *pl, const pmx_painter *p_, const 
 #ifdef PMX_GENERAL_FORMS_ONLY
     whole_r = false;       // (a build switch for measurements, right results: what the forms for blocks of any shape cost on a whole mesh)
 #endif
-#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<lean_grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, (int)dout.stride0, rseg)
+#define RLL(K, T, PE_, OE_, WH) readout_tile_lean_kernel<K, T, TileThreads<K, T>::readout, PE_, OE_, WH><<<grid, TileThreads<K, T>::readout, 0, st>>>(p, g, (const char *)canvas, dpos, (char *)const_cast<char *>(dout.data), pl->list, pl->offsets, pl->counts, pl->heavy_items, pl->nheavy, (uint32_t)pl->cap_heavy, (int)dout.stride0)
 #define RLW(K, T, PE_, OE_) do { if (whole_r) RLL(K, T, PE_, OE_, true); else RLL(K, T, PE_, OE_, false); } while (0)
 #define RLO(K, T, PE_) do { if (dout.elsize == 8) RLW(K, T, PE_, 8); else RLW(K, T, PE_, 4); } while (0)
 #define RL(K, T) do { if (dpos.elsize == 8) RLO(K, T, 8); else RLO(K, T, 4); } while (0)
