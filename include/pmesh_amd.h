@@ -236,6 +236,15 @@ int pmx_paint_binned(pmx_binplan *plan, const pmx_painter *p, void *canvas, cons
                      const pmx_vec *mass, double mass_scalar, int32_t overwrite, void *stream);
 int pmx_readout_binned(pmx_binplan *plan, const pmx_painter *p, const void *canvas,
                        const pmx_vec *pos, const pmx_vec *out, void *stream);
+/* [r6] The readout of up to PMX_MAXFIELDS canvases of one block geometry (same painter) at the same positions, the results
+ * side by side in the rows of `out`: out(i, f) = canvas f at x_i (`out`: ncol >= ncanvas, any stride0 / stride1) — the
+ * three force components of a PM step written once per row (the reference's caller fills F[..., d] column by column,
+ * examples/nbody.py:214-216; a column at a time every 64-byte piece of F goes to memory and back three times).  Serves
+ * what the default path of pmx_readout_binned serves (relaxed arithmetic, plans without the tile-ordered copy, dense rows
+ * of three positions); PMX_EUNSUPPORTED otherwise — the caller then reads the canvases one by one. */
+#define PMX_MAXFIELDS 4
+int pmx_readout_binned_multi(pmx_binplan *plan, const pmx_painter *p, const void *const *canvases, int32_t ncanvas,
+                             const pmx_vec *pos, const pmx_vec *out, void *stream);
 /* [r4] The halo merge of a paint left to its consumer.  pmx_paint_binned ends with a pass that adds the staged
  * halos of all tiles (the cells of a tile's region beyond its own box) to their owners with atomics: a
  * read-modify-write of a quarter (CIC) to two thirds (PCS) of the mesh on top of the paint itself.  In the PM cycle

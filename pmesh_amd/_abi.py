@@ -8,6 +8,7 @@ import ctypes as C
 
 PMX_MAXDIM = 3
 PMX_MAXRANKS = 64
+PMX_MAXFIELDS = 4
 
 PMX_OK, PMX_EINVAL, PMX_EUNSUPPORTED, PMX_EHIP, PMX_EFFT, PMX_ENOMEM = range(6)
 STATUS_NAMES = {0: 'PMX_OK', 1: 'PMX_EINVAL', 2: 'PMX_EUNSUPPORTED', 3: 'PMX_EHIP',
@@ -121,6 +122,7 @@ DEVICE_ONLY = {
     'binplan_build': (C.c_int, [_vp, _P(Painter), _P(Vec), _i64, _vp]),
     'paint_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _f64, _i32, _vp]),
     'readout_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _vp]),
+    'readout_binned_multi': (C.c_int, [_vp, _P(Painter), _P(_vp), _i32, _P(Vec), _P(Vec), _vp]),
     'paint_binned_defer': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _f64, _i32, _P(_i32), _vp]),
     'halo_merge': (C.c_int, [_vp, _P(Painter), _vp, _vp]),
     'binplan_halo_source': (C.c_int, [_vp, _vp, _i32, _P(_vp), _P(_i32), _P(_i32), _i32]),

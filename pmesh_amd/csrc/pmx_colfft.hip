@@ -564,7 +564,14 @@ template <typename T, int LOGN, int RB> struct ColPipe {
 #define PMX_COL_REGS 1
 #endif
 template <typename T, int LOGN, bool APPLY, bool REMAP> struct ColRegs { static constexpr bool value = PMX_COL_REGS != 0; };
-template <typename T, int LOGN> struct RoundRegs { static constexpr bool value = PMX_ROUND_REGS != 0 && sizeof(T) == 8 && LOGN <= 9; };
+// (PMX_ROUND_REGS_F4 / PMX_ROUND_REGS_MAXLOG: measurement builds of the forms that spill — scripts/r06/round_regs_ab.sh)
+#ifndef PMX_ROUND_REGS_F4
+#define PMX_ROUND_REGS_F4 0
+#endif
+#ifndef PMX_ROUND_REGS_MAXLOG
+#define PMX_ROUND_REGS_MAXLOG 9
+#endif
+template <typename T, int LOGN> struct RoundRegs { static constexpr bool value = PMX_ROUND_REGS != 0 && (sizeof(T) == 8 || PMX_ROUND_REGS_F4) && LOGN <= PMX_ROUND_REGS_MAXLOG; };
 template <typename T, int LOGN, int RB> struct RoundPipe2 {
     static constexpr bool value = PMX_ROUND_PIPE2 && LOGN < 16 && !ColPipe<T, LOGN, RB>::value && ColPipe<T, LOGN, RB>::bytes > 53 * 1024;
 };

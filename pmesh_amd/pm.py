@@ -1409,6 +1409,29 @@ class ParticleMesh(object):
             return array
         return Staged(array, backend.get().device)
 
+    def readout(self, fields, pos, out=None, resampler=None, transform=None, gradient=None, layout=None):
+        """ Read several real fields of this mesh at the same positions (an extension; the reference has no
+            counterpart: its callers read field by field into the columns of their array, examples/nbody.py:214-216).
+
+            fields : sequence of RealField (e.g. the three components of the force); pos : (n, ndim);
+            out : (n, len(fields)) device tensor or None (a new float64 one).  Returns out[i, f] = fields[f] at pos[i] —
+            on one rank from one launch that writes every row of `out` once (ResampleWindow.readout_many); with a
+            `layout` field by field through RealField.readout (the partial sums of the ghosts travel per field). """
+        fields = list(fields)
+        for f in fields:
+            if not isinstance(f, RealField) or f.pm is not self:
+                raise TypeError('fields must be RealField objects of this ParticleMesh')
+        transform = transform or self.affine
+        resampler = FindResampler(self.resampler if resampler is None else resampler)
+        if layout is None:
+            return resampler.readout_many([f.value for f in fields], pos, out=out, diffdir=gradient, transform=transform)
+        be = backend.get()
+        if out is None:
+            out = torch.empty((len(pos), len(fields)), dtype=torch.float64, device=be.device)
+        for k, f in enumerate(fields):
+            f.readout(pos, out=out[:, k], resampler=resampler, transform=transform, gradient=gradient, layout=layout)
+        return out
+
     def tile_order(self, pos, transform=None):
         """ A permutation of the rows of `pos` that makes them spatially coherent (an extension;
             the reference has no counterpart).

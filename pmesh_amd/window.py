@@ -162,6 +162,7 @@ class _BinCache(object):
     def __init__(self):
         self.entries = []     # [key, plan handle, pos tensor (kept alive), built, clock, shape]
         self.clock = 0
+        self._told = {}       # id(entry) -> [(deterministic, exact), (form, sorted)] as last told to the library
 
     def _key(self, pos, painter):
         return (pos.data_ptr(), version_of(pos), tuple(pos.shape), pos.stride(), pos.dtype, WALK, SORTED,
@@ -176,8 +177,7 @@ class _BinCache(object):
                 e[4] = self._tick()
                 if self._warn_if_stale(be, e):
                     break                        # (built again below)
-                be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
-                be.call('binplan_exact', e[1], int(bool(EXACT)))
+                self._options(be, e)
                 return e[1]
         # a plan that last served the same geometry and about as many particles rebuilds in a single
         # pass over the positions (csrc/pmx_binned.hip: slot ranges of the previous build; "about": within an eighth —
@@ -211,10 +211,7 @@ class _BinCache(object):
         else:
             e = min(free or self.entries, key=lambda q: q[4])
         e[0], e[2], e[3], e[5] = key, pos, False, shape
-        be.call('binplan_deterministic', e[1], int(bool(DETERMINISTIC)))
-        be.call('binplan_exact', e[1], int(bool(EXACT)))
-        be.call('binplan_configure', e[1], _FORMS[WALK])
-        be.call('binplan_sorted', e[1], _SORTS[SORTED], None)
+        self._options(be, e, build=True)
         be.call('binplan_build', e[1], C.byref(painter), C.byref(pv), n, be.stream())
         e[3] = True
         # what the plan's counter of skipped rows shows NOW belongs to the positions it served before (the counter is
@@ -225,6 +222,23 @@ class _BinCache(object):
             e[6] = int(c.value)
         e[4] = self._tick()
         return e[1]
+
+    def _options(self, be, e, build=False):
+        """the module-level switches a plan object follows (arithmetic and summation mode always, the form of its
+        kernels and the tile-ordered copy when it is built): told to the library when they CHANGE — four calls per
+        lookup otherwise, for values that a run sets once"""
+        want = (int(bool(DETERMINISTIC)), int(bool(EXACT)))
+        opts = self._told.setdefault(id(e), [None, None])
+        if opts[0] != want:
+            be.call('binplan_deterministic', e[1], want[0])
+            be.call('binplan_exact', e[1], want[1])
+            opts[0] = want
+        if build:
+            form = (_FORMS[WALK], _SORTS[SORTED])
+            if opts[1] != form:
+                be.call('binplan_configure', e[1], form[0])
+                be.call('binplan_sorted', e[1], form[1], None)
+                opts[1] = form
 
     def _tick(self):
         self.clock += 1
@@ -286,6 +300,7 @@ class _BinCache(object):
             except Exception:
                 pass
         self.entries = []
+        self._told = {}
 
 
 _bin_tls = threading.local()
@@ -638,6 +653,59 @@ class ResampleWindow(object):
         if ret_host:
             return to_numpy(dout)
         return dout
+
+
+    def readout_many(self, reals, pos, out=None, diffdir=None, transform=None):
+        """ Readout of several fields of one shape at the same positions (an extension; the reference's callers fill
+            a column at a time, examples/nbody.py:214-216): out[i, f] = reals[f] at pos[i].  `out`: a (n, len(reals))
+            device tensor (any strides) or None for a new float64 one; returned.  On the GPU the tile kernels read
+            every tile's positions once and write the components of a row together (pmx_readout_binned_multi); what
+            that entry does not serve is read field by field into the columns of `out`. """
+        self._require_built()
+        be = backend.get()
+        reals = list(reals)
+        if not reals:
+            raise ValueError('readout_many needs at least one field')
+        dpos, _ = to_device(pos, be.device, 'pos')
+        n = dpos.shape[0]
+        if out is None:
+            out = torch.empty((n, len(reals)), dtype=torch.float64, device=be.device)
+        if not (is_tensor(out) and out.dim() == 2 and tuple(out.shape) == (n, len(reals))):
+            raise ValueError('out must be a device tensor of shape (npart, nfields)')
+
+        def one_by_one():
+            for f, real in enumerate(reals):
+                self.readout(real, dpos, out=out[:, f], diffdir=diffdir, transform=transform)
+            return out
+        fused = (be.name == 'hip' and hasattr(be.lib, 'pmx_readout_binned_multi') and 1 < len(reals) <= _abi.PMX_MAXFIELDS
+                 and all(is_tensor(r) and r.device == be.device for r in reals)
+                 and out.device == be.device and out.dtype in (torch.float32, torch.float64))
+        if fused:
+            canvases = [real_view(r) for r in reals]
+            c0 = canvases[0]
+            fused = (c0.dtype in (torch.float32, torch.float64) and c0.dim() == 3 and
+                     all(c.dtype == c0.dtype and c.shape == c0.shape and c.stride() == c0.stride() for c in canvases))
+        if not fused:
+            return one_by_one()
+        if transform is None:
+            transform = Affine(c0.dim())
+        order = numpy.zeros(c0.dim(), dtype=int)
+        if diffdir is not None:
+            order[diffdir] = 1
+        p = self._painter(c0, order, transform)
+        pv = vec(dpos)
+        if not (n and dpos.dim() == 2 and _binned_ok(be, p, dpos, n, None)):
+            return one_by_one()
+        plan = bin_cache().lookup(be, dpos, p, pv, n)
+        ptrs = (C.c_void_p * len(canvases))(*[c.data_ptr() for c in canvases])
+        ov = vec(out)
+        rc = be.lib.pmx_readout_binned_multi(plan, C.byref(p), ptrs, len(canvases), C.byref(pv), C.byref(ov), be.stream())
+        if rc == _abi.PMX_EUNSUPPORTED:
+            return one_by_one()          # (exact arithmetic, a plan with the tile-ordered copy, positions with a pitch)
+        if rc != 0:
+            raise backend.PmxError('pmx_readout_binned_multi', rc, be.lib.pmx_last_error().decode())
+        touched(out)
+        return out
 
 
 def FindResampler(window):

@@ -881,3 +881,66 @@ def test_time_stepping_cycles_equal_oracle(hip, oracle, N, name, dtype, tol):
         assert err <= tol
     # one pooled plan served all three position tensors (the rebuilds had the previous slot ranges)
     assert len(set(served)) == 1, served
+
+
+@pytest.mark.parametrize('name', TUNED)
+@pytest.mark.parametrize('dtype,odtype', [('f8', 'f8'), ('f4', 'f4'), ('f8', 'f4')])
+def test_readout_of_several_fields_equals_field_by_field(hip, oracle, name, dtype, odtype):
+    """pmx_readout_binned_multi (ResampleWindow.readout_many / ParticleMesh.readout): out[i, f] = field f at x_i from
+    one launch == the lean readout of every field on its own, bit for bit (the same loop per canvas), == the oracle
+    within the readout's tolerance; rows of `out` with a pitch, float and double results, a slab-local block with
+    particles outside it (they read 0), and the fallbacks (exact arithmetic, one field) give the same numbers."""
+    W = windows[name]
+    rs = numpy.random.RandomState(12)
+    shape = (24, 48, 64)
+    aff = Affine(3, scale=[1.0, 0.5, 2.0], translate=[-4.0, 0.0, 0.0], period=[64, 48, 64])
+    n = 60000
+    pos_h = rs.uniform([-2, 0, 0], [34, 96, 32], size=(n, 3))
+    tdt = torch.float64 if dtype == 'f8' else torch.float32
+    fields_h = [rs.normal(size=shape).astype(dtype) for _ in range(3)]
+    fields = [torch.from_numpy(f).to(hip.device) for f in fields_h]
+    pos = torch.from_numpy(pos_h).to(hip.device)
+    window.BINNED = 'always'
+    window.clear_bin_cache()
+    wide = torch.full((n, 5), 7.0, dtype=torch.float64 if odtype == 'f8' else torch.float32, device=hip.device)
+    got = W.readout_many(fields, pos, out=wide[:, 1:4], transform=aff)
+    assert got.data_ptr() == wide[:, 1:4].data_ptr()
+    assert float(wide[:, 0].min()) == 7.0 and float(wide[:, 4].max()) == 7.0          # the neighbours of the rows are untouched
+    for f in range(3):
+        one = torch.empty(n, dtype=wide.dtype, device=hip.device)
+        W.readout(fields[f], pos, out=one, transform=aff)
+        assert torch.equal(got[:, f], one), (name, f)
+        want = oracle.Window(W.kind).readout(fields_h[f].astype('f8'), pos_h, transform=oracle.Affine(3, scale=aff.scale, translate=aff.translate, period=aff.period))
+        tol = 1e-13 if (dtype == 'f8' and odtype == 'f8') else 2e-6
+        assert float(abs(got[:, f].double().cpu().numpy() - want).max()) <= tol * 64 * float(abs(fields_h[f]).max())
+    # gradient weights, a new tensor for the results
+    g2 = W.readout_many(fields[:2], pos, diffdir=1, transform=aff)
+    assert g2.shape == (n, 2) and g2.dtype == torch.float64
+    for f in range(2):
+        assert torch.equal(g2[:, f], W.readout(fields[f], pos, diffdir=1, transform=aff))
+    # exact arithmetic is not what the fused entry serves: the same call falls back to field by field
+    window.EXACT = True
+    window.clear_bin_cache()
+    ge = W.readout_many(fields, pos, transform=aff)
+    for f in range(3):
+        assert torch.equal(ge[:, f], W.readout(fields[f], pos, transform=aff))
+    window.EXACT = False
+
+
+def test_particlemesh_readout_of_several_fields(hip):
+    """ParticleMesh.readout(fields, pos): the three force components of a PM step into the rows of one array"""
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    N = 64
+    pm = ParticleMesh(BoxSize=float(N), Nmesh=[N, N, N], dtype='f8', resampler='cic')
+    Q = pm.generate_uniform_particle_grid(shift=0.5)
+    g = torch.Generator(device=Q.device).manual_seed(5)
+    X = (Q + 0.3 * torch.randn(Q.shape, generator=g, dtype=Q.dtype, device=Q.device)) % float(N)
+    rhok = pm.paint(X).r2c()
+    comps = [rhok.c2r(transfer=Transfer.force(d)) for d in range(3)]
+    F = pm.readout(comps, X)
+    assert F.shape == (len(X), 3)
+    for d in range(3):
+        assert torch.equal(F[:, d], comps[d].readout(X))
+    with pytest.raises(TypeError):
+        pm.readout([rhok], X)

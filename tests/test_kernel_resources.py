@@ -126,6 +126,11 @@ def test_tile_kernel_budgets():
     # the deposit loop (whole mesh or not x element size of the positions)
     tsc = [v for k, v in tiles.items() if 'paint_tile_kernelILi6Ed' in k and 'ELb0ELi1E' in k]
     assert len(tsc) == 4 and all(v['VGPRs'] <= 80 and v['Occupancy'] >= 6 for v in tsc), tsc
+    # [r6] PCS (kind 7) through the index list on fixed-point regions: the kernel holds both forms of its deposit loop
+    # (one lane / four lanes per particle, tile_deposit_quadz); 80 KB regions allow two workgroups of 512 threads per CU,
+    # i.e. four waves per SIMD, if 128 VGPRs suffice (the whole-file build came to 129 unbounded: ONE workgroup per CU)
+    pcs = [v for k, v in tiles.items() if 'paint_tile_kernelILi7Ed' in k and 'ELb0ELi1E' in k]
+    assert len(pcs) == 4 and all(v['VGPRs'] <= 128 and v['Occupancy'] >= 4 and v['ScratchSize'] == 0 for v in pcs), pcs
     # [r5] the 32-bit regions of float canvases: TSC 45 KB (rows of 64 cells) x three workgroups of 512 threads per CU,
     # i.e. six waves per SIMD; PCS four waves per SIMD
     t32 = {k: v for k, v in tiles.items() if 'paint_tile32_kernel' in k}
