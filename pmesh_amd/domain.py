@@ -811,13 +811,27 @@ class GridND(object):
                              stamp=self.DomainAssign)
         return self._dev
 
+    def _split_axes(self):
+        """how many leading axes the classification has to look at: a grid of more dimensions than the ABI's
+        pmx_grid holds (PMX_MAXDIM) is classified by its first axes if all the others are ONE periodic domain — what
+        ParticleMesh makes for a mesh of 4 or more dimensions (slabs along axis 0): the flat index of a domain is
+        then its index over the leading axes"""
+        nd = self.ndim
+        if nd <= _abi.PMX_MAXDIM:
+            return nd
+        k = max([d + 1 for d in range(nd) if int(self.shape[d]) > 1] or [1])
+        if k > _abi.PMX_MAXDIM or not self.periodic:
+            raise NotImplementedError('a domain grid of %d dimensions is decomposed along its first %d axes only, '
+                                      'periodic' % (nd, _abi.PMX_MAXDIM))
+        return k
+
     def _cgrid(self, be):
         t = self._device_tables(be)
         g = _abi.Grid()
-        g.ndim = self.ndim
+        g.ndim = self._split_axes()
         g.periodic = int(bool(self.periodic))
         g.nranks = self.comm.size
-        for d in range(self.ndim):
+        for d in range(g.ndim):
             g.shape[d] = int(self.shape[d])
             g.edges[d] = t['edges'][d].data_ptr()
         g.assign = t['assign'].data_ptr()
@@ -960,8 +974,8 @@ class GridND(object):
             counts = torch.zeros(P, dtype=torch.int64, device=be.device)
             g = self._cgrid(be)
             pv = vec(pos)
-            be.call('decompose_count', C.byref(g), C.byref(pv), _abi.f64arr(scale, 3),
-                    _abi.f64arr(sm, 3), Npoint, masks.data_ptr(), counts.data_ptr(), be.stream())
+            be.call('decompose_count', C.byref(g), C.byref(pv), _abi.f64arr(scale[:g.ndim], 3),
+                    _abi.f64arr(sm[:g.ndim], 3), Npoint, masks.data_ptr(), counts.data_ptr(), be.stream())
             hcounts = counts.cpu().numpy()          # the one host sync of decompose
             offsets = numpy.zeros(P, dtype='i8')
             offsets[1:] = numpy.cumsum(hcounts)[:-1]

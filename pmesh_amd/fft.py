@@ -103,8 +103,10 @@ class Partition(object):
         self.is_c2c = bool(is_c2c)
         if nd == 1 and P > 1:
             raise ValueError("Running 1d transforms on multiple ranks is not supported")
-        if nd > 3 and P > 1:
-            raise NotImplementedError('meshes of more than 3 dimensions are transformed on one rank only')
+        if nd > 4 and P > 1:
+            # (4-d meshes on several ranks: slabs — the local stage is one batched 3-d rocFFT plan, Plan._execute_slab;
+            # beyond that the local stage itself needs more than one plan: one rank only)
+            raise NotImplementedError('meshes of more than 4 dimensions are transformed on one rank only')
         self.nproc = P
         # (a 2-d process mesh [P, 1] IS the slab: axis 0 of the real field distributed, axis 1 of the transposed spectrum;
         # [1, P] distributes axes 1 and 2, as PFFT lays it out: the pencil schedule with a first group of one)

@@ -1155,7 +1155,12 @@ class ParticleMesh(object):
         if np is None:
             # the reference's default (pm.py:1317-1325): a 2-d process mesh for 3-d meshes, the
             # most square factorisation of the communicator; a slab for 2-d meshes
-            if len(Nmesh) >= 3:
+            if len(Nmesh) > 3:
+                # [r6] meshes of 4 dimensions on several ranks: slabs along axis 0 (the reference hands PFFT a 2-d process
+                # mesh here too, pm.py:1319; its test only builds such a mesh, test_pm.py:381-384) — the local stage of
+                # a slab is one batched rocFFT plan over the trailing axes
+                np = [self.comm.size]
+            elif len(Nmesh) >= 3:
                 np = list(_fft.split_size_2d(self.comm.size))
                 if np[1] == 1:
                     # [P, 1] distributes axis 0 alone: exactly the slab [P], one transpose per transform

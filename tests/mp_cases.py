@@ -1061,7 +1061,69 @@ def case_comm_trace(be, comm):
     assert 0.7 * full <= total <= 1.3 * full, (total, full)
 
 
-CASES = [case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
+def case_mesh_of_four_dimensions(be, comm):
+    """[r6] a 4-d mesh on several ranks (the reference builds one under mpirun in its CI: pm.reshape(Nmesh=[8, 8, 8, 8],
+    BoxSize=8.0), pmesh/tests/test_pm.py:372-389): slabs along axis 0, the local stage one batched 3-d rocFFT plan
+    (Plan._execute_slab), the particles classified along the one split axis (GridND._split_axes), the generic n-d
+    window kernels on the slab block.  r2c == rfftn / prod(N) and c2r back (numpy.fft: the FFT oracle),
+    paint / readout through a layout == the oracle's n-d painter on the whole mesh; the untransposed spectrum; f4."""
+    from pmesh_amd.pm import ParticleMesh, UntransposedComplexField
+    from oracle import oracle as O
+    pm3 = ParticleMesh(BoxSize=8.0, Nmesh=[8, 8, 8], comm=comm, dtype='f8', np=[comm.size])
+    pm4 = pm3.reshape(Nmesh=[8, 8, 8, 8], BoxSize=8.0)
+    assert pm4.ndim == 4 and list(pm4.np) == [comm.size]
+    with pytest_raises(ValueError):
+        pm3.reshape(Nmesh=[8, 8, 8, 8])
+    N, L = [8, 6, 4, 10], [8.0, 3.0, 2.0, 5.0]
+    data = numpy.random.RandomState(3).normal(size=N)
+    ref = numpy.fft.rfftn(data) / numpy.prod(N)
+    rs = numpy.random.RandomState(40 + comm.rank)
+    npart = 150 + 20 * comm.rank
+    pos = rs.uniform(-1.0, 9.0, size=(npart, 4)) * numpy.array(L) / 8.0
+    mass = rs.uniform(0.5, 1.5, size=npart)
+    all_pos = numpy.concatenate(comm.allgather(pos), axis=0)
+    all_mass = numpy.concatenate(comm.allgather(mass), axis=0)
+    for dtype, tol in (('f8', 1e-13), ('f4', 5e-6)):
+        pm = ParticleMesh(BoxSize=L, Nmesh=N, comm=comm, dtype=dtype)
+        assert list(pm.np) == [comm.size]
+        real = pm.create('real', value=data[pm.create('real').slices].astype(dtype))
+        ck = real.r2c()
+        got = numpy.asarray(ck)
+        scale = comm.allreduce(float(abs(ref).max()), op='max')
+        assert float(abs(got - ref[ck.slices]).max()) <= tol * scale if got.size else True
+        back = numpy.asarray(ck.c2r())
+        assert float(abs(back - data[real.slices]).max()) <= 8 * tol * float(abs(data).max()) if back.size else True
+        cu = numpy.asarray(real.r2c(out=UntransposedComplexField(pm)))
+        assert float(abs(cu - ref[UntransposedComplexField(pm).slices]).max()) <= tol * scale if cu.size else True
+    pm = ParticleMesh(BoxSize=L, Nmesh=N, comm=comm, dtype='f8', resampler='cic')
+    aff = O.Affine(4, scale=numpy.array(N) / numpy.array(L), period=N)
+    truth = numpy.zeros(N)
+    O.Window('tunedcic').paint(truth, all_pos, mass=all_mass, transform=aff)
+    layout = pm.decompose(pos)
+    rho = pm.paint(pos, mass=mass, layout=layout)
+    assert_allclose(gather_field(comm, rho, tuple(N)), truth, rtol=0, atol=1e-12 * abs(truth).max())
+    fld = pm.create('real', value=data[rho.slices])
+    for grad in (None, 2):
+        want = O.Window('tunedcic').readout(data, pos, transform=aff, diffdir=grad)
+        assert_allclose(fld.readout(pos, layout=layout, gradient=grad), want, rtol=0, atol=1e-12 * max(1.0, abs(want).max()))
+    with pytest_raises(NotImplementedError):
+        ParticleMesh(BoxSize=4.0, Nmesh=[4, 4, 4, 4, 4], comm=comm, dtype='f8')
+
+
+class pytest_raises(object):
+    """(the cases also run outside pytest: python tests/mp_cases.py under torch.distributed.run)"""
+    def __init__(self, exc):
+        self.exc = exc
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        assert et is not None and issubclass(et, self.exc), 'expected %s, got %r' % (self.exc.__name__, ev)
+        return True
+
+
+CASES = [case_mesh_of_four_dimensions, case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
          case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial, case_halo_merge_left_to_the_slab_row_pass,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_uneven_blocks_decide_alike, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
