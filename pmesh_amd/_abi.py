@@ -1,8 +1,10 @@
-"""ctypes declarations of the C ABI in include/pmesh_amd.h.
+"""The structs of the C ABI in include/pmesh_amd.h as ctypes mirrors, and its prototypes as a ctypes table.
 
-One table of prototypes, bound to a library under a symbol prefix: ``pmx_`` for
-the product library (device pointers) and, from tests only, ``pmo_`` for the
-CPU oracle (host pointers).  Nothing here computes anything.
+The product binds the library through the Cython shim ``pmesh_amd._pmx`` (generated from the header,
+csrc/gen_pyx.py; backend.load_library): its wrappers take these struct mirrors (or their byref()) as pointer
+arguments.  The prototype table binds a library under a symbol prefix with ctypes alone: ``pmo_`` for the CPU oracle
+(host pointers; tests only) and, with PMESH_AMD_BINDING=ctypes, ``pmx_`` for the product library (a debugging aid).
+Nothing here computes anything.
 """
 import ctypes as C
 

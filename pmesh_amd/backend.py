@@ -1,8 +1,8 @@
 """Kernel backend: the one place where the host layer meets native code.
 
-The product backend is :class:`HipBackend`: it loads ``libpmesh_amd.so`` (the
-C ABI of include/pmesh_amd.h, hand-written HIP kernels for gfx950 + rocFFT) and
-runs on a real GPU.  There is NO CPU implementation in this package: if the
+The product backend is :class:`HipBackend`: it binds ``libpmesh_amd.so`` (the
+C ABI of include/pmesh_amd.h, hand-written HIP kernels for gfx950 + rocFFT)
+through the Cython shim ``pmesh_amd._pmx`` and runs on a real GPU.  There is NO CPU implementation in this package: if the
 library or the GPU is missing, :func:`get` raises — it never falls back.
 
 ``use(backend)`` exists so that tests can drive the host logic (argument
