@@ -225,6 +225,12 @@ int pmx_binplan_stale(pmx_binplan *plan, uint32_t *count);
  * a particle count within an eighth of the previous one: a time-stepping caller, also one whose particles migrate
  * between ranks) / in two passes (the first build, another geometry or count, the back-off after an overflow). */
 int pmx_binplan_builds(pmx_binplan *plan, uint32_t *single_pass, uint32_t *two_pass);
+/* [r6] The order of the rows that a built plan holds, for the caller: order[k] (npart int64 of device memory) = the row that
+ * stands k-th when the rows are taken tile by tile — inside a tile in the order of the rows themselves — and the rows
+ * that touch no local cell last.  A time-stepping caller re-sorts its particle arrays with it every few steps
+ * (ParticleMesh.tile_order; the reference has no counterpart): position gathers and result stores of the tile kernels
+ * then touch whole lines again, whatever the flow has done to the order the particles were made in. */
+int pmx_binplan_order(pmx_binplan *plan, int64_t *order, void *stream);
 /* PMX_OK if (painter, npart) can use the binned kernels */
 int pmx_binplan_supported(const pmx_painter *p, int64_t npart);
 /* bin the batch: tile id + slot per particle, per-tile counts, scan, index lists */

@@ -120,6 +120,7 @@ DEVICE_ONLY = {
     'binplan_stale': (C.c_int, [_vp, _P(C.c_uint32)]),
     'binplan_builds': (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_uint32)]),
     'binplan_sorted': (C.c_int, [_vp, _i32, _P(_i32)]),
+    'binplan_order': (C.c_int, [_vp, _vp, _vp]),
     'binplan_supported': (C.c_int, [_P(Painter), _i64]),
     'binplan_build': (C.c_int, [_vp, _P(Painter), _P(Vec), _i64, _vp]),
     'paint_binned': (C.c_int, [_vp, _P(Painter), _vp, _P(Vec), _P(Vec), _f64, _i32, _vp]),

@@ -1108,6 +1108,15 @@ __device__ __forceinline__ double uniform_double(double x)
 #ifndef PMX_QUAD_PCS
 #define PMX_QUAD_PCS 1
 #endif
+#ifndef PMX_DEAL_CROWDED
+#define PMX_DEAL_CROWDED 1
+#endif
+#ifndef PMX_DEAL_SAME_OF_64
+#define PMX_DEAL_SAME_OF_64 24       // neighbouring entries of the sample that share their first cell, from which on the rows count as cell-ordered
+#endif
+#ifndef PMX_DEAL_MIN_DEFAULT
+#define PMX_DEAL_MIN_DEFAULT (2 * TCELLS)
+#endif
 #ifndef PMX_QUAD_STRIDE8
 #define PMX_QUAD_STRIDE8 1
 #endif
@@ -1257,12 +1266,43 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     // PCS 2.77 / 2.90, with the odd-lane swap on top 1.78 / 3.22.  The kernel is not waiting for those conflicts.)
     double sink = 0;
     const uint32_t *tl = list + start;       // (a wave-uniform base + the lane's entry: nothing per thread for the compiler to keep across tiles)
-    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+    // [r6] Crowded tiles deal their entries: slot s of a trip of W takes entry (65 s) mod W.  Rows that arrive sorted by
+    // cell — a caller that keeps its particles in Peano-Hilbert or cell order, as tree codes do — put the particles of
+    // a crowded cell into neighbouring lanes, every lane of an instruction on ONE address: an evolved 512^3 state
+    // (scripts/clustered_state_probe.py) painted in 4.2 ms cell-sorted against 1.4 in random order.  With the deal a run
+    // of up to 65 particles of a cell sends one lane per instruction.  Tiles at the mean density of a uniform set keep
+    // the plain order (the lane deal measured nothing on the benchmark's lattice: round 4), as do the plans with the
+    // tile-ordered copy.
+    // Whether a crowded tile's rows ARE in cell order is looked up on 64 entries from the middle of its list: a wave
+    // compares the first stencil cells of neighbouring entries (rows that merely arrive in the order the particles were
+    // made in share cells too, but not as neighbours: dealt, they lose the locality of their gathers for nothing —
+    // the evolved state as its run left it 2.30 -> 3.18 ms with every crowded tile dealt, 2.3 with the sample deciding).
+    constexpr int W = TTHREADS * UNROLL;
+    bool deal = false;
+    if (PMX_DEAL_CROWDED && !sorted && (W & (W - 1)) == 0 && count >= g.deal_min) {      // (uniform per workgroup)
+        __shared__ int deal_flag;
+        if (threadIdx.x < 64) {
+            const int64_t row = (int64_t)tl[count / 2 + (int)threadIdx.x];
+            int key = 0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const double X = (double)pos_get<PE>(pos, row, d) * p.scale[d] + p.translate[d];
+                key = key * 1021 + Tuned<KIND>::first(X);
+            }
+            const int prev = __shfl_up(key, 1);
+            const unsigned long long same = __ballot(threadIdx.x > 0 && key == prev);
+            if (threadIdx.x == 0) deal_flag = __popcll(same) >= PMX_DEAL_SAME_OF_64;
+        }
+        __syncthreads();
+        deal = deal_flag != 0;
+    }
+    for (int jb = 0; jb < count; jb += W) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            int j = j0 + u * TTHREADS;
+            const int s = u * TTHREADS + (int)threadIdx.x;
+            const int j = jb + (deal ? ((s * 65) & (W - 1)) : s);
             idx[u] = j < count ? (sorted ? start + j : (int64_t)tl[j]) : -1;
         }
 #pragma unroll
@@ -2657,6 +2697,63 @@ extern "C" int pmx_binplan_builds(pmx_binplan *pl, uint32_t *single_pass, uint32
     return PMX_OK;
 }
 
+// ---- [r6] the plan's order of the rows, for the caller ------------------------------------------------------------------
+// order[k] = the row that stands k-th when the rows are taken tile by tile (tiles in index order, inside a tile in the
+// order the bin pass met them — the order of the rows themselves, block by block), the rows that touch no local cell
+// last: what ParticleMesh.tile_order hands a time-stepping caller to re-sort its particle arrays with.  The plan has
+// this order already (its index list, with slack between the tiles): an exclusive scan of the counts and one copy,
+// ~0.3 ms for 134 M rows where torch.argsort of 64-bit keys took 20.
+static __global__ void __launch_bounds__(1024) order_scan_kernel(const uint32_t *counts, int64_t nbuckets, int64_t *first)
+{
+    __shared__ int64_t sh[1024];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nbuckets; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < nbuckets ? (int64_t)counts[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int64_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nbuckets) first[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+}
+static __global__ void __launch_bounds__(TBLOCK) order_copy_kernel(const uint32_t *list, const int64_t *offsets, const uint32_t *counts,
+                                                            const int64_t *first, int64_t nbuckets, int64_t *order)
+{
+    for (int64_t t = blockIdx.x; t < nbuckets; t += gridDim.x) {
+        const uint32_t *src = list + offsets[t];
+        int64_t *dst = order + first[t];
+        const int64_t n = counts[t];
+        for (int64_t j = threadIdx.x; j < n; j += TBLOCK) dst[j] = (int64_t)src[j];
+    }
+}
+extern "C" int pmx_binplan_order(pmx_binplan *pl, int64_t *order, void *stream)
+{
+    PMX_REQUIRE(pl && pl->built, PMX_EINVAL, "bin plan is not built");
+    PMX_REQUIRE(order != nullptr || pl->npart == 0, PMX_EINVAL, "order is NULL");
+    if (pl->npart == 0) return PMX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nbuckets = pl->g.ntiles + 1;
+    int64_t *first = nullptr;
+    PMX_HIP_CHECK(hipMallocAsync((void **)&first, (size_t)nbuckets * sizeof(int64_t), st));
+    order_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, first);
+    const unsigned grid = (unsigned)(nbuckets < 65535 * 8 ? nbuckets : 65535 * 8);
+    order_copy_kernel<<<grid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, first, nbuckets, order);
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(first, st);
+    PMX_HIP_CHECK(e);
+    return PMX_OK;
+}
+
 extern "C" int pmx_binplan_stale(pmx_binplan *pl, uint32_t *count)
 {
     PMX_REQUIRE(pl != nullptr && count != nullptr, PMX_EINVAL, "NULL argument");
@@ -2753,6 +2850,10 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
         // 64 rows, like a lattice — and does not stand out there.)  PMX_QUAD_MIN: experiments.
         static const int quad_min = [] { const char *e = getenv("PMX_QUAD_MIN"); return e ? atoi(e) : (int)(PMX_QUAD_MIN_DEFAULT); }();
         g.quad_min = quad_min;
+        // [r6] ... and which tiles of the one-lane loops deal their entries to the lanes (tile_deposit): from two particles
+        // per cell on (PMX_DEAL_MIN: experiments)
+        static const int deal_min = [] { const char *e = getenv("PMX_DEAL_MIN"); return e ? atoi(e) : (int)(PMX_DEAL_MIN_DEFAULT); }();
+        g.deal_min = deal_min;
     }
     g.chunk = 1 << 30;
     {

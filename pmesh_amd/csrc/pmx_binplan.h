@@ -58,6 +58,7 @@ struct BinGeom {
     int32_t o[3];         // tile-space offset per axis (S-1 unless the axis is the full period)
     int64_t ntiles;       // tiles of T0 x T1 x T2 cells
     int32_t chunk;        // list entries of a tile that the tile kernels take themselves
+    int32_t deal_min;     // [r6] tiles of at least this many entries deal them to the lanes of the one-lane deposit loops (tile_deposit)
     int32_t quad_min;     // [r6] PCS on fixed-point regions: a tile (or piece) of at least this many entries is deposited four lanes per particle (tile_deposit_quadz)
     uint32_t *stale;      // host-visible counter of list entries found outside their tile's region (a stale plan), or NULL
 };

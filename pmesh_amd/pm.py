@@ -30,7 +30,7 @@ from numpy.lib.mixins import NDArrayOperatorsMixin as NDArrayLike
 
 from . import _abi, backend, domain
 from . import fft as _fft
-from ._arrays import to_device, is_tensor, torch_dtype, numpy_dtype, to_numpy
+from ._arrays import to_device, is_tensor, torch_dtype, numpy_dtype, to_numpy, vec
 from ._devarr import DevArr, unwrap as _dev_unwrap
 from .comm import default_comm
 from .transfer import Transfer
@@ -41,6 +41,22 @@ _gettype = type
 
 def is_inplace(out):
     return out is Ellipsis
+
+
+class _BlockGeometry(object):
+    """shape / strides / element size of a rank's real block as ResampleWindow._painter reads them off a tensor (the
+    geometry of a bin plan without a field to go with it: ParticleMesh.tile_order)"""
+    def __init__(self, shape, strides, elsize):
+        self.shape, self._strides, self._elsize = tuple(shape), tuple(strides), elsize
+
+    def dim(self):
+        return len(self.shape)
+
+    def element_size(self):
+        return self._elsize
+
+    def stride(self, d=None):
+        return self._strides if d is None else self._strides[d]
 
 
 def _deprecated(message, replacement, *args):
@@ -1443,36 +1459,50 @@ class ParticleMesh(object):
 
             The tiled paint / readout kernels keep the caller's rows where they are and lean on
             neighbouring rows being neighbouring particles — what a simulation that stores its
-            particles in ID (lattice) order has.  Rows in random order cost 3-4x (DESIGN.md,
-            "Sensitivity to the order of the particles").  Reordering the particle arrays ONCE,
+            particles in ID (lattice) order has at the start, and loses by degrees as the flow mixes
+            them (scripts/nbody_long.py: the readout of a 512^3 run goes from 1.1 to 3.3 ms).
+            Reordering the particle arrays every few steps,
 
                 o = pm.tile_order(pos);  pos = pos[o];  vel = vel[o];  ...
 
-            restores the coherent case for as long as particles stay near their neighbours (an
-            N-body run: many steps).  The key is the mesh tile (8 x 16 x 32 cells, C order) of the
-            particle's cell, then the cell inside the tile; ties keep their order.  Returns an
-            int64 device tensor. """
+            restores it.  The order is tile by tile (8 x 16 x 32 cells, C order of the tiles of this
+            rank's block); INSIDE a tile the rows keep the order they had — sorting them by cell as
+            well would put the particles of a crowded cell into neighbouring lanes of the paint
+            kernel, the worst case of its LDS atomics (measured on an evolved 512^3 state: paint 4.2 ms
+            cell-sorted against 2.2 as the run left the rows and 1.4 in random order; the readout
+            wants the tile order alone).  [r6] The permutation is read off the bin plan of `pos`
+            (pmx_binplan_order: a scan and a copy, ~0.5 ms for 134 M rows — and the plan is the one
+            the next paint of these positions would have built anyway); rows that touch no cell of
+            this rank's block come last.  Returns an int64 device tensor. """
         be = backend.get()
         dpos, _ = to_device(pos, be.device, 'pos')
         if transform is None:
             transform = self.affine
         nd = self.ndim
+        n = dpos.shape[0]
+        resampler = FindResampler(self.resampler)
+        if be.name == 'hip' and nd == 3 and n and hasattr(be.lib, 'pmx_binplan_order'):
+            from .window import _binned_ok, bin_cache
+            part = self._get_partition(RealField)
+            es = numpy.dtype(self._rdtype).itemsize
+            block = _BlockGeometry([int(x) for x in part.local_i_shape], [int(x) for x in part.i_strides], es)
+            painter = resampler._painter(block, (0, 0, 0), transform)
+            if dpos.dim() == 2 and _binned_ok(be, painter, dpos, n, None):
+                pv = vec(dpos)
+                plan = bin_cache().lookup(be, dpos, painter, pv, n)
+                order = torch.empty(n, dtype=torch.int64, device=be.device)
+                be.call('binplan_order', plan, order.data_ptr(), be.stream())
+                return order
+        # (meshes of other dimensions, batches the tile kernels do not take: the same order from a stable sort by tile)
         scale = torch.as_tensor(numpy.broadcast_to(numpy.asarray(transform.scale, dtype='f8'), (nd,)).copy(),
                                 device=be.device)
         cell = torch.floor(dpos[:, :nd].to(torch.float64) * scale).to(torch.int64)
         tile = (8, 16, 32)[-nd:] if nd <= 3 else (8,) * nd
         key = torch.zeros(dpos.shape[0], dtype=torch.int64, device=be.device)
-        inner = torch.zeros_like(key)
         for d in range(nd):
-            n = int(self.Nmesh[d])
-            c = torch.remainder(cell[:, d], n)
-            nt = -(-n // tile[d])
-            key = key * nt + torch.div(c, tile[d], rounding_mode='floor')
-            inner = inner * tile[d] + torch.remainder(c, tile[d])
-        cells_per_tile = 1
-        for t in tile:
-            cells_per_tile *= t
-        return torch.argsort(key * cells_per_tile + inner, stable=True)
+            m = int(self.Nmesh[d])
+            key = key * (-(-m // tile[d])) + torch.div(torch.remainder(cell[:, d], m), tile[d], rounding_mode='floor')
+        return torch.argsort(key, stable=True)
 
     def decompose(self, pos, smoothing=None, transform=None):
         """

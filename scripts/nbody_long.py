@@ -57,6 +57,21 @@ def wrap(d):
     return torch.remainder(d + 0.5 * L, L) - 0.5 * L
 
 
+def stages(x):
+    """one force evaluation with the device drained between its stages (diagnostic, outside the timed steps): ms of
+    bin + paint, r2c, the three c2r, the readout"""
+    def timed(fn):
+        torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        return r, (time.perf_counter() - t) * 1e3
+    window.clear_bin_cache()
+    _, tb = timed(lambda: pm.resampler.prebin(pm.create('real').value, x, pm.affine))
+    rho, tp = timed(lambda: pm.paint(x))
+    rhok, tf = timed(lambda: rho.r2c(out=Ellipsis))
+    comps, tc = timed(lambda: [rhok.c2r(transfer=Transfer.force(d)) for d in range(3)])
+    _, tr = timed(lambda: pm.readout(comps, x))
+    return 'bin %.2f paint %.2f r2c %.2f 3 x c2r %.2f readout(3) %.2f' % (tb, tp, tf, tc, tr)
+
+
 for K in Ks:
     window.clear_bin_cache()
     q, x = initial()
@@ -89,6 +104,8 @@ for K in Ks:
             print('  steps %3d-%3d: %7.2f ms per step%s   rms displacement %5.2f cells, |v| rms %.3f cells/step, plans with the tile-ordered copy: %d'
                   % (s - 9, s, (t1 - t0) / 10 * 1e3, (' (of which re-sorting %.2f)' % (tsort / 10 * 1e3)) if K else '', disp,
                      float(v.pow(2).sum(dim=1).mean().sqrt()), sorted_plans), flush=True)
+            if os.environ.get('NBODY_STAGES'):
+                print('      stages: ' + stages(x), flush=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             tsort = 0.0

@@ -591,6 +591,44 @@ def test_tile_order(be):
     assert_allclose(a, b, rtol=0, atol=1e-12 * abs(a).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('resampler', ['cic', 'tsc', 'pcs'])
+def test_tile_order_from_the_bin_plan(resampler):
+    """[r6] on the GPU the permutation is read off the bin plan of the positions (pmx_binplan_order): a permutation,
+    tile-major in the plan's tiles (the tile of a particle's FIRST stencil cell), painting / reading the reordered rows
+    gives the same numbers, and the plan that was built for the order serves the paint that follows"""
+    from pmesh_amd import backend, window
+    backend.reset()
+    be = backend.get()
+    old = window.BINNED
+    try:
+        window.BINNED = 'always'
+        window.clear_bin_cache()
+        pm = ParticleMesh(BoxSize=64.0, Nmesh=[32, 64, 64], dtype='f8', resampler=resampler)
+        rs = numpy.random.RandomState(4)
+        pos_h = rs.uniform(-10, 80, size=(60000, 3))
+        pos = torch.from_numpy(pos_h).to(be.device)
+        o = pm.tile_order(pos)
+        assert o.dtype == torch.int64 and o.device == pos.device
+        oh = o.cpu().numpy()
+        assert numpy.array_equal(numpy.sort(oh), numpy.arange(len(pos_h)))
+        S = pm.resampler.support
+        first = numpy.floor(pos_h[oh] * (pm.Nmesh / pm.BoxSize) + (0.5 if S % 2 else 0.0)).astype('i8') - (S - 1) // 2
+        tile = (first % pm.Nmesh) // numpy.array([8, 16, 32])
+        tid = (tile[:, 0] * 4 + tile[:, 1]) * 2 + tile[:, 2]
+        assert (numpy.diff(tid) >= 0).all()
+        builds = window.bin_cache()
+        a = pm.paint(pos)
+        b = pm.paint(pos[o].contiguous())
+        assert_allclose(numpy.asarray(a), numpy.asarray(b), rtol=0, atol=1e-12 * abs(numpy.asarray(a)).max())
+        ra, rb = a.readout(pos), a.readout(pos[o].contiguous())
+        assert_allclose(numpy.asarray(ra.cpu())[oh], numpy.asarray(rb.cpu()), rtol=0, atol=1e-12)
+    finally:
+        window.BINNED = old
+        window.clear_bin_cache()
+        backend.reset()
+
+
 # ---- complex-to-complex meshes (ParticleMesh(dtype='c16' | 'c8')) ----------------------------
 
 def test_c2c(be):                             # test_pm.py:196-226
