@@ -1279,7 +1279,9 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     // the evolved state as its run left it 2.30 -> 3.18 ms with every crowded tile dealt, 2.3 with the sample deciding).
     constexpr int W = TTHREADS * UNROLL;
     bool deal = false;
-    if (PMX_DEAL_CROWDED && !sorted && (W & (W - 1)) == 0 && count >= g.deal_min) {      // (uniform per workgroup)
+    // (the floating-point regions only — NNB, CIC and the floating twins of the others: a ds_add_f64 pays most for lanes
+    // on one address; the fixed-point kernels of TSC / PCS have no registers to spare under their occupancy budgets)
+    if (PMX_DEAL_CROWDED && !FIXED && !sorted && (W & (W - 1)) == 0 && count >= g.deal_min) {      // (uniform per workgroup)
         __shared__ int deal_flag;
         if (threadIdx.x < 64) {
             const int64_t row = (int64_t)tl[count / 2 + (int)threadIdx.x];
@@ -1296,13 +1298,19 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
         __syncthreads();
         deal = deal_flag != 0;
     }
-    for (int jb = 0; jb < count; jb += W) {
+    // (kernels that cannot deal keep the loop of rounds 2-5 instruction for instruction: the fixed-point TSC kernel has
+    // not a register to spare under its six waves per SIMD)
+    constexpr bool CAN_DEAL = PMX_DEAL_CROWDED && !FIXED && !sorted && (W & (W - 1)) == 0;
+    for (int j0 = CAN_DEAL ? 0 : (int)threadIdx.x; j0 < count; j0 += W) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const int s = u * TTHREADS + (int)threadIdx.x;
-            const int j = jb + (deal ? ((s * 65) & (W - 1)) : s);
+            int j;
+            if constexpr (CAN_DEAL) {
+                const int s = u * TTHREADS + (int)threadIdx.x;
+                j = j0 + (deal ? ((s * 65) & (W - 1)) : s);
+            } else j = j0 + u * TTHREADS;
             idx[u] = j < count ? (sorted ? start + j : (int64_t)tl[j]) : -1;
         }
 #pragma unroll
