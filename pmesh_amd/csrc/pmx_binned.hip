@@ -1109,7 +1109,7 @@ __device__ __forceinline__ double uniform_double(double x)
 #define PMX_QUAD_PCS 1
 #endif
 #ifndef PMX_DEAL_CROWDED
-#define PMX_DEAL_CROWDED 1
+#define PMX_DEAL_CROWDED 0      // (an experiment: see tile_deposit)
 #endif
 #ifndef PMX_DEAL_SAME_OF_64
 #define PMX_DEAL_SAME_OF_64 24       // neighbouring entries of the sample that share their first cell, from which on the rows count as cell-ordered
@@ -1266,22 +1266,20 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
     // PCS 2.77 / 2.90, with the odd-lane swap on top 1.78 / 3.22.  The kernel is not waiting for those conflicts.)
     double sink = 0;
     const uint32_t *tl = list + start;       // (a wave-uniform base + the lane's entry: nothing per thread for the compiler to keep across tiles)
-    // [r6] Crowded tiles deal their entries: slot s of a trip of W takes entry (65 s) mod W.  Rows that arrive sorted by
-    // cell — a caller that keeps its particles in Peano-Hilbert or cell order, as tree codes do — put the particles of
-    // a crowded cell into neighbouring lanes, every lane of an instruction on ONE address: an evolved 512^3 state
-    // (scripts/clustered_state_probe.py) painted in 4.2 ms cell-sorted against 1.4 in random order.  With the deal a run
-    // of up to 65 particles of a cell sends one lane per instruction.  Tiles at the mean density of a uniform set keep
-    // the plain order (the lane deal measured nothing on the benchmark's lattice: round 4), as do the plans with the
-    // tile-ordered copy.
-    // Whether a crowded tile's rows ARE in cell order is looked up on 64 entries from the middle of its list: a wave
-    // compares the first stencil cells of neighbouring entries (rows that merely arrive in the order the particles were
-    // made in share cells too, but not as neighbours: dealt, they lose the locality of their gathers for nothing —
-    // the evolved state as its run left it 2.30 -> 3.18 ms with every crowded tile dealt, 2.3 with the sample deciding).
+#if PMX_DEAL_CROWDED
+    // [r6] (experiment builds only, -DPMX_DEAL_CROWDED=1) Crowded tiles deal their entries: slot s of a trip of W takes
+    // entry (65 s) mod W.  Rows that arrive sorted by cell — a caller that keeps its particles in Peano-Hilbert or cell
+    // order, as tree codes do — put the particles of a crowded cell into neighbouring lanes, every lane of an instruction
+    // on ONE address: an evolved 512^3 state (scripts/clustered_state_probe.py) painted in 4.2 ms cell-sorted against 1.4
+    // in random order, 2.2 with the deal.  Whether a crowded tile's rows ARE in cell order is looked up on 64 entries from
+    // the middle of its list (rows that merely arrive in the order the particles were made in lose the locality of
+    // their gathers for nothing when dealt: 2.30 -> 3.18 ms).  NOT in the product: the sample and the slots cost the CIC
+    // kernel 14 registers — 69 instead of 55, the fourth workgroup of a CU — and the benchmark's paint 7-12 %
+    // (scripts/r06/deal_ab.sh); pm.tile_order, which sorts by tile and NOT by cell, is the remedy a caller has.
     constexpr int W = TTHREADS * UNROLL;
+    constexpr bool CAN_DEAL = !FIXED && !sorted && (W & (W - 1)) == 0;
     bool deal = false;
-    // (the floating-point regions only — NNB, CIC and the floating twins of the others: a ds_add_f64 pays most for lanes
-    // on one address; the fixed-point kernels of TSC / PCS have no registers to spare under their occupancy budgets)
-    if (PMX_DEAL_CROWDED && !FIXED && !sorted && (W & (W - 1)) == 0 && count >= g.deal_min) {      // (uniform per workgroup)
+    if (CAN_DEAL && count >= g.deal_min) {      // (uniform per workgroup)
         __shared__ int deal_flag;
         if (threadIdx.x < 64) {
             const int64_t row = (int64_t)tl[count / 2 + (int)threadIdx.x];
@@ -1298,21 +1296,30 @@ __device__ __forceinline__ void tile_deposit(const pmx_painter &p, const BinGeom
         __syncthreads();
         deal = deal_flag != 0;
     }
-    // (kernels that cannot deal keep the loop of rounds 2-5 instruction for instruction: the fixed-point TSC kernel has
-    // not a register to spare under its six waves per SIMD)
-    constexpr bool CAN_DEAL = PMX_DEAL_CROWDED && !FIXED && !sorted && (W & (W - 1)) == 0;
-    for (int j0 = CAN_DEAL ? 0 : (int)threadIdx.x; j0 < count; j0 += W) {
+    int slot[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        const int s = u * TTHREADS + (int)threadIdx.x;
+        slot[u] = (CAN_DEAL && deal) ? ((s * 65) & (W - 1)) : s;
+    }
+    for (int j0 = 0; j0 < count; j0 += W) {
         int64_t idx[UNROLL];
         double x[UNROLL][3], m[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            int j;
-            if constexpr (CAN_DEAL) {
-                const int s = u * TTHREADS + (int)threadIdx.x;
-                j = j0 + (deal ? ((s * 65) & (W - 1)) : s);
-            } else j = j0 + u * TTHREADS;
+            const int j = j0 + slot[u];
             idx[u] = j < count ? (sorted ? start + j : (int64_t)tl[j]) : -1;
         }
+#else
+    for (int j0 = threadIdx.x; j0 < count; j0 += TTHREADS * UNROLL) {
+        int64_t idx[UNROLL];
+        double x[UNROLL][3], m[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            int j = j0 + u * TTHREADS;
+            idx[u] = j < count ? (sorted ? start + j : (int64_t)tl[j]) : -1;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             if (idx[u] >= 0) {
