@@ -37,6 +37,10 @@ def force(X, fused):
     # a column of an (n, 3) array is written in 8-byte pieces 24 bytes apart — every 64-byte piece of the array is read,
     # patched and written back by the memory system, 1.4 ms more per readout at 512^3 than a dense vector, whichever
     # kernel writes it (measured: scripts/r05/nbody_kstats.sh, 2.54 against 1.12 ms)
+    if fused == 3:
+        # [r6] the three components kept as fields and read by ONE launch into the rows of F (ParticleMesh.readout /
+        # pmx_readout_binned_multi): every row of F written once, the positions of a tile fetched once
+        return pm.readout([rhok.c2r(transfer=Transfer.force(d)) for d in range(3)], X, layout=None)
     F = torch.empty((3, len(X)), dtype=X.dtype, device=X.device).t() if fused == 2 else torch.empty_like(X)
     for d in range(3):
         # (the result goes straight into its column of the force array: readout's `out`, window.py:165-221)
@@ -47,7 +51,7 @@ def force(X, fused):
     return F
 
 
-for fused in (False, True, 2):
+for fused in (False, True, 2, 3):
     x, v = X.clone(), V.clone()
     F = force(x, fused)
 
@@ -69,5 +73,5 @@ for fused in (False, True, 2):
           % (st1['num_device_alloc'] - st0['num_device_alloc'], st1['num_device_free'] - st0['num_device_free'],
              st1['reserved_bytes.all.current'] / 1e9), flush=True)
     print('N=%d: %s: %.2f ms per step (one paint, one r2c, three c2r + readout; %d particles), |F| max %.3e'
-          % (N, ('fused Transfer.force on c2r' + (', force components contiguous' if fused == 2 else '')) if fused else "the caller's numpy-style force_transfer on device arrays",
+          % (N, ('fused Transfer.force on c2r' + (', force components contiguous' if fused == 2 else (', one readout of the three fields into (n, 3) rows' if fused == 3 else ''))) if fused else "the caller's numpy-style force_transfer on device arrays",
              ms, len(x), float(F.abs().max())), flush=True)
