@@ -58,7 +58,16 @@ namespace pmx {
 // its 256 rows with 16-byte-per-lane loads into LDS and every lane picks its row there.
 // slots reserved for a tile that held c particles: a quarter more plus a constant, so that the
 // next build of slowly moving particles can reuse the ranges (single pass, see bin_onepass)
-__host__ __device__ __forceinline__ int64_t slot_capacity(int64_t c) { return c + (c >> 2) + 64; }
+// slots a tile of c particles reserves for the single-pass rebuilds of the steps that follow.  level 0: a quarter + 64 of
+// slack; [r6] a plan whose rebuilds have overflowed reserves more (level 1: half + 256, level 2: as many again + 1024):
+// in a strongly clustered, fast-moving set SOME tile changes its population by more than a quarter in nearly every
+// step, and every such step pays the repair — a second pass over the rows (scripts/nbody_long.py, 200 steps: 9 builds
+// in 10 repaired late in the run; with the levels forced, steps 191-200 take 39.1 / 37.1 / 36.4 ms).  The list grows
+// from 1.25 to 2 entries of 4 bytes per particle; only the used entries are ever read.
+__host__ __device__ __forceinline__ int64_t slot_capacity(int64_t c, int level)
+{
+    return level <= 0 ? c + (c >> 2) + 64 : (level == 1 ? c + (c >> 1) + 256 : 2 * c + 1024);
+}
 
 // bucket of a particle at x: its tile (tiles in C order), or g.ntiles if it touches no local cell
 template <int KIND>
@@ -85,7 +94,7 @@ __device__ __forceinline__ int64_t particle_bucket(const pmx_painter &p, const B
 
 template <int NT>
 __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor,
-                                            uint32_t *zero);
+                                            uint32_t *zero, int level);
 
 // MODE 0: count pass of the two-pass build: tid[i] = tile, counts[tile]++.
 // MODE 1: single-pass build into the slot ranges of the previous build: the wave-aggregated
@@ -753,7 +762,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom
 
 template <int NT>
 __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor,
-                                            uint32_t *zero);
+                                            uint32_t *zero, int level);
 
 // [r5] The repair of a single pass that overflowed, for the rows the lean form takes.  The counts are exact (every
 // single-pass form adds before it looks at the range): a gated bin_scan_kernel lays the new ranges out from them and
@@ -775,7 +784,7 @@ __global__ void __launch_bounds__(TBLOCK) bin_repair_lean_kernel(pmx_painter p, 
 // exclusive scan of slot_capacity(counts) -> offsets[nbuckets+1]; one workgroup of NT threads
 template <int NT>
 __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntiles, int64_t *offsets, unsigned long long *cursor,
-                                            uint32_t *zero)
+                                            uint32_t *zero, int level)
 {
     __shared__ int64_t sh[NT];
     __shared__ int64_t carry;
@@ -783,7 +792,7 @@ __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntil
     __syncthreads();
     for (int64_t base = 0; base < ntiles; base += NT) {
         int64_t i = base + threadIdx.x;
-        int64_t v = i < ntiles ? slot_capacity(counts[i]) : 0;
+        int64_t v = i < ntiles ? slot_capacity(counts[i], level) : 0;
         if (zero != nullptr && i < ntiles) zero[i] = 0;       // (the counters start the pass that fills the ranges from 0)
         sh[threadIdx.x] = v;
         __syncthreads();
@@ -806,10 +815,10 @@ __device__ __forceinline__ void scan_ranges(const uint32_t *counts, int64_t ntil
 }
 
 static __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *counts, int64_t ntiles, int64_t *offsets,
-                                                        unsigned long long *cursor, const uint32_t *gate, uint32_t *zero = nullptr)
+                                                        unsigned long long *cursor, const uint32_t *gate, uint32_t *zero, int level)
 {
     if (gate != nullptr && *gate == 0) return;
-    scan_ranges<1024>(counts, ntiles, offsets, cursor, zero);
+    scan_ranges<1024>(counts, ntiles, offsets, cursor, zero, level);
 }
 
 static __global__ void __launch_bounds__(TBLOCK) bin_scatter_kernel(const int32_t *tid, unsigned long long *cursor, int64_t n,
@@ -2902,6 +2911,11 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             pl->seen_overflows = seen;
             pl->distrust = pl->distrust ? (pl->distrust < 64 ? 2 * pl->distrust : 64) : 1;
             pl->skip = pl->distrust;
+            // [r6] ... and the ranges of the builds that follow carry more slack (slot_capacity).  (The back-off above is a
+            // host-side hint: a caller that runs ten steps ahead of the device sees the flag ten steps late and the
+            // distrust never builds up; the slack, raised once, stays.)  PMX_SLACK_ADAPT=0: the fixed quarter.
+            static const bool adapt = [] { const char *e = getenv("PMX_SLACK_ADAPT"); return !(e && atoi(e) == 0); }();
+            if (adapt && pl->slack < 2) pl->slack++;
         } else if (pl->last_reuse && pl->distrust > 0) {
             // the previous single-pass build raised no flag (as far as the host has seen): trust returns
             // step by step, so that one overflow late in a long run does not cost 64 two-pass builds
@@ -2918,12 +2932,14 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
     pl->built = false;
     const int64_t nbuckets = g.ntiles + 1;            // + the bucket of particles in no tile
     size_t np1 = (size_t)(npart > 0 ? npart : 1);
-    // every bucket reserves slot_capacity(count) <= 1.25 count + 64 slots
-    size_t nlist = np1 + np1 / 4 + 64 * (size_t)nbuckets + 64;
+    // every bucket reserves slot_capacity(count, slack) slots: <= 1.25 count + 64 (1.5 count + 256, 2 count + 1024)
+    auto list_entries = [&](size_t np) { return (size_t)slot_capacity((int64_t)np, pl->slack) - (size_t)slot_capacity(0, pl->slack)
+                                                + (size_t)slot_capacity(0, pl->slack) * (size_t)nbuckets + 64; };
+    size_t nlist = list_entries(np1);
     if (np1 * 4 > pl->cap_part || nlist > pl->cap_list) {
         // (an eighth of room to grow: a count that creeps up does not reallocate — and start over — every step)
         const size_t npa = np1 + np1 / 8;
-        const size_t nla = npa + npa / 4 + 64 * (size_t)nbuckets + 64;
+        const size_t nla = list_entries(npa);
         size_t c1 = 0, c3 = 0;
         if (pl->tid) (void)hipFree(pl->tid);
         if (pl->list) (void)hipFree(pl->list);
@@ -3077,7 +3093,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
             // ([r6] two launches, both returning at once unless a tile overflowed: the scan of the exact counts into
             // new ranges as a workgroup of its own — the stream orders it before the fill; no workgroup waits for another)
             const bool lean_repair = inv == nullptr && pl->form != 2 && dense && PMX_LEAN_BIN && PMX_REPAIR_GRID > 0;
-            bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles + 1, pl->offsets, pl->cursor, gate, lean_repair ? pl->counts : nullptr);
+            bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, g.ntiles + 1, pl->offsets, pl->cursor, gate, lean_repair ? pl->counts : nullptr, pl->slack);
             if (lean_repair) block_pass(pl->list, gate);
             else BCK(3, small_grid, gate);
         } else {
@@ -3122,14 +3138,14 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                 inv = pl->inv;
             }
             if (lean2 && !want) {
-                bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate, pl->counts);
+                bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate, pl->counts, pl->slack);
                 block_pass(pl->list);
             } else {
                 if (lean2) {
                     PMX_HIP_CHECK(hipMemsetAsync(pl->counts, 0, (size_t)nbuckets * 4, st));
                     BCK(0, full_grid, nogate);
                 }
-                bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate);
+                bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nogate, nullptr, pl->slack);
                 bin_scatter_kernel<<<full_grid, TBLOCK, 0, st>>>(pl->tid, pl->cursor, npart, pl->list, nogate, inv);
             }
         }
@@ -3151,7 +3167,7 @@ extern "C" int pmx_binplan_build(pmx_binplan *pl, const pmx_painter *p_, const p
                 sort_copy_kernel<3><<<cgrid, TBLOCK, 0, st>>>(pl->list, pl->offsets, pl->counts, nbuckets, dpos, (uint32_t *)pl->pos_copy, copy_gate);
         }
     } else {
-        bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nullptr);
+        bin_scan_kernel<<<1, 1024, 0, st>>>(pl->counts, nbuckets, pl->offsets, pl->cursor, nullptr, nullptr, pl->slack);
     }
     if (npart > 0)
         heavy_items_kernel<<<grid_for(g.ntiles, TBLOCK, 1024), TBLOCK, 0, st>>>(pl->counts, g.ntiles, g.chunk, pl->heavy_items,

@@ -190,6 +190,7 @@ struct pmx_binplan {
     bool have_history = false;
     uint32_t seen_overflows = 0;
     int distrust = 0, skip = 0;  // back-off after an overflow
+    int slack = 0;               // [r6] how much room the slot ranges carry (slot_capacity): raised when a single-pass rebuild has overflowed
     bool last_reuse = false;     // the previous build was a single-pass (history) build
     uint32_t builds[2] = {0, 0}; // builds of this plan so far: single pass into the previous ranges / two passes (pmx_binplan_builds)
 };

@@ -101,9 +101,15 @@ for K in Ks:
             t1 = time.perf_counter()
             disp = float(wrap(x - q).pow(2).sum(dim=1).mean().sqrt())
             sorted_plans = window.bin_cache().sorted_plans(be)
-            print('  steps %3d-%3d: %7.2f ms per step%s   rms displacement %5.2f cells, |v| rms %.3f cells/step, plans with the tile-ordered copy: %d'
+            overflows = window.bin_cache().overflows(be)
+            single = two = 0
+            for e in window.bin_cache().entries:
+                a, b = C.c_uint32(0), C.c_uint32(0)
+                be.call('binplan_builds', e[1], C.byref(a), C.byref(b))
+                single, two = single + a.value, two + b.value
+            print('  steps %3d-%3d: %7.2f ms per step%s   rms displacement %5.2f cells, |v| rms %.3f cells/step, plans with the tile-ordered copy: %d, plan builds so far: %d in one pass (%d of them repaired), %d in two, %.1f GB reserved'
                   % (s - 9, s, (t1 - t0) / 10 * 1e3, (' (of which re-sorting %.2f)' % (tsort / 10 * 1e3)) if K else '', disp,
-                     float(v.pow(2).sum(dim=1).mean().sqrt()), sorted_plans), flush=True)
+                     float(v.pow(2).sum(dim=1).mean().sqrt()), sorted_plans, single, overflows, two, torch.cuda.memory_reserved() / 1e9), flush=True)
             if os.environ.get('NBODY_STAGES'):
                 print('      stages: ' + stages(x), flush=True)
             torch.cuda.synchronize()
