@@ -1110,6 +1110,41 @@ def case_mesh_of_four_dimensions(be, comm):
         ParticleMesh(BoxSize=4.0, Nmesh=[4, 4, 4, 4, 4], comm=comm, dtype='f8')
 
 
+def case_tile_order_on_rank_blocks(be, comm):
+    """[r6] ParticleMesh.tile_order on a rank's block (slabs and pencils): a permutation of the rank's rows — on the GPU
+    read off the bin plan of the block, rows that touch no local cell last — and painting / reading the re-sorted rows
+    through a layout gives what the rows gave as they were"""
+    from pmesh_amd import window as W
+    from pmesh_amd.pm import ParticleMesh
+    N, L = (64, 32, 64), 50.0
+    rs = numpy.random.RandomState(60 + comm.rank)
+    pos_h = rs.uniform(-5.0, 55.0, size=(40000 + 500 * comm.rank, 3))
+    old = (W.BINNED, W.BINNED_MIN_PARTICLES)
+    try:
+        comm.Barrier()
+        W.BINNED, W.BINNED_MIN_PARTICLES = 'auto', 1000
+        comm.Barrier()
+        for np_ in ([comm.size], None):
+            pm = ParticleMesh(BoxSize=L, Nmesh=N, comm=comm, dtype='f8', resampler='tsc', np=np_)
+            pos = torch.from_numpy(pos_h).to(be.device)
+            o = pm.tile_order(pos)
+            oh = o.cpu().numpy()
+            assert oh.dtype == numpy.int64 and numpy.array_equal(numpy.sort(oh), numpy.arange(len(pos_h)))
+            a = pm.paint(pos, layout=pm.decompose(pos))
+            ps = pos[o].contiguous()
+            lay = pm.decompose(ps)
+            b = pm.paint(ps, layout=lay)
+            av, bv = numpy.asarray(a), numpy.asarray(b)
+            assert float(abs(av - bv).max()) <= 1e-12 * max(1.0, float(abs(av).max())) if av.size else True
+            ra = numpy.asarray(a.readout(pos, layout=pm.decompose(pos)).cpu())
+            rb = numpy.asarray(a.readout(ps, layout=lay).cpu())
+            assert float(abs(ra[oh] - rb).max()) <= 1e-12 * max(1.0, float(abs(ra).max()))
+    finally:
+        comm.Barrier()
+        W.BINNED, W.BINNED_MIN_PARTICLES = old
+        W.clear_bin_cache()
+
+
 class pytest_raises(object):
     """(the cases also run outside pytest: python tests/mp_cases.py under torch.distributed.run)"""
     def __init__(self, exc):
@@ -1123,7 +1158,7 @@ class pytest_raises(object):
         return True
 
 
-CASES = [case_mesh_of_four_dimensions, case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
+CASES = [case_mesh_of_four_dimensions, case_tile_order_on_rank_blocks, case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
          case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial, case_halo_merge_left_to_the_slab_row_pass,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_uneven_blocks_decide_alike, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
