@@ -433,6 +433,19 @@ int pmx_colfft_to(int32_t elsize, int32_t inverse, const void *src, void *dst, i
                   double scale, const pmx_transfer *transfer, int64_t n1, int64_t n2, const int64_t *start,
                   const int64_t *nmesh, const double *boxsize, int64_t a_stride, int64_t n_stride, void *stream);
 
+/* [r6] The row pass of a pencil transform (PFFT's 2-d process mesh, pm.py:1417-1434) with the last-axis split of its
+ * first global transpose on it: inverse = 0: src = nrows rows of n reals (row pitch `pitch` complex elements) -> dst =
+ * the n/2 + 1 modes of every row in nparts blocks, block q = the modes [offsets[q], offsets[q + 1]) of all rows as one
+ * dense (nrows, offsets[q + 1] - offsets[q]) array at element nrows * offsets[q] — the send buffer of the all-to-all
+ * over the row group; inverse = 1: src = those blocks (the receive buffer) -> dst = rows of n reals.  Out of place.
+ * Replaces the pmx_slab_pack / pmx_slab_unpack sweep (n0 = nrows, n1 = n/2 + 1, n2 = 1) next to pmx_rowfft; same
+ * values.  Built for the power-of-two rows pmx_rowfft_halo_supported names and nparts <= PMX_MAXSEG (offsets: host,
+ * nparts + 1 entries from 0 to n/2 + 1, not decreasing — empty blocks are allowed). */
+#define PMX_MAXSEG 16
+int pmx_rowfft_split_supported(int64_t n, int32_t elsize, int32_t nparts);
+int pmx_rowfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t nrows, int64_t n,
+                     int64_t pitch, double scale, const int64_t *offsets, int32_t nparts, void *stream);
+
 /* Local transpose next to the all-to-all of a distributed FFT (PFFT's global transpose).
  * pmx_slab_pack  : src (n0, n1, n2) C order -> nparts contiguous blocks, block r = (n0,
  *                  n1 range [n1_offsets[r], n1_offsets[r+1]), n2): the send buffer of an

@@ -11,6 +11,7 @@ import ctypes as C
 PMX_MAXDIM = 3
 PMX_MAXRANKS = 64
 PMX_MAXFIELDS = 4
+PMX_MAXSEG = 16
 
 PMX_OK, PMX_EINVAL, PMX_EUNSUPPORTED, PMX_EHIP, PMX_EFFT, PMX_ENOMEM = range(6)
 STATUS_NAMES = {0: 'PMX_OK', 1: 'PMX_EINVAL', 2: 'PMX_EUNSUPPORTED', 3: 'PMX_EHIP',
@@ -132,6 +133,8 @@ DEVICE_ONLY = {
     'rowfft_halo_supported': (C.c_int, [_i64, _i32]),
     'rowfft_halo': (C.c_int, [_i32, _vp, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp, _vp, _i64, _i32, _vp]),
     'rowfft_to': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _f64, _i64, _i64, _vp]),
+    'rowfft_split_supported': (C.c_int, [_i64, _i32, _i32]),
+    'rowfft_split': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _f64, _P(_i64), _i32, _vp]),
     'colfft_to': (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _f64, _P(Transfer), _i64, _i64, _P(_i64),
                             _P(_i64), _P(_f64), _i64, _i64, _vp]),
     'fft_create': (C.c_int, [_P(_vp), _i32, _i32, _i32, _P(_i64), _P(_i64), _i64, _P(_i64), _i64,

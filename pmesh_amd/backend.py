@@ -189,6 +189,15 @@ class HipBackend(object):
                   int(a_stride), int(n_stride), self.stream())
 
     # -- slab transposes --------------------------------------------------
+    def rowfft_split_supported(self, n, elsize, nparts):
+        return self.lib.pmx_rowfft_split_supported(int(n), int(elsize), int(nparts)) == 0
+
+    def rowfft_split(self, elsize, inverse, src, dst, nrows, n, pitch, offsets, scale=1.0):
+        """the row pass with the last-axis split of a pencil transform's first transpose on it (forward: rows ->
+        blocks by mode range; inverse: blocks -> rows); out of place"""
+        self.call('rowfft_split', elsize, int(bool(inverse)), src.data_ptr(), dst.data_ptr(), nrows, n, pitch, float(scale),
+                  _abi.i64arr(offsets), len(offsets) - 1, self.stream())
+
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
         """(n0, n1, n2) -> blocks by n1 range (inverse: blocks -> (n0, n1, n2))"""
         self.call('slab_unpack' if inverse else 'slab_pack', src.data_ptr(), dst.data_ptr(), n0, n1, n2,

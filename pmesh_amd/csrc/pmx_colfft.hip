@@ -1033,6 +1033,16 @@ struct HaloSrc {
     int x0;                // plane of row 0 of this launch
 };
 
+// [r6] The last-axis split of a pencil transform's first transpose on the row pass itself (pmx_rowfft_split): the
+// modes 0 .. M of every row cut into n ranges [e[q], e[q + 1]), range q of all rows one dense (nrows, e[q + 1] - e[q])
+// array at element nrows * e[q] — the send buffer of the all-to-all over the row group (what pmx_slab_pack makes of the
+// (nrows, M + 1) block in a sweep of its own).  Forward passes write that layout, inverse passes read it.
+struct RowSeg {
+    int n;                      // ranges (<= PMX_MAXSEG)
+    int last;                   // e[n - 1]: the range the Nyquist mode M lies in starts here
+    int e[PMX_MAXSEG + 1];
+};
+
 // One thread's LPT elements: column n (cells 2n, 2n + 1) of the rows yb, yb + RSTEP, ... of plane x, all inside one tile
 // row (a workgroup's rows start at a multiple of their count, which divides T1); `sink(u, a0, a1)` adds to element u —
 // the row's own elements, still on their way: they are only touched when a batch of staged values has arrived.  Two batches — the staged cells of this lane's own
@@ -1162,11 +1172,13 @@ template <typename T, int LOGM, int RB> struct RowHalfTw {
     static constexpr bool value = PMX_ROW_HALFTW && LOGM < 16 && full > 80 * 1024 && half <= 80 * 1024;
 };
 
-template <typename T, int LOGM, bool INV, int RB, bool HALO = false>
+template <typename T, int LOGM, bool INV, int RB, bool HALO = false, bool SEG = false>
 __global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)), (RowHalfTw<T, LOGM, RB>::value ? 4 : 1))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
-              int64_t rpp, int64_t plane_extra, HaloSrc hs, cpx<T> *dst_)
+              int64_t rpp, int64_t plane_extra, HaloSrc hs, cpx<T> *dst_, RowSeg seg)
 {
+    // SEG: the complex side of the pass is the split layout of RowSeg (forward: dst_, inverse: data_), dense rows
+    // without planes; the other side is laid out as always
     // dst_: where the rows are written (the same layout as data_); nullptr: in place
     // (measured and taken out again: the same gather in the 3 * 2^k / 5 * 2^k kernels — parity-green, and slower than the
     // merge kernel it replaces: 384^3 2.56 -> 2.65 ms per cycle, 768^3 20.5 -> 20.9; their row passes pay more for the
@@ -1177,6 +1189,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
     constexpr int LPT = PMX_ROW_LPT;   // row elements per thread
     constexpr int TPC = M / LPT;
     constexpr int NT = TPC * W;
+    static_assert(!SEG || (LOGM < 16 && NT % M == 0 && !HALO), "the split layout rides on the power-of-two rows whose threads keep one position");
     extern __shared__ __align__(16) unsigned char smem[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
     constexpr bool HT = RowHalfTw<T, LOGM, RB>::value;
@@ -1215,6 +1228,23 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             const bool full = r0 + W <= nrows;                 // all but (at most) the last tile
             cpx<T> *gthread = data + ((r0 + rt) * pitch + n);
             cpx<T> *gstore = dout + ((r0 + rt) * pitch + n);
+            // strides between a thread's successive rows, elements: uniform but on the split side, where the range the
+            // thread's position lies in decides
+            int64_t ldstep = (int64_t)RSTEP * pitch, ststep = (int64_t)RSTEP * pitch;
+            if constexpr (SEG) {
+                int eq = 0, eq1 = seg.e[1];
+#pragma unroll
+                for (int s = 1; s < PMX_MAXSEG; s++)
+                    if (s < seg.n && n >= seg.e[s]) { eq = seg.e[s]; eq1 = seg.e[s + 1]; }
+                const int wq = eq1 - eq;
+                const int64_t at0 = nrows * eq + (r0 + rt) * wq + (n - eq);
+                if (INV) { gthread = data_ + at0; ldstep = (int64_t)RSTEP * wq; }
+                else { gstore = dst_ + at0; ststep = (int64_t)RSTEP * wq; }
+            }
+            // the Nyquist mode of row r on the split side
+            auto nyquist = [&](int64_t r) __attribute__((always_inline)) {
+                return nrows * seg.last + r * (int64_t)(M + 1 - seg.last) + (M - seg.last);
+            };
             const RowBase<T, RB> nb_ = row_base<T, RB>(n, 0);
             auto at = [&](const RowBase<T, RB> &b, int r) __attribute__((always_inline)) {
                 return b.e[0] + ((b.cr + r) & (W - 1));
@@ -1224,13 +1254,16 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             for (int u = 0; u < LPT; u++) ld[u] = cpx<T>{0, 0};
             if (full) {
 #pragma unroll
-                for (int u = 0; u < LPT; u++) ld[u] = gthread[(int64_t)(u * RSTEP) * pitch];
+                for (int u = 0; u < LPT; u++) ld[u] = gthread[u * ldstep];
             } else {
 #pragma unroll
                 for (int u = 0; u < LPT; u++)
-                    if (r0 + rt + u * RSTEP < nrows) ld[u] = gthread[(int64_t)(u * RSTEP) * pitch];
+                    if (r0 + rt + u * RSTEP < nrows) ld[u] = gthread[u * ldstep];
             }
-            if (INV && tid < W) xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
+            if (INV && tid < W) {
+                if constexpr (SEG) xm[tid] = (r0 + tid < nrows) ? data_[nyquist(r0 + tid)] : cpx<T>{0, 0};
+                else xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
+            }
             if constexpr (HALO) {
                 // rows r0 .. r0 + W - 1 lie in one plane and one tile row (rpp is a multiple of W, W divides T1; whole
                 // planes: every tile is full): x is the workgroup's, y the row's
@@ -1310,16 +1343,17 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 for (int u = 0; u < LPT; u++) {
                     const int r = rt + u * RSTEP;
                     cpx<T> X = mode(buf[at(nb_, r)], buf[at(bq, r)], w);
-                    if (full || r0 + r < nrows) gstore[(int64_t)(u * RSTEP) * pitch] = X;
+                    if (full || r0 + r < nrows) gstore[u * ststep] = X;
                 }
                 constexpr int LINE = 128 / (int)sizeof(cpx<T>);
-                const int tail = (pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
+                const int tail = (!SEG && pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
                 const RowBase<T, RB> b0 = row_base<T, RB>(0, 0);
                 for (int q = tid; q < W * tail; q += NT) {
                     const int r = q / tail, j = q - r * tail;
                     if (r0 + r < nrows) {
                         cpx<T> z0 = buf[at(b0, r)];
-                        dout[(r0 + r) * pitch + M + j] = (j == 0) ? mode(z0, z0, cpx<T>{(T)-1, (T)0}) : cpx<T>{(T)0, (T)0};
+                        if constexpr (SEG) dst_[nyquist(r0 + r)] = mode(z0, z0, cpx<T>{(T)-1, (T)0});
+                        else dout[(r0 + r) * pitch + M + j] = (j == 0) ? mode(z0, z0, cpx<T>{(T)-1, (T)0}) : cpx<T>{(T)0, (T)0};
                     }
                 }
             } else {
@@ -1328,7 +1362,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                     const int r = rt + u * RSTEP;
                     cpx<T> v = buf[at(nb_, r)];
                     v.x *= sc; v.y *= sc;
-                    if (full || r0 + r < nrows) gstore[(int64_t)(u * RSTEP) * pitch] = v;
+                    if (full || r0 + r < nrows) gstore[u * ststep] = v;
                 }
             }
             continue;
@@ -1630,7 +1664,8 @@ template int dispatch_logn<float>(const ColGeom &, const void *, void *, const v
 
 template <typename T, int LOGM, int RB = 128>
 static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale, const void *tw, bool inverse,
-                         int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo = nullptr, void *dst = nullptr)
+                         int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo = nullptr, void *dst = nullptr,
+                         const RowSeg *seg = nullptr)
 {
     constexpr int M = Len<LOGM>::N;
     constexpr int W = RB / (int)sizeof(cpx<T>);
@@ -1641,12 +1676,30 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 row tiles in one pass");
     unsigned grid = (unsigned)((PMX_ROW_ONE_TILE && M < 512) ? tiles : (tiles < 256 * 64 ? tiles : 256 * 64));
     const HaloSrc none = {nullptr, 0, 0, 0, 0, 0};
-    if (halo) {
+    RowSeg noseg;
+    noseg.n = 0;
+    if (seg) {
+        if constexpr (LOGM < 16 && NT % M == 0) {
+            PMX_REQUIRE(!halo && dst != nullptr && dst != data, PMX_EINVAL, "the split row pass works out of place");
+            if (inverse) {
+                auto k = rowfft_kernel<T, LOGM, true, RB, false, true>;
+                PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst, *seg);
+            } else {
+                auto k = rowfft_kernel<T, LOGM, false, RB, false, true>;
+                PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst, *seg);
+            }
+        } else {
+            set_error("pmx_rowfft_split: row length not built");
+            return PMX_EUNSUPPORTED;
+        }
+    } else if (halo) {
         if constexpr (LOGM < 16 && NT % M == 0) {
             PMX_REQUIRE(!inverse && rpp > 0, PMX_EINVAL, "the halo gather rides on the forward pass over whole planes");
             auto k = rowfft_kernel<T, LOGM, false, RB, true>;
             PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, *halo, (cpx<T> *)dst);
+            k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, *halo, (cpx<T> *)dst, noseg);
         } else {
             set_error("pmx_rowfft_halo: row length not built");
             return PMX_EUNSUPPORTED;
@@ -1654,11 +1707,11 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     } else if (inverse) {
         auto k = rowfft_kernel<T, LOGM, true, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst, noseg);
     } else {
         auto k = rowfft_kernel<T, LOGM, false, RB>;
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst);
+        k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst, noseg);
     }
     PMX_HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -1666,30 +1719,31 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
 
 template <typename T>
 PMX_DISPATCH int dispatch_logm(int logm, void *data, int64_t nrows, int64_t pitch, double scale, const void *tw,
-                         bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo, void *dst)
+                         bool inverse, int64_t rpp, int64_t plane_extra, hipStream_t st, const HaloSrc *halo, void *dst,
+                         const RowSeg *seg)
 {
     switch (logm) {
-    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
-    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
-    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
-    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
+    case 6: return launch_rowfft<T, 6>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst, seg);
+    case 7: return launch_rowfft<T, 7>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst, seg);
+    case 8: return launch_rowfft<T, 8>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst, seg);
+    case 9: return launch_rowfft<T, 9>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst, seg);
     // 2048 reals: 64-byte tile rows (8 float / 4 double rows per workgroup) keep 1024 / 512 threads
-    case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst);
+    case 10: return launch_rowfft<T, 10, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, halo, dst, seg);
     // n = 384, 768, 1536 reals: M = 192, 384, 768
-    case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
-    case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
-    case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
+    case 22: return launch_rowfft<T, 22>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst, seg);
+    case 23: return launch_rowfft<T, 23>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst, seg);
+    case 24: return launch_rowfft<T, 24, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst, seg);
     // n = 640, 1280 reals: M = 320, 640
-    case 38: return launch_rowfft<T, 38>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
-    case 39: return launch_rowfft<T, 39, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst);
+    case 38: return launch_rowfft<T, 38>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst, seg);
+    case 39: return launch_rowfft<T, 39, 64>(data, nrows, pitch, scale, tw, inverse, rpp, plane_extra, st, nullptr, dst, seg);
     }
     set_error("pmx_rowfft: length code %d is not built", logm);
     return PMX_EUNSUPPORTED;
 }
 #if PMX_COLFFT_PART == 1
-extern template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *, void *);
+extern template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *, void *, const RowSeg *);
 #elif PMX_COLFFT_PART == 2
-template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *, void *);
+template int dispatch_logm<float>(int, void *, int64_t, int64_t, double, const void *, bool, int64_t, int64_t, hipStream_t, const HaloSrc *, void *, const RowSeg *);
 #endif
 
 }  // namespace pmx
@@ -1735,8 +1789,8 @@ static int rowfft_any(int32_t elsize, int32_t inverse, void *data, void *dst, in
     int logm = length_code(n / 2);
     if (dst == data) dst = nullptr;
     if (elsize == 8)
-        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr, dst);
-    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr, dst);
+        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr, dst, nullptr);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, inverse != 0, rows_per_plane, plane_extra, st, nullptr, dst, nullptr);
 }
 
 extern "C" int pmx_rowfft(int32_t elsize, int32_t inverse, void *data, int64_t nrows, int64_t n, int64_t pitch,
@@ -1798,8 +1852,53 @@ extern "C" int pmx_rowfft_halo(int32_t elsize, void *data, void *dst, int64_t nr
     if (rc) return rc;
     int logm = length_code(n / 2);
     if (elsize == 8)
-        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs, dst);
-    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs, dst);
+        return dispatch_logm<double>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs, dst, nullptr);
+    return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs, dst, nullptr);
+}
+
+// [r6] PMX_OK if pmx_rowfft_split is built for rows of n reals cut into nparts ranges: the power-of-two rows whose
+// threads keep one position along the row (as pmx_rowfft_halo), at most PMX_MAXSEG ranges
+extern "C" int pmx_rowfft_split_supported(int64_t n, int32_t elsize, int32_t nparts)
+{
+    int rc = pmx_rowfft_halo_supported(n, elsize);
+    if (rc) return rc;
+    return (nparts >= 1 && nparts <= PMX_MAXSEG) ? PMX_OK : PMX_EUNSUPPORTED;
+}
+
+// The row pass of a pencil transform with the last-axis split of its first global transpose on it (RowSeg above):
+// inverse = 0: src = nrows rows of n reals (row pitch `pitch` complex elements) -> dst = the n/2 + 1 modes of every row
+// in nparts blocks, block q = the modes [offsets[q], offsets[q + 1]) of all rows, dense, at element nrows * offsets[q];
+// inverse = 1: src = those blocks -> dst = rows of n reals.  Out of place.  What pmx_rowfft + pmx_slab_pack (n0 = nrows,
+// n1 = n/2 + 1, n2 = 1) make in two sweeps.
+extern "C" int pmx_rowfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t nrows, int64_t n,
+                                int64_t pitch, double scale, const int64_t *offsets, int32_t nparts, void *stream)
+{
+    int rc = pmx_rowfft_split_supported(n, elsize, nparts);
+    if (rc) { set_error("pmx_rowfft_split: rows of %lld reals in %d ranges are not built", (long long)n, (int)nparts); return rc; }
+    PMX_REQUIRE(src != nullptr && dst != nullptr && src != dst && nrows >= 0 && pitch >= n / 2 + 1, PMX_EINVAL, "bad arguments");
+    PMX_REQUIRE(offsets != nullptr && offsets[0] == 0 && offsets[nparts] == n / 2 + 1, PMX_EINVAL,
+                "offsets must run from 0 to n/2 + 1");
+    // (the kernel indexes rows of the blocks with 32-bit widths times 64-bit rows: nothing to bound here)
+    RowSeg seg;
+    seg.n = nparts;
+    for (int q = 0; q <= PMX_MAXSEG; q++) seg.e[q] = (int)(n / 2 + 1);
+    for (int q = 0; q <= nparts; q++) {
+        PMX_REQUIRE(q == 0 || offsets[q] >= offsets[q - 1], PMX_EINVAL, "offsets must not decrease");
+        seg.e[q] = (int)offsets[q];
+    }
+    // the range that holds the Nyquist mode: the last one that is not empty
+    seg.last = 0;
+    for (int q = 0; q < nparts; q++)
+        if (offsets[q + 1] > offsets[q]) seg.last = (int)offsets[q];
+    if (nrows == 0) return PMX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    void *tw = nullptr;
+    rc = get_twiddles((int)n, elsize, &tw, st);
+    if (rc) return rc;
+    int logm = length_code(n / 2);
+    if (elsize == 8)
+        return dispatch_logm<double>(logm, (void *)src, nrows, pitch, scale, tw, inverse != 0, 0, 0, st, nullptr, dst, &seg);
+    return dispatch_logm<float>(logm, (void *)src, nrows, pitch, scale, tw, inverse != 0, 0, 0, st, nullptr, dst, &seg);
 }
 #endif
 

@@ -351,6 +351,9 @@ def _c_strides(shape):
 #: cast, apply with a callable ...) runs the deferred pass then (`settle`): the values are those of the eager
 #: transform either way, bit for bit.  One rank, the LDS column kernels (Plan._execute_local_hybrid).
 DEFER_LAST_PASS = os.environ.get('PMESH_AMD_DEFER_LAST_PASS', '1') not in ('0', '', 'false')
+# pencil transforms: the last-axis split of the first transpose rides on the row pass (pmx_rowfft_split); 0 = the row
+# pass and pmx_slab_pack as two sweeps (A/B and the parity tests)
+ROW_SPLIT = os.environ.get('PMESH_AMD_ROW_SPLIT', '1') not in ('0', '', 'false')
 
 
 class _Pending(object):
@@ -598,24 +601,31 @@ class Plan(object):
                  all(e1i[q + 1] - e1i[q] == n1l for q in range(P1)) and
                  all(e1o[q + 1] - e1o[q] == m1 for q in range(P0)))
         planes = None if c2c else self._plane_chunks(p, rowc, colc, fuse1, n0l, N0, P0)
+        # the last-axis split on the row pass itself (pmx_rowfft_split: rows -> the blocks of the first transpose and
+        # back, no pack sweep and no copy of an input the caller keeps)
+        split = (not c2c and ROW_SPLIT and COLFFT != 'never' and hasattr(be, 'rowfft_split') and
+                 be.rowfft_split_supported(N2, self.elsize, P1))
         if planes:
             return self._execute_pencil_pipelined(be, bufin, bufout, transfer, planes, same, rowc, colc,
-                                                  N0, N1, N2, N2c, n0l, n1l, m1, m2, e2o, e0i, norm, W0, W1, W2)
+                                                  N0, N1, N2, N2c, n0l, n1l, m1, m2, e2o, e0i, norm, W0, W1, W2, split)
         if self.forward:
-            X = bufin.storage
-            if not same:
-                nreal = n0l * n1l * 2 * N2c
-                W0[:nreal].copy_(bufin.storage[:nreal])
-                X = W0
-            row(X, n0l * n1l, False)
-            be.slab_pack(X, W1, n0l * n1l, N2c, 1, e2o, elb)                 # split the last axis
+            if split:
+                be.rowfft_split(self.elsize, False, bufin.storage, W1, n0l * n1l, N2, N2c, e2o)
+            else:
+                X = bufin.storage
+                if not same:
+                    nreal = n0l * n1l * 2 * N2c
+                    W0[:nreal].copy_(bufin.storage[:nreal])
+                    X = W0
+                row(X, n0l * n1l, False)
+                be.slab_pack(X, W1, n0l * n1l, N2c, 1, e2o, elb)                 # split the last axis
             rowc.alltoall(W1[:sum(s1)], W2[:sum(r1)], s1, r1)
             if fuse1:
                 # unpack, axis-1 pass and pack in one kernel: split by P1 in, split by P0 out
                 if n0l and m2:
                     be.colfft_resplit(self.elsize, False, W2, W1, n0l, N1, m2, n1l, m1)
             else:
-                Y = X if X is W0 else W0
+                Y = W0
                 be.slab_pack(W2, Y, n0l, N1, m2, e1i, elb, inverse=True)    # blocks -> (n0l, N1, m2)
                 self._col(be, Y, n0l, N1, m2, False)
                 be.slab_pack(Y, W1, n0l, N1, m2, e1o, elb)                  # split axis 1 by P0
@@ -637,11 +647,14 @@ class Plan(object):
                 be.slab_pack(W1, Y, n0l, N1, m2, e1o, elb, inverse=True)
                 self._col(be, Y, n0l, N1, m2, True)
                 be.slab_pack(Y, W1, n0l, N1, m2, e1i, elb)
-            Z = S if S is W0 else W0
+            Z = W0
             rowc.alltoall(W1[:sum(r1)], Z[:sum(s1)], r1, s1)
             out = bufout.storage
-            be.slab_pack(Z, out, n0l * n1l, N2c, 1, e2o, elb, inverse=True)
-            row(out, n0l * n1l, True)
+            if split:
+                be.rowfft_split(self.elsize, True, Z, out, n0l * n1l, N2, N2c, e2o)
+            else:
+                be.slab_pack(Z, out, n0l * n1l, N2c, 1, e2o, elb, inverse=True)
+                row(out, n0l * n1l, True)
 
     def _execute_pencil_untransposed(self, bufin, bufout, mode=None):
         """The untransposed complex layout on a 2-d process mesh — (N0 / P0, N1 / P1, N2c), distributed like
@@ -727,7 +740,7 @@ class Plan(object):
         return out if len(out) > 1 else None
 
     def _execute_pencil_pipelined(self, be, bufin, bufout, transfer, planes, same, rowc, colc,
-                                  N0, N1, N2, N2c, n0l, n1l, m1, m2, e2o, e0i, norm, W0, W1, W2):
+                                  N0, N1, N2, N2c, n0l, n1l, m1, m2, e2o, e0i, norm, W0, W1, W2, split=False):
         """The pencil transform with BOTH global transposes cut into chunks of the local planes (axis 0 of
         the real side, which neither the row transform, nor the first transpose, nor the axis-1 pass mixes):
         chunk c is row-transformed and packed while the first transpose of chunk c - 1 is on the wire
@@ -753,15 +766,18 @@ class Plan(object):
         out = bufout.storage
         if self.forward:
             X = bufin.storage
-            if not same:
+            if not same and not split:
                 nreal = n0l * n1l * 2 * N2c
                 W0[:nreal].copy_(bufin.storage[:nreal])
                 X = W0
             w1 = []
             for (a, n), q1, q2 in zip(planes, o1, o2):
                 rows = X[2 * a * n1l * N2c:]
-                self._row(be, rows, n * n1l, N2, N2c, False)
-                be.slab_pack(rows, W1[q1:], n * n1l, N2c, 1, e2o, elb)          # split the last axis
+                if split:
+                    be.rowfft_split(es, False, rows, W1[q1:], n * n1l, N2, N2c, e2o)
+                else:
+                    self._row(be, rows, n * n1l, N2, N2c, False)
+                    be.slab_pack(rows, W1[q1:], n * n1l, N2c, 1, e2o, elb)          # split the last axis
                 w1.append(rowc.alltoall(W1[q1:q1 + 2 * n * n1l * N2c], W2[q2:q2 + 2 * n * N1 * m2], t1s(n), t1r(n),
                                         async_op=True))
             w2 = []
@@ -807,8 +823,11 @@ class Plan(object):
             for (a, n), q1, w in zip(planes, o1, w1):
                 w.wait()
                 rows = out[2 * a * n1l * N2c:]
-                be.slab_pack(Z[q1:], rows, n * n1l, N2c, 1, e2o, elb, inverse=True)
-                self._row(be, rows, n * n1l, N2, N2c, True)
+                if split:
+                    be.rowfft_split(es, True, Z[q1:], rows, n * n1l, N2, N2c, e2o)
+                else:
+                    be.slab_pack(Z[q1:], rows, n * n1l, N2c, 1, e2o, elb, inverse=True)
+                    self._row(be, rows, n * n1l, N2, N2c, True)
 
     def fills_output(self):
         """True if an out-of-place execute(bufin, bufout) writes every element of `bufout` that any later reader looks

@@ -672,6 +672,45 @@ def case_pencil_pipelined_equals_single_exchange(be, comm):
         F.OVERLAP_CHUNKS = saved
 
 
+def case_pencil_row_split_equals_two_sweeps(be, comm):
+    """fft.ROW_SPLIT: the last-axis split of the pencil transform's first transpose on the row pass itself
+    (pmx_rowfft_split) gives the bits of the row pass followed by pmx_slab_pack — single and pipelined exchanges, in
+    place and out of place (an out-of-place r2c keeps its input without a copy), with the fused transfer; last axes
+    whose mode count does not divide by the row group, and one the split form is not built for"""
+    from pmesh_amd import fft as F
+    from pmesh_amd.pm import ParticleMesh
+    from pmesh_amd.transfer import Transfer
+    shapes = {2: [1, 2], 4: [2, 2], 8: [2, 4]}
+    if comm.size not in shapes:
+        return
+    np_ = shapes[comm.size]
+    saved = F.ROW_SPLIT, F.OVERLAP_CHUNKS
+    T = Transfer.dx1(2)
+    try:
+        for Nmesh, dtype in (([64, 64, 128], 'f8'), ([64, 128, 256], 'f4'), ([64, 64, 384], 'f8')):
+            data = numpy.random.RandomState(17).normal(size=Nmesh)
+            for chunks in (1, 2):
+                F.OVERLAP_CHUNKS = chunks
+                res = {}
+                for split in (False, True):
+                    F.ROW_SPLIT = split
+                    pm = ParticleMesh(BoxSize=[3.0, 2.0, 5.0], Nmesh=Nmesh, comm=comm, dtype=dtype, np=np_)
+                    real = pm.create('real', value=data[pm.create('real').slices])
+                    before = numpy.asarray(real.value.cpu()).copy()
+                    ck = real.r2c()
+                    assert_array_equal(numpy.asarray(real.value.cpu()), before)      # the input of r2c is kept
+                    back = ck.c2r()
+                    f = ck.c2r(transfer=T)
+                    ck2 = real.copy().r2c(out=Ellipsis)
+                    back2 = ck2.copy().c2r(out=Ellipsis)
+                    res[split] = [numpy.asarray(x.value.cpu()).copy() for x in (ck, back, f, ck2, back2)]
+                    assert_allclose(res[split][1], data[back.slices], rtol=0, atol=1e-12 if dtype == 'f8' else 2e-5)
+                for x, y in zip(res[False], res[True]):
+                    assert_array_equal(x, y)
+    finally:
+        F.ROW_SPLIT, F.OVERLAP_CHUNKS = saved
+
+
 def case_deferred_last_pass_on_slabs(be, comm):
     """fft.DEFER_LAST_PASS on a slab decomposition: r2c leaves the axis-0 pass on the received block (one exchange) or
     on the chunk buffers of the pipelined exchange; an in-place c2r runs both axis-0 passes and the transfer as one
@@ -1159,7 +1198,7 @@ class pytest_raises(object):
 
 
 CASES = [case_mesh_of_four_dimensions, case_tile_order_on_rank_blocks, case_comm_trace, case_async_ghost_exchange, case_readout_into_strided_and_float_out, case_length_check_is_collective, case_promote_and_pack, case_pencil,
-         case_pencil_pipelined_equals_single_exchange, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial, case_halo_merge_left_to_the_slab_row_pass,
+         case_pencil_pipelined_equals_single_exchange, case_pencil_row_split_equals_two_sweeps, case_pencil_untransposed_and_c2c, case_deferred_last_pass_on_slabs, case_deferred_last_pass_on_pencils, case_exchange, case_period_empty_ranks, case_paint_distributed_equals_serial, case_halo_merge_left_to_the_slab_row_pass,
          case_ghosts_only_equals_literal, case_slab_fft, case_pipelined_equals_single_exchange, case_uneven_blocks_decide_alike, case_fused_transfer_slab, case_whitenoise, case_ravel_resample_preview, case_untransposed, case_c2c, case_cycle]
 
 

@@ -117,6 +117,83 @@ def test_rowfft_c2r_ignores_imag_of_dc_and_nyquist(be, elsize, tol):
     assert rel(got, want) < 2 * tol * numpy.log2(n)
 
 
+def _mode_ranges(n, nparts, kind):
+    M1 = n // 2 + 1
+    if kind == 'even':                    # what fft.block_edges gives a row group of nparts ranks
+        return [(M1 * q) // nparts for q in range(nparts + 1)]
+    if kind == 'empty':                   # more ranks than the split leaves modes for some: empty blocks, also at the end
+        e = [0, 0, 5, 5, M1 - 1, M1, M1, M1]
+        return e[:nparts] + [M1] if nparts < len(e) else e + [M1] * (nparts + 1 - len(e))
+    rs = numpy.random.RandomState(n + nparts)
+    return [0] + sorted(int(v) for v in rs.randint(0, M1 + 1, size=nparts - 1)) + [M1]
+
+
+@pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
+@pytest.mark.parametrize('n,nparts,kind', [(128, 1, 'even'), (128, 4, 'even'), (256, 3, 'ragged'), (512, 4, 'even'),
+                                           (512, 16, 'ragged'), (1024, 2, 'even'), (2048, 8, 'ragged'), (256, 7, 'empty'),
+                                           (512, 5, 'empty')])
+def test_rowfft_split(be, elsize, tol, n, nparts, kind):
+    """the row pass with the last-axis split of a pencil transform's first transpose on it: bit for bit what the plain
+    row pass followed by slab_pack (forward) / slab_unpack followed by the plain pass (inverse) deliver, the input kept"""
+    if not be.rowfft_split_supported(n, elsize, nparts):
+        assert n == 2048 and elsize == 8           # (the one power of two whose threads walk along the row)
+        pytest.skip('length not built for this precision')
+    rdt, cdt = ('f8', 'c16') if elsize == 8 else ('f4', 'c8')
+    M1 = n // 2 + 1
+    e = _mode_ranges(n, nparts, kind)
+    assert len(e) == nparts + 1 and e[0] == 0 and e[-1] == M1
+    rs = numpy.random.RandomState(n * 31 + nparts)
+    for nrows, pitch in ((5, M1), (19, M1 + 7), (64, M1)):
+        buf = numpy.zeros((nrows, 2 * pitch), dtype=rdt)
+        x = rs.normal(size=(nrows, n)).astype(rdt)
+        buf[:, :n] = x
+        src = torch.from_numpy(buf.copy()).reshape(-1).to(be.device)
+        keep = src.clone()
+        dst = torch.full((2 * nrows * M1 + 8,), 7.0, dtype=src.dtype, device=be.device)
+        be.rowfft_split(elsize, False, src, dst, nrows, n, pitch, e, scale=2.0)
+        assert torch.equal(src, keep)                               # input preserved
+        assert bool((dst[2 * nrows * M1:] == 7.0).all())            # nothing written past the blocks
+        got = dst[:2 * nrows * M1].cpu().numpy().view(cdt)
+        want = numpy.fft.rfft(x.astype('f8'), axis=1) * 2.0
+        for q in range(nparts):
+            blk = got[nrows * e[q]:nrows * e[q + 1]].reshape(nrows, e[q + 1] - e[q])
+            if blk.size:
+                assert rel(blk, want[:, e[q]:e[q + 1]]) < tol * numpy.log2(n), q
+        # the two-sweep form, bit for bit
+        plain = keep.clone()
+        be.rowfft(elsize, False, plain, nrows, n, pitch, scale=2.0)
+        dense = torch.view_as_real(torch.view_as_complex(plain.view(nrows, pitch, 2))[:, :M1].contiguous()).reshape(-1)
+        packed = torch.zeros_like(dense)
+        be.slab_pack(dense, packed, nrows, M1, 1, e, 2 * elsize)
+        assert torch.equal(packed, dst[:2 * nrows * M1])
+        # inverse: blocks -> rows (the pad of every row is not written: compare the n reals)
+        back = torch.full_like(keep, 3.0)
+        be.rowfft_split(elsize, True, dst, back, nrows, n, pitch, e, scale=1.0 / (2.0 * n))
+        assert rel(back.cpu().numpy().reshape(nrows, 2 * pitch)[:, :n], x) < 2 * tol * numpy.log2(n)
+        two = torch.zeros((nrows, pitch, 2), dtype=src.dtype, device=be.device)
+        unp = torch.zeros_like(dense)
+        be.slab_pack(dst[:2 * nrows * M1].contiguous(), unp, nrows, M1, 1, e, 2 * elsize, inverse=True)
+        two[:, :M1] = unp.view(nrows, M1, 2)
+        two = two.reshape(-1)
+        be.rowfft(elsize, True, two, nrows, n, pitch, scale=1.0 / (2.0 * n))
+        assert torch.equal(two.view(nrows, 2 * pitch)[:, :n], back.view(nrows, 2 * pitch)[:, :n])
+
+
+def test_rowfft_split_rejects(be):
+    src = torch.zeros(2 * 4 * 65, dtype=torch.float64, device=be.device)
+    dst = torch.zeros_like(src)
+    from pmesh_amd.backend import PmxError
+    with pytest.raises(PmxError):                   # offsets that do not end at n/2 + 1
+        be.rowfft_split(8, False, src, dst, 4, 128, 65, [0, 30, 64])
+    with pytest.raises(PmxError):                   # decreasing
+        be.rowfft_split(8, False, src, dst, 4, 128, 65, [0, 40, 30, 65])
+    with pytest.raises(PmxError):                   # in place
+        be.rowfft_split(8, False, src, src, 4, 128, 65, [0, 65])
+    assert not be.rowfft_split_supported(384, 8, 2)             # 3 * 2^k rows: the two-sweep form
+    assert not be.rowfft_split_supported(512, 8, _abi.PMX_MAXSEG + 1)
+    assert be.rowfft_split_supported(512, 8, _abi.PMX_MAXSEG)
+
+
 @pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
 @pytest.mark.parametrize('N,nsplit', [(64, 8), (128, 64), (256, 1), (512, 64), (64, 64)])
 def test_colfft_split(be, elsize, tol, N, nsplit):
