@@ -439,8 +439,8 @@ int pmx_colfft_to(int32_t elsize, int32_t inverse, const void *src, void *dst, i
  * dense (nrows, offsets[q + 1] - offsets[q]) array at element nrows * offsets[q] — the send buffer of the all-to-all
  * over the row group; inverse = 1: src = those blocks (the receive buffer) -> dst = rows of n reals.  Out of place.
  * Replaces the pmx_slab_pack / pmx_slab_unpack sweep (n0 = nrows, n1 = n/2 + 1, n2 = 1) next to pmx_rowfft; same
- * values.  Built for the power-of-two rows pmx_rowfft_halo_supported names and nparts <= PMX_MAXSEG (offsets: host,
- * nparts + 1 entries from 0 to n/2 + 1, not decreasing — empty blocks are allowed). */
+ * values.  Built for every length of pmx_rowfft and nparts <= PMX_MAXSEG (offsets: host, nparts + 1 entries from 0
+ * to n/2 + 1, not decreasing — empty blocks are allowed). */
 #define PMX_MAXSEG 16
 int pmx_rowfft_split_supported(int64_t n, int32_t elsize, int32_t nparts);
 int pmx_rowfft_split(int32_t elsize, int32_t inverse, const void *src, void *dst, int64_t nrows, int64_t n,

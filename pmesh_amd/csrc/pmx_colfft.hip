@@ -1189,7 +1189,7 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
     constexpr int LPT = PMX_ROW_LPT;   // row elements per thread
     constexpr int TPC = M / LPT;
     constexpr int NT = TPC * W;
-    static_assert(!SEG || (LOGM < 16 && NT % M == 0 && !HALO), "the split layout rides on the power-of-two rows whose threads keep one position");
+    static_assert(!SEG || !HALO, "the split layout and the halo gather do not meet (pencil blocks merge their halos before)");
     extern __shared__ __align__(16) unsigned char smem[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem);
     constexpr bool HT = RowHalfTw<T, LOGM, RB>::value;
@@ -1216,6 +1216,17 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
         // planes) whose stride exceeds rpp*pitch by plane_extra elements
         cpx<T> *data = data_ + (rpp > 0 ? (r0 / rpp) * plane_extra : 0);
         cpx<T> *dout = dst_ ? dst_ + (rpp > 0 ? (r0 / rpp) * plane_extra : 0) : data;
+        // the split side (SEG): mode k of row r, and the Nyquist mode of row r
+        auto seg_at = [&](int64_t r, int k) __attribute__((always_inline)) {
+            int eq = 0, eq1 = seg.e[1];
+#pragma unroll
+            for (int s = 1; s < PMX_MAXSEG; s++)
+                if (s < seg.n && k >= seg.e[s]) { eq = seg.e[s]; eq1 = seg.e[s + 1]; }
+            return nrows * eq + r * (int64_t)(eq1 - eq) + (k - eq);
+        };
+        auto nyquist = [&](int64_t r) __attribute__((always_inline)) {
+            return nrows * seg.last + r * (int64_t)(M + 1 - seg.last) + (M - seg.last);
+        };
         __syncthreads();
         if constexpr (LOGM < 16 && NT % M == 0) {
             // Power-of-two rows.  NT is a multiple of M (all but 2048 reals in double, whose tile has 4 rows), so a thread keeps ONE position along the row for all
@@ -1241,10 +1252,6 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 if (INV) { gthread = data_ + at0; ldstep = (int64_t)RSTEP * wq; }
                 else { gstore = dst_ + at0; ststep = (int64_t)RSTEP * wq; }
             }
-            // the Nyquist mode of row r on the split side
-            auto nyquist = [&](int64_t r) __attribute__((always_inline)) {
-                return nrows * seg.last + r * (int64_t)(M + 1 - seg.last) + (M - seg.last);
-            };
             const RowBase<T, RB> nb_ = row_base<T, RB>(n, 0);
             auto at = [&](const RowBase<T, RB> &b, int r) __attribute__((always_inline)) {
                 return b.e[0] + ((b.cr + r) & (W - 1));
@@ -1373,9 +1380,13 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
         for (int u = 0; u < LPT; u++) {
             int flat = tid + u * NT;
             int r = flat / M, n = flat % M;
-            ld[u] = (r0 + r < nrows) ? data[(r0 + r) * pitch + n] : cpx<T>{0, 0};
+            if constexpr (SEG && INV) ld[u] = (r0 + r < nrows) ? data_[seg_at(r0 + r, n)] : cpx<T>{0, 0};
+            else ld[u] = (r0 + r < nrows) ? data[(r0 + r) * pitch + n] : cpx<T>{0, 0};
         }
-        if (INV && tid < W) xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
+        if (INV && tid < W) {
+            if constexpr (SEG) xm[tid] = (r0 + tid < nrows) ? data_[nyquist(r0 + tid)] : cpx<T>{0, 0};
+            else xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
+        }
 #pragma unroll
         for (int u = 0; u < LPT; u++) {
             int flat = tid + u * NT;
@@ -1459,13 +1470,15 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             };
             for (int q = tid; q < W * M; q += NT) {
                 const int r = q / M, k = q % M;
-                if (r0 + r < nrows) dout[(r0 + r) * pitch + k] = mode(r, k);
+                if constexpr (SEG) { if (r0 + r < nrows) dst_[seg_at(r0 + r, k)] = mode(r, k); }
+                else if (r0 + r < nrows) dout[(r0 + r) * pitch + k] = mode(r, k);
             }
             constexpr int LINE = 128 / (int)sizeof(cpx<T>);
-            const int tail = (pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
+            const int tail = (!SEG && pitch >= M + LINE) ? LINE : 1;       // elements M .. M + tail - 1 of every row
             for (int q = tid; q < W * tail; q += NT) {
                 const int r = q / tail, j = q - r * tail;
-                if (r0 + r < nrows) dout[(r0 + r) * pitch + M + j] = (j == 0) ? mode(r, M) : cpx<T>{(T)0, (T)0};
+                if constexpr (SEG) { if (r0 + r < nrows) dst_[nyquist(r0 + r)] = mode(r, M); }
+                else if (r0 + r < nrows) dout[(r0 + r) * pitch + M + j] = (j == 0) ? mode(r, M) : cpx<T>{(T)0, (T)0};
             }
         } else {
 #pragma unroll
@@ -1679,7 +1692,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     RowSeg noseg;
     noseg.n = 0;
     if (seg) {
-        if constexpr (LOGM < 16 && NT % M == 0) {
+        {
             PMX_REQUIRE(!halo && dst != nullptr && dst != data, PMX_EINVAL, "the split row pass works out of place");
             if (inverse) {
                 auto k = rowfft_kernel<T, LOGM, true, RB, false, true>;
@@ -1690,9 +1703,6 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
                 PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 k<<<grid, NT, lds, st>>>((cpx<T> *)data, nrows, pitch, scale, (const cpx<T> *)tw, rpp, plane_extra, none, (cpx<T> *)dst, *seg);
             }
-        } else {
-            set_error("pmx_rowfft_split: row length not built");
-            return PMX_EUNSUPPORTED;
         }
     } else if (halo) {
         if constexpr (LOGM < 16 && NT % M == 0) {
@@ -1856,11 +1866,11 @@ extern "C" int pmx_rowfft_halo(int32_t elsize, void *data, void *dst, int64_t nr
     return dispatch_logm<float>(logm, data, nrows, pitch, scale, tw, false, rows_per_plane, plane_extra, st, &hs, dst, nullptr);
 }
 
-// [r6] PMX_OK if pmx_rowfft_split is built for rows of n reals cut into nparts ranges: the power-of-two rows whose
-// threads keep one position along the row (as pmx_rowfft_halo), at most PMX_MAXSEG ranges
+// [r6] PMX_OK if pmx_rowfft_split is built for rows of n reals cut into nparts ranges: every length of pmx_rowfft,
+// at most PMX_MAXSEG ranges
 extern "C" int pmx_rowfft_split_supported(int64_t n, int32_t elsize, int32_t nparts)
 {
-    int rc = pmx_rowfft_halo_supported(n, elsize);
+    int rc = pmx_rowfft_supported(n, elsize);
     if (rc) return rc;
     return (nparts >= 1 && nparts <= PMX_MAXSEG) ? PMX_OK : PMX_EUNSUPPORTED;
 }

@@ -131,12 +131,13 @@ def _mode_ranges(n, nparts, kind):
 @pytest.mark.parametrize('elsize,tol', [(8, 2e-15), (4, 1e-6)])
 @pytest.mark.parametrize('n,nparts,kind', [(128, 1, 'even'), (128, 4, 'even'), (256, 3, 'ragged'), (512, 4, 'even'),
                                            (512, 16, 'ragged'), (1024, 2, 'even'), (2048, 8, 'ragged'), (256, 7, 'empty'),
-                                           (512, 5, 'empty')])
+                                           (512, 5, 'empty'), (2048, 4, 'even'), (384, 4, 'even'), (768, 3, 'ragged'),
+                                           (1536, 2, 'even'), (640, 4, 'ragged'), (1280, 5, 'empty')])
 def test_rowfft_split(be, elsize, tol, n, nparts, kind):
     """the row pass with the last-axis split of a pencil transform's first transpose on it: bit for bit what the plain
     row pass followed by slab_pack (forward) / slab_unpack followed by the plain pass (inverse) deliver, the input kept"""
-    if not be.rowfft_split_supported(n, elsize, nparts):
-        assert n == 2048 and elsize == 8           # (the one power of two whose threads walk along the row)
+    assert be.rowfft_split_supported(n, elsize, nparts) == be.rowfft_supported(n, elsize)
+    if not be.rowfft_supported(n, elsize):
         pytest.skip('length not built for this precision')
     rdt, cdt = ('f8', 'c16') if elsize == 8 else ('f4', 'c8')
     M1 = n // 2 + 1
@@ -189,7 +190,7 @@ def test_rowfft_split_rejects(be):
         be.rowfft_split(8, False, src, dst, 4, 128, 65, [0, 40, 30, 65])
     with pytest.raises(PmxError):                   # in place
         be.rowfft_split(8, False, src, src, 4, 128, 65, [0, 65])
-    assert not be.rowfft_split_supported(384, 8, 2)             # 3 * 2^k rows: the two-sweep form
+    assert not be.rowfft_split_supported(96, 8, 2)              # (not a length of pmx_rowfft)
     assert not be.rowfft_split_supported(512, 8, _abi.PMX_MAXSEG + 1)
     assert be.rowfft_split_supported(512, 8, _abi.PMX_MAXSEG)
 
