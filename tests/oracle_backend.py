@@ -207,6 +207,30 @@ class OracleBackend(object):
             y = numpy.fft.rfft(real[:, :n].astype('f8'), axis=1)
             cplx[:, :n // 2 + 1] = y * scale
 
+    def rowfft_split_supported(self, n, elsize, nparts):
+        return self.rowfft_supported(n, elsize) and 1 <= nparts <= _abi.PMX_MAXSEG
+
+    def rowfft_split(self, elsize, inverse, src, dst, nrows, n, pitch, offsets, scale=1.0):
+        """rows <-> the blocks of a pencil transform's first transpose (csrc/pmx_colfft.hip: pmx_rowfft_split)"""
+        rdt, cdt = ('f4', 'c8') if elsize == 4 else ('f8', 'c16')
+        M1 = n // 2 + 1
+        e = [int(v) for v in offsets]
+        if (not self.rowfft_split_supported(n, elsize, len(e) - 1) or e[0] != 0 or e[-1] != M1 or
+                any(b < a for a, b in zip(e, e[1:])) or src.data_ptr() == dst.data_ptr()):
+            raise backend.PmxError('pmx_rowfft_split', _abi.PMX_EINVAL, 'bad arguments')
+        rows = (dst if inverse else src).detach().numpy().reshape(-1)
+        blocks = (src if inverse else dst).detach().numpy().reshape(-1).view(cdt)
+        real = rows.view(rdt)[:nrows * 2 * pitch].reshape(nrows, 2 * pitch)
+        if inverse:
+            X = numpy.empty((nrows, M1), dtype='c16')
+            for a, b in zip(e, e[1:]):
+                X[:, a:b] = blocks[nrows * a:nrows * b].reshape(nrows, b - a)
+            real[:, :n] = numpy.fft.irfft(X, n=n, axis=1) * n * scale
+        else:
+            y = (numpy.fft.rfft(real[:, :n].astype('f8'), axis=1) * scale).astype(cdt)
+            for a, b in zip(e, e[1:]):
+                blocks[nrows * a:nrows * b] = y[:, a:b].reshape(-1)
+
     # ---- slab transposes (numpy restatement of csrc/pmx_fft.hip kernels) ----
     def slab_pack(self, src, dst, n0, n1, n2, n1_offsets, elbytes, inverse=False):
         cdt = 'c8' if elbytes == 8 else 'c16'
