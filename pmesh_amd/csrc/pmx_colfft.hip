@@ -1018,6 +1018,12 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
 #ifndef PMX_ROW_HALFTW
 #define PMX_ROW_HALFTW 1
 #endif
+#ifndef PMX_ROW_PACK_NYQUIST
+#define PMX_ROW_PACK_NYQUIST 1
+#endif
+#ifndef PMX_ROW_BOUND_1024
+#define PMX_ROW_BOUND_1024 2
+#endif
 // [r4] The halo merge of the paint inside the forward row pass (pmx_rowfft_halo).  pmx_paint_binned_defer has left
 // the halo cells of every tile — the part of a tile's region beyond its own T0 x T1 x T2 box — in the plan's staging
 // buffer (compact numbering, Region<S>::halo_index) instead of adding them to their owners with atomics.  A canvas
@@ -1168,12 +1174,25 @@ __device__ __forceinline__ void halo_gather(const HaloSrc &h, int x, int yb, int
 
 template <typename T, int LOGM, int RB> struct RowHalfTw {
     static constexpr int M = Len<LOGM>::N, W = RB / (int)sizeof(cpx<T>);
-    static constexpr size_t full = (size_t)(M * W + 2 * M + W) * sizeof(cpx<T>), half = (size_t)(M * W + M + W) * sizeof(cpx<T>);
+    // [r6] XM: the slots of the rows' Nyquist modes (inverse passes).  PACK: the power-of-two rows whose threads walk
+    // along the row (2048 reals in double: a tile of 4 rows, 512 threads) keep that mode in the imaginary part of the DC
+    // slot instead — both are real by definition — and need none: with the first M twiddles their tile is 80 KB to the
+    // byte, two workgroups per CU
+    static constexpr bool PACK = PMX_ROW_PACK_NYQUIST && LOGM < 16 && (M / PMX_ROW_LPT * W) % M != 0;
+    static constexpr int XM = PACK ? 0 : W;
+    static constexpr size_t full = (size_t)(M * W + 2 * M + XM) * sizeof(cpx<T>), half = (size_t)(M * W + M + XM) * sizeof(cpx<T>);
     static constexpr bool value = PMX_ROW_HALFTW && LOGM < 16 && full > 80 * 1024 && half <= 80 * 1024;
+    static constexpr size_t lds = value ? half : full;
+    // waves per SIMD the kernel is held to: two workgroups per CU where two tiles fit the LDS — 512 threads: 4 (128
+    // registers), [r6] 1024 threads (float rows of 1024 / 2048 reals, 65-67 registers unbounded: ONE workgroup): 8 (64)
+    static constexpr int NT = M / PMX_ROW_LPT * W;
+    static constexpr int tight = (PMX_ROW_BOUND_1024 && NT == 1024 && lds <= 80 * 1024) ? 8 : (value ? 4 : 1);
+    static constexpr int loose = value ? 4 : 1;          // (the forms that would spill under the tight bound)
 };
 
 template <typename T, int LOGM, bool INV, int RB, bool HALO = false, bool SEG = false>
-__global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)), (RowHalfTw<T, LOGM, RB>::value ? 4 : 1))
+__global__ void __launch_bounds__(Len<LOGM>::N / PMX_ROW_LPT * (RB / (int)sizeof(cpx<T>)),
+                                  ((HALO || (SEG && INV && PMX_ROW_BOUND_1024 < 2)) ? RowHalfTw<T, LOGM, RB>::loose : RowHalfTw<T, LOGM, RB>::tight))
 rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const cpx<T> *twiddle /* length 2M */,
               int64_t rpp, int64_t plane_extra, HaloSrc hs, cpx<T> *dst_, RowSeg seg)
 {
@@ -1383,7 +1402,20 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
             if constexpr (SEG && INV) ld[u] = (r0 + r < nrows) ? data_[seg_at(r0 + r, n)] : cpx<T>{0, 0};
             else ld[u] = (r0 + r < nrows) ? data[(r0 + r) * pitch + n] : cpx<T>{0, 0};
         }
-        if (INV && tid < W) {
+        constexpr bool PACK = RowHalfTw<T, LOGM, RB>::PACK;
+        if constexpr (PACK) {
+            // the DC and the Nyquist mode of a real row are real (see below): the Nyquist mode travels in the DC slot's
+            // imaginary part, no slots of its own.  flat = tid + u NT is a multiple of M for thread 0 alone (NT divides M)
+            static_assert(M % NT == 0 && (M / NT) * (W - 1) < LPT, "row kernel: thread 0 holds the DC slots of the tile's rows");
+            if (INV && tid == 0) {
+#pragma unroll
+                for (int r = 0; r < W; r++)
+                    if (r0 + r < nrows) {
+                        if constexpr (SEG) ld[r * (M / NT)].y = data_[nyquist(r0 + r)].x;
+                        else ld[r * (M / NT)].y = data[(r0 + r) * pitch + M].x;
+                    }
+            }
+        } else if (INV && tid < W) {
             if constexpr (SEG) xm[tid] = (r0 + tid < nrows) ? data_[nyquist(r0 + tid)] : cpx<T>{0, 0};
             else xm[tid] = (r0 + tid < nrows) ? data[(r0 + tid) * pitch + M] : cpx<T>{0, 0};
         }
@@ -1399,7 +1431,9 @@ rowfft_kernel(cpx<T> *data_, int64_t nrows, int64_t pitch, double scale, const c
                 int r = q / (M / 2 + 1), k = q % (M / 2 + 1);
                 int k2 = M - k;
                 cpx<T> xk = buf[lds_index<T, RB>(k, r)];
-                cpx<T> xq = (k == 0) ? xm[r] : buf[lds_index<T, RB>(k2, r)];
+                cpx<T> xq;
+                if constexpr (PACK) xq = (k == 0) ? cpx<T>{xk.y, 0} : buf[lds_index<T, RB>(k2, r)];
+                else xq = (k == 0) ? xm[r] : buf[lds_index<T, RB>(k2, r)];
                 // the DC and Nyquist modes of a real row are real: their imaginary parts are
                 // ignored, as FFTW's c2r (behind PFFT) and numpy.fft.irfft do — it matters for
                 // spectra that are not exactly Hermitian, e.g. after i k / k^2 on the Nyquist planes
@@ -1684,7 +1718,7 @@ static int launch_rowfft(void *data, int64_t nrows, int64_t pitch, double scale,
     constexpr int W = RB / (int)sizeof(cpx<T>);
     constexpr int NT = M / PMX_ROW_LPT * W;
     static_assert(NT <= 1024 && NT % 64 == 0, "row kernel: workgroup size");
-    size_t lds = (size_t)(M * W + (RowHalfTw<T, LOGM, RB>::value ? M : 2 * M) + W) * sizeof(cpx<T>);
+    size_t lds = RowHalfTw<T, LOGM, RB>::lds;
     int64_t tiles = (nrows + W - 1) / W;
     PMX_REQUIRE(tiles < (1ll << 31), PMX_EUNSUPPORTED, "more than 2^31 row tiles in one pass");
     unsigned grid = (unsigned)((PMX_ROW_ONE_TILE && M < 512) ? tiles : (tiles < 256 * 64 ? tiles : 256 * 64));

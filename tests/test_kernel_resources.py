@@ -82,7 +82,15 @@ def test_column_fft_budgets():
             # workgroups per CU, i.e. three waves per SIMD: 168 registers
             if re.search(r'ELb0ELi128ELb1ELb0EEE', k):
                 limit = 168
-            assert v['ScratchSize'] == 0 and v['VGPRs'] <= limit, (k, v)
+            # [r6] float rows of 1024 / 2048 reals are 1024-thread workgroups whose tile is under 80 KB: held to 64
+            # registers two of them share a CU (row pass of 1024 reals 3.8 -> 4.9 TB/s); the forms that read the split
+            # layout of a pencil transpose park up to 18 words per lane for it (measured: still ahead), the 2048 forward
+            # pass two
+            spill = 0
+            if re.match(r'I[f]Li(9|10)E', tail) and not re.search(r'ELb1ELb0EEE', k):
+                limit = 64
+                spill = 72 if re.search(r'If\w*Li(9|10)ELb1ELi\d+ELb0ELb1EEE', k) else (8 if 'Li10E' in tail else 0)
+            assert v['ScratchSize'] <= spill and v['VGPRs'] <= limit, (k, v)
         if 'colfft_kernel' in k and 'Li11E' in k:
             assert v['ScratchSize'] == 0, (k, v)
 
