@@ -218,6 +218,8 @@ struct ColGeom {
     // spills (measured: 60-116 bytes in every float variant) — so that direction keeps its stand-alone kernel.
     // nullptr: D = k_d.
     const double *dtab = nullptr;
+    // [r6] tiles in XCD order (xcd_tile below): set by the launchers
+    int32_t xcd = 0;
 };
 
 // LDS layout: one row of the tile = W columns = 128 bytes = half a bank row.  Rows 2m and
@@ -490,6 +492,26 @@ template <> struct Radices<25> { static constexpr int n = 4; static constexpr in
 template <> struct Radices<38> { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 5, 1}; };   // 320
 template <> struct Radices<39> { static constexpr int n = 4; static constexpr int r[4] = {8, 4, 4, 5}; };   // 640
 template <> struct Radices<40> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 5}; };   // 1280
+
+// [r6] Workgroups are handed to the 8 XCDs in turn (blockIdx mod 8), each with an L2 of its own.  A pass over lines that
+// do not start on 128-byte boundaries — the dense blocks of the distributed transforms' transposes: 257 or 65 modes to
+// a line — has neighbouring tiles share every HBM line their column groups straddle; with tile = blockIdx the two
+// halves are fetched by two XCDs.  xcd_tile gives every XCD a contiguous range of the tiles instead (workgroup b is the
+// (b / 8)-th of XCD b mod 8): neighbours in the array are neighbours in time on one L2.  Measured
+// (scripts/r06/col_xcd_ab.sh, profiles/r06_colxcd/): passes over dense lines 3.99 -> 4.72-4.76 TB/s at N = 512 in double
+// (257 modes to a line), 3.6 -> 4.6-4.8 in float, the round trip at N = 1024 in double 3.74 -> 3.98 on padded lines, 2.65 ->
+// 3.85 on dense ones — but the y pass of the ONE-rank transform, padded lines, inside its L3-sized blocks of planes
+// LOSES (512^3: r2c 0.83 -> 0.90 ms, float 0.48 -> 0.53).  So: 1 (default) = the round trip always, the plain passes
+// where a line does not start on a 128-byte boundary; 2 = every pass (the measurement build); 0 = none.
+#ifndef PMX_COL_XCD
+#define PMX_COL_XCD 1
+#endif
+__device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t n)
+{
+    const uint32_t ub = (uint32_t)b, un = (uint32_t)n;
+    const uint32_t x = ub & 7u, i = ub >> 3, q = un >> 3, r = un & 7u;
+    return (int64_t)(x * q + (x < r ? x : r) + i);
+}
 
 // column kernel: lengths from this one on walk their tiles with a grid-stride loop
 #ifndef PMX_COL_STRIDE_FROM
@@ -787,6 +809,7 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         }
     };
     int64_t tile = blockIdx.x;
+    if (PMX_COL_XCD && ONE_TILE && g.xcd) tile = xcd_tile(tile, ntiles);
     if (PIPE) {
         // The first tile is peeled off the loop: the loop is then only ever entered with "8 loads, then 8 stores"
         // in flight, and the wait for the prefetched lines at its top lets the stores behind them drain on their
@@ -989,6 +1012,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
     };
     int64_t tile = blockIdx.x;
     if (tile >= tilesB) return;
+    if (PMX_COL_XCD && !PIPE && g.xcd) tile = xcd_tile(tile, tilesB);
     __syncthreads();
     if (PIPE) {
         load_tile(tile, ld);
@@ -1644,11 +1668,18 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     } else if (ColPipe<T, LOGN, RB>::value && !(apply && sizeof(T) == 4)) {
         grid = (unsigned)tiles;
     }
+    // tiles in XCD order where the lines of either side do not start on 128-byte boundaries (see xcd_tile)
+    ColGeom gx = g;
+    {
+        constexpr int64_t LINE = 128 / (int64_t)sizeof(cpx<T>);
+        auto ragged = [&](const ColAddr &a) { return a.sn % LINE != 0 || (g.A > 1 && a.sa % LINE != 0) || (a.cw > 0 && (a.cw % LINE != 0 || a.cpitch % LINE != 0)); };
+        gx.xcd = PMX_COL_XCD >= 2 || (PMX_COL_XCD == 1 && (ragged(g.in) || ragged(g.out)));
+    }
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
         auto k = colfft_kernel<T, LOGN, INV, AP, RB, RM>;                                                      \
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k<<<grid, NT, lds, st>>>(g, (const cpx<T> *)src, (cpx<T> *)dst, (const cpx<T> *)tw);                   \
+        k<<<grid, NT, lds, st>>>(gx, (const cpx<T> *)src, (cpx<T> *)dst, (const cpx<T> *)tw);                  \
     } while (0)
     if (inverse) { if (apply) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (apply) LAUNCH(false, true); else LAUNCH(false, false); }
@@ -2074,11 +2105,13 @@ static int launch_round(const ColGeom &g, void *data, const void *tw, bool apply
         const int64_t cus = compute_units() * (RoundPipe2<T, LOGN, RB>::value ? 2 : 1);
         grid = (unsigned)(tiles < cus ? tiles : cus);
     }
+    ColGeom gx = g;
+    gx.xcd = PMX_COL_XCD >= 1;
 #define LAUNCH(AP)                                                                                             \
     do {                                                                                                       \
         auto k = colfft_round_kernel<T, LOGN, AP, RB>;                                                         \
         PMX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k<<<grid, NT, lds, st>>>(g, (cpx<T> *)data, (const cpx<T> *)tw);                                       \
+        k<<<grid, NT, lds, st>>>(gx, (cpx<T> *)data, (const cpx<T> *)tw);                                      \
     } while (0)
     if (apply) LAUNCH(true); else LAUNCH(false);
 #undef LAUNCH
