@@ -2328,6 +2328,16 @@ __device__ __forceinline__ void tile_gather_lean(const pmx_painter &p, const Bin
 // (768 threads — PCS on double canvases, an 81 KB region: TWO workgroups per CU need 6 waves per SIMD, i.e. at most 80
 // VGPRs.  The form for blocks of any shape came to 83 and ran ONE: 2.62 ms against 1.75 at 512^3 — every pencil rank
 // of config 5 runs that form.  The bound makes the compiler hold it.)
+// [r6] PMX_READOUT_XCD: tiles in XCD order (xcd_tile): the z- and y-neighbours of a tile, which fetch the face lines of
+// its region as rows of their own, run at the same time on the same L2.  Measured between two builds of this file that
+// differ in nothing else (scripts/r06/lib_ab2.sh, profiles/r06_rxcd/): PCS gains (512^3 1.75-1.77 -> 1.66-1.69 ms,
+// config 5's per-GPU load 33.1-33.4 -> 32.5-32.6: its region is 11 x 19 x 35 cells for a box of 8 x 16 x 32, the faces are
+// half of what it fetches), CIC and TSC LOSE (1.12-1.16 -> 1.19-1.24, 1.46 -> 1.49-1.50; rows that have drifted 4 cells
+// 2.03 -> 2.63): eight far-apart streams through the particle rows, which are most of their traffic, instead of one.
+// 1 (default): PCS only; 2: every window (the measurement build); 0: none.
+#ifndef PMX_READOUT_XCD
+#define PMX_READOUT_XCD 1
+#endif
 template <int KIND, typename T, int TTHREADS, int PE, int OE, bool WHOLE>
 __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WAVES : 1)) readout_tile_lean_kernel(pmx_painter p, BinGeom g, const char *canvas,
                                                                    DVec pos, char *out, const uint32_t *list,
@@ -2352,6 +2362,7 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
     const int64_t nh = *nitems < cap ? *nitems : cap;
     for (int64_t unit = blockIdx.x; unit < g.ntiles + nh; unit += gridDim.x) {
         int64_t tile = unit, first = 0;
+        if ((PMX_READOUT_XCD >= 2 || (PMX_READOUT_XCD == 1 && S >= 4)) && unit < g.ntiles) tile = xcd_tile(unit, g.ntiles);
         if (unit >= g.ntiles) {
             const uint64_t it = items[unit - g.ntiles];
             tile = (int64_t)(it >> 20);
@@ -2410,6 +2421,7 @@ __global__ void __launch_bounds__(TTHREADS, (TTHREADS == 768 ? PMX_READOUT768_WA
     const int64_t nh = *nitems < cap ? *nitems : cap;
     for (int64_t unit = blockIdx.x; unit < g.ntiles + nh; unit += gridDim.x) {
         int64_t tile = unit, first = 0;
+        if ((PMX_READOUT_XCD >= 2 || (PMX_READOUT_XCD == 1 && S >= 4)) && unit < g.ntiles) tile = xcd_tile(unit, g.ntiles);
         if (unit >= g.ntiles) {
             const uint64_t it = items[unit - g.ntiles];
             tile = (int64_t)(it >> 20);

@@ -496,8 +496,8 @@ template <> struct Radices<40> { static constexpr int n = 4; static constexpr in
 // [r6] Workgroups are handed to the 8 XCDs in turn (blockIdx mod 8), each with an L2 of its own.  A pass over lines that
 // do not start on 128-byte boundaries — the dense blocks of the distributed transforms' transposes: 257 or 65 modes to
 // a line — has neighbouring tiles share every HBM line their column groups straddle; with tile = blockIdx the two
-// halves are fetched by two XCDs.  xcd_tile gives every XCD a contiguous range of the tiles instead (workgroup b is the
-// (b / 8)-th of XCD b mod 8): neighbours in the array are neighbours in time on one L2.  Measured
+// halves are fetched by two XCDs.  xcd_tile (pmx_common.h) gives every XCD a contiguous range of the tiles instead
+// (workgroup b is the (b / 8)-th of XCD b mod 8): neighbours in the array are neighbours in time on one L2.  Measured
 // (scripts/r06/col_xcd_ab.sh, profiles/r06_colxcd/): passes over dense lines 3.99 -> 4.72-4.76 TB/s at N = 512 in double
 // (257 modes to a line), 3.6 -> 4.6-4.8 in float, the round trip at N = 1024 in double 3.74 -> 3.98 on padded lines, 2.65 ->
 // 3.85 on dense ones — but the y pass of the ONE-rank transform, padded lines, inside its L3-sized blocks of planes
@@ -506,12 +506,6 @@ template <> struct Radices<40> { static constexpr int n = 4; static constexpr in
 #ifndef PMX_COL_XCD
 #define PMX_COL_XCD 1
 #endif
-__device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t n)
-{
-    const uint32_t ub = (uint32_t)b, un = (uint32_t)n;
-    const uint32_t x = ub & 7u, i = ub >> 3, q = un >> 3, r = un & 7u;
-    return (int64_t)(x * q + (x < r ? x : r) + i);
-}
 
 // column kernel: lengths from this one on walk their tiles with a grid-stride loop
 #ifndef PMX_COL_STRIDE_FROM

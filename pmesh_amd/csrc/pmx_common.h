@@ -59,6 +59,17 @@ struct DVec {
 
 // position loads with the element size known at compile time (PE = 4 / 8) or read from the vector (PE = 0):
 // the tile kernels choose once per launch (see tile_gather) instead of once per component
+// [r6] Workgroups are handed to the 8 XCDs in turn (blockIdx mod 8), each with an L2 of its own.  Where neighbouring work
+// items share HBM lines (column passes over lines off 128-byte boundaries, the face lines of the readout's regions),
+// xcd_tile gives every XCD a contiguous range of the n items instead — workgroup b is the (b / 8)-th of XCD b mod 8 —
+// so that neighbours in the array are neighbours in time on ONE L2.  A bijection of [0, n) for any n < 2^32.
+__device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t n)
+{
+    const uint32_t ub = (uint32_t)b, un = (uint32_t)n;
+    const uint32_t x = ub & 7u, i = ub >> 3, q = un >> 3, r = un & 7u;
+    return (int64_t)(x * q + (x < r ? x : r) + i);
+}
+
 template <int PE> __device__ __forceinline__ double pos_get(const DVec &pos, int64_t i, int c)
 {
     if (PE == 0) return pos.get(i, c);
