@@ -803,7 +803,8 @@ colfft_kernel(ColGeom g, const cpx<T> *src, cpx<T> *dst, const cpx<T> *twiddle)
         }
     };
     int64_t tile = blockIdx.x;
-    if (PMX_COL_XCD && ONE_TILE && g.xcd) tile = xcd_tile(tile, ntiles);
+    // (persistent / grid-stride forms: XCD order within every round of gridDim.x tiles)
+    if (PMX_COL_XCD && g.xcd) tile = xcd_tile(tile, ONE_TILE ? ntiles : (int64_t)gridDim.x);
     if (PIPE) {
         // The first tile is peeled off the loop: the loop is then only ever entered with "8 loads, then 8 stores"
         // in flight, and the wait for the prefetched lines at its top lets the stores behind them drain on their
@@ -1006,7 +1007,7 @@ colfft_round_kernel(ColGeom g, cpx<T> *data, const cpx<T> *twiddle)
     };
     int64_t tile = blockIdx.x;
     if (tile >= tilesB) return;
-    if (PMX_COL_XCD && !PIPE && g.xcd) tile = xcd_tile(tile, tilesB);
+    if (PMX_COL_XCD && g.xcd) tile = xcd_tile(tile, PIPE ? (int64_t)gridDim.x : tilesB);
     __syncthreads();
     if (PIPE) {
         load_tile(tile, ld);
@@ -1667,7 +1668,8 @@ static int launch_colfft_rm(const ColGeom &g, const void *src, void *dst, const 
     {
         constexpr int64_t LINE = 128 / (int64_t)sizeof(cpx<T>);
         auto ragged = [&](const ColAddr &a) { return a.sn % LINE != 0 || (g.A > 1 && a.sa % LINE != 0) || (a.cw > 0 && (a.cw % LINE != 0 || a.cpitch % LINE != 0)); };
-        gx.xcd = PMX_COL_XCD >= 2 || (PMX_COL_XCD == 1 && (ragged(g.in) || ragged(g.out)));
+        // (and where a tile's row segments are half a line — RB = 64, the 2048-point passes: the other half is the next tile's)
+        gx.xcd = PMX_COL_XCD >= 2 || (PMX_COL_XCD == 1 && (RB < 128 || ragged(g.in) || ragged(g.out)));
     }
 #define LAUNCH(INV, AP)                                                                                        \
     do {                                                                                                       \
