@@ -752,8 +752,14 @@ __device__ __forceinline__ void lean_blocks(const pmx_painter &p, const BinGeom 
     }
 }
 
+// [r6] waves per SIMD the kernel is held to.  Positions in float need 83 registers unbounded — five waves where 80
+// allow six; held there (no spill) config 3's bin pass goes 0.61 -> 0.56 ms, CIC f4 0.57 -> 0.54.  Positions in double
+// need 93, and held to 80 they spill: 0.76 -> 0.85-0.90 (to 64: 1.3).  `profiles/r06_lean_waves_ab.txt`.
+#ifndef PMX_LEAN_WAVES
+#define PMX_LEAN_WAVES 0
+#endif
 template <int KIND, int PE, bool WHOLE>
-__global__ void __launch_bounds__(TBLOCK) bin_lean_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
+__global__ void __launch_bounds__(TBLOCK, (PMX_LEAN_WAVES ? PMX_LEAN_WAVES : (PE == 4 ? 6 : 1))) bin_lean_kernel(pmx_painter p, BinGeom g, DVec pos, int64_t n,
                                                           uint32_t *counts, uint32_t *flags, const int64_t *offsets,
                                                           uint32_t *list, uint32_t *host_flag)
 {
