@@ -163,4 +163,8 @@ def test_tile_kernel_budgets():
     lean = {k: v for k, v in t.items() if 'bin_lean_kernel' in k}
     assert len(lean) == 16
     for k, v in lean.items():
-        assert v['ScratchSize'] == 0 and v['VGPRs'] <= 96 and v['LDS'] <= 20480, (k, v)
+        # [r6] the forms for positions in float (PE = 4) are held to six waves per SIMD — 80 registers, where they took 83
+        # and ran five; up to three words per lane parked for it (measured: 0.61 -> 0.56 ms on config 3's rows)
+        f4 = re.search(r'bin_lean_kernelILi\dELi4E', k) is not None
+        assert v['ScratchSize'] <= (12 if f4 else 0) and v['VGPRs'] <= (80 if f4 else 96) and v['LDS'] <= 20480, (k, v)
+        assert not f4 or v['Occupancy'] >= 6, (k, v)
