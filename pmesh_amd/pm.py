@@ -659,6 +659,9 @@ class _hslab(numpy.ndarray):
     pass
 
 
+slab = _hslab          # (the reference's name for the array type its slab iterators hand out, pm.py:84)
+
+
 def out_is_view_of(a, b):
     return a.data_ptr() == b.data_ptr() and tuple(a.shape) == tuple(b.shape) and a.stride() == b.stride()
 
